@@ -1,0 +1,254 @@
+"""CPU oracle for the token-cluster hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``centerclip_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and only as the checker / the timed CPU baseline.
+
+It is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm, with
+two independent formulations:
+
+* ``literal_*``  - the same ATen op sequence the reference issues (cdist,
+  chunk-max shift, KKZ re-gather, [B,K,N,N] masked sum, chunk-mean stop test),
+  so on one host it reproduces the reference bit for bit and costs what the
+  reference costs.  This is what ``bench.py`` times as ``cpu_baseline``
+  (kind "port").
+* ``select_streamlined`` - a per-problem numpy restatement built only from the
+  exact equivalences listed in SURVEY.md §8(a) (running-min KKZ, member-list
+  row sums in ascending index order, fixed-point stop).  It is the executable
+  spec of what the HIP selection kernel does.
+
+Pinning: the reference ships no golden vectors for this path, so
+the oracle is pinned by fixtures generated from the imported reference in the
+dev container (``oracle/gen_golden.py`` -> ``tests/golden/cluster_*.npz``) and
+checked in ``tests/test_oracle_cluster.py``.
+
+Reference citations are relative to /root/reference.
+"""
+import numpy as np
+import torch
+
+METRICS = ("euclidean", "cosine")
+
+
+# --------------------------------------------------------------------------- C3
+def literal_pairwise_distance(a, b, metric="euclidean", self_nearest=True,
+                              all_negative=False, p=2.0):
+    """modules/cluster/cluster_utils.py:8-43.
+
+    euclidean -> torch.cdist(p) (:22); cosine -> 1 - a_hat @ b_hat^T with
+    x_hat = x / (|x| + 1e-6) (:24-30); all_negative subtracts the max of the
+    WHOLE tensor handed in (one split chunk) and 1 (:35-36); self_nearest
+    subtracts another 1 on the diagonal (:38-41).
+    """
+    if metric == "euclidean":
+        d = torch.cdist(a, b, p=p)
+    elif metric == "cosine":
+        ah = a / (a.norm(dim=-1, keepdim=True) + 1e-6)
+        bh = b / (b.norm(dim=-1, keepdim=True) + 1e-6)
+        if a.ndim == 3:
+            d = 1.0 - torch.bmm(ah, bh.transpose(-2, -1))
+        else:
+            d = 1.0 - torch.matmul(ah, bh.transpose(-2, -1))
+    else:
+        raise NotImplementedError("{} metric is not implemented".format(metric))
+    if all_negative:
+        d = d - torch.max(d) - 1.0
+    if self_nearest:
+        idx = torch.arange(d.shape[-1], dtype=torch.long)
+        d[..., idx, idx] -= 1.0
+    return d
+
+
+# --------------------------------------------------------------------------- C4
+def literal_kkz(l2_norm, D, K):
+    """Batched KKZ init, modules/cluster/cluster_utils.py:93,106-118.
+
+    l2_norm [B,N] = torch.norm(X, dim=-1) (:93).  First medoid = first argmax
+    of the norm; medoid i = argmax_n min_{j<i} D[b, m_j, n] (rows of D).
+    """
+    B, N = l2_norm.shape
+    rows = torch.arange(B, dtype=torch.long).unsqueeze(1)
+    med = torch.arange(K, dtype=torch.long).unsqueeze(0).repeat(B, 1)
+    med[:, 0] = torch.max(l2_norm, dim=1)[1]
+    for i in range(1, K):
+        nearest = torch.min(D[rows, med[:, :i], :], dim=1)[0]        # [B,N]
+        med[:, i] = torch.max(nearest, dim=1)[1]
+    return med
+
+
+# --------------------------------------------------------------------------- C5
+def literal_select(D, l2_norm, K, X=None, threshold=1e-5, iter_limit=60, id_sort=True):
+    """k-medoids selection from a finished distance tensor D [B,N,N].
+
+    modules/cluster/fast_kmeans.py:65-97.  ``X`` is only needed for the
+    reference's stop test (chunk mean of sum_k |X[m_k]-X[m_k_prev]|_2 < thr,
+    :85-88); with X=None the equivalent fixed-point test "no medoid of the
+    chunk changed" is used (SURVEY §8a equivalence 4).
+    Returns (assign [B,N] i64, medoids [B,K] i64, iterations executed).
+    """
+    B, N, _ = D.shape
+    big = D.unsqueeze(1).repeat(1, K, 1, 1)                           # :65
+    med = literal_kkz(l2_norm, D, K)                                  # :67
+    rows = torch.arange(B, dtype=torch.long).unsqueeze(1)
+    kid = torch.arange(K, dtype=torch.long).reshape(1, K, 1)
+    steps = 0
+    assign = None
+    for _ in range(iter_limit):
+        steps += 1
+        prev = med
+        assign = torch.min(D[rows, med, :], dim=1)[1]                 # :75-76
+        member = assign.unsqueeze(1) == kid                           # [B,K,N]
+        masked = big * member.unsqueeze(-1) * member.unsqueeze(-2)    # :81
+        med = torch.argmin(torch.sum(masked, dim=-1), dim=-1)         # :82
+        if X is not None:
+            shift = torch.sum((X[rows, med, :] - X[rows, prev, :]) ** 2, dim=-1).sqrt().sum(dim=-1).mean()
+            if shift < threshold:                                     # :85-88
+                break
+        elif torch.equal(med, prev):
+            break
+    if id_sort:
+        med = torch.sort(med, dim=1)[0]                               # :90-94
+        assign = torch.min(D[rows, med, :], dim=1)[1]
+    return assign, med, steps
+
+
+def literal_batch_kmedoids(X, K, distance="euclidean", threshold=1e-5, iter_limit=60,
+                           id_sort=True, norm_p=2.0, return_steps=False):
+    """modules/cluster/fast_kmeans.py:45-97 (one split chunk)."""
+    assert distance in METRICS and X.ndim == 3
+    D = literal_pairwise_distance(X, X, metric=distance, all_negative=True,
+                                  self_nearest=True, p=norm_p)
+    assign, med, steps = literal_select(D, torch.norm(X, dim=-1), K, X=X, threshold=threshold,
+                                        iter_limit=iter_limit, id_sort=id_sort)
+    return (assign, med, steps) if return_steps else (assign, med)
+
+
+# --------------------------------------------------------------------------- C2
+def literal_batch_kmedoids_with_split(X, K, distance="euclidean", threshold=1e-5, iter_limit=60,
+                                      id_sort=True, norm_p=2.0, split_size=4, pre_norm=False):
+    """modules/cluster/fast_kmeans.py:14-40: optional L2 pre-norm, then the
+    batch is cut into chunks of ``split_size`` problems that are solved
+    independently (the chunk is the scope of the max in C3 and of the stop test)."""
+    X = X.float()
+    if pre_norm:
+        X = X / (X.norm(dim=-1, keepdim=True) + 1e-6)
+    outs = [literal_batch_kmedoids(c, K, distance, threshold, iter_limit, id_sort, norm_p)
+            for c in torch.split(X, split_size, dim=0)]
+    return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+
+
+# --------------------------------------------------------------------------- C1
+def regroup_segments(x_lnd, T, T_new):
+    """Layout contract of TokenClusterInter.forward (modules/cluster/cluster.py:239-250).
+
+    x_lnd [1+n, B*T, W] (column = b*T + t).  Returns
+      tokens [T_new*B, fd*n, W]  problem p = s*B + b, token j = f*n + i
+      cls    [B, T, W]
+    """
+    L, BT, W = x_lnd.shape
+    n, B, fd = L - 1, BT // T, T // T_new
+    x = x_lnd.permute(1, 0, 2)                                        # [B*T, L, W]
+    cls = x[:, 0, :].reshape(B, T, W)
+    patches = x[:, 1:, :].reshape(B, T_new, fd, n, W)                 # t = s*fd + f
+    tokens = patches.permute(1, 0, 2, 3, 4).reshape(T_new * B, fd * n, W)
+    return tokens.contiguous(), cls
+
+
+def literal_token_cluster(x_lnd, T, T_new, K, distance="euclidean", threshold=1e-6, iter_limit=100,
+                          norm_p=2.0, split_size=16, pre_norm=False, return_ids=False):
+    """kmediods++ / aggregation=None branch of TokenClusterInter.forward
+    (modules/cluster/cluster.py:206-216,239-260,287-289,303-310,350-352).
+    Output [1+K, B*T_new, W] with column b*T_new + s; CLS of a segment is the
+    mean of its fd frame CLS tokens (:307-308)."""
+    L, BT, W = x_lnd.shape
+    B, fd = BT // T, T // T_new
+    tokens, cls = regroup_segments(x_lnd, T, T_new)
+    assign, med = literal_batch_kmedoids_with_split(tokens, K, distance, threshold, iter_limit,
+                                                    True, norm_p, split_size, pre_norm)
+    P = tokens.shape[0]
+    picked = tokens[torch.arange(P).unsqueeze(-1), med]               # [T_new*B, K, W]  (:289)
+    picked = picked.reshape(T_new, B, K, W).permute(1, 0, 2, 3).reshape(B * T_new, K, W)   # (:303)
+    seg_cls = torch.stack([c.mean(dim=1) for c in torch.split(cls, fd, dim=1)], dim=1)      # (:307)
+    out = torch.cat([seg_cls.reshape(B * T_new, 1, W), picked], dim=1).permute(1, 0, 2).contiguous()
+    return (out, med, assign) if return_ids else out
+
+
+# ------------------------------------------------------- streamlined (kernel spec)
+def select_streamlined(D, first, K, iter_limit=60, id_sort=True):
+    """Per-problem selection from one finished D [N,N] (numpy fp32), using only
+    the exact equivalences of SURVEY §8(a):
+
+      1. KKZ with a running minimum over rows of D;
+      2. update via member lists: s_i = sum_{j in cluster(i), ascending j} D[i,j]
+         accumulated sequentially in fp32, medoid = member with the smallest
+         s_i (lowest index on ties; an empty cluster yields index 0, as argmin
+         over an all-zero row does in the reference);
+      4. stop when the medoid vector is unchanged (fixed point) or at iter_limit;
+      6. final sort + re-assignment.
+    ``first`` is the first KKZ medoid (argmax of the token L2 norms).
+    Returns (assign [N] i64, medoids [K] i64, iterations).
+    """
+    D = np.asarray(D, dtype=np.float32)
+    N = D.shape[0]
+    med = np.empty(K, dtype=np.int64)
+    med[0] = first
+    nearest = D[first].copy()
+    for i in range(1, K):
+        m = int(np.argmax(nearest))                 # first max
+        med[i] = m
+        nearest = np.minimum(nearest, D[m])
+    steps = 0
+    assign = np.zeros(N, dtype=np.int64)
+    for _ in range(iter_limit):
+        steps += 1
+        assign = np.argmin(D[med], axis=0)          # first k on ties
+        new = np.zeros(K, dtype=np.int64)
+        for k in range(K):
+            mem = np.nonzero(assign == k)[0]
+            if mem.size == 0:
+                continue
+            best, best_s = -1, None
+            for i in mem:
+                s = np.float32(0.0)
+                for j in mem:
+                    s = np.float32(s + D[i, j])
+                if best < 0 or s < best_s:
+                    best, best_s = int(i), s
+            new[k] = best
+        same = np.array_equal(new, med)
+        med = new
+        if same:
+            break
+    if id_sort:
+        med = np.sort(med)
+        assign = np.argmin(D[med], axis=0)
+    return assign.astype(np.int64), med, steps
+
+
+def exact_zero_diag_distance(X, metric="euclidean", p=2.0, chunk_max=None):
+    """The HIP kernel's own distance arithmetic, restated on the CPU (numpy):
+    Gram via an fp32 dot per pair, squared norms taken from the Gram diagonal
+    (=> d(i,i) == 0 and D symmetric), sqrt(max(n_i+n_j-2g,0)); shift by the
+    chunk max and 1, diagonal minus another 1.  On exactly representable
+    (integer-lattice) inputs this equals literal_pairwise_distance bit for bit
+    (SURVEY §8c P1); on generic floats it differs from ATen's cdist in the last
+    bits (P3).  X [B,N,W] -> D [B,N,N] fp32."""
+    X = np.asarray(X, dtype=np.float32)
+    if metric == "euclidean" and p == 2.0:
+        g = np.einsum("bnw,bmw->bnm", X.astype(np.float64), X.astype(np.float64)).astype(np.float32)
+        sq = np.einsum("bnn->bn", g)
+        d2 = (sq[:, :, None] + sq[:, None, :]) - np.float32(2.0) * g
+        d = np.sqrt(np.maximum(d2, np.float32(0.0)), dtype=np.float32)
+    elif metric == "euclidean":
+        diff = np.abs(X[:, :, None, :].astype(np.float64) - X[:, None, :, :].astype(np.float64))
+        d = (diff ** p).sum(-1) ** (1.0 / p) if p != 1.0 else diff.sum(-1)
+        d = d.astype(np.float32)
+    else:
+        nrm = np.sqrt((X.astype(np.float64) ** 2).sum(-1)).astype(np.float32) + np.float32(1e-6)
+        g = np.einsum("bnw,bmw->bnm", X.astype(np.float64), X.astype(np.float64)).astype(np.float32)
+        d = np.float32(1.0) - g / nrm[:, :, None] / nrm[:, None, :]
+    mx = np.float32(d.max() if chunk_max is None else chunk_max)
+    d = (d - mx) - np.float32(1.0)
+    idx = np.arange(d.shape[-1])
+    d[:, idx, idx] -= np.float32(1.0)
+    return d.astype(np.float32)

@@ -1,0 +1,138 @@
+"""Pin the CPU oracle (oracle/cluster_oracle.py) against fixtures captured from the
+imported reference (tests/golden/cluster_golden.npz, written by oracle/gen_golden.py).
+
+CPU only.  Parity levels follow SURVEY.md §8(c):
+  C3/C4        literal op restatement == reference output (same ATen ops; tolerance 0 on
+               this torch build, 1e-5 relative guard for a different BLAS on another host)
+  P0           selection from the STORED fp32 distance tensor: indices bit-exact
+  P1 / P2      from-X on lattice / dyadic inputs: indices bit-exact
+  C1           module output (gather + CLS mean + restack): exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cluster_oracle as co
+from oracle.recipes import dyadic, lattice
+
+t = torch.from_numpy
+
+
+@pytest.mark.parametrize("tag", ["n12", "n32"])
+def test_c3_pairwise_distance(cluster_golden, tag):
+    g = cluster_golden
+    X = t(g[f"c3_{tag}_x"])
+    for metric, p, mtag in (("euclidean", 2.0, "l2"), ("euclidean", 1.0, "l1"), ("cosine", 2.0, "cos")):
+        for an in (False, True):
+            for sn in (False, True):
+                d = co.literal_pairwise_distance(X, X, metric=metric, self_nearest=sn, all_negative=an, p=p)
+                np.testing.assert_allclose(d.numpy(), g[f"c3_{tag}_{mtag}_an{int(an)}_sn{int(sn)}"], rtol=1e-5, atol=1e-5)
+    d2 = co.literal_pairwise_distance(X[0], X[0], metric="euclidean", self_nearest=True, all_negative=True)
+    np.testing.assert_allclose(d2.numpy(), g[f"c3_{tag}_l2_2d"], rtol=1e-5, atol=1e-5)
+
+
+def test_c3_unknown_metric_raises():
+    with pytest.raises(NotImplementedError):
+        co.literal_pairwise_distance(torch.zeros(2, 3), torch.zeros(2, 3), metric="manhattan")
+
+
+def test_c4_kkz_with_ties(cluster_golden):
+    g = cluster_golden
+    D, X = t(g["c4_d"]), t(g["c4_x"])
+    med = co.literal_kkz(torch.norm(X, dim=-1), D, 7)
+    assert np.array_equal(med.numpy(), g["c4_batch"])
+    for b in range(D.shape[0]):
+        first = int(torch.argmax(torch.norm(X[b], dim=-1)))
+        _, m, _ = co.select_streamlined(D[b].numpy(), first, 7, iter_limit=0, id_sort=False)
+        assert np.array_equal(m, g["c4_batch"][b])
+        # the reference's non-batched KKZ (cluster_utils.py:95-101, not on the hot path) walks
+        # COLUMNS of D where the batched one walks rows: on a non-symmetric D they differ.
+        _, mt, _ = co.select_streamlined(D[b].numpy().T.copy(), first, 7, iter_limit=0, id_sort=False)
+        assert np.array_equal(mt, g["c4_single"][b])
+
+
+@pytest.mark.parametrize("tag", ["p0_small_l2", "p0_small_cos", "p0_real_l2", "p0_n392_l2"])
+def test_p0_selection_from_stored_distance(cluster_golden, tag):
+    g = cluster_golden
+    D, nrm, K = t(g[f"{tag}_d"]), t(g[f"{tag}_norm"]), int(g[f"{tag}_k"])
+    a, m, _ = co.literal_select(D, nrm, K, X=None, iter_limit=100, id_sort=True)
+    assert np.array_equal(m.numpy(), g[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g[f"{tag}_assign"].astype(np.int64))
+    a, m, _ = co.literal_select(D, nrm, K, X=None, iter_limit=100, id_sort=False)
+    assert np.array_equal(m.numpy(), g[f"{tag}_medoids_nosort"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g[f"{tag}_assign_nosort"].astype(np.int64))
+    # the streamlined formulation (the HIP kernel's algorithm) reproduces the same indices
+    for b in range(D.shape[0]):
+        first = int(torch.argmax(nrm[b]))
+        a_s, m_s, _ = co.select_streamlined(D[b].numpy(), first, K, iter_limit=100, id_sort=True)
+        assert np.array_equal(m_s, g[f"{tag}_medoids"][b].astype(np.int64))
+        assert np.array_equal(a_s, g[f"{tag}_assign"][b].astype(np.int64))
+
+
+def test_p0_update_step_ties(cluster_golden):
+    g = cluster_golden
+    D, X = g["p0_tie_d"], g["p0_tie_x"]
+    a, m, _ = co.literal_select(t(D), torch.norm(t(X), dim=-1), 5, X=t(X), threshold=1e-6, iter_limit=50)
+    assert np.array_equal(m.numpy(), g["p0_tie_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g["p0_tie_assign"].astype(np.int64))
+    for b in range(D.shape[0]):
+        first = int(np.argmax(np.linalg.norm(X[b], axis=-1)))
+        a_s, m_s, _ = co.select_streamlined(D[b], first, 5, iter_limit=50)
+        assert np.array_equal(m_s, g["p0_tie_medoids"][b].astype(np.int64))
+        assert np.array_equal(a_s, g["p0_tie_assign"][b].astype(np.int64))
+
+
+P1 = ["p1_cfg2", "p1_cfg3", "p1_cfg4", "p1_cfg5", "p1_ragged", "p1_k_eq_n", "p1_k1"]
+
+
+@pytest.mark.parametrize("tag", P1)
+def test_p1_lattice_from_x(cluster_golden, tag):
+    g = cluster_golden
+    seed, P, N, W, K, split, iters = [int(v) for v in g[f"{tag}_cfg"]]
+    if P * N * N * K > 4e8:       # keep the CPU suite short: check a prefix of whole chunks
+        P = split * max(1, min(P // split, 1))
+    X = t(lattice(seed, (int(g[f"{tag}_cfg"][1]), N, W)))[:P]
+    a, m = co.literal_batch_kmedoids_with_split(X, K, "euclidean", 1e-6, iters, True, 2.0, split, False)
+    assert np.array_equal(m.numpy(), g[f"{tag}_medoids"][:P].astype(np.int64))
+    assert np.array_equal(a.numpy(), g[f"{tag}_assign"][:P].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag", ["p1_cfg3", "p1_ragged", "p1_k_eq_n", "p1_k1"])
+def test_p1_streamlined_with_exact_zero_diagonal(cluster_golden, tag):
+    """The kernel's own arithmetic (Gram-diagonal norms, exact zero diagonal, member-list sums)
+    gives the reference's indices on lattice inputs - chunk by chunk, as the reference splits."""
+    g = cluster_golden
+    seed, P, N, W, K, split, iters = [int(v) for v in g[f"{tag}_cfg"]]
+    X = lattice(seed, (P, N, W))
+    P = min(P, 2 * split)
+    for c0 in range(0, P, split):
+        Xc = X[c0:min(c0 + split, P)]
+        D = co.exact_zero_diag_distance(Xc)
+        for b in range(Xc.shape[0]):
+            first = int(np.argmax(np.sqrt((Xc[b].astype(np.float64) ** 2).sum(-1)).astype(np.float32)))
+            a_s, m_s, _ = co.select_streamlined(D[b], first, K, iter_limit=iters)
+            assert np.array_equal(m_s, g[f"{tag}_medoids"][c0 + b].astype(np.int64))
+            assert np.array_equal(a_s, g[f"{tag}_assign"][c0 + b].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag", ["p2_cfg2", "p2_cfg3", "p2_small"])
+def test_p2_l1_from_x(cluster_golden, tag):
+    g = cluster_golden
+    seed, P, N, W, K, split, iters = [int(v) for v in g[f"{tag}_cfg"]]
+    X = t(dyadic(seed, (P, N, W)))
+    a, m = co.literal_batch_kmedoids_with_split(X, K, "euclidean", 1e-6, iters, True, 1.0, split, False)
+    assert np.array_equal(m.numpy(), g[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g[f"{tag}_assign"].astype(np.int64))
+
+
+C1 = ["c1_12_3", "c1_12_4", "c1_12_6", "c1_64_8", "c1_12_12", "c1_b16"]
+
+
+@pytest.mark.parametrize("tag", C1)
+def test_c1_token_cluster_module(cluster_golden, tag):
+    g = cluster_golden
+    seed, B, T, T_new, n, W, K, split = [int(v) for v in g[f"{tag}_cfg"]]
+    x = t(lattice(seed, (1 + n, B * T, W)))
+    y = co.literal_token_cluster(x, T, T_new, K, "euclidean", 1e-6, 100, 2.0, split, False)
+    assert tuple(y.shape) == (1 + K, B * T_new, W)
+    assert np.array_equal(y.numpy(), g[f"{tag}_out"])
