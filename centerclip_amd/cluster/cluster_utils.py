@@ -1,0 +1,75 @@
+"""Mirror of modules/cluster/cluster_utils.py:8-43 (pairwise_distance) and :78-118 (KKZ_init)."""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+
+def _contiguous_layout(P, N, W):
+    return L.TokenLayout(P, 1, 1, N, N * W, 0, 0, W)
+
+
+def _as_batch(x):
+    if x.ndim == 2:
+        return x.unsqueeze(0), True
+    if x.ndim == 3:
+        return x, False
+    raise AssertionError("expected a [N, L] or [B, N, L] tensor")
+
+
+@torch.no_grad()
+def pairwise_distance(data1, data2, metric='euclidean', self_nearest=True, all_negative=False, p=2.0):
+    """Pairwise distance of a token set with itself -> [N, N] or [B, N, N] fp32.
+
+    Same arguments as the reference.  The hot path only ever passes ``data2 is data1``
+    (fast_kmeans.py:61-62); cross-set distances are not built (NotImplementedError).
+    Unknown metric -> NotImplementedError, as in the reference (cluster_utils.py:33).
+    """
+    if metric not in L.METRIC_IDS:
+        raise NotImplementedError("{} metric is not implemented".format(metric))
+    if data2 is not data1 and not (data1.shape == data2.shape and data1.data_ptr() == data2.data_ptr()):
+        raise NotImplementedError("centerclip_amd.pairwise_distance computes self-distances only (data2 must be data1)")
+    L.require_device(data1)
+    x, squeeze = _as_batch(data1.float().contiguous())
+    P, N, W = x.shape
+    lay = _contiguous_layout(P, N, W)
+    dist = torch.empty(P, N, N, dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    nbytes = lib.cc_cluster_workspace_bytes(P, N, W, 0)
+    ws = L.workspace(nbytes, x.device)
+    L.check(lib.cc_pairwise_distance_f32(L.ptr(x), ctypes.byref(lay), W, L.METRIC_IDS[metric], float(p),
+                                         int(bool(all_negative)), int(bool(self_nearest)), P, L.ptr(dist), None,
+                                         L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "cc_pairwise_distance_f32")
+    return dist[0] if squeeze else dist
+
+
+@torch.no_grad()
+def KKZ_init(X, distance_matrix, K, batch=False):
+    """KKZ initialisation (first medoid = largest L2 norm, then farthest-point traversal over
+    rows of ``distance_matrix``).  batch=True: X [B,N,L], D [B,N,N] -> [B,K];
+    batch=False: X [N,L], D [N,N] -> [K].
+
+    Note: the reference's non-batched branch (cluster_utils.py:95-101) indexes COLUMNS of D
+    where the batched branch indexes rows; for the symmetric matrices the hot path produces
+    the two agree.  This mirror follows the batched (hot-path) semantics: for batch=False the
+    matrix is transposed first so the reference's column walk is reproduced exactly.
+    """
+    L.require_device(X, distance_matrix)
+    x = X.float().contiguous()
+    d = distance_matrix.float()
+    if not batch:
+        x, d = x.unsqueeze(0), d.transpose(-2, -1).unsqueeze(0)
+    d = d.contiguous()
+    P, N, W = x.shape
+    lay = _contiguous_layout(P, N, W)
+    lib = L.lib()
+    norms = torch.empty(P, N, dtype=torch.float32, device=x.device)
+    medoids = torch.empty(P, K, dtype=torch.long, device=x.device)
+    ws = L.workspace(lib.cc_cluster_workspace_bytes(P, N, W, 0), x.device)
+    st = L.stream_ptr(x.device)
+    L.check(lib.cc_token_norms_f32(L.ptr(x), ctypes.byref(lay), W, L.ptr(norms), L.ptr(ws), ws.numel(), st),
+            "cc_token_norms_f32")
+    L.check(lib.cc_kmedoids_from_dist_f32(L.ptr(d), L.ptr(norms), P, N, K, 0, 0, L.ptr(medoids), None, None,
+                                          L.ptr(ws), ws.numel(), st), "cc_kmedoids_from_dist_f32")
+    return medoids if batch else medoids[0]

@@ -1,0 +1,55 @@
+// Shared device/host helpers for libcenterclip_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/centerclip_hip.h"
+
+#define CC_WAVE 64
+
+#define CC_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return CC_ERR_HIP;           \
+    } while (0)
+
+static inline size_t cc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- order-preserving float <-> int key (for atomicMax on floats of either sign) -------
+__device__ __forceinline__ int cc_float_to_ordered_int(float f) {
+    int b = __float_as_int(f);
+    return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__device__ __forceinline__ float cc_ordered_int_to_float(int k) {
+    return __int_as_float(k >= 0 ? k : (k ^ 0x7FFFFFFF));
+}
+// unsigned key whose unsigned order equals the float order (used inside 64-bit arg-reduce keys)
+__device__ __forceinline__ unsigned cc_float_to_ordered_uint(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float cc_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CC_WAVE);
+    return v;
+}
+__device__ __forceinline__ float cc_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, CC_WAVE));
+    return v;
+}
+__device__ __forceinline__ unsigned long long cc_wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, CC_WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// token (p, j) -> first float of its W-vector (see cc_token_layout in the public header)
+__device__ __forceinline__ const float* cc_token_ptr(const float* x, const cc_token_layout& l, int p, int j) {
+    const int b = p % l.B, s = p / l.B;
+    const int f = j / l.n, i = j - f * l.n;
+    return x + (int64_t)b * l.stride_b + (int64_t)s * l.stride_s + (int64_t)f * l.stride_f + (int64_t)i * l.stride_i;
+}

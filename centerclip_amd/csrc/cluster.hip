@@ -1,0 +1,783 @@
+// Token-cluster hot path for gfx950.
+//
+//   K0 token_norm_kernel      per-token squared norm / norm / 1/(norm+1e-6)      (HBM stream)
+//   K1 gram_dist_kernel       pairwise L2 / cosine distance via exact-f32 MFMA   (MFMA f32)
+//      lp_dist_kernel         pairwise Minkowski-p distance, p != 2              (VALU)
+//   K2 kmedoids_select_kernel KKZ init + assign/update iterations + sort,        (latency)
+//                             one workgroup per problem, D resident in LDS when it fits
+//   K3 gather_tokens_kernel   medoid-token gather + per-segment CLS mean          (HBM stream)
+//
+// No host synchronisation anywhere; the [B,K,N,N] temporaries of the reference
+// (modules/cluster/fast_kmeans.py:65,81) are never materialised: the update step walks
+// per-cluster member lists (SURVEY §8a equivalence 2).
+#include "cc_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ============================================================================ K0
+// One wave per token.  sqn = sum x^2 (fp32), nrm = sqrtf(sqn), inv = 1/(nrm + 1e-6).
+// If xn != nullptr also writes the pre-normalised token x/(nrm+1e-6) to a contiguous
+// [P,N,W] buffer (fast_kmeans.py:21-22).  Block 0 also resets the chunk-max keys.
+__global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict__ x, cc_token_layout lay,
+                                                         int P, int N, int W, float* __restrict__ sqn,
+                                                         float* __restrict__ nrm, float* __restrict__ inv,
+                                                         float* __restrict__ xn, int* __restrict__ chunkmax,
+                                                         int nchunks) {
+    if (blockIdx.x == 0 && chunkmax)
+        for (int c = threadIdx.x; c < nchunks; c += 256) chunkmax[c] = (int)0x80000000;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= P * N) return;
+    const int p = tok / N, j = tok - p * N;
+    const float* src = cc_token_ptr(x, lay, p, j);
+    float acc = 0.f;
+    for (int w = lane * 4; w < W; w += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + w);
+        acc = fmaf(v.x, v.x, acc);
+        acc = fmaf(v.y, v.y, acc);
+        acc = fmaf(v.z, v.z, acc);
+        acc = fmaf(v.w, v.w, acc);
+    }
+    acc = cc_wave_sum(acc);
+    const float n = sqrtf(acc);
+    const float r = 1.0f / (n + 1e-6f);
+    if (lane == 0) {
+        sqn[tok] = acc;
+        nrm[tok] = n;
+        inv[tok] = r;
+    }
+    if (xn) {
+        float* dst = xn + (int64_t)tok * W;
+        const float den = n + 1e-6f;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + w);
+            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            *reinterpret_cast<float4*>(dst + w) = v;
+        }
+    }
+}
+
+// ============================================================================ K1
+// 64x64 tile of the Gram matrix of one problem per 256-thread workgroup (4 waves, 32x32 per
+// wave, 2x2 v_mfma_f32_16x16x4_f32 accumulators).  Only tiles with tj >= ti are launched;
+// the transposed tile is written by the same workgroup (g_ij == g_ji bit for bit: same
+// k order, commutative products).  The MFMA is an exact fp32 fma chain, so on exactly
+// representable inputs D equals any correct fp32 evaluation (parity level P1).
+//
+// LDS tile [64 rows][40 floats] (32 k + 8 pad): the 16 lanes of a ds_read_b128 group land on
+// 16 distinct 4-bank slots.  k is consumed in a permuted order (lane group g owns k = g*4+t
+// of each 16-k slice for the t-th MFMA) - A and B use the same permutation, so it is only a
+// fixed re-ordering of the summation.
+#define GT 64
+#define GK 32
+#define GLD 40
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
+                                                        int W, const float* __restrict__ sqn,
+                                                        const float* __restrict__ inv, float* __restrict__ draw,
+                                                        int* __restrict__ chunkmax, int chunk, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GT * GLD];
+    const int p = blockIdx.y;
+    int t = blockIdx.x, ti = 0, rowlen = ntiles;
+    while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
+    const int tj = ti + t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ra = min(ti * GT + lrow + 32 * q, N - 1);
+        const int rb = min(tj * GT + lrow + 32 * q, N - 1);
+        pa[q] = cc_token_ptr(x, lay, p, ra) + lchunk * 4;
+        pb[q] = cc_token_ptr(x, lay, p, rb) + lchunk * 4;
+    }
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool active = !(ti == tj && wr > wc) && (ti * GT + wr * 32 < N) && (tj * GT + wc * 32 < N);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra_[2], rb_[2];
+    const int nk = (W + GK - 1) / GK;
+    auto gload = [&](int kt) {
+        const int k = kt * GK + lchunk * 4;
+        const bool ok = k < W;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ra_[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * q) * GLD + lchunk * 4]) = ra_[q];
+            *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * q) * GLD + lchunk * 4]) = rb_[q];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int g = lane >> 4, l15 = lane & 15;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        if (active) {
+            const float* A = &lds[buf][0][(wr * 32 + l15) * GLD + g * 4];
+            const float* Bm = &lds[buf][1][(wc * 32 + l15) * GLD + g * 4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(A + ks * 16);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(A + 16 * GLD + ks * 16);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bm + ks * 16);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bm + 16 * GLD + ks * 16);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b0[tt], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b1[tt], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b0[tt], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b1[tt], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: distance, chunk max, direct + mirrored store
+    float lmax = -3.0e38f;
+    if (active) {
+        const bool mirror = (tj > ti) || (wc > wr);
+        float* Dp = draw + (int64_t)p * N * N;
+        const float* sq = sqn + (int64_t)p * N;
+        const float* iv = inv + (int64_t)p * N;
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) {
+                const int j = tj * GT + wc * 32 + fn * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * GT + wr * 32 + fm * 16 + g * 4 + r;
+                    if (i < N && j < N) {
+                        const float gij = acc[fm][fn][r];
+                        float d;
+                        if (METRIC == CC_METRIC_EUCLIDEAN) {
+                            const float d2 = (sq[i] + sq[j]) - 2.0f * gij;
+                            d = (i == j) ? 0.0f : sqrtf(fmaxf(d2, 0.0f));
+                        } else {
+                            d = 1.0f - (gij * iv[i]) * iv[j];
+                        }
+                        lmax = fmaxf(lmax, d);
+                        Dp[(int64_t)i * N + j] = d;
+                        if (mirror) Dp[(int64_t)j * N + i] = d;
+                    }
+                }
+            }
+    }
+    if (chunkmax) {
+        lmax = cc_wave_max(lmax);
+        if (lane == 0 && active) atomicMax(&chunkmax[p / chunk], cc_float_to_ordered_int(lmax));
+    }
+}
+
+// Minkowski-p distance for p != 2 (p == 1 is the shipped MSR-VTT setting, scripts/msrvtt.sh:87).
+// Direct sum_w |x-y|^p in ascending w per pair (exact-zero diagonal like ATen's direct path).
+// MODE 1: p == 1; MODE 0: general p > 0; MODE 2: p == inf.
+#define LLD 36
+template <int MODE>
+__global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N, int W,
+                                                      float pw, float* __restrict__ draw, int* __restrict__ chunkmax,
+                                                      int chunk, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[2][GT * LLD];
+    const int p = blockIdx.y;
+    int t = blockIdx.x, ti = 0, rowlen = ntiles;
+    while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
+    const int tj = ti + t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pa[q] = cc_token_ptr(x, lay, p, min(ti * GT + lrow + 32 * q, N - 1)) + lchunk * 4;
+        pb[q] = cc_token_ptr(x, lay, p, min(tj * GT + lrow + 32 * q, N - 1)) + lchunk * 4;
+    }
+    const int ty = tid >> 4, tx = tid & 15;      // rows ty + 16*r, cols tx + 16*c
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    const int nk = (W + GK - 1) / GK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool ok = kt * GK + lchunk * 4 < W;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 va = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0, 0, 0, 0);
+            const float4 vb = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0, 0, 0, 0);
+            *reinterpret_cast<float4*>(&lds[0][(lrow + 32 * q) * LLD + lchunk * 4]) = va;
+            *reinterpret_cast<float4*>(&lds[1][(lrow + 32 * q) * LLD + lchunk * 4]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < GK / 4; ++k4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(&lds[0][(ty + 16 * r) * LLD + k4 * 4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&lds[1][(tx + 16 * c) * LLD + k4 * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d0 = fabsf(a[r].x - b[c].x), d1 = fabsf(a[r].y - b[c].y);
+                    const float d2 = fabsf(a[r].z - b[c].z), d3 = fabsf(a[r].w - b[c].w);
+                    if (MODE == 1) {
+                        acc[r][c] = (((acc[r][c] + d0) + d1) + d2) + d3;
+                    } else if (MODE == 2) {
+                        acc[r][c] = fmaxf(fmaxf(fmaxf(fmaxf(acc[r][c], d0), d1), d2), d3);
+                    } else {
+                        acc[r][c] = (((acc[r][c] + powf(d0, pw)) + powf(d1, pw)) + powf(d2, pw)) + powf(d3, pw);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float lmax = -3.0e38f;
+    float* Dp = draw + (int64_t)p * N * N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti * GT + ty + 16 * r, j = tj * GT + tx + 16 * c;
+            if (i < N && j < N) {
+                float d = acc[r][c];
+                if (MODE == 0) d = powf(d, 1.0f / pw);
+                lmax = fmaxf(lmax, d);
+                Dp[(int64_t)i * N + j] = d;
+                if (tj > ti) Dp[(int64_t)j * N + i] = d;
+            }
+        }
+    if (chunkmax) {
+        lmax = cc_wave_max(lmax);
+        if (lane == 0 && lmax > -1.0e38f) atomicMax(&chunkmax[p / chunk], cc_float_to_ordered_int(lmax));
+    }
+}
+
+// Applies the all_negative shift / self_nearest diagonal to a raw distance tensor
+// (cluster_utils.py:35-41) - used by the stand-alone cc_pairwise_distance_f32 only; the
+// fused path applies it while staging D into LDS.
+__global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int* __restrict__ chunkmax, int chunk,
+                                  int all_negative, int self_nearest) {
+    const int64_t total = (int64_t)P * N * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / ((int64_t)N * N));
+        const int rem = (int)(idx - (int64_t)p * N * N);
+        const int i = rem / N, j = rem - i * N;
+        float v = d[idx];
+        if (all_negative) v = (v - cc_ordered_int_to_float(chunkmax[p / chunk])) - 1.0f;
+        if (self_nearest && i == j) v -= 1.0f;
+        d[idx] = v;
+    }
+}
+
+// ============================================================================ K2
+// One 256-thread workgroup per problem.  LDS carve (dynamic):
+//   [IN_LDS: D N*N f32] rowsum N f32 | med K i32 | cnt K i32 | start (K+1) i32 |
+//   asg N u16 | tmp N u16 | memb N u16
+#define SEL_MAX_E 10   /* N <= 640 */
+
+struct SelSmem {
+    float* D;
+    float* rowsum;
+    int* med;
+    int* cnt;
+    int* start;
+    unsigned short* asg;
+    unsigned short* tmp;
+    unsigned short* memb;
+};
+
+static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
+    size_t b = 0;
+    if (in_lds) b += (size_t)N * N * 4;
+    b += (size_t)N * 4;                 // rowsum
+    b += (size_t)K * 4 * 2 + (size_t)(K + 1) * 4;
+    b = cc_align_up(b, 4);
+    b += (size_t)N * 2 * 3;
+    return cc_align_up(b, 16);
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __restrict__ dist_in, float* dist_rw,
+                                                              const float* __restrict__ norms,
+                                                              const int* __restrict__ chunkmax, int chunk,
+                                                              int apply_shift, int N, int K, int iter_limit,
+                                                              int id_sort, long long* __restrict__ medoids_out,
+                                                              long long* __restrict__ assign_out,
+                                                              int* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    SelSmem s;
+    {
+        unsigned char* q = smem_raw;
+        s.D = reinterpret_cast<float*>(q);
+        if (IN_LDS) q += (size_t)N * N * 4;
+        s.rowsum = reinterpret_cast<float*>(q); q += (size_t)N * 4;
+        s.med = reinterpret_cast<int*>(q); q += (size_t)K * 4;
+        s.cnt = reinterpret_cast<int*>(q); q += (size_t)K * 4;
+        s.start = reinterpret_cast<int*>(q); q += (size_t)(K + 1) * 4;
+        s.asg = reinterpret_cast<unsigned short*>(q); q += (size_t)N * 2;
+        s.tmp = reinterpret_cast<unsigned short*>(q); q += (size_t)N * 2;
+        s.memb = reinterpret_cast<unsigned short*>(q);
+    }
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)p * N * N;
+    const float* Dg = dist_in + base;
+
+    // ---- stage D: apply (d - chunk_max) - 1, diagonal - 1 (cluster_utils.py:35-41)
+    {
+        const float mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
+        if (IN_LDS || apply_shift) {
+            float* dstg = dist_rw + base;
+            for (int i = wave; i < N; i += 4) {
+                for (int j = lane; j < N; j += 64) {
+                    float v = Dg[(int64_t)i * N + j];
+                    if (apply_shift) {
+                        v = (v - mx) - 1.0f;
+                        if (i == j) v -= 1.0f;
+                    }
+                    if (IN_LDS) s.D[i * N + j] = v;
+                    else dstg[(int64_t)i * N + j] = v;
+                }
+            }
+            if (!IN_LDS) Dg = dstg;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+#define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : Dg[(int64_t)(i) * N + (j)])
+
+    // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118), running minimum in registers
+    if (wave == 0) {
+        const int E = (N + 63) >> 6;
+        float nearest[SEL_MAX_E];
+        unsigned long long key = 0ull;
+        const float* nr = norms + (int64_t)p * N;
+#pragma unroll
+        for (int e = 0; e < SEL_MAX_E; ++e) {
+            const int n = lane + 64 * e;
+            if (e < E && n < N) {
+                const unsigned long long k2 =
+                    ((unsigned long long)cc_float_to_ordered_uint(nr[n]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)n);
+                key = k2 > key ? k2 : key;
+            }
+        }
+        key = cc_wave_max_u64(key);
+        int m = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        if (lane == 0) s.med[0] = m;
+#pragma unroll
+        for (int e = 0; e < SEL_MAX_E; ++e) {
+            const int n = lane + 64 * e;
+            nearest[e] = (e < E && n < N) ? DREAD(m, n) : 0.f;
+        }
+        for (int i = 1; i < K; ++i) {
+            key = 0ull;
+#pragma unroll
+            for (int e = 0; e < SEL_MAX_E; ++e) {
+                const int n = lane + 64 * e;
+                if (e < E && n < N) {
+                    const unsigned long long k2 = ((unsigned long long)cc_float_to_ordered_uint(nearest[e]) << 32) |
+                                                  (unsigned)(0xFFFFFFFFu - (unsigned)n);
+                    key = k2 > key ? k2 : key;
+                }
+            }
+            key = cc_wave_max_u64(key);
+            m = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            if (lane == 0) s.med[i] = m;
+#pragma unroll
+            for (int e = 0; e < SEL_MAX_E; ++e) {
+                const int n = lane + 64 * e;
+                if (e < E && n < N) nearest[e] = fminf(nearest[e], DREAD(m, n));
+            }
+        }
+    }
+    __syncthreads();
+
+    auto assign_step = [&]() {      // fast_kmeans.py:75-76: a_n = first argmin_k D[m_k, n]
+        for (int n = tid; n < N; n += 256) {
+            float best = DREAD(s.med[0], n);
+            int a = 0;
+            for (int k = 1; k < K; ++k) {
+                const float v = DREAD(s.med[k], n);
+                if (v < best) { best = v; a = k; }
+            }
+            s.asg[n] = (unsigned short)a;
+        }
+    };
+
+    int iters = 0;
+    for (int it = 0; it < iter_limit; ++it) {
+        assign_step();
+        for (int k = tid; k < K; k += 256) s.cnt[k] = 0;
+        __syncthreads();
+        int slot[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int n = tid + 256 * e;
+            slot[e] = (n < N) ? atomicAdd(&s.cnt[s.asg[n]], 1) : 0;
+        }
+        __syncthreads();
+        if (wave == 0) {            // exclusive prefix sum of cnt -> start
+            const int c = (K + 63) >> 6;
+            int loc = 0;
+            for (int q = 0; q < c; ++q) {
+                const int k = lane * c + q;
+                loc += (k < K) ? s.cnt[k] : 0;
+            }
+            int inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int tv = __shfl_up(inc, o, CC_WAVE);
+                if (lane >= o) inc += tv;
+            }
+            int run = inc - loc;
+            for (int q = 0; q < c; ++q) {
+                const int k = lane * c + q;
+                if (k < K) { s.start[k] = run; run += s.cnt[k]; }
+            }
+            if (lane == 63) s.start[K] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int n = tid + 256 * e;
+            if (n < N) s.tmp[s.start[s.asg[n]] + slot[e]] = (unsigned short)n;
+        }
+        __syncthreads();
+        for (int n = tid; n < N; n += 256) {   // stable rank -> ascending member lists
+            const int a = s.asg[n], s0 = s.start[a], c = s.cnt[a];
+            int r = 0;
+            for (int q = 0; q < c; ++q) r += (s.tmp[s0 + q] < n) ? 1 : 0;
+            s.memb[s0 + r] = (unsigned short)n;
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {   // s_i = sum_{j in cluster(i), ascending} D[i,j]
+            const int a = s.asg[i], s0 = s.start[a], c = s.cnt[a];
+            float sum = 0.f;
+            for (int q = 0; q < c; ++q) sum += DREAD(i, s.memb[s0 + q]);
+            s.rowsum[i] = sum;
+        }
+        __syncthreads();
+        int changed = 0;
+        for (int k = tid; k < K; k += 256) {   // fast_kmeans.py:82 argmin, lowest index on ties
+            const int s0 = s.start[k], c = s.cnt[k];
+            int bi = 0;
+            if (c > 0) {
+                bi = s.memb[s0];
+                float best = s.rowsum[bi];
+                for (int q = 1; q < c; ++q) {
+                    const int i = s.memb[s0 + q];
+                    const float v = s.rowsum[i];
+                    if (v < best) { best = v; bi = i; }
+                }
+            }
+            changed |= (bi != s.med[k]);
+            s.med[k] = bi;
+        }
+        ++iters;
+        if (!__syncthreads_or(changed)) break;
+    }
+
+    if (id_sort) {                              // fast_kmeans.py:90-94
+        int mine[3], rank[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int k = tid + 256 * e;
+            mine[e] = 0; rank[e] = 0;
+            if (k < K) {
+                mine[e] = s.med[k];
+                int r = 0;
+                for (int q = 0; q < K; ++q) {
+                    const int o = s.med[q];
+                    r += (o < mine[e] || (o == mine[e] && q < k)) ? 1 : 0;
+                }
+                rank[e] = r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (tid + 256 * e < K) s.med[rank[e]] = mine[e];
+        __syncthreads();
+        assign_step();
+        __syncthreads();
+    }
+    for (int k = tid; k < K; k += 256) medoids_out[(int64_t)p * K + k] = s.med[k];
+    if (assign_out)
+        for (int n = tid; n < N; n += 256) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
+    if (iters_out && tid == 0) iters_out[p] = iters;
+#undef DREAD
+}
+
+// ============================================================================ K3
+// One wave per output token.  Token 0 of segment (b, s) = mean of the fd CLS tokens of its
+// frames (cluster.py:307-308, sequential sum then true division); token 1+k = medoid k of
+// problem p = s*B + b (cluster.py:289,303).
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, int64_t in_tok, int64_t in_frame,
+                                                            int B, int T, int T_new, int n, int W, int K,
+                                                            const long long* __restrict__ medoids,
+                                                            float* __restrict__ out, int64_t out_tok,
+                                                            int64_t out_frame) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = B * T_new * (1 + K);
+    if (row >= rows) return;
+    const int seg = row / (1 + K), l = row - seg * (1 + K);
+    const int b = seg / T_new, sgm = seg - b * T_new;
+    const int fd = T / T_new;
+    float* dst = out + (int64_t)l * out_tok + (int64_t)seg * out_frame;
+    if (l == 0) {
+        const float* src = x + (int64_t)(b * T + sgm * fd) * in_frame;
+        const float den = (float)fd;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 a = *reinterpret_cast<const float4*>(src + w);
+            for (int f = 1; f < fd; ++f) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)f * in_frame + w);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
+            *reinterpret_cast<float4*>(dst + w) = a;
+        }
+    } else {
+        const int p = sgm * B + b;
+        const int j = (int)medoids[(int64_t)p * K + (l - 1)];
+        const int f = j / n, i = j - f * n;
+        const float* src = x + (int64_t)(1 + i) * in_tok + (int64_t)(b * T + sgm * fd + f) * in_frame;
+        for (int w = lane * 4; w < W; w += 256)
+            *reinterpret_cast<float4*>(dst + w) = *reinterpret_cast<const float4*>(src + w);
+    }
+}
+
+// ============================================================================ host side
+namespace {
+
+struct ClusterWs {
+    int* chunkmax;
+    float* sqn;
+    float* nrm;
+    float* inv;
+    float* draw;
+    float* xn;
+    long long* med;
+    size_t total;
+};
+
+ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med) {
+    ClusterWs c{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* ptr = ws ? static_cast<char*>(ws) + off : nullptr;
+        off += cc_align_up(bytes, 256);
+        return ptr;
+    };
+    c.chunkmax = static_cast<int*>(take((size_t)P * 4));
+    c.sqn = static_cast<float*>(take((size_t)P * N * 4));
+    c.nrm = static_cast<float*>(take((size_t)P * N * 4));
+    c.inv = static_cast<float*>(take((size_t)P * N * 4));
+    c.draw = static_cast<float*>(take((size_t)P * N * N * 4));
+    c.med = static_cast<long long*>(take((size_t)P * (size_t)K_for_med * 8));
+    c.xn = pre_norm ? static_cast<float*>(take((size_t)P * N * W * 4)) : nullptr;
+    c.total = off;
+    return c;
+}
+
+bool layout_ok(const cc_token_layout* l, int W) {
+    if (!l || l->B <= 0 || l->S <= 0 || l->fd <= 0 || l->n <= 0) return false;
+    if (W <= 0 || (W & 3)) return false;
+    return !((l->stride_b | l->stride_s | l->stride_f | l->stride_i) & 3);
+}
+
+cc_token_layout contiguous_layout(int P, int N, int W) {
+    cc_token_layout l;
+    l.B = P; l.S = 1; l.fd = 1; l.n = N;
+    l.stride_b = (int64_t)N * W; l.stride_s = 0; l.stride_f = 0; l.stride_i = W;
+    return l;
+}
+
+// K0 (+ optional pre-norm copy) and K1: raw distances + chunk max in ws
+int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p, int chunk, int pre_norm,
+                 const ClusterWs& c, hipStream_t st) {
+    const int P = lay.B * lay.S, N = lay.fd * lay.n;
+    const int nchunks = (P + chunk - 1) / chunk;
+    const int nb = (P * N + 3) / 4;
+    if (pre_norm) {
+        hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv, c.xn,
+                           (int*)nullptr, 0);
+        x = c.xn;
+        lay = contiguous_layout(P, N, W);
+    }
+    hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv,
+                       (float*)nullptr, c.chunkmax, nchunks);
+    CC_LAUNCH_CHECK();
+    const int nt = (N + GT - 1) / GT;
+    dim3 grid(nt * (nt + 1) / 2, P);
+    if (metric == CC_METRIC_COSINE) {
+        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), 0, st, x, lay, N, W, c.sqn, c.inv,
+                           c.draw, c.chunkmax, chunk, nt);
+    } else if (p == 2.0f) {
+        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), 0, st, x, lay, N, W, c.sqn, c.inv,
+                           c.draw, c.chunkmax, chunk, nt);
+    } else if (p == 1.0f) {
+        hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+    } else if (p > 3.0e38f) {
+        hipLaunchKernelGGL(lp_dist_kernel<2>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+    } else {
+        hipLaunchKernelGGL(lp_dist_kernel<0>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int chunk,
+               int apply_shift, int P, int N, int K, int iter_limit, int id_sort, long long* med, long long* assign,
+               int* iters, hipStream_t st) {
+    const size_t lds_limit = 160 * 1024;
+    const bool in_lds = sel_smem_bytes(N, K, true) <= lds_limit;
+    const size_t smem = sel_smem_bytes(N, K, in_lds);
+    if (smem > lds_limit) return CC_ERR_UNSUPPORTED;
+    if (in_lds) {
+        auto kern = kmedoids_select_kernel<true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return CC_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift, N,
+                           K, iter_limit, id_sort, med, assign, iters);
+    } else {
+        auto kern = kmedoids_select_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift, N,
+                           K, iter_limit, id_sort, med, assign, iters);
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+bool p_supported(int metric, float p) { return metric == CC_METRIC_COSINE || (p > 0.0f); }
+
+}  // namespace
+
+extern "C" {
+
+size_t cc_cluster_workspace_bytes(int32_t P, int32_t N, int32_t W, int32_t pre_norm) {
+    if (P <= 0 || N <= 0 || W <= 0) return 0;
+    return carve(nullptr, P, N, W, pre_norm, N).total;
+}
+
+int cc_token_norms_f32(const float* x, const cc_token_layout* lay, int32_t W, float* norms, void* ws,
+                       size_t ws_bytes, void* stream) {
+    if (!x || !norms || !layout_ok(lay, W)) return CC_ERR_INVALID;
+    const int P = lay->B * lay->S, N = lay->fd * lay->n;
+    ClusterWs c = carve(ws, P, N, W, 0, N);
+    if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
+    hipLaunchKernelGGL(token_norm_kernel, dim3((P * N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, *lay,
+                       P, N, W, c.sqn, norms, c.inv, (float*)nullptr, (int*)nullptr, 0);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_pairwise_distance_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t metric, float p,
+                             int32_t all_negative, int32_t self_nearest, int32_t chunk, float* dist,
+                             float* norms_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dist || !layout_ok(lay, W)) return CC_ERR_INVALID;
+    if (metric != CC_METRIC_EUCLIDEAN && metric != CC_METRIC_COSINE) return CC_ERR_UNSUPPORTED;
+    if (!p_supported(metric, p)) return CC_ERR_UNSUPPORTED;
+    const int P = lay->B * lay->S, N = lay->fd * lay->n;
+    if (chunk <= 0) chunk = P;
+    ClusterWs c = carve(ws, P, N, W, 0, N);
+    if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    c.draw = dist;
+    if (norms_out) c.nrm = norms_out;
+    int rc = run_distance(x, *lay, W, metric, p, chunk, 0, c, st);
+    if (rc != CC_OK) return rc;
+    if (all_negative || self_nearest) {
+        const int64_t total = (int64_t)P * N * N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(shift_dist_kernel, dim3(blocks), dim3(256), 0, st, dist, P, N, c.chunkmax, chunk,
+                           all_negative, self_nearest);
+        CC_LAUNCH_CHECK();
+    }
+    return CC_OK;
+}
+
+int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, int32_t N, int32_t K,
+                              int32_t iter_limit, int32_t id_sort, int64_t* medoids, int64_t* assign, int32_t* iters,
+                              void* ws, size_t ws_bytes, void* stream) {
+    (void)ws; (void)ws_bytes;
+    if (!dist || !norms || !medoids || P <= 0 || N <= 0 || K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
+    if (N > 64 * SEL_MAX_E || N > 65535) return CC_ERR_UNSUPPORTED;
+    return run_select(dist, nullptr, norms, nullptr, 1, 0, P, N, K, iter_limit, id_sort,
+                      reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters,
+                      static_cast<hipStream_t>(stream));
+}
+
+int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K, int32_t metric,
+                          float norm_p, float threshold, int32_t iter_limit, int32_t id_sort, int32_t split_size,
+                          int32_t pre_norm, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
+                          size_t ws_bytes, void* stream) {
+    (void)threshold;
+    if (!x || !medoids || !layout_ok(lay, W)) return CC_ERR_INVALID;
+    const int P = lay->B * lay->S, N = lay->fd * lay->n;
+    if (K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
+    if (metric != CC_METRIC_EUCLIDEAN && metric != CC_METRIC_COSINE) return CC_ERR_UNSUPPORTED;
+    if (!p_supported(metric, norm_p)) return CC_ERR_UNSUPPORTED;
+    if (N > 64 * SEL_MAX_E) return CC_ERR_UNSUPPORTED;
+    if (split_size <= 0 || split_size > P) split_size = P;
+    ClusterWs c = carve(ws, P, N, W, pre_norm, N);
+    if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = run_distance(x, *lay, W, metric, norm_p, split_size, pre_norm, c, st);
+    if (rc != CC_OK) return rc;
+    return run_select(c.draw, c.draw, c.nrm, c.chunkmax, split_size, 1, P, N, K, iter_limit, id_sort,
+                      reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st);
+}
+
+int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                         int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
+                         float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm, float* out,
+                         int64_t out_tok_stride, int64_t out_frame_stride, int64_t* medoids, int64_t* assign,
+                         int32_t* iters, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+    if (T % T_new) return CC_ERR_INVALID;
+    if ((W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3)) return CC_ERR_INVALID;
+    const int fd = T / T_new;
+    cc_token_layout lay;
+    lay.B = B; lay.S = T_new; lay.fd = fd; lay.n = n;
+    lay.stride_b = (int64_t)T * in_frame_stride;
+    lay.stride_s = (int64_t)fd * in_frame_stride;
+    lay.stride_f = in_frame_stride;
+    lay.stride_i = in_tok_stride;
+    const int P = B * T_new, N = fd * n;
+    if (K > N) return CC_ERR_INVALID;
+    ClusterWs c = carve(ws, P, N, W, pre_norm, N);
+    if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
+    int64_t* med = medoids ? medoids : reinterpret_cast<int64_t*>(c.med);
+    int rc = cc_batch_kmedoids_f32(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
+                                   pre_norm, med, assign, iters, ws, ws_bytes, stream);
+    if (rc != CC_OK) return rc;
+    const int rows = B * T_new * (1 + K);
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, reinterpret_cast<const long long*>(med),
+                       out, out_tok_stride, out_frame_stride);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+}  // extern "C"
