@@ -1,0 +1,57 @@
+"""ctypes declarations for the CLIP-forward part of the C ABI (include/centerclip_hip.h)."""
+import ctypes as c
+
+CC_MAX_LAYERS = 32
+EPI = {"f16": 0, "f16_gelu": 1, "f32_resid": 2, "f32": 4}
+
+
+class BlockWeights(c.Structure):
+    """struct cc_block_weights"""
+    _fields_ = [(n, c.c_void_p) for n in (
+        "ln_1_weight", "ln_1_bias", "in_proj_weight_f16", "in_proj_bias", "out_proj_weight_f16", "out_proj_bias",
+        "ln_2_weight", "ln_2_bias", "c_fc_weight_f16", "c_fc_bias", "c_proj_weight_f16", "c_proj_bias")]
+
+
+class VitModel(c.Structure):
+    """struct cc_vit_model"""
+    _fields_ = [("layers", c.c_int32), ("width", c.c_int32), ("heads", c.c_int32), ("patch", c.c_int32),
+                ("resolution", c.c_int32), ("embed_dim", c.c_int32),
+                ("conv1_weight_f16", c.c_void_p), ("class_embedding", c.c_void_p),
+                ("positional_embedding", c.c_void_p), ("ln_pre_weight", c.c_void_p), ("ln_pre_bias", c.c_void_p),
+                ("ln_post_weight", c.c_void_p), ("ln_post_bias", c.c_void_p), ("proj", c.c_void_p),
+                ("blocks", c.POINTER(BlockWeights)),
+                ("cluster_frames", c.c_int32 * CC_MAX_LAYERS), ("cluster_tokens", c.c_int32 * CC_MAX_LAYERS),
+                ("cluster_metric", c.c_int32), ("cluster_norm_p", c.c_float), ("cluster_threshold", c.c_float),
+                ("cluster_iter_limit", c.c_int32), ("cluster_split_size", c.c_int32), ("cluster_pre_norm", c.c_int32)]
+
+
+class TextModel(c.Structure):
+    """struct cc_text_model"""
+    _fields_ = [("layers", c.c_int32), ("width", c.c_int32), ("heads", c.c_int32), ("context_length", c.c_int32),
+                ("vocab_size", c.c_int32), ("embed_dim", c.c_int32),
+                ("token_embedding", c.c_void_p), ("positional_embedding", c.c_void_p),
+                ("ln_final_weight", c.c_void_p), ("ln_final_bias", c.c_void_p), ("text_projection", c.c_void_p),
+                ("blocks", c.POINTER(BlockWeights))]
+
+
+def declare(lib):
+    vp, i32, i64, f32, sz = c.c_void_p, c.c_int32, c.c_int64, c.c_float, c.c_size_t
+    lib.cc_linear_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.cc_layernorm_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, f32, i32, vp]
+    lib.cc_attention_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.cc_vit_workspace_bytes.restype = sz
+    lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
+    lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_token_gather_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
+    lib.cc_token_gather_f32.restype = c.c_int
+    lib.cc_text_workspace_bytes.restype = sz
+    lib.cc_text_workspace_bytes.argtypes = [c.POINTER(TextModel), i32, i32]
+    lib.cc_text_encode.argtypes = [c.POINTER(TextModel), vp, i32, i32, vp, vp, sz, vp]
+    lib.cc_similarity_workspace_bytes.restype = sz
+    lib.cc_similarity_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.cc_video_pool_normalize_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.cc_loose_similarity_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, sz, vp]
+    lib.cc_scaled_dot_nt_f32.argtypes = [vp, vp, i32, i32, i32, f32, vp, i32, vp]
+    for name in ("cc_linear_f16", "cc_layernorm_f32", "cc_attention_f16", "cc_vit_encode", "cc_text_encode",
+                 "cc_video_pool_normalize_f32", "cc_loose_similarity_f32", "cc_scaled_dot_nt_f32"):
+        getattr(lib, name).restype = c.c_int

@@ -749,6 +749,20 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
                       reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st);
 }
 
+int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                        int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
+                        int64_t out_tok_stride, int64_t out_frame_stride, void* stream) {
+    if (!x || !out || !medoids || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+    if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
+        return CC_ERR_INVALID;
+    const int rows = B * T_new * (1 + K);
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, reinterpret_cast<const long long*>(medoids),
+                       out, out_tok_stride, out_frame_stride);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                          int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
                          float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm, float* out,

@@ -1,0 +1,198 @@
+// Retrieval tail on gfx950: per-frame L2 normalise -> masked mean over the
+// temporal segments -> L2 normalise (CLIP4Clip._mean_pooling_for_similarity_visual + _loose_similarity,
+// modules/clip4clip.py:305-316,357-366), and the text x video cosine-logit matrix as ONE exact-fp32
+// MFMA "NT" GEMM per row block instead of the reference's batch_size_val^2 tiny matmuls with a
+// device->host copy each (main.py:502-534).
+#include "cc_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// rows [R, E] -> rows / |row|   (one wave per row)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int R, int E) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* src = in + (int64_t)r * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
+    const float nrm = sqrtf(cc_wave_sum(s));
+    for (int e = lane; e < E; e += 64) out[(int64_t)r * E + e] = src[e] / nrm;
+}
+
+// visual [Bv, Tn, E], mask [Bv, Tn] int64 -> pooled [Bv, E]   (one wave per video)
+__global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
+                                                         const long long* __restrict__ mask,
+                                                         float* __restrict__ pooled, int Bv, int Tn, int E) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= Bv) return;
+    constexpr int MAXE = 16;                      // E <= 1024
+    float acc[MAXE];
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) acc[q] = 0.f;
+    float cnt = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        const float* src = visual + ((int64_t)v * Tn + t) * E;
+        float x[MAXE];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            x[q] = e < E ? src[e] : 0.f;
+            s = fmaf(x[q], x[q], s);
+        }
+        const float nrm = sqrtf(cc_wave_sum(s));
+        const float mk = (float)mask[(int64_t)v * Tn + t];
+        cnt += mk;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
+    }
+    if (cnt == 0.f) cnt = 1.f;                    // "avoid zero divide", clip4clip.py:313
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        acc[q] = acc[q] / cnt;
+        s = fmaf(acc[q], acc[q], s);
+    }
+    const float nrm = sqrtf(cc_wave_sum(s));
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int e = lane + 64 * q;
+        if (e < E) pooled[(int64_t)v * E + e] = acc[q] / nrm;
+    }
+}
+
+// C[i][j] = mult * sum_k A[i][k] B[j][k]; 64x64 tile per workgroup, exact-fp32 MFMA (16x16x4),
+// same LDS layout as the Gram kernel of cluster.hip.
+#define ST 64
+#define SK 32
+#define SLD 40
+__global__ __launch_bounds__(256) void dot_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                     float* __restrict__ C, int M, int N, int K, int ldc,
+                                                     float mult) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][ST * SLD];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pa[q] = A + (int64_t)min(ti * ST + lrow + 32 * q, M - 1) * K + lchunk * 4;
+        pb[q] = B + (int64_t)min(tj * ST + lrow + 32 * q, N - 1) * K + lchunk * 4;
+    }
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[2];
+    const int nk = (K + SK - 1) / SK;
+    auto gload = [&](int kt) {
+        const bool ok = kt * SK + lchunk * 4 < K;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ra[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * SK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * SK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * q) * SLD + lchunk * 4]) = ra[q];
+            *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * q) * SLD + lchunk * 4]) = rb[q];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int g = lane >> 4, l15 = lane & 15;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* As = &lds[buf][0][(wr * 32 + l15) * SLD + g * 4];
+        const float* Bs = &lds[buf][1][(wc * 32 + l15) * SLD + g * 4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ks * 16);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 16 * SLD + ks * 16);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + ks * 16);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + 16 * SLD + ks * 16);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                // B fragment as the A operand: a lane then owns 4 consecutive j of one i (16-byte stores)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[tt], a0[tt], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[tt], a0[tt], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[tt], a1[tt], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[tt], a1[tt], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const int i = ti * ST + wr * 32 + fm * 16 + l15;
+        if (i >= M) continue;
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) {
+            const int j = tj * ST + wc * 32 + fn * 16 + g * 4;
+            float* dst = C + (int64_t)i * ldc + j;
+            const f32x4 v = acc[fm][fn];
+            if (j + 3 < N && ((ldc & 3) == 0)) {
+                *reinterpret_cast<float4*>(dst) = make_float4(mult * v[0], mult * v[1], mult * v[2], mult * v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < N) dst[e] = mult * v[e];
+            }
+        }
+    }
+}
+
+extern "C" {
+
+size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E) {
+    if (Bt <= 0 || Bv <= 0 || E <= 0) return 0;
+    return cc_align_up((size_t)Bt * E * 4, 256) + cc_align_up((size_t)Bv * E * 4, 256);
+}
+
+int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
+                                float* pooled, void* stream) {
+    if (!visual || !video_mask || !pooled || Bv <= 0 || Tn <= 0 || E <= 0) return CC_ERR_INVALID;
+    if (E > 1024) return CC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(video_pool_kernel, dim3((Bv + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), visual,
+                       reinterpret_cast<const long long*>(video_mask), pooled, Bv, Tn, E);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult, float* logits,
+                         int32_t ldl, void* stream) {
+    if (!a || !b || !logits || Bt <= 0 || Bv <= 0 || E <= 0 || (E & 3) || ldl < Bv) return CC_ERR_INVALID;
+    dim3 grid((Bv + ST - 1) / ST, (Bt + ST - 1) / ST);
+    hipLaunchKernelGGL(dot_nt_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, b, logits, Bt, Bv, E, ldl,
+                       mult);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t Bt, int32_t Bv,
+                            int32_t Tn, int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (!text || !visual || !video_mask || !logits) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < cc_similarity_workspace_bytes(Bt, Bv, E)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* tn = static_cast<float*>(ws);
+    float* vp = pooled_out ? pooled_out
+                           : reinterpret_cast<float*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, tn, Bt, E);
+    CC_LAUNCH_CHECK();
+    int rc = cc_video_pool_normalize_f32(visual, video_mask, Bv, Tn, E, vp, stream);
+    if (rc) return rc;
+    return cc_scaled_dot_nt_f32(tn, vp, Bt, Bv, E, expf(logit_scale), logits, ldl, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+// Non-GEMM kernels of the CLIP forward on gfx950: LayerNorm (fp32 statistics), small-sequence
+// multi-head attention on MFMA, patch im2col, embeddings and the projection heads.
+// Reference semantics: modules/clip.py:183-189 (LayerNorm in fp32, eps 1e-5), :205,220-226
+// (nn.MultiheadAttention: packed in_proj q,k,v; heads = contiguous 64-wide slices; softmax(q k^T /
+// sqrt(64) + mask) v), :326-338 (patch embed + CLS + positional embedding + ln_pre), :448-454
+// (causal mask), :463-464 / :480-484 (ln_post / ln_final + projection of the CLS / EOT row).
+#include "cc_kernels.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ============================================================================ LayerNorm
+// One wave per row, row cached in registers (W <= 1024, W % 4 == 0).  Two-pass statistics in
+// fp32 (mean, then centred second moment) like ATen.  OUT_F16: write fp16 (GEMM operand) else
+// fp32 (may alias the input: ln_pre runs in place).  Rows are addressed as
+// in + row*in_stride so a strided subset (CLS rows) can be normalised directly.
+template <bool OUT_F16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int64_t in_stride,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out,
+                                                        int64_t out_stride, int rows, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = in + (int64_t)row * in_stride;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        v[t] = (w < W) ? *reinterpret_cast<const float4*>(src + w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    }
+    const float mean = cc_wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        if (w < W) {
+            const float a = v[t].x - mean, b = v[t].y - mean, c = v[t].z - mean, d = v[t].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(cc_wave_sum(q) / (float)W + eps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        if (w < W) {
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + w);
+            const float4 bt = *reinterpret_cast<const float4*>(beta + w);
+            const float o0 = (v[t].x - mean) * rstd * gm.x + bt.x, o1 = (v[t].y - mean) * rstd * gm.y + bt.y;
+            const float o2 = (v[t].z - mean) * rstd * gm.z + bt.z, o3 = (v[t].w - mean) * rstd * gm.w + bt.w;
+            if (OUT_F16) {
+                h4 o = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (int64_t)row * out_stride + w) = o;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * out_stride + w) =
+                    make_float4(o0, o1, o2, o3);
+            }
+        }
+    }
+}
+
+// ============================================================================ attention
+// One workgroup (4 waves) per (sequence, head); head_dim = 64; L <= 256 tokens.
+//   K   -> LDS [KT keys][64] fp16, 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7)
+//   V^T -> LDS [64 d][VS halfs]   (VS/2 words == 40 mod 64 -> conflict-free ds_read_b128)
+//   per wave, per 16-query tile:  S^T = K Q^T (MFMA, K fragment as A operand so a lane owns 4
+//   consecutive keys of one query) -> masked softmax in registers (fp32) -> P (fp16) to a
+//   per-wave LDS strip -> O^T = V^T P^T (MFMA) -> fp16 store, 4 consecutive d per lane.
+#define ATT_D 64
+#define ATT_MAX_KT 256
+
+__host__ __device__ inline int att_vs_halfs(int KT) {      // row stride of V^T / P in halfs
+    int words = KT / 2 + 4;
+    while ((words & 63) != 40) ++words;
+    return words * 2;
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
+                                                        int L, int heads, int W, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const int KT = (L + 31) & ~31;
+    const int VS = att_vs_halfs(KT);
+    _Float16* Ks = reinterpret_cast<_Float16*>(smem);                       // KT * 64
+    _Float16* Vt = Ks + KT * ATT_D;                                          // 64 * VS
+    _Float16* Ps = Vt + ATT_D * VS;                                          // 4 waves * 16 * VS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ld = 3 * (int64_t)W;
+    const _Float16* base = qkv + (int64_t)seq * L * ld + head * ATT_D;
+
+    // ---- stage K (swizzled) and V^T; rows >= L are zero
+    for (int idx = tid; idx < KT * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+        if (r < L) {
+            kv = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + W + c * 8);
+            vv = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + 2 * W + c * 8);
+        }
+        *reinterpret_cast<h8*>(reinterpret_cast<unsigned char*>(Ks) + r * 128 + ((c ^ (r & 7)) << 4)) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VS + r] = vv[e];
+    }
+    __syncthreads();
+
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nkt = KT / 16;                       // 16-key tiles
+    _Float16* Pw = Ps + wave * 16 * VS;
+    const int qtiles = (L + 15) / 16;
+    for (int qt = wave; qt < qtiles; qt += 4) {
+        const int q = qt * 16 + l15;               // this lane's query row (as B-operand column)
+        const int qc = min(q, L - 1);
+        h8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)qc * ld + (ks * 4 + lg) * 8);
+        // S^T tiles: lane holds S[q][key = kt*16 + lg*4 + r]
+        f32x4 s[ATT_MAX_KT / 16];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < ATT_MAX_KT / 16; ++kt) {
+            if (kt < nkt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                const int r = kt * 16 + l15;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const h8 kf = *reinterpret_cast<const h8*>(reinterpret_cast<const unsigned char*>(Ks) + r * 128 +
+                                                               (((ks * 4 + lg) ^ (r & 7)) << 4));
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kt * 16 + lg * 4 + e;
+                    const bool ok = key < L && (!CAUSAL || key <= q);
+                    a[e] = ok ? a[e] * scale : -3.0e38f;
+                    mx = fmaxf(mx, a[e]);
+                }
+                s[kt] = a;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < ATT_MAX_KT / 16; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pexp = (s[kt][e] > -1.0e38f) ? __expf(s[kt][e] - mx) : 0.f;
+                    s[kt][e] = pexp;
+                    sum += pexp;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, CC_WAVE);
+        sum += __shfl_xor(sum, 32, CC_WAVE);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < ATT_MAX_KT / 16; ++kt) {
+            if (kt < nkt) {
+                h4 ph = {(_Float16)(s[kt][0] * inv), (_Float16)(s[kt][1] * inv), (_Float16)(s[kt][2] * inv),
+                         (_Float16)(s[kt][3] * inv)};
+                *reinterpret_cast<h4*>(Pw + l15 * VS + kt * 16 + lg * 4) = ph;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the strip is private to this wave
+        __builtin_amdgcn_wave_barrier();
+        // O^T = V^T P^T : lane holds O[q = l15][d = dt*16 + lg*4 + e]
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < KT / 32; ++kb) {
+            const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * VS + kb * 32 + lg * 8);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const h8 vf = *reinterpret_cast<const h8*>(Vt + (dt * 16 + l15) * VS + kb * 32 + lg * 8);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < L) {
+            _Float16* dst = out + ((int64_t)seq * L + q) * W + head * ATT_D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                *reinterpret_cast<h4*>(dst + dt * 16 + lg * 4) = oh;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ============================================================================ embeddings
+// conv1 as GEMM: A[f*n + (ph*g + pw)][c*p*p + kh*p + kw] = video[f][c][ph*p+kh][pw*p+kw]  (fp16)
+__global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict__ video, _Float16* __restrict__ A,
+                                                         int F, int res, int p) {
+    const int g = res / p, n = g * g, Kc = 3 * p * p;
+    const int64_t total = (int64_t)F * n * Kc / 8;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t e = idx * 8;
+        const int k = (int)(e % Kc);
+        const int64_t row = e / Kc;
+        const int f = (int)(row / n), pi = (int)(row - (int64_t)f * n);
+        const int ph = pi / g, pw = pi - ph * g;
+        const int c = k / (p * p), rem = k - c * p * p, kh = rem / p, kw = rem - kh * p;
+        const float* src = video + (((int64_t)f * 3 + c) * res + (ph * p + kh)) * res + pw * p + kw;
+        const float4 a = *reinterpret_cast<const float4*>(src);
+        const float4 b = *reinterpret_cast<const float4*>(src + 4);
+        h8 o = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        *reinterpret_cast<h8*>(A + e) = o;
+    }
+}
+
+// h[f][0][:] = class_embedding + positional_embedding[0]      (modules/clip.py:334-336)
+__global__ void cls_pos_kernel(float* __restrict__ h, const float* __restrict__ cls, const float* __restrict__ pos,
+                               int F, int Ltok, int W) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * W) return;
+    const int f = idx / W, w = idx - f * W;
+    h[(int64_t)f * Ltok * W + w] = cls[w] + pos[w];
+}
+
+// text: h[b*Lt + t] = token_embedding[ids[b,t]] + positional_embedding[t]; eot[b] = first argmax ids[b,:]
+__global__ __launch_bounds__(256) void text_embed_kernel(const long long* __restrict__ ids,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos, float* __restrict__ h,
+                                                         int* __restrict__ eot, int Bt, int Lt, int W) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Bt * Lt) return;
+    const int b = row / Lt, t = row - b * Lt;
+    const long long id = ids[row];
+    const float* src = tok_emb + (int64_t)id * W;
+    for (int w = lane * 4; w < W; w += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(src + w);
+        const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)t * W + w);
+        *reinterpret_cast<float4*>(h + (int64_t)row * W + w) = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+    }
+    if (t == 0) {      // one wave scans the row for the first maximum id (modules/clip.py:484)
+        unsigned long long key = 0ull;
+        for (int u = lane; u < Lt; u += 64) {
+            const unsigned long long k2 = ((unsigned long long)(ids[(int64_t)b * Lt + u] + 0x40000000LL) << 32) |
+                                          (unsigned)(0xFFFFFFFFu - (unsigned)u);
+            key = k2 > key ? k2 : key;
+        }
+        key = cc_wave_max_u64(key);
+        if (lane == 0) eot[b] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    }
+}
+
+// out[r][:] = LN(h[row_of(r)]) @ proj[W, E]   (fp32 throughout; r < R rows, one workgroup each)
+//   row_of(r) = r*row_mul + (row_idx ? row_idx[r] : 0)
+__global__ __launch_bounds__(256) void head_project_kernel(const float* __restrict__ h, int row_mul,
+                                                           const int* __restrict__ row_idx,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ proj, float* __restrict__ out,
+                                                           int W, int E, float eps) {
+    __shared__ float xn[1024];
+    __shared__ float red[8];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = h + ((int64_t)r * row_mul + (row_idx ? row_idx[r] : 0)) * W;
+    float s = 0.f;
+    for (int w = tid; w < W; w += 256) { const float v = src[w]; xn[w] = v; s += v; }
+    s = cc_wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
+    float q = 0.f;
+    for (int w = tid; w < W; w += 256) { const float d = xn[w] - mean; q += d * d; }
+    q = cc_wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + eps);
+    for (int w = tid; w < W; w += 256) xn[w] = (xn[w] - mean) * rstd * gamma[w] + beta[w];
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        float acc = 0.f;
+        for (int w = 0; w < W; ++w) acc = fmaf(xn[w], proj[(int64_t)w * E + e], acc);
+        out[(int64_t)r * E + e] = acc;
+    }
+}
+
+// ============================================================================ C ABI (single ops)
+extern "C" {
+
+int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta, void* out,
+                     int64_t out_stride, int32_t rows, int32_t W, float eps, int32_t out_f16, void* stream) {
+    if (!in || !gamma || !beta || !out || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (out_f16)
+        hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, st, in, in_stride, gamma, beta, out, out_stride, rows, W, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, st, in, in_stride, gamma, beta, out, out_stride, rows, W, eps);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_attention_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads, int32_t W,
+                     int32_t causal, void* stream) {
+    if (!qkv_f16 || !out_f16 || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * ATT_D) return CC_ERR_INVALID;
+    if (L > ATT_MAX_KT) return CC_ERR_UNSUPPORTED;
+    const int KT = (L + 31) & ~31, VS = att_vs_halfs(KT);
+    const size_t smem = (size_t)(KT * ATT_D + ATT_D * VS + 4 * 16 * VS) * 2;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float scale = 0.125f;
+    dim3 grid(nseq * heads), block(256);
+    if (causal) {
+        auto k = attention_kernel<true>;
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CC_ERR_HIP;
+        hipLaunchKernelGGL(k, grid, block, smem, st, static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), L, heads, W, scale);
+    } else {
+        auto k = attention_kernel<false>;
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CC_ERR_HIP;
+        hipLaunchKernelGGL(k, grid, block, smem, st, static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), L, heads, W, scale);
+    }
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+}  // extern "C"
+
+// ---- launch helpers used by clip_forward.hip (same translation-unit-external linkage)
+int cc_launch_im2col(const float* video, _Float16* A, int F, int res, int p, hipStream_t st) {
+    if ((p & 7) || res % p) return CC_ERR_INVALID;
+    const int64_t total = (int64_t)F * (res / p) * (res / p) * 3 * p * p / 8;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col_f16_kernel, dim3(blocks), dim3(256), 0, st, video, A, F, res, p);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_launch_cls_pos(float* h, const float* cls, const float* pos, int F, int Ltok, int W, hipStream_t st) {
+    hipLaunchKernelGGL(cls_pos_kernel, dim3((F * W + 255) / 256), dim3(256), 0, st, h, cls, pos, F, Ltok, W);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float* pos, float* h, int* eot, int Bt,
+                         int Lt, int W, hipStream_t st) {
+    hipLaunchKernelGGL(text_embed_kernel, dim3((Bt * Lt + 3) / 4), dim3(256), 0, st, ids, tok_emb, pos, h, eot, Bt, Lt, W);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, const float* gamma, const float* beta,
+                           const float* proj, float* out, int R, int W, int E, hipStream_t st) {
+    if (W > 1024) return CC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(head_project_kernel, dim3(R), dim3(256), 0, st, h, row_mul, row_idx, gamma, beta, proj, out, W, E, 1e-5f);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}

@@ -1,0 +1,86 @@
+"""Thin tensor-level wrappers over the single-op C entry points (used by the module mirrors and
+by the op-level parity tests).  Every function enqueues on the current torch stream."""
+import torch
+
+from . import _lib as L
+from ._lib_clip import EPI
+
+
+def linear_f16(a, w, bias, epilogue="f16", out=None, tile=0):
+    """y = a @ w.T + bias with a fused epilogue; a [M,K] fp16, w [N,K] fp16, bias [N] fp32|None.
+    epilogue: 'f16' | 'f16_gelu' (QuickGELU) | 'f32' | 'f32_resid' (out += ..., out required)."""
+    L.require_device(a, w, bias, out)
+    assert a.dtype == torch.float16 and w.dtype == torch.float16 and a.is_contiguous() and w.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        assert epilogue != "f32_resid"
+        out = torch.empty(M, N, device=a.device, dtype=torch.float16 if epilogue.startswith("f16") else torch.float32)
+    L.check(L.lib().cc_linear_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, out.stride(0), EPI[epilogue],
+                                  tile, L.stream_ptr(a.device)), "cc_linear_f16")
+    return out
+
+
+def layernorm(x, weight, bias, eps=1e-5, out_f16=False):
+    """LayerNorm over the last dim of a contiguous fp32 [..., W] tensor (statistics in fp32)."""
+    L.require_device(x, weight, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    W = x.shape[-1]
+    rows = x.numel() // W
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
+    L.check(L.lib().cc_layernorm_f32(L.ptr(x), W, L.ptr(weight), L.ptr(bias), L.ptr(out), W, rows, W, float(eps),
+                                     int(out_f16), L.stream_ptr(x.device)), "cc_layernorm_f32")
+    return out
+
+
+def attention_f16(qkv, nseq, L_tok, heads, causal=False):
+    """qkv [nseq*L, 3W] fp16 -> [nseq*L, W] fp16 (softmax(q k^T / 8 [+ causal mask]) v per head)."""
+    L.require_device(qkv)
+    assert qkv.dtype == torch.float16 and qkv.is_contiguous()
+    W = qkv.shape[1] // 3
+    out = torch.empty(nseq * L_tok, W, device=qkv.device, dtype=torch.float16)
+    L.check(L.lib().cc_attention_f16(L.ptr(qkv), L.ptr(out), nseq, L_tok, heads, W, int(causal),
+                                     L.stream_ptr(qkv.device)), "cc_attention_f16")
+    return out
+
+
+def loose_similarity(text, visual, video_mask, logit_scale, return_pooled=False):
+    """meanP retrieval logits [Bt,Bv] (CLIP4Clip._loose_similarity, eval branch)."""
+    L.require_device(text, visual, video_mask)
+    text = text.float().contiguous()
+    visual = visual.float().contiguous()
+    mask = video_mask.to(torch.long).contiguous()
+    Bt, E = text.shape
+    Bv, Tn, _ = visual.shape
+    lib = L.lib()
+    logits = torch.empty(Bt, Bv, device=text.device, dtype=torch.float32)
+    pooled = torch.empty(Bv, E, device=text.device, dtype=torch.float32) if return_pooled else None
+    ws = L.workspace(lib.cc_similarity_workspace_bytes(Bt, Bv, E), text.device)
+    L.check(lib.cc_loose_similarity_f32(L.ptr(text), L.ptr(visual), L.ptr(mask), Bt, Bv, Tn, E, float(logit_scale),
+                                        L.ptr(logits), Bv, L.ptr(pooled), L.ptr(ws), ws.numel(),
+                                        L.stream_ptr(text.device)), "cc_loose_similarity_f32")
+    return (logits, pooled) if return_pooled else logits
+
+
+def video_pool_normalize(visual, video_mask):
+    L.require_device(visual, video_mask)
+    visual = visual.float().contiguous()
+    mask = video_mask.to(torch.long).contiguous()
+    Bv, Tn, E = visual.shape
+    pooled = torch.empty(Bv, E, device=visual.device, dtype=torch.float32)
+    L.check(L.lib().cc_video_pool_normalize_f32(L.ptr(visual), L.ptr(mask), Bv, Tn, E, L.ptr(pooled),
+                                                L.stream_ptr(visual.device)), "cc_video_pool_normalize_f32")
+    return pooled
+
+
+def scaled_dot_nt(a, b, mult=1.0, out=None):
+    """out[Bt,Bv] = mult * a @ b.T in exact fp32 (rows already normalised)."""
+    L.require_device(a, b, out)
+    a, b = a.float().contiguous(), b.float().contiguous()
+    Bt, E = a.shape
+    Bv = b.shape[0]
+    if out is None:
+        out = torch.empty(Bt, Bv, device=a.device, dtype=torch.float32)
+    L.check(L.lib().cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, Bv, E, float(mult), L.ptr(out), out.stride(0),
+                                         L.stream_ptr(a.device)), "cc_scaled_dot_nt_f32")
+    return out

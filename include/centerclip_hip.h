@@ -132,6 +132,134 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
                          int64_t* medoids, int64_t* assign, int32_t* iters,
                          void* ws, size_t ws_bytes, void* stream);
 
+
+/*
+ * C6 alone - the gather half of TokenClusterInter.forward for given medoid ids:
+ *      x_tmp = res_tmp[batch_index, mediods_ids] (modules/cluster/cluster.py:289), the per-segment
+ *      CLS mean (:307-308) and the restack (:303,310).  medoids [T_new*B, K] int64, p = s*B + b.
+ */
+int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride,
+                        int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                        const int64_t* medoids, float* out, int64_t out_tok_stride,
+                        int64_t out_frame_stride, void* stream);
+
+/* ==========================================================================================
+ * CLIP forward path.  fp16 MFMA operands, fp32 accumulate,
+ * fp32 residual stream / LayerNorm / softmax (modules/clip.py:183-189 keeps LN in fp32; the
+ * reference runs fp16 weights on GPU via convert_weights, clip.py:515-536).
+ * Weight tensors keep the reference's state-dict layouts: Linear / in_proj
+ * weights [out, in] row-major, conv1 weight [W, 3, p, p] == [W, 3*p*p]; "f16" pointers are IEEE
+ * binary16 copies of those tensors, everything else fp32.
+ * ========================================================================================== */
+
+/* epilogue ids of cc_linear_f16 */
+#define CC_EPI_F16 0        /* C(fp16) = A W^T + b                                           */
+#define CC_EPI_F16_GELU 1   /* C(fp16) = QuickGELU(A W^T + b)         modules/clip.py:192-194 */
+#define CC_EPI_F32_RESID 2  /* C(fp32) += A W^T + b   (residual add)  modules/clip.py:240,251 */
+#define CC_EPI_F32 4        /* C(fp32) = A W^T + b                                           */
+
+/* nn.Linear forward, y = x W^T + b  (c_fc / c_proj / out_proj: modules/clip.py:207-211; the
+ * packed in_proj of nn.MultiheadAttention: clip.py:205).  a [M,K] fp16, w [N,K] fp16, bias
+ * [N] fp32 or NULL, c row stride ldc elements.  K % 64 == 0, N % 64 == 0.  tile: 0 = auto. */
+int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
+                  int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
+                  void* stream);
+
+/* LayerNorm over the last dim (fp32 statistics, eps as given) - modules/clip.py:183-189.
+ * Row r is read at in + r*in_stride and written at out + r*out_stride (elements); out is fp16
+ * when out_f16 != 0, else fp32 (may alias in). */
+int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta,
+                     void* out, int64_t out_stride, int32_t rows, int32_t W, float eps,
+                     int32_t out_f16, void* stream);
+
+/* Multi-head self-attention core of nn.MultiheadAttention (modules/clip.py:220-226):
+ * qkv [nseq*L, 3W] fp16 (row = seq*L + token; q | k | v, heads = contiguous 64-wide slices),
+ * out [nseq*L, W] fp16 = softmax(q k^T / 8 + mask) v; causal != 0 adds the strict upper
+ * triangular -inf mask of clip.py:448-454.  head_dim is 64 (W == 64*heads), L <= 256. */
+int cc_attention_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads,
+                     int32_t W, int32_t causal, void* stream);
+
+/* One ResidualAttentionBlock (state-dict keys resblocks.{i}.*) */
+typedef struct cc_block_weights {
+    const float* ln_1_weight;  const float* ln_1_bias;
+    const void* in_proj_weight_f16;   /* [3W, W] */   const float* in_proj_bias;    /* [3W] */
+    const void* out_proj_weight_f16;  /* [W, W]  */   const float* out_proj_bias;   /* [W]  */
+    const float* ln_2_weight;  const float* ln_2_bias;
+    const void* c_fc_weight_f16;      /* [4W, W] */   const float* c_fc_bias;       /* [4W] */
+    const void* c_proj_weight_f16;    /* [W, 4W] */   const float* c_proj_bias;     /* [W]  */
+} cc_block_weights;
+
+#define CC_MAX_LAYERS 32
+
+/* VisualTransformer + the ln_post/proj tail of CLIP.encode_image (modules/clip.py:272-349,460-469) */
+typedef struct cc_vit_model {
+    int32_t layers, width, heads, patch, resolution, embed_dim;
+    const void* conv1_weight_f16;         /* [W, 3*p*p]                         */
+    const float* class_embedding;         /* [W]                                */
+    const float* positional_embedding;    /* [1 + (res/p)^2, W]                 */
+    const float* ln_pre_weight;  const float* ln_pre_bias;
+    const float* ln_post_weight; const float* ln_post_bias;
+    const float* proj;                    /* [W, embed_dim] fp32                */
+    const cc_block_weights* blocks;       /* HOST array [layers]                */
+    /* token-cluster plan, one entry per block (the per-block decision of get_cluster_inter,
+     * modules/cluster/cluster.py:15-37): cluster_tokens[i] > 0 => before the attention of block i
+     * (0-based) the clip's frames are cut to cluster_frames[i] segments of cluster_tokens[i]
+     * medoid tokens (clip.py:236-242). */
+    int32_t cluster_frames[CC_MAX_LAYERS];
+    int32_t cluster_tokens[CC_MAX_LAYERS];
+    int32_t cluster_metric;   float cluster_norm_p;   float cluster_threshold;
+    int32_t cluster_iter_limit, cluster_split_size, cluster_pre_norm;
+} cc_vit_model;
+
+size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T);
+
+/* CLIP.encode_image(image, video_frame=T) (modules/clip.py:460-469): video [B*T, 3, res, res]
+ * fp32 -> features [B*T_final, embed_dim] fp32 (CLS row of ln_post(hidden) @ proj; only the
+ * CLS row is projected - identical values).  hidden_out (optional):
+ * the final hidden state [B*T_final, L_final, W] fp32 before ln_post (VisualTransformer.forward
+ * output, clip.py:304-349).  medoids_out (optional): int64 [T_new*B, K] of the LAST cluster block.
+ * forced_medoids (optional, test hook for "embeddings given identical medoid sets"):
+ * int64 [T_new*B, K]; when non-NULL every cluster block skips the k-medoids selection and gathers
+ * these ids instead (meaningful for plans with one cluster block, which is all shipped configs). */
+int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t T,
+                  float* features, float* hidden_out, int64_t* medoids_out,
+                  const int64_t* forced_medoids, void* ws, size_t ws_bytes, void* stream);
+
+/* Text transformer + ln_final/text_projection tail of CLIP.encode_text (modules/clip.py:471-496) */
+typedef struct cc_text_model {
+    int32_t layers, width, heads, context_length, vocab_size, embed_dim;
+    const float* token_embedding;         /* [vocab, W]        */
+    const float* positional_embedding;    /* [context, W]      */
+    const float* ln_final_weight; const float* ln_final_bias;
+    const float* text_projection;         /* [W, embed_dim]    */
+    const cc_block_weights* blocks;       /* HOST array [layers] */
+} cc_text_model;
+
+size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt);
+
+/* ids [Bt, Lt] int64 -> features [Bt, embed_dim] fp32: row at the first argmax of the ids
+ * (EOT has the largest id, clip.py:484) of ln_final(x) @ text_projection. */
+int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt,
+                   float* features, void* ws, size_t ws_bytes, void* stream);
+
+/* S2 - the meanP similarity tail, CLIP4Clip._loose_similarity (modules/clip4clip.py:357-366) with
+ * _mean_pooling_for_similarity_visual (:305-316):
+ *   v_hat = v/|v| per frame; v_bar = sum_t mask*v_hat / max(sum_t mask, 1 if 0); v_bar /= |v_bar|
+ *   t_hat = t/|t|;  logits[Bt,Bv] = exp(logit_scale) * t_hat v_bar^T           (all fp32)
+ * visual [Bv, Tn, E] fp32, video_mask [Bv, Tn] int64 (as the reference passes it), text [Bt, E].
+ * pooled_out (optional) [Bv, E] receives v_bar.  ws: (Bv + Bt) * E floats. */
+size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E);
+int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn,
+                                int32_t E, float* pooled, void* stream);
+int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask,
+                            int32_t Bt, int32_t Bv, int32_t Tn, int32_t E, float logit_scale,
+                            float* logits, int32_t ldl, float* pooled_out,
+                            void* ws, size_t ws_bytes, void* stream);
+/* logits[Bt,Bv] = mult * a[Bt,E] b[Bv,E]^T for already-normalised rows (the sharded eval
+ * similarity matrix, main.py:502-534, computed in one launch per row block). */
+int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult,
+                         float* logits, int32_t ldl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

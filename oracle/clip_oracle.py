@@ -1,0 +1,145 @@
+"""CPU oracle for the CLIP forward / similarity rows of the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/cluster_oracle.py for the rules).  Plain PyTorch fp32,
+functional, driven by a state dict with the reference's key names.  Pinned against
+the imported reference by tests/golden/clip_golden.npz (oracle/gen_golden.py clip).
+
+Citations are relative to /root/reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import cluster_oracle as co
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    """modules/clip.py:183-189: nn.LayerNorm evaluated in fp32."""
+    return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps)
+
+
+def quick_gelu(x):
+    """modules/clip.py:192-194."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def mha(x, sd, pre, heads, causal):
+    """nn.MultiheadAttention forward on [N, L, W] (batch first here; the reference feeds LND,
+    clip.py:205,220-226): packed in_proj (rows q,k,v), heads = contiguous W/heads slices,
+    softmax(q k^T / sqrt(d) + mask) v, out_proj."""
+    N, L, W = x.shape
+    d = W // heads
+    qkv = x @ sd[pre + "attn.in_proj_weight"].float().t() + sd[pre + "attn.in_proj_bias"].float()
+    q, k, v = qkv.split(W, dim=-1)
+    q = q.view(N, L, heads, d).transpose(1, 2)
+    k = k.view(N, L, heads, d).transpose(1, 2)
+    v = v.view(N, L, heads, d).transpose(1, 2)
+    s = (q @ k.transpose(-2, -1)) / math.sqrt(d)
+    if causal:                                             # clip.py:448-454
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(N, L, W)
+    return o @ sd[pre + "attn.out_proj.weight"].float().t() + sd[pre + "attn.out_proj.bias"].float()
+
+
+def resblock(x, sd, pre, heads, causal):
+    """ResidualAttentionBlock without the cluster hook (clip.py:240,251), x [N, L, W]."""
+    x = x + mha(layer_norm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"]), sd, pre, heads, causal)
+    h = layer_norm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
+    h = quick_gelu(h @ sd[pre + "mlp.c_fc.weight"].float().t() + sd[pre + "mlp.c_fc.bias"].float())
+    return x + h @ sd[pre + "mlp.c_proj.weight"].float().t() + sd[pre + "mlp.c_proj.bias"].float()
+
+
+def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_medoids=None, return_hidden=False):
+    """VisualTransformer.forward + the ln_post/proj tail of CLIP.encode_image
+    (clip.py:304-349,460-469).  video [B*T,3,H,W]; cluster_plan {block_index(0-based): (T_new, K)};
+    cluster_cfg dict(distance, threshold, iter_limit, norm_p, split_size, pre_norm).
+    forced_medoids {block_index: int64 [T_new*B, K]} replaces the k-medoids result (to compare
+    embeddings "given identical medoid sets").  Returns features [B*T_final, E]
+    (and the hidden state [B*T_final, L, W])."""
+    W = sd["visual.conv1.weight"].shape[0]
+    p = sd["visual.conv1.weight"].shape[-1]
+    heads = W // 64
+    layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    x = F.conv2d(video.float(), sd["visual.conv1.weight"].float(), stride=p)          # clip.py:324
+    x = x.reshape(x.shape[0], W, -1).permute(0, 2, 1)                                  # [BT, n, W]
+    cls = sd["visual.class_embedding"].float().expand(x.shape[0], 1, W)
+    x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"].float()         # :334-336
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])            # :338
+    frames = T
+    cluster_plan = cluster_plan or {}
+    for i in range(layers):
+        if i in cluster_plan:                                                           # :236-242
+            T_new, K = cluster_plan[i]
+            x_lnd = x.permute(1, 0, 2).contiguous()
+            if forced_medoids is not None and i in forced_medoids:
+                x_lnd = gather_with_medoids(x_lnd, frames, T_new, forced_medoids[i])
+            else:
+                c = cluster_cfg or {}
+                x_lnd = co.literal_token_cluster(x_lnd, frames, T_new, K, c.get("distance", "euclidean"),
+                                                 c.get("threshold", 1e-6), c.get("iter_limit", 100),
+                                                 c.get("norm_p", 2.0), c.get("split_size", 16),
+                                                 c.get("pre_norm", False))
+            x = x_lnd.permute(1, 0, 2).contiguous()
+            frames = T_new
+        x = resblock(x, sd, "visual.transformer.resblocks.%d." % i, heads, causal=False)
+    feat = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"].float()
+    return (feat, x) if return_hidden else feat
+
+
+def gather_with_medoids(x_lnd, T, T_new, medoids):
+    """The gather / CLS-mean half of TokenClusterInter.forward with given medoid ids
+    (modules/cluster/cluster.py:287-289,303-310)."""
+    tokens, cls = co.regroup_segments(x_lnd, T, T_new)
+    P, _, W = tokens.shape
+    B, fd, K = P // T_new, T // T_new, medoids.shape[1]
+    picked = tokens[torch.arange(P).unsqueeze(-1), medoids]
+    picked = picked.reshape(T_new, B, K, W).permute(1, 0, 2, 3).reshape(B * T_new, K, W)
+    seg_cls = torch.stack([c.mean(dim=1) for c in torch.split(cls, fd, dim=1)], dim=1).reshape(B * T_new, 1, W)
+    return torch.cat([seg_cls, picked], dim=1).permute(1, 0, 2).contiguous()
+
+
+def text_forward(sd, ids):
+    """CLIP.encode_text (clip.py:471-496): embed + positional, 12 causal blocks, ln_final,
+    text_projection, row at the first argmax of the ids."""
+    W = sd["ln_final.weight"].shape[0]
+    heads = W // 64
+    layers = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
+    x = sd["token_embedding.weight"].float()[ids] + sd["positional_embedding"].float()[:ids.shape[1]]
+    for i in range(layers):
+        x = resblock(x, sd, "transformer.resblocks.%d." % i, heads, causal=True)
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"]) @ sd["text_projection"].float()
+    return x[torch.arange(x.shape[0]), ids.argmax(dim=-1)]
+
+
+def video_mask_after_cluster(video_mask, max_frames, final_frames):
+    """clip4clip.py:436-447: a segment inherits the mask of its last frame."""
+    fd = max_frames // final_frames
+    inds = torch.arange(fd - 1, video_mask.shape[-1], video_mask.shape[-1] // final_frames)
+    return video_mask[:, inds]
+
+
+def mean_pool_visual(visual, video_mask):
+    """clip4clip.py:305-316 preceded/followed by the L2 normalisations of :357-360."""
+    v = visual / visual.norm(dim=-1, keepdim=True)
+    m = video_mask.to(torch.float).unsqueeze(-1)
+    s = torch.sum(m, dim=1, dtype=torch.float)
+    s[s == 0.] = 1.
+    v = torch.sum(v * m, dim=1) / s
+    return v / v.norm(dim=-1, keepdim=True)
+
+
+def loose_similarity(sequence_output, visual_output, video_mask, logit_scale):
+    """clip4clip.py:357-366 (meanP, eval branch): exp(logit_scale) * t_hat @ v_bar^T."""
+    v = mean_pool_visual(visual_output.float(), video_mask)
+    t = sequence_output.float().squeeze(1)
+    t = t / t.norm(dim=-1, keepdim=True)
+    return math.exp(float(logit_scale)) * torch.matmul(t, v.t())
+
+
+def similarity_matrix_blocked(seq_batches, vis_batches, mask_batches, logit_scale):
+    """main.py:502-534 (_run_on_single_gpu): text-batch x video-batch blocks concatenated."""
+    rows = []
+    for t in seq_batches:
+        rows.append(torch.cat([loose_similarity(t, v, m, logit_scale) for v, m in zip(vis_batches, mask_batches)], dim=-1))
+    return torch.cat(rows, dim=0)

@@ -1,0 +1,238 @@
+"""Parity of the HIP CLIP forward / similarity path (through the C ABI) against the oracle and the
+fixtures captured from the reference.  Needs a real MI355X (``-m gpu``).
+
+Tolerances (north star: "within 1e-3 fp32 for embeddings/similarities"):
+  * single ops, fp32 outputs ............ 2e-4 relative to the tensor's max magnitude
+  * single ops, fp16 outputs ............ 2e-3 relative (one fp16 rounding = 4.9e-4)
+  * L2-normalised embeddings, cosine similarities ... max|delta| <= 1e-3 absolute, asserted
+    GIVEN IDENTICAL MEDOID SETS (raw 512-d features have norm ~22, so the absolute
+    1e-3 contract is stated on normalised embeddings; raw features are checked at 1e-3 relative).
+  * fp32-only paths (pooling, similarity GEMM, metrics) ... 2e-5 absolute.
+"""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import clip_oracle as clo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN)
+
+
+def golden_state_dict(g):
+    return {k[3:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+            for k in g.files if k.startswith("sd/")}
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------- single ops
+@pytest.mark.parametrize("M,N,K", [(9600, 2304, 768), (2400, 768, 3072), (100, 128, 64), (513, 3072, 768), (77, 512, 2048)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_linear_f16_epilogues(M, N, K, tile):
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=gen)).half()
+    w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
+    bias = torch.randn(N, generator=gen)
+    ref = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    y = ops.linear_f16(ad, wd, bd, "f32", tile=tile).cpu()
+    assert relerr(y, ref) < 2e-4
+    y = ops.linear_f16(ad, wd, None, "f32", tile=tile).cpu()
+    assert relerr(y, ref - bias.double()) < 2e-4
+    y = ops.linear_f16(ad, wd, bd, "f16", tile=tile).float().cpu()
+    assert relerr(y, ref) < 2e-3
+    y = ops.linear_f16(ad, wd, bd, "f16_gelu", tile=tile).float().cpu()
+    assert relerr(y, ref * torch.sigmoid(1.702 * ref)) < 2e-3
+    resid = torch.randn(M, N, generator=gen)
+    out = resid.to(DEV).clone()
+    ops.linear_f16(ad, wd, bd, "f32_resid", out=out, tile=tile)
+    assert relerr(out.cpu(), ref + resid.double()) < 2e-4
+
+
+def test_linear_detects_transposed_operands():
+    """asymmetric A=I check (a symmetric B would hide a row/col swap)."""
+    from centerclip_amd import ops
+    K = N = 128
+    a = torch.eye(64, K).half()
+    w = (torch.arange(N * K).reshape(N, K) % 17).half()
+    y = ops.linear_f16(a.to(DEV), w.to(DEV), None, "f32").cpu()
+    assert torch.equal(y, w.float().t()[:64])
+
+
+@pytest.mark.parametrize("rows,W", [(9600, 768), (37, 512), (5, 128), (1, 1024)])
+def test_layernorm(rows, W):
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, W, generator=gen) * 3 + 0.5
+    w, b = torch.randn(W, generator=gen), torch.randn(W, generator=gen)
+    ref = F.layer_norm(x.double(), (W,), w.double(), b.double(), 1e-5)
+    y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    assert float((y.double() - ref).abs().max()) < 2e-5
+    y16 = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), out_f16=True).float().cpu()
+    assert relerr(y16, ref) < 2e-3
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", [(24, 50, 12, False), (3, 197, 12, False), (5, 101, 2, False),
+                                                 (4, 161, 2, False), (16, 32, 8, True), (3, 77, 8, True), (2, 1, 2, False),
+                                                 (2, 7, 2, True)])
+def test_attention(nseq, L, heads, causal):
+    from centerclip_amd import ops
+    W = heads * 64
+    gen = torch.Generator().manual_seed(L * 7 + heads)
+    qkv = (torch.randn(nseq * L, 3 * W, generator=gen) * 1.5).half()
+    q, k, v = qkv.double().view(nseq, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-2, -1) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(nseq * L, W)
+    y = ops.attention_f16(qkv.to(DEV), nseq, L, heads, causal).float().cpu()
+    assert float((y.double() - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------- small model vs reference goldens
+def small_model(g, cluster):
+    from centerclip_amd.clip import build_clip_model
+    T = int(g["cfg"][11])
+    args = Namespace(cluster_inter=int(cluster), cluster_algo='kmediods++', max_frames=T,
+                     target_frames_blocks=[4, 2, 2], cluster_num_blocks=[16, 6, 6], cluster_distance='euclidean',
+                     cluster_threshold=1e-6, cluster_iter_limit=100, minkowski_norm_p=2.0,
+                     pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False)
+    model, cfg = build_clip_model(golden_state_dict(g), args=args)
+    return model.to(DEV), T
+
+
+def nrm(x):
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def test_small_visual_forward_given_reference_medoids(g):
+    model, T = small_model(g, cluster=True)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    feat, hidden = model.visual.encode(video, T, want_hidden=True, forced_medoids=torch.from_numpy(g["v_medoids"]))
+    ref, refh = torch.from_numpy(g["v_feat"]), torch.from_numpy(g["v_hidden"])
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    assert relerr(feat.cpu(), ref) <= 1e-3
+    assert relerr(hidden.cpu(), refh) <= 1e-3
+    # reference-shaped API: encode_image -> (features, cluster_loss)
+    f2, closs = model.encode_image(video, video_frame=T)
+    assert f2.shape == ref.shape and float(closs) == 0.0
+
+
+def test_small_visual_forward_own_medoids_close_or_reported(g):
+    """End to end with the HIP k-medoids: medoid sets on generic floats are not a bit-exact target
+    (P3); report agreement and check the embedding only where the sets agree."""
+    model, T = small_model(g, cluster=True)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    feat, _ = model.visual.encode(video, T, want_medoids=True)
+    med = model.visual.last_medoids.cpu().numpy()
+    same = np.array_equal(med, g["v_medoids"])
+    print(f"[small ViT] own medoids identical to the reference's: {same}")
+    if same:
+        assert float((nrm(feat.cpu()) - nrm(torch.from_numpy(g["v_feat"]))).abs().max()) <= 1e-3
+
+
+def test_small_visual_forward_without_cluster(g):
+    model, T = small_model(g, cluster=False)
+    feat, _ = model.encode_image(torch.from_numpy(g["video"]).to(DEV), video_frame=T)
+    ref = torch.from_numpy(g["v_feat_nocluster"])
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    assert relerr(feat.cpu(), ref) <= 1e-3
+
+
+def test_small_text_forward(g):
+    model, _ = small_model(g, cluster=False)
+    feat = model.encode_text(torch.from_numpy(g["t_ids"]).to(DEV))
+    ref = torch.from_numpy(g["t_feat"])
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    assert relerr(feat.cpu(), ref) <= 1e-3
+
+
+def test_loose_similarity_and_mask(g):
+    from centerclip_amd import ops
+    seq, vis = torch.from_numpy(g["s_seq"]).to(DEV), torch.from_numpy(g["s_vis"]).to(DEV)
+    m3 = torch.from_numpy(g["s_mask3"]).to(DEV)
+    logits, pooled = ops.loose_similarity(seq.squeeze(1), vis, m3, float(g["s_logit_scale"]), return_pooled=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["s_logits"], rtol=0, atol=2e-5)
+    ref_pool = clo.mean_pool_visual(torch.from_numpy(g["s_vis"]), torch.from_numpy(g["s_mask3"]))
+    np.testing.assert_allclose(pooled.cpu().numpy(), ref_pool.numpy(), rtol=0, atol=2e-6)
+
+
+def test_clip4clip_module_eval_path(g):
+    """CLIP4Clip.forward -> get_similarity_logits with the reference's calling convention (main.py:430-449,518)."""
+    from centerclip_amd.clip4clip import CLIP4Clip
+    T = int(g["cfg"][11])
+    cfg = Namespace(cluster_inter=0, cluster_algo='kmediods++', max_frames=T, target_frames_blocks=[4, 4, 4],
+                    cluster_num_blocks=[16, 16, 16], cluster_distance='euclidean', cluster_threshold=1e-6,
+                    cluster_iter_limit=100, minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None,
+                    pre_norm=False, loose_type=True, sim_header='meanP', linear_patch='2d')
+    sd = golden_state_dict(g)
+    model = CLIP4Clip.from_state_dict(sd, cfg).to(DEV).eval()
+    B = 2
+    video = torch.from_numpy(g["video"]).view(B, 1, T, 3, 64, 64).to(DEV)
+    vmask = torch.ones(B, 1, T, dtype=torch.long, device=DEV)
+    vmask[1, 0, 2:] = 0
+    ids = torch.from_numpy(g["t_ids"]).to(DEV)
+    amask = (ids > 0).long()
+    out = model(ids, torch.zeros_like(ids), amask, video, vmask)
+    assert out["sequence_output"].shape == (3, 1, 64) and out["visual_output"].shape == (B, T, 64)
+    logits, extra = model.get_similarity_logits(out["sequence_output"], out["visual_output"], amask, vmask)
+    assert extra == () and logits.shape == (3, B)
+    vfeat = clo.visual_forward(sd, torch.from_numpy(g["video"]), T).view(B, T, 64)
+    tfeat = clo.text_forward(sd, torch.from_numpy(g["t_ids"])).view(3, 1, 64)
+    ref = clo.loose_similarity(tfeat, vfeat, vmask.view(B, T).cpu(), float(sd["logit_scale"]))
+    scale = float(torch.tensor(float(sd["logit_scale"])).exp())
+    assert float((logits.cpu() - ref).abs().max()) <= 1e-3 * scale          # cosine similarities within 1e-3
+
+
+# ------------------------------------------------------------------------------- full-size ViT-B/32 vs fp32 oracle
+def test_vitb32_full_size_against_fp32_oracle():
+    """ViT-B/32, 12 frames -> 3 segments at block 7, K=49 (MSR-VTT shaped, one clip), random weights with
+    CLIP's init statistics rounded through fp16.  HIP (fp16 MFMA operands) vs the plain fp32 CPU oracle
+    given the HIP path's own medoid ids."""
+    from centerclip_amd.clip import CLIP
+    torch.manual_seed(0)
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=12,
+                     target_frames_blocks=[12] * 6 + [3] * 6, cluster_num_blocks=[49] * 12,
+                     cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False)
+    model = CLIP(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12, video_frames=12, args=args)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.half().float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    video = torch.randn(12, 3, 224, 224)
+    feat, _ = model.visual.encode(video.to(DEV), 12, want_medoids=True)
+    med = model.visual.last_medoids.cpu()
+    assert med.shape == (3, 49) and bool((med[:, 1:] > med[:, :-1]).all())
+    ref = clo.visual_forward(sd, video, 12, cluster_plan={6: (3, 49)}, forced_medoids={6: med})
+    d = float((nrm(feat.cpu()) - nrm(ref)).abs().max())
+    print(f"[ViT-B/32 full] max|delta| normalised embedding = {d:.2e}; raw rel = {relerr(feat.cpu(), ref):.2e}")
+    assert d <= 1e-3
+    ids = torch.zeros(4, 32, dtype=torch.long)
+    for b in range(4):
+        ln = 6 + 5 * b
+        ids[b, 0], ids[b, ln - 1] = 49406, 49407
+        ids[b, 1:ln - 1] = torch.randint(1, 49405, (ln - 2,))
+    tfeat = model.encode_text(ids.to(DEV)).cpu()
+    tref = clo.text_forward(sd, ids)
+    dt = float((nrm(tfeat) - nrm(tref)).abs().max())
+    print(f"[text full] max|delta| normalised embedding = {dt:.2e}")
+    assert dt <= 1e-3
+    sim = nrm(tfeat) @ nrm(feat.cpu()).t()
+    simref = nrm(tref) @ nrm(ref).t()
+    assert float((sim - simref).abs().max()) <= 1e-3
