@@ -1,0 +1,299 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the CenterCLIP retrieval hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): clips/sec (ViT-B/32, 12 frames) - plus token-cluster Mtokens/s and
+pairwise-similarities/s as extra fields.  Workload at N=1 = BASELINE.json configs[1]
+("MSR-VTT-shaped synthetic: ViT-B/32, 12 frames, 3 segments, k=49 medoids, batch 16").
+
+One step = one pass of the hot path over one batch that is already resident in HBM:
+  video [16,1,12,3,224,224] fp32 + ids [16,32]  ->  CLIP4Clip.forward (text tower, ViT with the
+  token-cluster op in block 7)  ->  [N>1: packed RCCL all-gather of the features]  ->
+  get_similarity_logits (this rank's row block of the [G*16, G*16] logits).
+Weak scaling: every rank owns its own 16 clips; value = all ranks' clips / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
+dominant kernel (measured live with HIP events on the launch stream) and `cpu_baseline` (the
+oracle = plain-PyTorch CPU port of the reference path, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0               # HBM3E spec peak
+
+CFG2 = dict(name="cfg2 MSR-VTT-shaped: ViT-B/32 224^2, 12 frames -> 3 segments @block 7, K=49, batch 16, 32 words",
+            B=16, T=12, T_new=3, K=49, cluster_block=7, words=32, patch=32, res=224, width=768, layers=12)
+
+
+def task_config(c):
+    return Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=c["T"],
+                     target_frames_blocks=[c["T"]] * (c["cluster_block"] - 1) + [c["T_new"]] * (13 - c["cluster_block"]),
+                     cluster_num_blocks=[c["K"]] * 12, cluster_distance='euclidean', cluster_threshold=1e-6,
+                     cluster_iter_limit=100, minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None,
+                     pre_norm=False, loose_type=True, sim_header='meanP', linear_patch='2d')
+
+
+def random_state_dict(c, seed):
+    """Random-init weights of the named architecture with CLIP.initialize_parameters statistics
+    (modules/clip.py:419-446), rounded through fp16 as convert_weights does."""
+    from centerclip_amd.clip import CLIP
+    torch.manual_seed(seed)
+    m = CLIP(512, c["res"], c["layers"], c["width"], c["patch"], 77, 49408, 512, 8, 12, video_frames=c["T"], args=None)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.half().float())
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def synthetic_batch(c, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    video = torch.randn(c["B"], 1, c["T"], 3, c["res"], c["res"], generator=g)
+    vmask = torch.ones(c["B"], 1, c["T"], dtype=torch.long)
+    vmask[-1, 0, c["T"] - 2:] = 0                      # one clip with trailing padding frames
+    ids = torch.zeros(c["B"], c["words"], dtype=torch.long)
+    for b in range(c["B"]):
+        ln = int(torch.randint(4, c["words"] + 1, (1,), generator=g))
+        ids[b, 0], ids[b, ln - 1] = 49406, 49407
+        ids[b, 1:ln - 1] = torch.randint(1, 49405, (ln - 2,), generator=g)
+    amask = (ids > 0).long()
+    return [t.to(device) for t in (ids, amask, video, vmask)]
+
+
+def event_time_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/pmc.sh -> profiles/*traffic_pmc.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE);
+    None when no counter pass exists for this kernel."""
+    import glob
+    import re
+    epi = {"c_fc": 1, "in_proj": 0, "c_proj": 2}.get(kernel.split(":")[-1])
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
+    if epi is None or not files:
+        return None
+    data = json.load(open(files[-1]))
+    for name, v in data.items():
+        if re.search(r"gemm_f16_kernel<.*, %d>" % epi, name):
+            return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch_bytes": round(v["fetch_bytes_per_launch"]),
+                    "write_bytes": round(v["write_bytes_per_launch"]), "source": os.path.basename(files[-1])}
+    return None
+
+
+def gemm_roofline(c, device):
+    """Time every distinct GEMM of one step alone (HIP events on the launch stream, back-to-back
+    launches) and return the dominant one.  Algorithmic flops = 2*M*N*K."""
+    from centerclip_amd import ops
+    W, B, T = c["width"], c["B"], c["T"]
+    L0, L1 = 50, c["K"] + 1
+    M0, M1 = B * T * L0, B * c["T_new"] * L1
+    n0, n1 = c["cluster_block"] - 1, 13 - c["cluster_block"]
+    shapes = [("patch_embed", B * T * 49, W, 3 * 32 * 32, "f32", 1),
+              ("in_proj", M0, 3 * W, W, "f16", n0), ("out_proj", M0, W, W, "f32_resid", n0),
+              ("c_fc", M0, 4 * W, W, "f16_gelu", n0), ("c_proj", M0, W, 4 * W, "f32_resid", n0),
+              ("in_proj@clustered", M1, 3 * W, W, "f16", n1), ("out_proj@clustered", M1, W, W, "f32_resid", n1),
+              ("c_fc@clustered", M1, 4 * W, W, "f16_gelu", n1), ("c_proj@clustered", M1, W, 4 * W, "f32_resid", n1)]
+    rows = []
+    for name, M, N, K, epi, calls in shapes:
+        a = torch.randn(M, K, device=device).half()
+        w = (torch.randn(N, K, device=device) * K ** -0.5).half()
+        bias = torch.randn(N, device=device)
+        out = torch.zeros(M, N, device=device, dtype=torch.float16 if epi.startswith("f16") else torch.float32)
+        ms = event_time_ms(lambda: ops.linear_f16(a, w, bias, epi, out=out), 20)
+        flops = 2.0 * M * N * K
+        rows.append(dict(kernel="gemm_f16_kernel:" + name, M=M, N=N, K=K, calls_per_step=calls, avg_us=ms * 1e3,
+                         tflops=flops / ms / 1e9, step_share_us=ms * 1e3 * calls))
+    dom = max(rows, key=lambda r: r["step_share_us"])
+    roof = dict(bound="mfma", kernel=dom["kernel"], achieved=round(dom["tflops"], 1), peak=MFMA_F16_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_F16_PEAK_TFLOPS, 4), traffic=pmc_traffic(dom["kernel"]),
+                avg_launch_us=round(dom["avg_us"], 2), algorithmic_flops_per_launch=2.0 * dom["M"] * dom["N"] * dom["K"])
+    gemm_us = sum(r["step_share_us"] for r in rows)
+    gemm_flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"] for r in rows)
+    return roof, rows, gemm_us, gemm_flops
+
+
+def cluster_bench(c, device):
+    """token-cluster Mtokens/s: the op alone on cfg-2 shaped activations (P=48 problems of 196 tokens)."""
+    from centerclip_amd.cluster import TokenClusterInter
+    B, T, Tn, K, W = c["B"], c["T"], c["T_new"], c["K"], c["width"]
+    x = torch.randn(B * T, 50, W, device=device)
+    mod = TokenClusterInter(before_cluster_num=49, cluster_num=K, before_block_frames=T, after_block_frames=Tn,
+                            original_frame=T, threshold=1e-6, iter_limit=100, split_size=16, norm_p=2.0)
+    ms = event_time_ms(lambda: mod.cluster_frame_major(x), 30)
+    P, N = B * Tn, (T // Tn) * 49
+    tokens = P * N
+    alg_bytes = P * N * W * 4 + P * K * W * 4 + P * K * 8
+    return dict(mtokens_per_s=round(tokens / ms / 1e3, 2), us_per_call=round(ms * 1e3, 1),
+                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
+                              algorithmic_bytes_per_launch=alg_bytes))
+
+
+def similarity_bench(device):
+    """pairwise-similarities/s: 10k texts x 1k videos (3 segments each), pooling + exact-fp32 MFMA NT GEMM."""
+    from centerclip_amd import ops
+    Nt, Nv, Tn, E = 10000, 1000, 3, 512
+    t = torch.randn(Nt, E, device=device)
+    v = torch.randn(Nv, Tn, E, device=device)
+    m = torch.ones(Nv, Tn, dtype=torch.long, device=device)
+    ms = event_time_ms(lambda: ops.loose_similarity(t, v, m, 1.0), 20)
+    flops = 2.0 * Nt * Nv * E
+    return dict(pairs_per_s=round(Nt * Nv / ms * 1e3, 0), us_per_call=round(ms * 1e3, 1),
+                tflops_fp32=round(flops / ms / 1e9, 2), frac_of_fp32_mfma_peak=round(flops / ms / 1e9 / 157.3, 4))
+
+
+def cpu_baseline(c, state_dict):
+    """The reference path restated in plain PyTorch on the host CPU (oracle/, kind 'port'): text tower +
+    ViT with the literal k-medoids + meanP similarity, all cores, on a bounded sample of the same workload."""
+    from oracle import clip_oracle as clo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(cores, 64))
+    used = torch.get_num_threads()
+    plan = {c["cluster_block"] - 1: (c["T_new"], c["K"])}
+
+    def run(nclips, seed):
+        g = torch.Generator().manual_seed(seed)
+        video = torch.randn(nclips * c["T"], 3, c["res"], c["res"], generator=g)
+        ids = torch.randint(1, 49405, (nclips, c["words"]), generator=g)
+        ids[:, 0], ids[:, -1] = 49406, 49407
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            v = clo.visual_forward(state_dict, video, c["T"], cluster_plan=plan).view(nclips, c["T_new"], -1)
+            t = clo.text_forward(state_dict, ids).view(nclips, 1, -1)
+            clo.loose_similarity(t, v, torch.ones(nclips, c["T_new"], dtype=torch.long), float(state_dict["logit_scale"]))
+        return time.perf_counter() - t0
+
+    run(1, 0)                                            # warm-up (thread pools, allocator)
+    t1 = run(1, 1)
+    n = int(max(1, min(c["B"], round(12.0 / max(t1, 1e-3)))))
+    t = run(n, 2)
+    return dict(value=round(n / t, 3), unit="clips/s", cores=used, kind="port",
+                sample="%d clip(s) x 12 frames + %d caption(s) through oracle/clip_oracle.py (fp32, literal k-medoids), "
+                       "%.1f s of CPU work; single clip %.2f s" % (n, n, t, t1))
+
+
+def cpu_baseline_cluster(c):
+    from oracle import cluster_oracle as co
+    X = torch.randn(c["B"] * c["T_new"], (c["T"] // c["T_new"]) * 49, c["width"])
+    co.literal_batch_kmedoids_with_split(X[:16], c["K"], "euclidean", 1e-6, 100, True, 2.0, 16, False)
+    t0 = time.perf_counter()
+    co.literal_batch_kmedoids_with_split(X, c["K"], "euclidean", 1e-6, 100, True, 2.0, 16, False)
+    t = time.perf_counter() - t0
+    return dict(value=round(X.shape[0] * X.shape[1] / t / 1e6, 4), unit="Mtokens/s", cores=torch.get_num_threads(), kind="port",
+                sample="one call on [48,196,768] fp32, %.2f s" % t)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cluster / similarity side measurements")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus or world == 1, "launch N>1 through torch.distributed.run"
+
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd import dist as ccdist, ops
+    c = CFG2
+    sd = random_state_dict(c, seed=0)                    # same weights on every rank
+    model = CLIP4Clip.from_state_dict(dict(sd), task_config(c)).to(device).eval()
+    ids, amask, video, vmask = synthetic_batch(c, device, seed=100 + rank)
+    logit_mult = float(torch.tensor(float(sd["logit_scale"])).exp())
+
+    def step():
+        out = model(ids, torch.zeros_like(ids), amask, video, vmask)
+        seq, vis = out["sequence_output"], out["visual_output"]
+        vm = model.get_video_mask_after_cluster(vmask.view(-1, vmask.shape[-1]))
+        if world > 1:
+            # exchange step: one packed all-gather of (video features, mask), then this rank's row block
+            vis_all, vm_all = ccdist.all_gather(vis, vm)
+            return ops.loose_similarity(seq.squeeze(1), vis_all, vm_all, float(sd["logit_scale"]))
+        return model.get_similarity_logits(seq, vis, amask, vmask)[0]
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            logits = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            logits = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    assert logits.shape == (c["B"], c["B"] * world) and bool(torch.isfinite(logits).all())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        clips = c["B"] * world * a.steps
+        res = {"metric": "clips/sec (ViT-B/32, 12f)", "value": round(clips / elapsed, 2), "unit": "clips/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 MFMA operands, fp32 accumulate/residual/LN/softmax; cluster + similarity fp32",
+               "data": "synthetic (N(0,1) frames, random token ids, random-init weights with CLIP init statistics rounded through fp16)",
+               "config": {"workload": c["name"], "global_batch": c["B"] * world, "parallelism": "dp%d (clips sharded, packed RCCL feature all-gather)" % world if world > 1 else "single GPU"}}
+        if world == 1 and not a.no_extras:
+            with torch.no_grad():
+                roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device)
+                res["roofline"] = roof
+                res["gemm_breakdown"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+                res["gemm_time_share_of_step"] = round(gemm_us / (ms_per_step * 1e3), 3)
+                res["forward_algorithmic_tflops"] = round(gemm_flops * 1.0 / (ms_per_step * 1e-3) / 1e12, 1)
+                res["token_cluster"] = cluster_bench(c, device)
+                res["similarity_10k_x_1k"] = similarity_bench(device)
+        else:
+            res["roofline"] = None
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(c, sd)
+            res["token_cluster_cpu_baseline"] = cpu_baseline_cluster(c)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

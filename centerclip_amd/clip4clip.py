@@ -46,9 +46,21 @@ class CLIP4Clip(nn.Module):
         if self.training:
             raise NotImplementedError("the training branch (loss + DDP) is out of scope; call .eval()")
         output_dict = {'sequence_output': None, 'visual_output': None, 'loss': None}
+        side = None
         if input_ids is not None:
             input_ids = input_ids.view(-1, input_ids.shape[-1])
-            output_dict['sequence_output'] = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
+            if video is not None and input_ids.is_cuda:
+                # the two towers are independent: the (launch-latency bound) text tower runs on a side
+                # stream underneath the visual tower instead of in front of it
+                cur = torch.cuda.current_stream(input_ids.device)
+                side = self._side_stream(input_ids.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    seq = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
+                seq.record_stream(cur)
+                output_dict['sequence_output'] = seq
+            else:
+                output_dict['sequence_output'] = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
         if video is not None:
             video = torch.as_tensor(video).float()
             b, pair, video_frame, channel, h, w = video.shape
@@ -60,7 +72,24 @@ class CLIP4Clip(nn.Module):
             if self.pre_visual_pooling:
                 visual_output = ops.video_pool_normalize(visual_output, video_mask)
             output_dict['visual_output'] = visual_output
+        if side is not None:
+            torch.cuda.current_stream(input_ids.device).wait_stream(side)
         return output_dict
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st
+
+    def _logit_scale_value(self):
+        """Python float of clip.logit_scale, cached per parameter version (no device->host sync per call)."""
+        p = self.clip.logit_scale
+        key = (p.data_ptr(), p._version)
+        if getattr(self, "_ls_key", None) != key:
+            self._ls_key, self._ls_val = key, float(p.detach())
+        return self._ls_val
 
     def get_sequence_output(self, input_ids, token_type_ids=None, attention_mask=None):
         """-> [bs_pair, 1, D] fp32   (clip4clip.py:265-272)"""
@@ -89,7 +118,7 @@ class CLIP4Clip(nn.Module):
         if gather:
             visual_output, video_mask, sequence_output = all_gather(visual_output, video_mask, sequence_output)
         text = sequence_output.squeeze(1)
-        scale = float(self.clip.logit_scale.detach())
+        scale = self._logit_scale_value()
         if visual_output.ndim == 2:      # already pooled + normalised (pre_visual_pooling)
             L.require_device(text)
             tn = ops.scaled_dot_nt(text / text.norm(dim=-1, keepdim=True), visual_output, mult=float(torch.tensor(scale).exp()))

@@ -12,7 +12,7 @@
         if (e__ != hipSuccess) return CC_ERR_HIP;           \
     } while (0)
 
-static inline size_t cc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ static inline size_t cc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- order-preserving float <-> int key (for atomicMax on floats of either sign) -------
 __device__ __forceinline__ int cc_float_to_ordered_int(float f) {

@@ -289,30 +289,52 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 }
 
 // ============================================================================ K2
-// One 256-thread workgroup per problem.  LDS carve (dynamic):
-//   [IN_LDS: D N*N f32] rowsum N f32 | med K i32 | cnt K i32 | start (K+1) i32 |
-//   asg N u16 | tmp N u16 | memb N u16
+// One 256-thread workgroup per problem; the whole selection (KKZ init, assignment / update
+// iterations, ascending sort, final assignment) runs inside it with no host round trip.
+// Everything here is latency-bound dependent work on a 38-346 K-entry matrix, so the kernel is
+// organised to keep >= 4-8 independent LDS/L2 loads in flight per lane and to avoid LDS
+// crossbar shuffles on the critical path (wave arg-max = 4 DPP steps + readlane, ties resolved
+// to the lowest index with ballots).  Cluster membership is kept as per-cluster bit masks
+// (ballot over 64 consecutive tokens): walking the set bits yields each cluster's members in
+// ascending index order, which is the summation order of the update step.
+//
+// LDS carve (dynamic): [IN_LDS: D N*N f32] rowsum N f32 | med K i32 | cmask K*E u64 | asg N u16
 #define SEL_MAX_E 10   /* N <= 640 */
+
+// debug hook (not part of the public ABI): per-problem phase timestamps of K2
+__device__ long long* g_sel_prof = nullptr;
+#define SEL_STAMP(slot)                                                      \
+    do {                                                                     \
+        if (prof && tid == 0) prof[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
 
 struct SelSmem {
     float* D;
     float* rowsum;
     int* med;
-    int* cnt;
-    int* start;
+    unsigned long long* cmask;
     unsigned short* asg;
-    unsigned short* tmp;
-    unsigned short* memb;
 };
 
 static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
+    const int E = (N + 63) / 64;
     size_t b = 0;
-    if (in_lds) b += (size_t)N * N * 4;
-    b += (size_t)N * 4;                 // rowsum
-    b += (size_t)K * 4 * 2 + (size_t)(K + 1) * 4;
-    b = cc_align_up(b, 4);
-    b += (size_t)N * 2 * 3;
+    if (in_lds) b += cc_align_up((size_t)N * N * 4, 8);
+    b += cc_align_up((size_t)N * 4, 8);
+    b += cc_align_up((size_t)K * 4, 8);
+    b += (size_t)K * E * 8;
+    b += (size_t)N * 2;
     return cc_align_up(b, 16);
+}
+
+__device__ __forceinline__ unsigned cc_wave_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
 }
 
 template <bool IN_LDS>
@@ -324,177 +346,202 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
                                                               long long* __restrict__ assign_out,
                                                               int* __restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int E = (N + 63) >> 6;
     SelSmem s;
     {
         unsigned char* q = smem_raw;
         s.D = reinterpret_cast<float*>(q);
-        if (IN_LDS) q += (size_t)N * N * 4;
-        s.rowsum = reinterpret_cast<float*>(q); q += (size_t)N * 4;
-        s.med = reinterpret_cast<int*>(q); q += (size_t)K * 4;
-        s.cnt = reinterpret_cast<int*>(q); q += (size_t)K * 4;
-        s.start = reinterpret_cast<int*>(q); q += (size_t)(K + 1) * 4;
-        s.asg = reinterpret_cast<unsigned short*>(q); q += (size_t)N * 2;
-        s.tmp = reinterpret_cast<unsigned short*>(q); q += (size_t)N * 2;
-        s.memb = reinterpret_cast<unsigned short*>(q);
+        if (IN_LDS) q += cc_align_up((size_t)N * N * 4, 8);
+        s.rowsum = reinterpret_cast<float*>(q); q += cc_align_up((size_t)N * 4, 8);
+        s.med = reinterpret_cast<int*>(q); q += cc_align_up((size_t)K * 4, 8);
+        s.cmask = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * E * 8;
+        s.asg = reinterpret_cast<unsigned short*>(q);
     }
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)p * N * N;
     const float* Dg = dist_in + base;
+    long long* prof = g_sel_prof;
+    SEL_STAMP(0);
 
-    // ---- stage D: apply (d - chunk_max) - 1, diagonal - 1 (cluster_utils.py:35-41)
-    {
+    // ---- stage D: (d - chunk_max) - 1, then the diagonal - 1 (cluster_utils.py:35-41); 8 loads in flight
+    if (IN_LDS || apply_shift) {
         const float mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
-        if (IN_LDS || apply_shift) {
-            float* dstg = dist_rw + base;
-            for (int i = wave; i < N; i += 4) {
-                for (int j = lane; j < N; j += 64) {
-                    float v = Dg[(int64_t)i * N + j];
-                    if (apply_shift) {
-                        v = (v - mx) - 1.0f;
-                        if (i == j) v -= 1.0f;
-                    }
-                    if (IN_LDS) s.D[i * N + j] = v;
-                    else dstg[(int64_t)i * N + j] = v;
-                }
+        float* dst = IN_LDS ? s.D : (dist_rw + base);
+        const int total = N * N;
+        for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                v[u] = idx < total ? Dg[idx] : 0.f;
             }
-            if (!IN_LDS) Dg = dstg;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                if (idx < total) dst[idx] = apply_shift ? (v[u] - mx) - 1.0f : v[u];
+            }
         }
+        if (!IN_LDS) Dg = dist_rw + base;
         __threadfence_block();
+        __syncthreads();
+        if (apply_shift) {
+            float* dd = IN_LDS ? s.D : (dist_rw + base);
+            for (int i = tid; i < N; i += 256) dd[(int64_t)i * N + i] -= 1.0f;
+            __threadfence_block();
+        }
         __syncthreads();
     }
 #define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : Dg[(int64_t)(i) * N + (j)])
+    SEL_STAMP(1);
 
-    // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118), running minimum in registers
+    // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118).  The running minimum lives in registers as
+    // order-preserving uint keys; arg-max = DPP max + ballots (lowest index wins ties).
     if (wave == 0) {
-        const int E = (N + 63) >> 6;
-        float nearest[SEL_MAX_E];
-        unsigned long long key = 0ull;
+        unsigned nearest[SEL_MAX_E];
         const float* nr = norms + (int64_t)p * N;
+        auto argmax_keys = [&]() -> int {
+            unsigned loc = 0u;
+#pragma unroll
+            for (int e = 0; e < SEL_MAX_E; ++e)
+                if (e < E) loc = max(loc, nearest[e]);
+            const unsigned mx = cc_wave_umax(loc);
+            int found = 0;
+            bool done = false;
+#pragma unroll
+            for (int e = 0; e < SEL_MAX_E; ++e) {
+                if (e < E && !done) {
+                    const unsigned long long b = __ballot(nearest[e] == mx);
+                    if (b) { found = 64 * e + (__ffsll((long long)b) - 1); done = true; }
+                }
+            }
+            return found;
+        };
 #pragma unroll
         for (int e = 0; e < SEL_MAX_E; ++e) {
             const int n = lane + 64 * e;
-            if (e < E && n < N) {
-                const unsigned long long k2 =
-                    ((unsigned long long)cc_float_to_ordered_uint(nr[n]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)n);
-                key = k2 > key ? k2 : key;
-            }
+            nearest[e] = (e < E && n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
         }
-        key = cc_wave_max_u64(key);
-        int m = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        int m = argmax_keys();
         if (lane == 0) s.med[0] = m;
 #pragma unroll
         for (int e = 0; e < SEL_MAX_E; ++e) {
             const int n = lane + 64 * e;
-            nearest[e] = (e < E && n < N) ? DREAD(m, n) : 0.f;
+            nearest[e] = (e < E && n < N) ? cc_float_to_ordered_uint(DREAD(m, n)) : 0u;
         }
         for (int i = 1; i < K; ++i) {
-            key = 0ull;
-#pragma unroll
-            for (int e = 0; e < SEL_MAX_E; ++e) {
-                const int n = lane + 64 * e;
-                if (e < E && n < N) {
-                    const unsigned long long k2 = ((unsigned long long)cc_float_to_ordered_uint(nearest[e]) << 32) |
-                                                  (unsigned)(0xFFFFFFFFu - (unsigned)n);
-                    key = k2 > key ? k2 : key;
-                }
-            }
-            key = cc_wave_max_u64(key);
-            m = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            m = argmax_keys();
             if (lane == 0) s.med[i] = m;
 #pragma unroll
             for (int e = 0; e < SEL_MAX_E; ++e) {
                 const int n = lane + 64 * e;
-                if (e < E && n < N) nearest[e] = fminf(nearest[e], DREAD(m, n));
+                if (e < E && n < N) nearest[e] = min(nearest[e], cc_float_to_ordered_uint(DREAD(m, n)));
             }
         }
     }
     __syncthreads();
+    SEL_STAMP(2);
 
-    auto assign_step = [&]() {      // fast_kmeans.py:75-76: a_n = first argmin_k D[m_k, n]
-        for (int n = tid; n < N; n += 256) {
-            float best = DREAD(s.med[0], n);
+    // a_n = first argmin_k D[m_k, n]  (fast_kmeans.py:75-76); 8 medoid rows in flight per lane
+    auto assign_step = [&](bool build_masks) {
+        for (int e = 0; e < 3; ++e) {
+            const int n = tid + 256 * e;
+            if (e * 256 >= N) break;                                 // uniform
+            const int nn = min(n, N - 1);
+            float best = DREAD(s.med[0], nn);
             int a = 0;
-            for (int k = 1; k < K; ++k) {
-                const float v = DREAD(s.med[k], n);
+            int k = 1;
+            for (; k + 8 <= K; k += 8) {
+                int mk[8];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mk[u] = s.med[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = DREAD(mk[u], nn);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (v[u] < best) { best = v[u]; a = k + u; }
+            }
+            for (; k < K; ++k) {
+                const float v = DREAD(s.med[k], nn);
                 if (v < best) { best = v; a = k; }
             }
-            s.asg[n] = (unsigned short)a;
+            if (n < N) s.asg[n] = (unsigned short)a;
+            if (build_masks) {
+                // membership bit masks: word w = n / 64 of cluster k  <-  ballot(a == k) over this wave's 64 tokens
+                const int w = (wave + 4 * e);
+                if (w < E) {
+                    const int av = (n < N) ? a : -1;
+                    for (int kb = 0; kb < K; kb += 64) {
+                        unsigned long long mine = 0ull;
+                        const int kend = min(64, K - kb);
+                        for (int kk = 0; kk < kend; ++kk) {
+                            const unsigned long long b = __ballot(av == kb + kk);
+                            if (lane == kk) mine = b;
+                        }
+                        if (lane < kend) s.cmask[(size_t)(kb + lane) * E + w] = mine;
+                    }
+                }
+            }
         }
     };
 
     int iters = 0;
     for (int it = 0; it < iter_limit; ++it) {
-        assign_step();
-        for (int k = tid; k < K; k += 256) s.cnt[k] = 0;
+        assign_step(true);
         __syncthreads();
-        int slot[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int n = tid + 256 * e;
-            slot[e] = (n < N) ? atomicAdd(&s.cnt[s.asg[n]], 1) : 0;
-        }
-        __syncthreads();
-        if (wave == 0) {            // exclusive prefix sum of cnt -> start
-            const int c = (K + 63) >> 6;
-            int loc = 0;
-            for (int q = 0; q < c; ++q) {
-                const int k = lane * c + q;
-                loc += (k < K) ? s.cnt[k] : 0;
-            }
-            int inc = loc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int tv = __shfl_up(inc, o, CC_WAVE);
-                if (lane >= o) inc += tv;
-            }
-            int run = inc - loc;
-            for (int q = 0; q < c; ++q) {
-                const int k = lane * c + q;
-                if (k < K) { s.start[k] = run; run += s.cnt[k]; }
-            }
-            if (lane == 63) s.start[K] = inc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int n = tid + 256 * e;
-            if (n < N) s.tmp[s.start[s.asg[n]] + slot[e]] = (unsigned short)n;
-        }
-        __syncthreads();
-        for (int n = tid; n < N; n += 256) {   // stable rank -> ascending member lists
-            const int a = s.asg[n], s0 = s.start[a], c = s.cnt[a];
-            int r = 0;
-            for (int q = 0; q < c; ++q) r += (s.tmp[s0 + q] < n) ? 1 : 0;
-            s.memb[s0 + r] = (unsigned short)n;
-        }
-        __syncthreads();
-        for (int i = tid; i < N; i += 256) {   // s_i = sum_{j in cluster(i), ascending} D[i,j]
-            const int a = s.asg[i], s0 = s.start[a], c = s.cnt[a];
+        // s_i = sum_{j in cluster(i), ascending j} D[i,j]  (fast_kmeans.py:81, equivalence 2); 4 loads in flight
+        for (int i = tid; i < N; i += 256) {
+            const unsigned long long* cm = s.cmask + (size_t)s.asg[i] * E;
             float sum = 0.f;
-            for (int q = 0; q < c; ++q) sum += DREAD(i, s.memb[s0 + q]);
+            for (int w = 0; w < E; ++w) {
+                unsigned long long m = cm[w];
+                while (m) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = m != 0ull;
+                        const int j = 64 * w + (ok ? (__ffsll((long long)m) - 1) : 0);
+                        m &= m - 1ull;
+                        v[u] = ok ? DREAD(i, j) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum += v[u];
+                }
+            }
             s.rowsum[i] = sum;
         }
         __syncthreads();
         int changed = 0;
-        for (int k = tid; k < K; k += 256) {   // fast_kmeans.py:82 argmin, lowest index on ties
-            const int s0 = s.start[k], c = s.cnt[k];
+        for (int k = tid; k < K; k += 256) {   // fast_kmeans.py:82: argmin of the row sums, lowest index on ties
+            const unsigned long long* cm = s.cmask + (size_t)k * E;
             int bi = 0;
-            if (c > 0) {
-                bi = s.memb[s0];
-                float best = s.rowsum[bi];
-                for (int q = 1; q < c; ++q) {
-                    const int i = s.memb[s0 + q];
-                    const float v = s.rowsum[i];
-                    if (v < best) { best = v; bi = i; }
+            float best = 0.f;
+            bool have = false;
+            for (int w = 0; w < E; ++w) {
+                unsigned long long m = cm[w];
+                while (m) {
+                    float v[4];
+                    int idx[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = m != 0ull;
+                        idx[u] = ok ? 64 * w + (__ffsll((long long)m) - 1) : -1;
+                        m &= m - 1ull;
+                        v[u] = ok ? s.rowsum[idx[u]] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (idx[u] >= 0 && (!have || v[u] < best)) { best = v[u]; bi = idx[u]; have = true; }
                 }
             }
             changed |= (bi != s.med[k]);
-            s.med[k] = bi;
+            s.med[k] = bi;                      // empty cluster -> 0, as argmin over an all-zero row
         }
         ++iters;
         if (!__syncthreads_or(changed)) break;
     }
+    SEL_STAMP(3);
 
     if (id_sort) {                              // fast_kmeans.py:90-94
         int mine[3], rank[3];
@@ -517,13 +564,15 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         for (int e = 0; e < 3; ++e)
             if (tid + 256 * e < K) s.med[rank[e]] = mine[e];
         __syncthreads();
-        assign_step();
+        if (assign_out) assign_step(false);
         __syncthreads();
     }
     for (int k = tid; k < K; k += 256) medoids_out[(int64_t)p * K + k] = s.med[k];
     if (assign_out)
         for (int n = tid; n < N; n += 256) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
     if (iters_out && tid == 0) iters_out[p] = iters;
+    SEL_STAMP(4);
+    if (prof && tid == 0) prof[(int64_t)blockIdx.x * 16 + 5] = iters;
 #undef DREAD
 }
 
@@ -674,6 +723,10 @@ bool p_supported(int metric, float p) { return metric == CC_METRIC_COSINE || (p 
 }  // namespace
 
 extern "C" {
+
+int cc_debug_set_select_profile(long long* buf) {   // debug only; buf [P,16] int64 device memory or NULL
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), &buf, sizeof(buf)) == hipSuccess ? CC_OK : CC_ERR_HIP;
+}
 
 size_t cc_cluster_workspace_bytes(int32_t P, int32_t N, int32_t W, int32_t pre_norm) {
     if (P <= 0 || N <= 0 || W <= 0) return 0;

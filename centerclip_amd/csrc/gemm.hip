@@ -27,15 +27,19 @@ __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ float quick_gelu(float x) {      // modules/clip.py:192-194
-    return x / (1.0f + __expf(-1.702f * x));
+__device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702 x), modules/clip.py:192-194
+    // 5 VALU ops (v_exp_f32 + v_rcp_f32, ~1 ulp each): the epilogue of a 128x128 tile evaluates this
+    // 64 times per lane, an IEEE divide + expf here costs more than the tile's MFMA work.
+    const float e = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
-    constexpr int MI = BM / 32, NI = BN / 32;            // 16x16 fragments per wave (wave tile BM/2 x BN/2)
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs g) {
+    constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * (A_BYTES + B_BYTES)
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
     // tiles (tn fastest) so tiles sharing an A panel hit the same L2.
@@ -45,33 +49,41 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    // grouped rasterisation inside the XCD's run: the ~64 tiles an XCD has in flight form an
+    // 8-row x 8-column patch, so both operand panels (8 A row-tiles + 8 W column-tiles) stay in its
+    // 4 MiB L2 instead of streaming the whole weight matrix past it for every row of tiles.
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int in_group = bid - group * per_group;
+    const int tm = first_m + in_group % gsz, tn = in_group / gsz;
     const int row0 = tm * BM, col0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     // ---- staging addresses: LDS chunk idx -> (row r, chunk position cp); source chunk = cp ^ (r & 7)
-    constexpr int A_LOADS = BM * 8 / 256, B_LOADS = BN * 8 / 256;
+    constexpr int A_LOADS = BM * 8 / THREADS, B_LOADS = BN * 8 / THREADS;
     const _Float16* asrc[A_LOADS];
     const _Float16* bsrc[B_LOADS];
 #pragma unroll
     for (int q = 0; q < A_LOADS; ++q) {
-        const int idx = (q * 4 + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
+        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
         asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8;
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
-        const int idx = (q * 4 + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
+        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
         bsrc[q] = g.W + (int64_t)(col0 + r) * g.K + c * 8;
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
         _Float16* lb = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES) + A_BYTES);
 #pragma unroll
-        for (int q = 0; q < A_LOADS; ++q) glds16(asrc[q] + kt * GEMM_BK, la + (q * 4 + wave) * 512);
+        for (int q = 0; q < A_LOADS; ++q) glds16(asrc[q] + kt * GEMM_BK, la + (q * NWAVES + wave) * 512);
 #pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) glds16(bsrc[q] + kt * GEMM_BK, lb + (q * 4 + wave) * 512);
+        for (int q = 0; q < B_LOADS; ++q) glds16(bsrc[q] + kt * GEMM_BK, lb + (q * NWAVES + wave) * 512);
     };
 
     f32x4 acc[MI][NI];
@@ -94,12 +106,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             h8 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int r = wr * (BM / 2) + i * 16 + l15;
+                const int r = wr * (BM / WM) + i * 16 + l15;
                 af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int r = wc * (BN / 2) + j * 16 + l15;
+                const int r = wc * (BN / WN) + j * 16 + l15;
                 bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
             }
 #pragma unroll
@@ -114,11 +126,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     // ---- epilogue: lane holds C[m = .. + l15][n = .. + lg*4 + 0..3]
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = row0 + wr * (BM / 2) + i * 16 + l15;
+        const int m = row0 + wr * (BM / WM) + i * 16 + l15;
         if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = col0 + wc * (BN / 2) + j * 16 + lg * 4;
+            const int n = col0 + wc * (BN / WN) + j * 16 + lg * 4;
             f32x4 v = acc[i][j];
             if (g.bias) {
                 const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
@@ -153,42 +165,66 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 
 namespace {
 
-template <int BM, int BN>
-int launch_tile(GemmArgs g, int epi, hipStream_t st) {
-    g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = g.N / BN;
-    dim3 grid(g.tiles_m * g.tiles_n), block(256);
-    switch (epi) {
-        case EPI_F16: hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI_F16>), grid, block, 0, st, g); break;
-        case EPI_F16_GELU: hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI_F16_GELU>), grid, block, 0, st, g); break;
-        case EPI_F32_RESID: hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI_F32_RESID>), grid, block, 0, st, g); break;
-        case EPI_F32_PATCH: hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI_F32_PATCH>), grid, block, 0, st, g); break;
-        case EPI_F32: hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI_F32>), grid, block, 0, st, g); break;
-        default: return CC_ERR_INVALID;
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_one(const GemmArgs& g, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(BM + BN) * GEMM_BK * 2;
+    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI>;
+    if (smem > 64 * 1024) {
+        static bool configured = false;      // per instantiation; benign race (idempotent call)
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem) != hipSuccess)
+                return CC_ERR_HIP;
+            configured = true;
+        }
     }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), smem, st, g);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_tile(GemmArgs g, int epi, hipStream_t st) {
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = g.N / BN;
+    switch (epi) {
+        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16>(g, st);
+        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(g, st);
+        case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID>(g, st);
+        case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH>(g, st);
+        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(g, st);
+        default: return CC_ERR_INVALID;
+    }
+}
+
 }  // namespace
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128 (8 waves)
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % GEMM_BK) || (g.N % 64)) return CC_ERR_INVALID;
     if (tile == 0) {
-        // fill >= ~2 tiles per CU when possible; otherwise shrink the tile for parallelism
-        const long t128 = (long)((g.M + 127) / 128) * (g.N / 128);
-        const long t12864 = (long)((g.M + 127) / 128) * (g.N / 64);
-        if ((g.N % 128) == 0 && t128 >= 512) tile = 1;
-        else if (t12864 >= 512) tile = 2;
+        // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
+        // >= ~1.5 workgroups per CU; below that trade tile efficiency for parallelism.
+        const long mt128 = (g.M + 127) / 128, mt64 = (g.M + 63) / 64;
+        const bool n128 = (g.N % 128) == 0;
+        const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
+        // 256x256 (one 8-wave workgroup per CU) halves the L2->LDS bytes per flop; it only pays when the
+        // tile count fills whole rounds of the 256 CUs
+        if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.85) tile = 5;
+        else if (n128 && mt128 * (g.N / 128) >= 400) tile = 1;
+        else if (n128 && mt64 * (g.N / 128) >= 400) tile = 3;
+        else if (mt128 * (g.N / 64) >= 400) tile = 2;
         else tile = 4;
     }
-    if ((tile == 1 || tile == 3) && (g.N % 128)) return CC_ERR_INVALID;
+    if ((tile == 1 || tile == 3 || tile == 6) && (g.N % 128)) return CC_ERR_INVALID;
+    if (tile == 5 && (g.N % 256)) return CC_ERR_INVALID;
     switch (tile) {
-        case 1: return launch_tile<128, 128>(g, epi, st);
-        case 2: return launch_tile<128, 64>(g, epi, st);
-        case 3: return launch_tile<64, 128>(g, epi, st);
-        case 4: return launch_tile<64, 64>(g, epi, st);
+        case 1: return launch_tile<128, 128, 2, 2>(g, epi, st);
+        case 2: return launch_tile<128, 64, 2, 2>(g, epi, st);
+        case 3: return launch_tile<64, 128, 2, 2>(g, epi, st);
+        case 4: return launch_tile<64, 64, 2, 2>(g, epi, st);
+        case 5: return launch_tile<256, 256, 2, 4>(g, epi, st);
+        case 6: return launch_tile<256, 128, 4, 2>(g, epi, st);
         default: return CC_ERR_INVALID;
     }
 }

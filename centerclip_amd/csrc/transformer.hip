@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long long* __rest
     }
 }
 
-// out[r][:] = LN(h[row_of(r)]) @ proj[W, E]   (fp32 throughout; r < R rows, one workgroup each)
+// out[r][e0:e0+64] = LN(h[row_of(r)]) @ proj[W, E]   (fp32 throughout).  grid = (E/64, R): every
+// workgroup re-normalises its row (W floats, cheap) and produces 64 outputs; the 256 threads are
+// 4 k-slices x 64 outputs, proj reads are coalesced over the output index.
 //   row_of(r) = r*row_mul + (row_idx ? row_idx[r] : 0)
 __global__ __launch_bounds__(256) void head_project_kernel(const float* __restrict__ h, int row_mul,
                                                            const int* __restrict__ row_idx,
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
                                                            int W, int E, float eps) {
     __shared__ float xn[1024];
     __shared__ float red[8];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float part[4][64];
+    const int r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = h + ((int64_t)r * row_mul + (row_idx ? row_idx[r] : 0)) * W;
     float s = 0.f;
     for (int w = tid; w < W; w += 256) { const float v = src[w]; xn[w] = v; s += v; }
@@ -277,11 +280,24 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + eps);
     for (int w = tid; w < W; w += 256) xn[w] = (xn[w] - mean) * rstd * gamma[w] + beta[w];
     __syncthreads();
-    for (int e = tid; e < E; e += 256) {
-        float acc = 0.f;
-        for (int w = 0; w < W; ++w) acc = fmaf(xn[w], proj[(int64_t)w * E + e], acc);
-        out[(int64_t)r * E + e] = acc;
+    const int e = blockIdx.x * 64 + lane;
+    const int wq = (W + 3) / 4, w0 = wave * wq, w1 = min(W, w0 + wq);
+    float acc = 0.f;
+    if (e < E) {
+        const float* pp = proj + e;
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {            // 8 independent loads in flight per lane
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = pp[(int64_t)(w + u) * E];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(xn[w + u], pv[u], acc);
+        }
+        for (; w < w1; ++w) acc = fmaf(xn[w], pp[(int64_t)w * E], acc);
     }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && e < E) out[(int64_t)r * E + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // ============================================================================ C ABI (single ops)
@@ -350,7 +366,7 @@ int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float
 int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, const float* gamma, const float* beta,
                            const float* proj, float* out, int R, int W, int E, hipStream_t st) {
     if (W > 1024) return CC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(head_project_kernel, dim3(R), dim3(256), 0, st, h, row_mul, row_idx, gamma, beta, proj, out, W, E, 1e-5f);
+    hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, R), dim3(256), 0, st, h, row_mul, row_idx, gamma, beta, proj, out, W, E, 1e-5f);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

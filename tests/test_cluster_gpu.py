@@ -212,3 +212,22 @@ def test_fixed_point_idempotence(cl):
             mem = np.nonzero(an[p] == k)[0]
             sums = np.array([np.float32(sum(np.float32(Dn[p, i, j]) for j in mem)) for i in mem])
             assert mem[int(np.argmin(sums))] == mn[p, k]
+
+
+def test_pre_norm_equals_clustering_the_normalised_tokens(cl):
+    """pre_norm=True == clustering X / (|X| + 1e-6) (fast_kmeans.py:21-22), checked with the library's own
+    token norms so both runs see bit-identical inputs."""
+    import ctypes
+    from centerclip_amd import _lib as L
+    X = dev(np.random.default_rng(9).standard_normal((5, 60, 64)).astype(np.float32))
+    P, N, W = X.shape
+    lay = L.TokenLayout(P, 1, 1, N, N * W, 0, 0, W)
+    norms = torch.empty(P, N, device=DEV)
+    ws = L.workspace(L.lib().cc_cluster_workspace_bytes(P, N, W, 1), X.device)
+    L.check(L.lib().cc_token_norms_f32(L.ptr(X), ctypes.byref(lay), W, L.ptr(norms), L.ptr(ws), ws.numel(),
+                                       L.stream_ptr(X.device)), "norms")
+    np.testing.assert_allclose(norms.cpu().numpy(), torch.norm(X, dim=-1).cpu().numpy(), rtol=2e-6)
+    Xn = X / (norms.unsqueeze(-1) + 1e-6)
+    a1, m1 = cl.batch_fast_kmedoids_with_split(X, 9, split_size=2, pre_norm=True, iter_limit=100)
+    a2, m2 = cl.batch_fast_kmedoids_with_split(Xn, 9, split_size=2, pre_norm=False, iter_limit=100)
+    assert torch.equal(m1, m2) and torch.equal(a1, a2)
