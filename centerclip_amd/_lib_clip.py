@@ -47,6 +47,10 @@ def declare(lib):
     lib.cc_text_workspace_bytes.restype = sz
     lib.cc_text_workspace_bytes.argtypes = [c.POINTER(TextModel), i32, i32]
     lib.cc_text_encode.argtypes = [c.POINTER(TextModel), vp, i32, i32, vp, vp, sz, vp]
+    lib.cc_clip_workspace_bytes.restype = sz
+    lib.cc_clip_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32, c.POINTER(TextModel), i32, i32]
+    lib.cc_clip_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, c.POINTER(TextModel), vp, i32, i32, vp, vp, sz, vp]
+    lib.cc_clip_encode.restype = c.c_int
     lib.cc_similarity_workspace_bytes.restype = sz
     lib.cc_similarity_workspace_bytes.argtypes = [i32, i32, i32]
     lib.cc_video_pool_normalize_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp]

@@ -269,6 +269,30 @@ class CLIP(nn.Module):
         pk.struct = m
         return m
 
+    def encode_pair(self, image, text, video_frame=-1):
+        """encode_image + encode_text of one CLIP4Clip.forward call in a single enqueue (cc_clip_encode):
+        block i of the text tower shares its launches with block i of the ViT.
+        -> (image features [N', embed_dim], text features [B, embed_dim])"""
+        L.require_device(image, text)
+        vis = self.visual
+        x = image.float().contiguous()
+        ids = text.to(torch.long).contiguous()
+        T = video_frame if video_frame and video_frame > 0 else 1
+        if not any(b.tokencluster_inter is not None for b in vis.transformer.resblocks):
+            T = 1
+        B = x.shape[0] // T
+        Bt, Lt = ids.shape
+        vm, tm = vis._model(), self._text_model()
+        frames, _ = vis.final_shape(T)
+        lib = L.lib()
+        vfeat = torch.empty(B * frames, self.embed_dim, device=x.device, dtype=torch.float32)
+        tfeat = torch.empty(Bt, self.embed_dim, device=x.device, dtype=torch.float32)
+        ws = L.workspace(lib.cc_clip_workspace_bytes(ctypes.byref(vm), B, T, ctypes.byref(tm), Bt, Lt), x.device)
+        L.check(lib.cc_clip_encode(ctypes.byref(vm), L.ptr(x), B, T, L.ptr(vfeat), None, ctypes.byref(tm), L.ptr(ids),
+                                   Bt, Lt, L.ptr(tfeat), L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
+                "cc_clip_encode")
+        return vfeat, tfeat
+
     def encode_text(self, text, return_hidden=False):
         """ids [B, n_ctx] -> [B, embed_dim]: EOT row of ln_final(x) @ text_projection (clip.py:471-496)."""
         if return_hidden:

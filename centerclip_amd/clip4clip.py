@@ -46,21 +46,8 @@ class CLIP4Clip(nn.Module):
         if self.training:
             raise NotImplementedError("the training branch (loss + DDP) is out of scope; call .eval()")
         output_dict = {'sequence_output': None, 'visual_output': None, 'loss': None}
-        side = None
         if input_ids is not None:
             input_ids = input_ids.view(-1, input_ids.shape[-1])
-            if video is not None and input_ids.is_cuda:
-                # the two towers are independent: the (launch-latency bound) text tower runs on a side
-                # stream underneath the visual tower instead of in front of it
-                cur = torch.cuda.current_stream(input_ids.device)
-                side = self._side_stream(input_ids.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    seq = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
-                seq.record_stream(cur)
-                output_dict['sequence_output'] = seq
-            else:
-                output_dict['sequence_output'] = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
         if video is not None:
             video = torch.as_tensor(video).float()
             b, pair, video_frame, channel, h, w = video.shape
@@ -68,20 +55,20 @@ class CLIP4Clip(nn.Module):
             video_mask = video_mask.view(-1, video_mask.shape[-1])
             if self.cluster_inter or self.deep_cluster:
                 video_mask = self.get_video_mask_after_cluster(video_mask)
+        if input_ids is not None and video is not None:
+            # both towers in one enqueue: the text tower's blocks share their launches with the ViT's
+            vfeat, tfeat = self.clip.encode_pair(video, input_ids, video_frame=video_frame)
+            output_dict['sequence_output'] = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
+            visual_output = vfeat.view(video_mask.size(0), -1, vfeat.size(-1))
+        elif input_ids is not None:
+            output_dict['sequence_output'] = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
+        elif video is not None:
             visual_output, _ = self.get_visual_output(video, video_mask, video_frame=video_frame)
+        if video is not None:
             if self.pre_visual_pooling:
                 visual_output = ops.video_pool_normalize(visual_output, video_mask)
             output_dict['visual_output'] = visual_output
-        if side is not None:
-            torch.cuda.current_stream(input_ids.device).wait_stream(side)
         return output_dict
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            self._side = st
-        return st
 
     def _logit_scale_value(self):
         """Python float of clip.logit_scale, cached per parameter version (no device->host sync per call)."""

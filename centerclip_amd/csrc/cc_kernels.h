@@ -15,7 +15,26 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
+// Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
+// visual and the text tower: the small text problem rides in the tail round of the large one).
+struct GemmPair {
+    GemmArgs p[2];
+    int tiles0;          // workgroups [0, tiles0) -> p[0], the rest -> p[1]
+};
+
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st);
+int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st);
+
+struct LnArgs {
+    const float* in; int64_t in_stride; const float* gamma; const float* beta; void* out; int64_t out_stride;
+    int rows, W;
+};
+int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_f16, hipStream_t st);
+
+struct AttArgs {
+    const _Float16* qkv; _Float16* out; int nseq, L, heads, W, causal;
+};
+int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
 int cc_launch_im2col(const float* video, _Float16* A, int F, int res, int p, hipStream_t st);
 int cc_launch_cls_pos(float* h, const float* cls, const float* pos, int F, int Ltok, int W, hipStream_t st);

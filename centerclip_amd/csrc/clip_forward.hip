@@ -67,25 +67,190 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
     return v;
 }
 
-int run_block(const cc_block_weights& w, float* h, _Float16* xn, _Float16* qkv, _Float16* att, _Float16* u, int nseq,
-              int L, int W, int heads, int causal, hipStream_t st) {
-    const int M = nseq * L;
+struct BlockCtx {          // one tower's activations for the current block
+    float* h;
+    _Float16* xn;
+    _Float16* qkv;
+    _Float16* att;
+    _Float16* u;
+    int nseq, L, W, heads, causal;
+};
+
+// One ResidualAttentionBlock for up to two towers at once (modules/clip.py:240,251).  Every phase is
+// ONE launch covering both problems: the text tower (M = 16*32 rows, launch-latency bound on its own:
+// 86 kernels of a few microseconds) rides inside the visual tower's launches and fills their tail round.
+int run_block_pair(const cc_block_weights* w0, const BlockCtx* c0, const cc_block_weights* w1, const BlockCtx* c1,
+                   hipStream_t st) {
+    if (!w0) { w0 = w1; c0 = c1; w1 = nullptr; c1 = nullptr; }
+    const int M0 = c0->nseq * c0->L, M1 = c1 ? c1->nseq * c1->L : 0;
     int rc;
-    // x = x + attn(ln_1(x))                                        modules/clip.py:240
-    rc = cc_layernorm_f32(h, W, w.ln_1_weight, w.ln_1_bias, xn, W, M, W, 1e-5f, 1, st);
+    auto ln = [&](const float* g0, const float* b0, const float* g1, const float* b1) {
+        LnArgs a0{c0->h, c0->W, g0, b0, c0->xn, c0->W, M0, c0->W};
+        LnArgs a1{};
+        if (c1) a1 = LnArgs{c1->h, c1->W, g1, b1, c1->xn, c1->W, M1, c1->W};
+        return cc_launch_layernorm2(a0, c1 ? &a1 : nullptr, 1e-5f, 1, st);
+    };
+    auto gemm = [&](const _Float16* A0, const void* W0, const float* bias0, void* C0, int N0, int K0,
+                    const _Float16* A1, const void* W1, const float* bias1, void* C1, int N1, int K1, int epi) {
+        GemmArgs g0{};
+        g0.A = A0; g0.W = static_cast<const _Float16*>(W0); g0.bias = bias0; g0.C = C0;
+        g0.M = M0; g0.N = N0; g0.K = K0; g0.ldc = N0;
+        GemmArgs g1{};
+        if (c1) {
+            g1.A = A1; g1.W = static_cast<const _Float16*>(W1); g1.bias = bias1; g1.C = C1;
+            g1.M = M1; g1.N = N1; g1.K = K1; g1.ldc = N1;
+        }
+        return cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, epi, 0, st);
+    };
+    const int Wa = c0->W, Wb = c1 ? c1->W : 0;
+    // x = x + attn(ln_1(x))
+    rc = ln(w0->ln_1_weight, w0->ln_1_bias, w1 ? w1->ln_1_weight : nullptr, w1 ? w1->ln_1_bias : nullptr);
     if (rc) return rc;
-    rc = cc_linear_f16(xn, w.in_proj_weight_f16, w.in_proj_bias, qkv, M, 3 * W, W, 3 * W, EPI_F16, 0, st);
+    rc = gemm(c0->xn, w0->in_proj_weight_f16, w0->in_proj_bias, c0->qkv, 3 * Wa, Wa,
+              c1 ? c1->xn : nullptr, w1 ? w1->in_proj_weight_f16 : nullptr, w1 ? w1->in_proj_bias : nullptr,
+              c1 ? c1->qkv : nullptr, 3 * Wb, Wb, EPI_F16);
     if (rc) return rc;
-    rc = cc_attention_f16(qkv, att, nseq, L, heads, W, causal, st);
+    {
+        AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal};
+        AttArgs a1{};
+        if (c1) a1 = AttArgs{c1->qkv, c1->att, c1->nseq, c1->L, c1->heads, c1->W, c1->causal};
+        rc = cc_launch_attention2(a0, c1 ? &a1 : nullptr, st);
+        if (rc) return rc;
+    }
+    rc = gemm(c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa,
+              c1 ? c1->att : nullptr, w1 ? w1->out_proj_weight_f16 : nullptr, w1 ? w1->out_proj_bias : nullptr,
+              c1 ? c1->h : nullptr, Wb, Wb, EPI_F32_RESID);
     if (rc) return rc;
-    rc = cc_linear_f16(att, w.out_proj_weight_f16, w.out_proj_bias, h, M, W, W, W, EPI_F32_RESID, 0, st);
+    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))
+    rc = ln(w0->ln_2_weight, w0->ln_2_bias, w1 ? w1->ln_2_weight : nullptr, w1 ? w1->ln_2_bias : nullptr);
     if (rc) return rc;
-    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      modules/clip.py:251
-    rc = cc_layernorm_f32(h, W, w.ln_2_weight, w.ln_2_bias, xn, W, M, W, 1e-5f, 1, st);
+    rc = gemm(c0->xn, w0->c_fc_weight_f16, w0->c_fc_bias, c0->u, 4 * Wa, Wa,
+              c1 ? c1->xn : nullptr, w1 ? w1->c_fc_weight_f16 : nullptr, w1 ? w1->c_fc_bias : nullptr,
+              c1 ? c1->u : nullptr, 4 * Wb, Wb, EPI_F16_GELU);
     if (rc) return rc;
-    rc = cc_linear_f16(xn, w.c_fc_weight_f16, w.c_fc_bias, u, M, 4 * W, W, 4 * W, EPI_F16_GELU, 0, st);
-    if (rc) return rc;
-    return cc_linear_f16(u, w.c_proj_weight_f16, w.c_proj_bias, h, M, W, 4 * W, W, EPI_F32_RESID, 0, st);
+    return gemm(c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa,
+                c1 ? c1->u : nullptr, w1 ? w1->c_proj_weight_f16 : nullptr, w1 ? w1->c_proj_bias : nullptr,
+                c1 ? c1->h : nullptr, Wb, 4 * Wb, EPI_F32_RESID);
+}
+
+struct TextWs {
+    float* h;
+    _Float16* xn;
+    _Float16* qkv;
+    _Float16* att;
+    _Float16* u;
+    int* eot;
+    size_t total;
+};
+
+TextWs carve_text(const cc_text_model* m, int Bt, int Lt, void* ws) {
+    TextWs t{};
+    Carver c(ws);
+    const size_t M = (size_t)Bt * Lt, W = m->width;
+    t.h = c.take<float>(M * W);
+    t.xn = c.take<_Float16>(M * W);
+    t.qkv = c.take<_Float16>(M * 3 * W);
+    t.att = c.take<_Float16>(M * W);
+    t.u = c.take<_Float16>(M * 4 * W);
+    t.eot = c.take<int>(Bt);
+    t.total = c.off;
+    return t;
+}
+
+bool vit_ok(const cc_vit_model* m) {
+    if (m->layers <= 0 || m->layers > CC_MAX_LAYERS || m->width != m->heads * 64) return false;
+    return !(m->resolution % m->patch || (m->patch & 7) || (m->width % 64) || ((3 * m->patch * m->patch) % 64));
+}
+
+bool text_ok(const cc_text_model* m, int Lt) {
+    return m->layers > 0 && m->layers <= CC_MAX_LAYERS && m->width == m->heads * 64 && Lt <= m->context_length;
+}
+
+// Both towers, block i of the one paired with block i of the other (either may be absent).
+int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, float* vfeat, float* hidden_out,
+                  int64_t* medoids_out, const int64_t* forced_medoids, const cc_text_model* tm, const int64_t* ids,
+                  int Bt, int Lt, float* tfeat, void* ws, size_t ws_bytes, hipStream_t st) {
+    VitWs v{};
+    TextWs t{};
+    size_t off = 0;
+    if (vm) { v = carve_vit(vm, B, T, ws); off = v.total; }
+    if (tm) { t = carve_text(tm, Bt, Lt, static_cast<char*>(ws) + off); off += t.total; }
+    if (!ws || ws_bytes < off) return CC_ERR_WORKSPACE;
+    int rc;
+    float* h = nullptr;
+    float* hother = nullptr;
+    int frames = T, tokens = 0, W = 0;
+    if (vm) {
+        const int g = vm->resolution / vm->patch, n = g * g, F = B * T;
+        W = vm->width;
+        tokens = n;
+        // patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
+        rc = cc_launch_im2col(video, v.im2col, F, vm->resolution, vm->patch, st);
+        if (rc) return rc;
+        GemmArgs ga{};
+        ga.A = v.im2col;
+        ga.W = static_cast<const _Float16*>(vm->conv1_weight_f16);
+        ga.C = v.h;
+        ga.pos = vm->positional_embedding;
+        ga.M = F * n; ga.N = W; ga.K = 3 * vm->patch * vm->patch; ga.ldc = W;
+        ga.patch_n = n;
+        rc = cc_gemm_dispatch(ga, EPI_F32_PATCH, 0, st);
+        if (rc) return rc;
+        rc = cc_launch_cls_pos(v.h, vm->class_embedding, vm->positional_embedding, F, n + 1, W, st);
+        if (rc) return rc;
+        rc = cc_layernorm_f32(v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, 1e-5f, 0, st);
+        if (rc) return rc;
+        h = v.h;
+        hother = v.h2;
+    }
+    if (tm) {
+        rc = cc_launch_text_embed(reinterpret_cast<const long long*>(ids), tm->token_embedding,
+                                  tm->positional_embedding, t.h, t.eot, Bt, Lt, tm->width, st);
+        if (rc) return rc;
+    }
+    const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
+    for (int i = 0; i < (vl > tl ? vl : tl); ++i) {
+        BlockCtx cv{}, ct{};
+        const bool hv = i < vl, ht = i < tl;
+        if (hv) {
+            if (vm->cluster_tokens[i] > 0) {        // token cluster before the attention of this block (clip.py:236-242)
+                const int Tn = vm->cluster_frames[i], K = vm->cluster_tokens[i];
+                if (Tn <= 0 || frames % Tn) return CC_ERR_INVALID;
+                if (forced_medoids)
+                    rc = cc_token_gather_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                             forced_medoids, hother, W, (int64_t)(K + 1) * W, st);
+                else
+                    rc = cc_token_cluster_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                              vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
+                                              vm->cluster_iter_limit, vm->cluster_split_size, vm->cluster_pre_norm,
+                                              hother, W, (int64_t)(K + 1) * W, medoids_out, nullptr, nullptr,
+                                              v.cluster, v.cluster_bytes, st);
+                if (rc) return rc;
+                float* tmp = h; h = hother; hother = tmp;
+                frames = Tn;
+                tokens = K;
+            }
+            cv = BlockCtx{h, v.xn, v.qkv, v.att, v.u, B * frames, tokens + 1, W, vm->heads, 0};
+        }
+        if (ht) ct = BlockCtx{t.h, t.xn, t.qkv, t.att, t.u, Bt, Lt, tm->width, tm->heads, 1};
+        rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[i] : nullptr,
+                            ht ? &ct : nullptr, st);
+        if (rc) return rc;
+    }
+    if (vm) {       // ln_post + proj on the CLS rows only (clip.py:463-464)
+        rc = cc_launch_head_project(h, tokens + 1, nullptr, vm->ln_post_weight, vm->ln_post_bias, vm->proj, vfeat,
+                                    B * frames, W, vm->embed_dim, st);
+        if (rc) return rc;
+        if (hidden_out && hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
+                                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return CC_ERR_HIP;
+    }
+    if (tm) {       // ln_final + text_projection on the EOT rows only (clip.py:480-484)
+        rc = cc_launch_head_project(t.h, Lt, t.eot, tm->ln_final_weight, tm->ln_final_bias, tm->text_projection,
+                                    tfeat, Bt, tm->width, tm->embed_dim, st);
+        if (rc) return rc;
+    }
+    return CC_OK;
 }
 
 }  // namespace
@@ -101,109 +266,39 @@ int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t 
                   float* hidden_out, int64_t* medoids_out, const int64_t* forced_medoids, void* ws, size_t ws_bytes,
                   void* stream) {
     if (!m || !video || !features || !m->blocks || B <= 0 || T <= 0) return CC_ERR_INVALID;
-    if (m->layers <= 0 || m->layers > CC_MAX_LAYERS || m->width != m->heads * 64) return CC_ERR_UNSUPPORTED;
-    if (m->resolution % m->patch || (m->patch & 7) || (m->width % 64) || ((3 * m->patch * m->patch) % 64))
-        return CC_ERR_UNSUPPORTED;
-    VitWs v = carve_vit(m, B, T, ws);
-    if (!ws || ws_bytes < v.total) return CC_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int g = m->resolution / m->patch, n = g * g, W = m->width, F = B * T;
-    int rc;
-
-    // ---- patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
-    rc = cc_launch_im2col(video, v.im2col, F, m->resolution, m->patch, st);
-    if (rc) return rc;
-    {
-        GemmArgs ga{};
-        ga.A = v.im2col;
-        ga.W = static_cast<const _Float16*>(m->conv1_weight_f16);
-        ga.bias = nullptr;
-        ga.C = v.h;
-        ga.pos = m->positional_embedding;
-        ga.M = F * n; ga.N = W; ga.K = 3 * m->patch * m->patch; ga.ldc = W;
-        ga.patch_n = n;
-        rc = cc_gemm_dispatch(ga, EPI_F32_PATCH, 0, st);
-        if (rc) return rc;
-    }
-    rc = cc_launch_cls_pos(v.h, m->class_embedding, m->positional_embedding, F, n + 1, W, st);
-    if (rc) return rc;
-    rc = cc_layernorm_f32(v.h, W, m->ln_pre_weight, m->ln_pre_bias, v.h, W, F * (n + 1), W, 1e-5f, 0, st);
-    if (rc) return rc;
-
-    // ---- transformer blocks, token cluster before the attention of the planned blocks (clip.py:236-242)
-    float* h = v.h;
-    float* hother = v.h2;
-    int frames = T, tokens = n;
-    for (int i = 0; i < m->layers; ++i) {
-        if (m->cluster_tokens[i] > 0) {
-            const int Tn = m->cluster_frames[i], K = m->cluster_tokens[i];
-            if (Tn <= 0 || frames % Tn) return CC_ERR_INVALID;
-            if (forced_medoids)
-                rc = cc_token_gather_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K, forced_medoids,
-                                         hother, W, (int64_t)(K + 1) * W, st);
-            else
-                rc = cc_token_cluster_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                          m->cluster_metric, m->cluster_norm_p, m->cluster_threshold,
-                                          m->cluster_iter_limit, m->cluster_split_size, m->cluster_pre_norm, hother, W,
-                                          (int64_t)(K + 1) * W, medoids_out, nullptr, nullptr, v.cluster,
-                                          v.cluster_bytes, st);
-            if (rc) return rc;
-            float* t = h; h = hother; hother = t;
-            frames = Tn;
-            tokens = K;
-        }
-        rc = run_block(m->blocks[i], h, v.xn, v.qkv, v.att, v.u, B * frames, tokens + 1, W, m->heads, 0, st);
-        if (rc) return rc;
-    }
-    // ---- ln_post + proj on the CLS rows only (clip.py:463-464)
-    rc = cc_launch_head_project(h, tokens + 1, nullptr, m->ln_post_weight, m->ln_post_bias, m->proj, features,
-                                B * frames, W, m->embed_dim, st);
-    if (rc) return rc;
-    if (hidden_out) {
-        if (hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
-                           hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return CC_ERR_HIP;
-    }
-    return CC_OK;
+    if (!vit_ok(m)) return CC_ERR_UNSUPPORTED;
+    return encode_towers(m, video, B, T, features, hidden_out, medoids_out, forced_medoids, nullptr, nullptr, 0, 0,
+                         nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt) {
     if (!m || Bt <= 0 || Lt <= 0) return 0;
-    Carver c(nullptr);
-    const size_t M = (size_t)Bt * Lt, W = m->width;
-    c.take<float>(M * W);
-    c.take<_Float16>(M * W);
-    c.take<_Float16>(M * 3 * W);
-    c.take<_Float16>(M * W);
-    c.take<_Float16>(M * 4 * W);
-    c.take<int>(Bt);
-    return c.off;
+    return carve_text(m, Bt, Lt, nullptr).total;
 }
 
 int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt, float* features, void* ws,
                    size_t ws_bytes, void* stream) {
     if (!m || !ids || !features || !m->blocks || Bt <= 0 || Lt <= 0) return CC_ERR_INVALID;
     if (Lt > m->context_length) return CC_ERR_INVALID;
-    if (m->layers <= 0 || m->layers > CC_MAX_LAYERS || m->width != m->heads * 64) return CC_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < cc_text_workspace_bytes(m, Bt, Lt)) return CC_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    Carver c(ws);
-    const size_t M = (size_t)Bt * Lt, W = m->width;
-    float* h = c.take<float>(M * W);
-    _Float16* xn = c.take<_Float16>(M * W);
-    _Float16* qkv = c.take<_Float16>(M * 3 * W);
-    _Float16* att = c.take<_Float16>(M * W);
-    _Float16* u = c.take<_Float16>(M * 4 * W);
-    int* eot = c.take<int>(Bt);
-    int rc = cc_launch_text_embed(reinterpret_cast<const long long*>(ids), m->token_embedding,
-                                  m->positional_embedding, h, eot, Bt, Lt, (int)W, st);
-    if (rc) return rc;
-    for (int i = 0; i < m->layers; ++i) {
-        rc = run_block(m->blocks[i], h, xn, qkv, att, u, Bt, Lt, (int)W, m->heads, 1, st);
-        if (rc) return rc;
-    }
-    return cc_launch_head_project(h, Lt, eot, m->ln_final_weight, m->ln_final_bias, m->text_projection, features, Bt,
-                                  (int)W, m->embed_dim, st);
+    if (!text_ok(m, Lt)) return CC_ERR_UNSUPPORTED;
+    return encode_towers(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m, ids, Bt, Lt, features, ws,
+                         ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t cc_clip_workspace_bytes(const cc_vit_model* vm, int32_t B, int32_t T, const cc_text_model* tm, int32_t Bt,
+                               int32_t Lt) {
+    return cc_vit_workspace_bytes(vm, B, T) + cc_text_workspace_bytes(tm, Bt, Lt);
+}
+
+int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_t T, float* visual_features,
+                   int64_t* medoids_out, const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
+                   float* text_features, void* ws, size_t ws_bytes, void* stream) {
+    if (!vm || !tm || !video || !ids || !visual_features || !text_features || !vm->blocks || !tm->blocks)
+        return CC_ERR_INVALID;
+    if (B <= 0 || T <= 0 || Bt <= 0 || Lt <= 0 || Lt > tm->context_length) return CC_ERR_INVALID;
+    if (!vit_ok(vm) || !text_ok(tm, Lt)) return CC_ERR_UNSUPPORTED;
+    return encode_towers(vm, video, B, T, visual_features, nullptr, medoids_out, nullptr, tm, ids, Bt, Lt,
+                         text_features, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -35,7 +35,9 @@ __device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
+    const bool second = (int)blockIdx.x >= pr.tiles0;
+    const GemmArgs g = second ? pr.p[1] : pr.p[0];
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs g) {
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
     // tiles (tn fastest) so tiles sharing an A panel hit the same L2.
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
+    int bid = (int)blockIdx.x - (second ? pr.tiles0 : 0);
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs g) {
 namespace {
 
 template <int BM, int BN, int WM, int WN, int EPI>
-int launch_one(const GemmArgs& g, hipStream_t st) {
+int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     constexpr size_t smem = 2 * (size_t)(BM + BN) * GEMM_BK * 2;
     auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI>;
     if (smem > 64 * 1024) {
@@ -178,56 +180,82 @@ int launch_one(const GemmArgs& g, hipStream_t st) {
             configured = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), smem, st, pr);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_tile(GemmArgs g, int epi, hipStream_t st) {
-    g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = g.N / BN;
+int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
+    GemmPair pr{};
+    g0.tiles_m = (g0.M + BM - 1) / BM;
+    g0.tiles_n = g0.N / BN;
+    pr.p[0] = g0;
+    pr.tiles0 = g0.tiles_m * g0.tiles_n;
+    int total = pr.tiles0;
+    if (g1) {
+        pr.p[1] = *g1;
+        pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
+        pr.p[1].tiles_n = g1->N / BN;
+        total += pr.p[1].tiles_m * pr.p[1].tiles_n;
+    } else {
+        pr.p[1] = g0;
+    }
     switch (epi) {
-        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16>(g, st);
-        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(g, st);
-        case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID>(g, st);
-        case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH>(g, st);
-        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(g, st);
+        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16>(pr, total, st);
+        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(pr, total, st);
+        case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID>(pr, total, st);
+        case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH>(pr, total, st);
+        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(pr, total, st);
         default: return CC_ERR_INVALID;
     }
 }
 
 }  // namespace
 
+static bool gemm_shape_ok(const GemmArgs& g) {
+    return g.M > 0 && g.N > 0 && g.K > 0 && (g.K % GEMM_BK) == 0 && (g.N % 64) == 0;
+}
+
+static int pick_tile(const GemmArgs& g) {
+    // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
+    // >= ~1.5 workgroups per CU; below that trade tile efficiency for parallelism.
+    const long mt128 = (g.M + 127) / 128, mt64 = (g.M + 63) / 64;
+    const bool n128 = (g.N % 128) == 0;
+    const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
+    // 256x256 (one 8-wave workgroup per CU) halves the L2->LDS bytes per flop; it only pays when the
+    // tile count fills whole rounds of the 256 CUs
+    if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.85) return 5;
+    if (n128 && mt128 * (g.N / 128) >= 400) return 1;
+    if (n128 && mt64 * (g.N / 128) >= 400) return 3;
+    if (mt128 * (g.N / 64) >= 400) return 2;
+    return 4;
+}
+
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128 (8 waves)
-int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % GEMM_BK) || (g.N % 64)) return CC_ERR_INVALID;
+int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
+    if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
-        // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
-        // >= ~1.5 workgroups per CU; below that trade tile efficiency for parallelism.
-        const long mt128 = (g.M + 127) / 128, mt64 = (g.M + 63) / 64;
-        const bool n128 = (g.N % 128) == 0;
-        const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
-        // 256x256 (one 8-wave workgroup per CU) halves the L2->LDS bytes per flop; it only pays when the
-        // tile count fills whole rounds of the 256 CUs
-        if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.85) tile = 5;
-        else if (n128 && mt128 * (g.N / 128) >= 400) tile = 1;
-        else if (n128 && mt64 * (g.N / 128) >= 400) tile = 3;
-        else if (mt128 * (g.N / 64) >= 400) tile = 2;
-        else tile = 4;
+        tile = pick_tile(g0);
+        if (g1) {                                  // the rider must be divisible by the carrier's BN
+            const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
+            if (g1->N % bn) tile = (g1->N % 128 == 0 && (tile == 5)) ? 1 : 4;
+        }
     }
-    if ((tile == 1 || tile == 3 || tile == 6) && (g.N % 128)) return CC_ERR_INVALID;
-    if (tile == 5 && (g.N % 256)) return CC_ERR_INVALID;
+    const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
+    if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
     switch (tile) {
-        case 1: return launch_tile<128, 128, 2, 2>(g, epi, st);
-        case 2: return launch_tile<128, 64, 2, 2>(g, epi, st);
-        case 3: return launch_tile<64, 128, 2, 2>(g, epi, st);
-        case 4: return launch_tile<64, 64, 2, 2>(g, epi, st);
-        case 5: return launch_tile<256, 256, 2, 4>(g, epi, st);
-        case 6: return launch_tile<256, 128, 4, 2>(g, epi, st);
+        case 1: return launch_tile<128, 128, 2, 2>(g0, g1, epi, st);
+        case 2: return launch_tile<128, 64, 2, 2>(g0, g1, epi, st);
+        case 3: return launch_tile<64, 128, 2, 2>(g0, g1, epi, st);
+        case 4: return launch_tile<64, 64, 2, 2>(g0, g1, epi, st);
+        case 5: return launch_tile<256, 256, 2, 4>(g0, g1, epi, st);
+        case 6: return launch_tile<256, 128, 4, 2>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
 }
+
+int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_gemm_dispatch2(g, nullptr, epi, tile, st); }
 
 extern "C" {
 

@@ -15,15 +15,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fp32 (mean, then centred second moment) like ATen.  OUT_F16: write fp16 (GEMM operand) else
 // fp32 (may alias the input: ln_pre runs in place).  Rows are addressed as
 // in + row*in_stride so a strided subset (CLS rows) can be normalised directly.
+struct LnPair {
+    LnArgs a[2];
+    int blocks0;        // workgroups [0, blocks0) -> a[0]
+};
+
 template <bool OUT_F16>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int64_t in_stride,
-                                                        const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, void* __restrict__ out,
-                                                        int64_t out_stride, int rows, int W, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
+    const bool second = (int)blockIdx.x >= pr.blocks0;
+    const LnArgs a = second ? pr.a[1] : pr.a[0];
+    const int W = a.W;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* src = in + (int64_t)row * in_stride;
+    const int row = ((int)blockIdx.x - (second ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* src = a.in + (int64_t)row * a.in_stride;
     float4 v[4];
     float s = 0.f;
 #pragma unroll
@@ -38,8 +43,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int t = 0; t < 4; ++t) {
         const int w = lane * 4 + t * 256;
         if (w < W) {
-            const float a = v[t].x - mean, b = v[t].y - mean, c = v[t].z - mean, d = v[t].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+            const float c0 = v[t].x - mean, c1 = v[t].y - mean, c2 = v[t].z - mean, c3 = v[t].w - mean;
+            q += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
         }
     }
     const float rstd = 1.0f / sqrtf(cc_wave_sum(q) / (float)W + eps);
@@ -47,15 +52,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int t = 0; t < 4; ++t) {
         const int w = lane * 4 + t * 256;
         if (w < W) {
-            const float4 gm = *reinterpret_cast<const float4*>(gamma + w);
-            const float4 bt = *reinterpret_cast<const float4*>(beta + w);
+            const float4 gm = *reinterpret_cast<const float4*>(a.gamma + w);
+            const float4 bt = *reinterpret_cast<const float4*>(a.beta + w);
             const float o0 = (v[t].x - mean) * rstd * gm.x + bt.x, o1 = (v[t].y - mean) * rstd * gm.y + bt.y;
             const float o2 = (v[t].z - mean) * rstd * gm.z + bt.z, o3 = (v[t].w - mean) * rstd * gm.w + bt.w;
             if (OUT_F16) {
                 h4 o = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
-                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (int64_t)row * out_stride + w) = o;
+                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(a.out) + (int64_t)row * a.out_stride + w) = o;
             } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * out_stride + w) =
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (int64_t)row * a.out_stride + w) =
                     make_float4(o0, o1, o2, o3);
             }
         }
@@ -78,11 +83,21 @@ __host__ __device__ inline int att_vs_halfs(int KT) {      // row stride of V^T 
     return words * 2;
 }
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
-                                                        int L, int heads, int W, float scale) {
+struct AttPair {
+    AttArgs a[2];
+    int wgs0;           // workgroups [0, wgs0) -> a[0]
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const bool second = (int)blockIdx.x >= pr.wgs0;
+    const AttArgs at = second ? pr.a[1] : pr.a[0];
+    const _Float16* __restrict__ qkv = at.qkv;
+    _Float16* __restrict__ out = at.out;
+    const int L = at.L, heads = at.heads, W = at.W;
+    const bool CAUSAL = at.causal != 0;
+    const int wg = (int)blockIdx.x - (second ? pr.wgs0 : 0);
+    const int seq = wg / heads, head = wg - seq * heads;
     const int KT = (L + 31) & ~31;
     const int VS = att_vs_halfs(KT);
     _Float16* Ks = reinterpret_cast<_Float16*>(smem);                       // KT * 64
@@ -306,41 +321,63 @@ extern "C" {
 int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta, void* out,
                      int64_t out_stride, int32_t rows, int32_t W, float eps, int32_t out_f16, void* stream) {
     if (!in || !gamma || !beta || !out || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid((rows + 3) / 4), block(256);
-    if (out_f16)
-        hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, st, in, in_stride, gamma, beta, out, out_stride, rows, W, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, st, in, in_stride, gamma, beta, out, out_stride, rows, W, eps);
-    CC_LAUNCH_CHECK();
-    return CC_OK;
+    LnArgs a{in, in_stride, gamma, beta, out, out_stride, rows, W};
+    return cc_launch_layernorm2(a, nullptr, eps, out_f16, static_cast<hipStream_t>(stream));
 }
 
 int cc_attention_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads, int32_t W,
                      int32_t causal, void* stream) {
     if (!qkv_f16 || !out_f16 || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * ATT_D) return CC_ERR_INVALID;
     if (L > ATT_MAX_KT) return CC_ERR_UNSUPPORTED;
-    const int KT = (L + 31) & ~31, VS = att_vs_halfs(KT);
-    const size_t smem = (size_t)(KT * ATT_D + ATT_D * VS + 4 * 16 * VS) * 2;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const float scale = 0.125f;
-    dim3 grid(nseq * heads), block(256);
-    if (causal) {
-        auto k = attention_kernel<true>;
-        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CC_ERR_HIP;
-        hipLaunchKernelGGL(k, grid, block, smem, st, static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), L, heads, W, scale);
-    } else {
-        auto k = attention_kernel<false>;
-        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CC_ERR_HIP;
-        hipLaunchKernelGGL(k, grid, block, smem, st, static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), L, heads, W, scale);
-    }
-    CC_LAUNCH_CHECK();
-    return CC_OK;
+    AttArgs a{static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), nseq, L, heads, W, causal};
+    return cc_launch_attention2(a, nullptr, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"
 
 // ---- launch helpers used by clip_forward.hip (same translation-unit-external linkage)
+int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_f16, hipStream_t st) {
+    LnPair pr{};
+    pr.a[0] = a0;
+    pr.a[1] = a1 ? *a1 : a0;
+    pr.blocks0 = (a0.rows + 3) / 4;
+    const int total = pr.blocks0 + (a1 ? (a1->rows + 3) / 4 : 0);
+    if (a0.W > 1024 || (a0.W & 3) || (a1 && (a1->W > 1024 || (a1->W & 3)))) return CC_ERR_INVALID;
+    if (out_f16)
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3(total), dim3(256), 0, st, pr, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3(total), dim3(256), 0, st, pr, eps);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+static size_t att_smem_bytes(int L) {
+    const int KT = (L + 31) & ~31, VS = att_vs_halfs(KT);
+    return (size_t)(KT * ATT_D + ATT_D * VS + 4 * 16 * VS) * 2;
+}
+
+int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
+    if (a0.L > ATT_MAX_KT || (a1 && a1->L > ATT_MAX_KT)) return CC_ERR_UNSUPPORTED;
+    AttPair pr{};
+    pr.a[0] = a0;
+    pr.a[1] = a1 ? *a1 : a0;
+    pr.wgs0 = a0.nseq * a0.heads;
+    const int total = pr.wgs0 + (a1 ? a1->nseq * a1->heads : 0);
+    size_t smem = att_smem_bytes(a0.L);
+    if (a1 && att_smem_bytes(a1->L) > smem) smem = att_smem_bytes(a1->L);
+    static size_t configured = 64 * 1024;
+    if (smem > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return CC_ERR_HIP;
+        configured = smem;
+    }
+    hipLaunchKernelGGL(attention_kernel, dim3(total), dim3(256), smem, st, pr, 0.125f);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+
 int cc_launch_im2col(const float* video, _Float16* A, int F, int res, int p, hipStream_t st) {
     if ((p & 7) || res % p) return CC_ERR_INVALID;
     const int64_t total = (int64_t)F * (res / p) * (res / p) * 3 * p * p / 8;

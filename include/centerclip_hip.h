@@ -242,6 +242,17 @@ size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt);
 int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt,
                    float* features, void* ws, size_t ws_bytes, void* stream);
 
+/* Both encoders of one CLIP4Clip.forward call (modules/clip4clip.py:199-243: get_sequence_output
+ * + get_visual_output) in one enqueue.  Block i of the text tower shares every launch with block i
+ * of the ViT (horizontal fusion): same results as cc_vit_encode + cc_text_encode, fewer and fuller
+ * launches.  ws: cc_clip_workspace_bytes. */
+size_t cc_clip_workspace_bytes(const cc_vit_model* vm, int32_t B, int32_t T,
+                               const cc_text_model* tm, int32_t Bt, int32_t Lt);
+int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_t T,
+                   float* visual_features, int64_t* medoids_out,
+                   const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
+                   float* text_features, void* ws, size_t ws_bytes, void* stream);
+
 /* S2 - the meanP similarity tail, CLIP4Clip._loose_similarity (modules/clip4clip.py:357-366) with
  * _mean_pooling_for_similarity_visual (:305-316):
  *   v_hat = v/|v| per frame; v_bar = sum_t mask*v_hat / max(sum_t mask, 1 if 0); v_bar /= |v_bar|

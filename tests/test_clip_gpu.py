@@ -161,6 +161,18 @@ def test_small_text_forward(g):
     assert relerr(feat.cpu(), ref) <= 1e-3
 
 
+def test_paired_towers_equal_separate_encodes(g):
+    """cc_clip_encode (text blocks riding in the ViT's launches) gives bit-identical features to
+    cc_vit_encode + cc_text_encode: same kernels, same per-problem arithmetic, different grids."""
+    model, T = small_model(g, cluster=True)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    ids = torch.from_numpy(g["t_ids"]).to(DEV)
+    v1, _ = model.encode_image(video, video_frame=T)
+    t1 = model.encode_text(ids)
+    v2, t2 = model.encode_pair(video, ids, video_frame=T)
+    assert torch.equal(v1, v2) and torch.equal(t1, t2)
+
+
 def test_loose_similarity_and_mask(g):
     from centerclip_amd import ops
     seq, vis = torch.from_numpy(g["s_seq"]).to(DEV), torch.from_numpy(g["s_vis"]).to(DEV)
