@@ -9,7 +9,8 @@ class BlockWeights(c.Structure):
     """struct cc_block_weights"""
     _fields_ = [(n, c.c_void_p) for n in (
         "ln_1_weight", "ln_1_bias", "in_proj_weight_f16", "in_proj_bias", "out_proj_weight_f16", "out_proj_bias",
-        "ln_2_weight", "ln_2_bias", "c_fc_weight_f16", "c_fc_bias", "c_proj_weight_f16", "c_proj_bias")]
+        "ln_2_weight", "ln_2_bias", "c_fc_weight_f16", "c_fc_bias", "c_proj_weight_f16", "c_proj_bias",
+        "in_proj_ln_weight_f16", "in_proj_ln_c1", "in_proj_ln_c2", "c_fc_ln_weight_f16", "c_fc_ln_c1", "c_fc_ln_c2")]
 
 
 class VitModel(c.Structure):
@@ -39,6 +40,8 @@ def declare(lib):
     lib.cc_linear_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.cc_layernorm_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, f32, i32, vp]
     lib.cc_attention_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.cc_fold_layernorm_linear_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.cc_fold_layernorm_linear_f32.restype = c.c_int
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]

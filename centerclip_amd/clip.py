@@ -87,10 +87,29 @@ class _Pack:
         self.keep.append(t)
         return t.data_ptr()
 
+    def fold(self, linear_w, linear_b, ln):
+        """LayerNorm folded into the consuming Linear (cc_fold_layernorm_linear_f32) -> (w' f16, c1, c2) pointers."""
+        w = linear_w.detach().float().contiguous()
+        b = linear_b.detach().float().contiguous()
+        gamma, beta = ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous()
+        N, K = w.shape
+        wf = torch.empty(N, K, device=w.device, dtype=torch.float16)
+        c1 = torch.empty(N, device=w.device, dtype=torch.float32)
+        c2 = torch.empty(N, device=w.device, dtype=torch.float32)
+        L.check(L.lib().cc_fold_layernorm_linear_f32(L.ptr(w), L.ptr(b), L.ptr(gamma), L.ptr(beta), N, K, L.ptr(wf),
+                                                     L.ptr(c1), L.ptr(c2), L.stream_ptr(w.device)),
+                "cc_fold_layernorm_linear_f32")
+        self.keep += [wf, c1, c2]
+        return wf.data_ptr(), c1.data_ptr(), c2.data_ptr()
+
     def blocks(self, transformer):
         arr = (BlockWeights * len(transformer.resblocks))()
         for i, blk in enumerate(transformer.resblocks):
             b = arr[i]
+            b.in_proj_ln_weight_f16, b.in_proj_ln_c1, b.in_proj_ln_c2 = self.fold(
+                blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln_1)
+            b.c_fc_ln_weight_f16, b.c_fc_ln_c1, b.c_fc_ln_c2 = self.fold(
+                blk.mlp["c_fc"].weight, blk.mlp["c_fc"].bias, blk.ln_2)
             b.ln_1_weight, b.ln_1_bias = self.f32(blk.ln_1.weight), self.f32(blk.ln_1.bias)
             b.in_proj_weight_f16, b.in_proj_bias = self.f16(blk.attn.in_proj_weight), self.f32(blk.attn.in_proj_bias)
             b.out_proj_weight_f16 = self.f16(blk.attn.out_proj.weight)

@@ -26,7 +26,9 @@ struct VitWs {
     _Float16* im2col;
     float* h;        // residual stream (frame-major)
     float* h2;       // cluster output (ping-pong)
-    _Float16* xn;
+    _Float16* h16;   // fp16 copy of the residual stream (GEMM A operand; LayerNorm is folded into the GEMM)
+    float* st0;      // partial (sum, sumsq) of the rows entering in_proj  [M][CC_LN_MAX_SLOTS][2]
+    float* st1;      // ... entering c_fc
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
@@ -43,7 +45,9 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
     v.im2col = c.take<_Float16>(F * n * 3 * m->patch * m->patch);
     v.h = c.take<float>(M0 * W);
     v.h2 = c.take<float>(M0 * W);
-    v.xn = c.take<_Float16>(M0 * W);
+    v.h16 = c.take<_Float16>(M0 * W);
+    v.st0 = c.take<float>(M0 * CC_LN_MAX_SLOTS * 2);
+    v.st1 = c.take<float>(M0 * CC_LN_MAX_SLOTS * 2);
     v.qkv = c.take<_Float16>(M0 * 3 * W);
     v.att = c.take<_Float16>(M0 * W);
     v.u = c.take<_Float16>(M0 * 4 * W);
@@ -69,47 +73,49 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
 
 struct BlockCtx {          // one tower's activations for the current block
     float* h;
-    _Float16* xn;
+    _Float16* h16;
+    float* st0;
+    float* st1;
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
     int nseq, L, W, heads, causal;
+    int slots0, slots1;    // partial-sum slots per row currently held in st0 / st1
 };
 
 // One ResidualAttentionBlock for up to two towers at once (modules/clip.py:240,251).  Every phase is
 // ONE launch covering both problems: the text tower (M = 16*32 rows, launch-latency bound on its own:
 // 86 kernels of a few microseconds) rides inside the visual tower's launches and fills their tail round.
-int run_block_pair(const cc_block_weights* w0, const BlockCtx* c0, const cc_block_weights* w1, const BlockCtx* c1,
+// LayerNorm never runs as a pass of its own: ln_1 / ln_2 are folded into in_proj / c_fc (the row statistics
+// come out of the preceding residual epilogue), which removes two full reads of the fp32 residual stream
+// and two launches per block.
+int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weights* w1, BlockCtx* c1,
                    hipStream_t st) {
     if (!w0) { w0 = w1; c0 = c1; w1 = nullptr; c1 = nullptr; }
     const int M0 = c0->nseq * c0->L, M1 = c1 ? c1->nseq * c1->L : 0;
+    const int Wa = c0->W, Wb = c1 ? c1->W : 0;
     int rc;
-    auto ln = [&](const float* g0, const float* b0, const float* g1, const float* b1) {
-        LnArgs a0{c0->h, c0->W, g0, b0, c0->xn, c0->W, M0, c0->W};
-        LnArgs a1{};
-        if (c1) a1 = LnArgs{c1->h, c1->W, g1, b1, c1->xn, c1->W, M1, c1->W};
-        return cc_launch_layernorm2(a0, c1 ? &a1 : nullptr, 1e-5f, 1, st);
+    int slots[2];
+    auto base = [&](const BlockCtx* c, int M, const _Float16* A, const void* Wt, const float* bias, void* C, int N, int K) {
+        GemmArgs g{};
+        g.A = A; g.W = static_cast<const _Float16*>(Wt); g.bias = bias; g.C = C;
+        g.M = M; g.N = N; g.K = K; g.ldc = N;
+        g.ln_eps = 1e-5f;
+        (void)c;
+        return g;
     };
-    auto gemm = [&](const _Float16* A0, const void* W0, const float* bias0, void* C0, int N0, int K0,
-                    const _Float16* A1, const void* W1, const float* bias1, void* C1, int N1, int K1, int epi) {
-        GemmArgs g0{};
-        g0.A = A0; g0.W = static_cast<const _Float16*>(W0); g0.bias = bias0; g0.C = C0;
-        g0.M = M0; g0.N = N0; g0.K = K0; g0.ldc = N0;
+    // ---- q,k,v = in_proj(ln_1(x))   [LayerNorm folded]
+    {
+        GemmArgs g0 = base(c0, M0, c0->h16, w0->in_proj_ln_weight_f16, w0->in_proj_ln_c2, c0->qkv, 3 * Wa, Wa);
+        g0.ln_stats = c0->st0; g0.ln_slots = c0->slots0; g0.ln_c1 = w0->in_proj_ln_c1;
         GemmArgs g1{};
         if (c1) {
-            g1.A = A1; g1.W = static_cast<const _Float16*>(W1); g1.bias = bias1; g1.C = C1;
-            g1.M = M1; g1.N = N1; g1.K = K1; g1.ldc = N1;
+            g1 = base(c1, M1, c1->h16, w1->in_proj_ln_weight_f16, w1->in_proj_ln_c2, c1->qkv, 3 * Wb, Wb);
+            g1.ln_stats = c1->st0; g1.ln_slots = c1->slots0; g1.ln_c1 = w1->in_proj_ln_c1;
         }
-        return cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, epi, 0, st);
-    };
-    const int Wa = c0->W, Wb = c1 ? c1->W : 0;
-    // x = x + attn(ln_1(x))
-    rc = ln(w0->ln_1_weight, w0->ln_1_bias, w1 ? w1->ln_1_weight : nullptr, w1 ? w1->ln_1_bias : nullptr);
-    if (rc) return rc;
-    rc = gemm(c0->xn, w0->in_proj_weight_f16, w0->in_proj_bias, c0->qkv, 3 * Wa, Wa,
-              c1 ? c1->xn : nullptr, w1 ? w1->in_proj_weight_f16 : nullptr, w1 ? w1->in_proj_bias : nullptr,
-              c1 ? c1->qkv : nullptr, 3 * Wb, Wb, EPI_F16);
-    if (rc) return rc;
+        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F16_LN, 0, st);
+        if (rc) return rc;
+    }
     {
         AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal};
         AttArgs a1{};
@@ -117,25 +123,54 @@ int run_block_pair(const cc_block_weights* w0, const BlockCtx* c0, const cc_bloc
         rc = cc_launch_attention2(a0, c1 ? &a1 : nullptr, st);
         if (rc) return rc;
     }
-    rc = gemm(c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa,
-              c1 ? c1->att : nullptr, w1 ? w1->out_proj_weight_f16 : nullptr, w1 ? w1->out_proj_bias : nullptr,
-              c1 ? c1->h : nullptr, Wb, Wb, EPI_F32_RESID);
-    if (rc) return rc;
-    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))
-    rc = ln(w0->ln_2_weight, w0->ln_2_bias, w1 ? w1->ln_2_weight : nullptr, w1 ? w1->ln_2_bias : nullptr);
-    if (rc) return rc;
-    rc = gemm(c0->xn, w0->c_fc_weight_f16, w0->c_fc_bias, c0->u, 4 * Wa, Wa,
-              c1 ? c1->xn : nullptr, w1 ? w1->c_fc_weight_f16 : nullptr, w1 ? w1->c_fc_bias : nullptr,
-              c1 ? c1->u : nullptr, 4 * Wb, Wb, EPI_F16_GELU);
-    if (rc) return rc;
-    return gemm(c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa,
-                c1 ? c1->u : nullptr, w1 ? w1->c_proj_weight_f16 : nullptr, w1 ? w1->c_proj_bias : nullptr,
-                c1 ? c1->h : nullptr, Wb, 4 * Wb, EPI_F32_RESID);
+    // ---- x = x + out_proj(attn)   [+ fp16 copy and row statistics for ln_2]
+    {
+        GemmArgs g0 = base(c0, M0, c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa);
+        g0.c16 = c0->h16; g0.stats_out = c0->st1;
+        GemmArgs g1{};
+        if (c1) {
+            g1 = base(c1, M1, c1->att, w1->out_proj_weight_f16, w1->out_proj_bias, c1->h, Wb, Wb);
+            g1.c16 = c1->h16; g1.stats_out = c1->st1;
+        }
+        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F32_RESID_STATS, 0, st, slots);
+        if (rc) return rc;
+        c0->slots1 = slots[0];
+        if (c1) c1->slots1 = slots[1];
+    }
+    // ---- u = QuickGELU(c_fc(ln_2(x)))   [LayerNorm folded]
+    {
+        GemmArgs g0 = base(c0, M0, c0->h16, w0->c_fc_ln_weight_f16, w0->c_fc_ln_c2, c0->u, 4 * Wa, Wa);
+        g0.ln_stats = c0->st1; g0.ln_slots = c0->slots1; g0.ln_c1 = w0->c_fc_ln_c1;
+        GemmArgs g1{};
+        if (c1) {
+            g1 = base(c1, M1, c1->h16, w1->c_fc_ln_weight_f16, w1->c_fc_ln_c2, c1->u, 4 * Wb, Wb);
+            g1.ln_stats = c1->st1; g1.ln_slots = c1->slots1; g1.ln_c1 = w1->c_fc_ln_c1;
+        }
+        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F16_GELU_LN, 0, st);
+        if (rc) return rc;
+    }
+    // ---- x = x + c_proj(u)   [+ fp16 copy and row statistics for the next block's ln_1]
+    {
+        GemmArgs g0 = base(c0, M0, c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa);
+        g0.c16 = c0->h16; g0.stats_out = c0->st0;
+        GemmArgs g1{};
+        if (c1) {
+            g1 = base(c1, M1, c1->u, w1->c_proj_weight_f16, w1->c_proj_bias, c1->h, Wb, 4 * Wb);
+            g1.c16 = c1->h16; g1.stats_out = c1->st0;
+        }
+        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F32_RESID_STATS, 0, st, slots);
+        if (rc) return rc;
+        c0->slots0 = slots[0];
+        if (c1) c1->slots0 = slots[1];
+    }
+    return CC_OK;
 }
 
 struct TextWs {
     float* h;
-    _Float16* xn;
+    _Float16* h16;
+    float* st0;
+    float* st1;
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
@@ -148,7 +183,9 @@ TextWs carve_text(const cc_text_model* m, int Bt, int Lt, void* ws) {
     Carver c(ws);
     const size_t M = (size_t)Bt * Lt, W = m->width;
     t.h = c.take<float>(M * W);
-    t.xn = c.take<_Float16>(M * W);
+    t.h16 = c.take<_Float16>(M * W);
+    t.st0 = c.take<float>(M * CC_LN_MAX_SLOTS * 2);
+    t.st1 = c.take<float>(M * CC_LN_MAX_SLOTS * 2);
     t.qkv = c.take<_Float16>(M * 3 * W);
     t.att = c.take<_Float16>(M * W);
     t.u = c.take<_Float16>(M * 4 * W);
@@ -198,8 +235,11 @@ int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, floa
         if (rc) return rc;
         rc = cc_launch_cls_pos(v.h, vm->class_embedding, vm->positional_embedding, F, n + 1, W, st);
         if (rc) return rc;
-        rc = cc_layernorm_f32(v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, 1e-5f, 0, st);
-        if (rc) return rc;
+        {   // ln_pre in place (fp32) + fp16 copy + row statistics for block 1's folded ln_1
+            LnArgs a{v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, v.h16, v.st0};
+            rc = cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st);
+            if (rc) return rc;
+        }
         h = v.h;
         hother = v.h2;
     }
@@ -207,10 +247,13 @@ int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, floa
         rc = cc_launch_text_embed(reinterpret_cast<const long long*>(ids), tm->token_embedding,
                                   tm->positional_embedding, t.h, t.eot, Bt, Lt, tm->width, st);
         if (rc) return rc;
+        rc = cc_launch_row_stats(t.h, t.h16, t.st0, Bt * Lt, tm->width, st);
+        if (rc) return rc;
     }
     const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
+    BlockCtx cv{}, ct{};
+    cv.slots0 = ct.slots0 = 1;
     for (int i = 0; i < (vl > tl ? vl : tl); ++i) {
-        BlockCtx cv{}, ct{};
         const bool hv = i < vl, ht = i < tl;
         if (hv) {
             if (vm->cluster_tokens[i] > 0) {        // token cluster before the attention of this block (clip.py:236-242)
@@ -229,10 +272,17 @@ int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, floa
                 float* tmp = h; h = hother; hother = tmp;
                 frames = Tn;
                 tokens = K;
+                rc = cc_launch_row_stats(h, v.h16, v.st0, B * frames * (tokens + 1), W, st);
+                if (rc) return rc;
+                cv.slots0 = 1;
             }
-            cv = BlockCtx{h, v.xn, v.qkv, v.att, v.u, B * frames, tokens + 1, W, vm->heads, 0};
+            cv.h = h; cv.h16 = v.h16; cv.st0 = v.st0; cv.st1 = v.st1; cv.qkv = v.qkv; cv.att = v.att; cv.u = v.u;
+            cv.nseq = B * frames; cv.L = tokens + 1; cv.W = W; cv.heads = vm->heads; cv.causal = 0;
         }
-        if (ht) ct = BlockCtx{t.h, t.xn, t.qkv, t.att, t.u, Bt, Lt, tm->width, tm->heads, 1};
+        if (ht) {
+            ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
+            ct.nseq = Bt; ct.L = Lt; ct.W = tm->width; ct.heads = tm->heads; ct.causal = 1;
+        }
         rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[i] : nullptr,
                             ht ? &ct : nullptr, st);
         if (rc) return rc;

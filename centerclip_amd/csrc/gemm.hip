@@ -96,6 +96,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 
     const int nk = g.K / GEMM_BK;
     stage(0, 0);
+    // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
+    // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
+    float row_mu = 0.f, row_rs = 1.f;
+    if ((EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN) && tid < BM) {
+        const int m = min(row0 + tid, g.M - 1);
+        const float2* ps = reinterpret_cast<const float2*>(g.ln_stats) + (int64_t)m * g.ln_slots;
+        float sum = 0.f, sq = 0.f;
+        for (int q0 = 0; q0 < g.ln_slots; q0 += 8) {
+            float2 t2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t2[u] = (q0 + u < g.ln_slots) ? ps[q0 + u] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sum += t2[u].x; sq += t2[u].y; }
+        }
+        row_mu = sum / (float)g.K;
+        const float var = fmaxf(sq / (float)g.K - row_mu * row_mu, 0.f);
+        row_rs = 1.0f / sqrtf(var + g.ln_eps);
+    }
     __syncthreads();
     const int l15 = lane & 15, lg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
@@ -126,40 +144,141 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     }
 
     // ---- epilogue: lane holds C[m = .. + l15][n = .. + lg*4 + 0..3]
+    constexpr int WTM = BM / WM, WTN = BN / WN;              // wave tile
+    constexpr bool OUT_F16 = (EPI == EPI_F16 || EPI == EPI_F16_GELU || EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
+    constexpr bool FOLD_LN = (EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
+    constexpr bool GELU = (EPI == EPI_F16_GELU || EPI == EPI_F16_GELU_LN);
+    if (OUT_F16) {
+        // fp16 outputs go through LDS (the staging buffers are free now) so that a wave stores whole
+        // 128-byte row segments (8 lanes x 16 B) instead of 16 rows x 32 B per instruction.
+        constexpr int LDO = WTN + 8;                          // halfs per staged row (144-byte rows for WTN = 64)
+        constexpr int STATS_BYTES = FOLD_LN ? BM * 8 : 0;     // (mu, rstd) per tile row, at the start of smem
+        constexpr int RH_MAX = (2 * (A_BYTES + B_BYTES) - STATS_BYTES) / (NWAVES * LDO * 2);
+        constexpr int RH = (RH_MAX >= WTM) ? WTM : (RH_MAX >= 64 ? 64 : (RH_MAX >= 32 ? 32 : 16));
+        static_assert(WTM % RH == 0 && RH % 16 == 0, "epilogue staging geometry");
+        float2* rowst = reinterpret_cast<float2*>(smem);
+        if (FOLD_LN) {
+            static_assert(BM <= THREADS, "one thread per tile row");
+            if (tid < BM) rowst[tid] = make_float2(row_mu, row_rs);
+            __syncthreads();
+        }
+        _Float16* stg = reinterpret_cast<_Float16*>(smem + STATS_BYTES) + wave * (RH * LDO);
+        constexpr int LPR = WTN / 8;                          // lanes per row (16 B each)
+        constexpr int RPI = 64 / LPR;                         // rows per store instruction
+        const int lr = lane / LPR, lc = (lane % LPR) * 8;
+        _Float16* Cb = reinterpret_cast<_Float16*>(g.C);
+#pragma unroll
+        for (int h0 = 0; h0 < WTM; h0 += RH) {
+#pragma unroll
+            for (int i = h0 / 16; i < (h0 + RH) / 16; ++i) {
+                float mu = 0.f, rs = 1.f;
+                if (FOLD_LN) { const float2 t2 = rowst[wr * WTM + i * 16 + l15]; mu = t2.x; rs = t2.y; }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = col0 + wc * WTN + j * 16 + lg * 4;
+                    f32x4 v = acc[i][j];
+                    if (FOLD_LN) {
+                        const float4 c1 = *reinterpret_cast<const float4*>(g.ln_c1 + n);
+                        v[0] = rs * (v[0] - mu * c1.x); v[1] = rs * (v[1] - mu * c1.y);
+                        v[2] = rs * (v[2] - mu * c1.z); v[3] = rs * (v[3] - mu * c1.w);
+                    }
+                    if (g.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    if (GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                    }
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<h4*>(stg + (i * 16 + l15 - h0) * LDO + j * 16 + lg * 4) = o;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the strip is private to this wave
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r0 = 0; r0 < RH; r0 += RPI) {
+                const int m = row0 + wr * WTM + h0 + r0 + lr;
+                const h8 v = *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
+                if (m < g.M) *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = v;
+            }
+            if (h0 + RH < WTM) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    constexpr bool STATS = (EPI == EPI_F32_RESID_STATS);
+    constexpr int LDH = WTN + 8;                                  // staged fp16 row (halfs)
+    constexpr int RHS_MAX = (2 * (A_BYTES + B_BYTES)) / (NWAVES * LDH * 2);
+    constexpr int RHS = (RHS_MAX >= WTM) ? WTM : (RHS_MAX >= 64 ? 64 : (RHS_MAX >= 32 ? 32 : 16));
+    _Float16* hstg = reinterpret_cast<_Float16*>(smem) + wave * (RHS * LDH);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = row0 + wr * (BM / WM) + i * 16 + l15;
-        if (m >= g.M) continue;
+        const int m = row0 + wr * WTM + i * 16 + l15;
+        float psum = 0.f, psq = 0.f;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = col0 + wc * (BN / WN) + j * 16 + lg * 4;
+            const int n = col0 + wc * WTN + j * 16 + lg * 4;
             f32x4 v = acc[i][j];
             if (g.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
-            if (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
-                if (EPI == EPI_F16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            if (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) {
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < g.M) {
+                    float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+                    c = *reinterpret_cast<const float4*>(dst);
+                    c.x += v[0]; c.y += v[1]; c.z += v[2]; c.w += v[3];
+                    *reinterpret_cast<float4*>(dst) = c;
                 }
-                h4 o;
+                if (STATS) {
+                    h4 o = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
+                    *reinterpret_cast<h4*>(hstg + ((i * 16 + l15) % RHS) * LDH + j * 16 + lg * 4) = o;
+                    // statistics of what the consumer will actually multiply: the fp16-rounded row
+                    const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+                    psum += (q0 + q1) + (q2 + q3);
+                    psq += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                }
+            } else if (m < g.M) {
+                if (EPI == EPI_F32_PATCH) {
+                    const int f = m / g.patch_n, tok = m - f * g.patch_n + 1;
+                    const float4 pe = *reinterpret_cast<const float4*>(g.pos + (int64_t)tok * g.N + n);
+                    float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + n;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+                } else {
+                    float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        if (STATS) {
+            // this wave's partial over its WTN columns: combine the 4 lane groups, one slot per (tile column, wave column)
+            psum += __shfl_xor(psum, 16, 64); psq += __shfl_xor(psq, 16, 64);
+            psum += __shfl_xor(psum, 32, 64); psq += __shfl_xor(psq, 32, 64);
+            if (lg == 0 && m < g.M) {
+                const int slot = tn * WN + wc;
+                reinterpret_cast<float2*>(g.stats_out)[(int64_t)m * (g.tiles_n * WN) + slot] = make_float2(psum, psq);
+            }
+            // flush the staged fp16 rows of this RHS-row group as 16-byte x (WTN/8)-lane row segments
+            if (((i + 1) * 16) % RHS == 0) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                constexpr int LPR = WTN / 8, RPI = 64 / LPR;
+                const int lr = lane / LPR, lc = (lane % LPR) * 8;
+                const int h0 = (i + 1) * 16 - RHS;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n) = o;
-            } else if (EPI == EPI_F32_RESID) {
-                float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
-                float4 c = *reinterpret_cast<const float4*>(dst);
-                c.x += v[0]; c.y += v[1]; c.z += v[2]; c.w += v[3];
-                *reinterpret_cast<float4*>(dst) = c;
-            } else if (EPI == EPI_F32_PATCH) {
-                const int f = m / g.patch_n, tok = m - f * g.patch_n + 1;
-                const float4 pe = *reinterpret_cast<const float4*>(g.pos + (int64_t)tok * g.N + n);
-                float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + n;
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
-            } else {
-                float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                for (int r0 = 0; r0 < RHS; r0 += RPI) {
+                    const int mm = row0 + wr * WTM + h0 + r0 + lr;
+                    const h8 val = *reinterpret_cast<const h8*>(hstg + (r0 + lr) * LDH + lc);
+                    if (mm < g.M) *reinterpret_cast<h8*>(g.c16 + (int64_t)mm * g.ldc + col0 + wc * WTN + lc) = val;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -207,6 +326,9 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID>(pr, total, st);
         case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH>(pr, total, st);
         case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(pr, total, st);
+        case EPI_F16_LN: return launch_one<BM, BN, WM, WN, EPI_F16_LN>(pr, total, st);
+        case EPI_F16_GELU_LN: return launch_one<BM, BN, WM, WN, EPI_F16_GELU_LN>(pr, total, st);
+        case EPI_F32_RESID_STATS: return launch_one<BM, BN, WM, WN, EPI_F32_RESID_STATS>(pr, total, st);
         default: return CC_ERR_INVALID;
     }
 }
@@ -233,7 +355,7 @@ static int pick_tile(const GemmArgs& g) {
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128 (8 waves)
-int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
+int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
         tile = pick_tile(g0);
@@ -244,6 +366,12 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     }
     const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
+    if (slots_out) {
+        const int wn = (tile == 5) ? 4 : 2;
+        slots_out[0] = g0.N / bn * wn;
+        slots_out[1] = g1 ? g1->N / bn * wn : 0;
+        if (slots_out[0] > CC_LN_MAX_SLOTS || slots_out[1] > CC_LN_MAX_SLOTS) return CC_ERR_UNSUPPORTED;
+    }
     switch (tile) {
         case 1: return launch_tile<128, 128, 2, 2>(g0, g1, epi, st);
         case 2: return launch_tile<128, 64, 2, 2>(g0, g1, epi, st);
@@ -255,7 +383,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     }
 }
 
-int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_gemm_dispatch2(g, nullptr, epi, tile, st); }
+int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_gemm_dispatch2(g, nullptr, epi, tile, st, nullptr); }
 
 extern "C" {
 

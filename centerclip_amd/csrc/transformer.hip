@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
         }
     }
     const float rstd = 1.0f / sqrtf(cc_wave_sum(q) / (float)W + eps);
+    float osum = 0.f, osq = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int w = lane * 4 + t * 256;
@@ -62,8 +63,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (int64_t)row * a.out_stride + w) =
                     make_float4(o0, o1, o2, o3);
+                if (a.out16) {      // fp16 copy of the new residual row + its (sum, sumsq) for the folded LayerNorm
+                    h4 o = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+                    *reinterpret_cast<h4*>(a.out16 + (int64_t)row * W + w) = o;
+                    const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+                    osum += (q0 + q1) + (q2 + q3);
+                    osq += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                }
             }
         }
+    }
+    if (!OUT_F16 && a.stats) {
+        osum = cc_wave_sum(osum);
+        osq = cc_wave_sum(osq);
+        if (lane == 0) reinterpret_cast<float2*>(a.stats)[row] = make_float2(osum, osq);
+    }
+}
+
+// fp16 copy + (sum, sum of squares of the fp16-rounded values) of contiguous fp32 rows; one wave per row
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ h, _Float16* __restrict__ h16,
+                                                        float* __restrict__ stats, int rows, int W) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int w = lane * 4; w < W; w += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * W + w);
+        h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
+        const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+        s += (q0 + q1) + (q2 + q3);
+        q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+    }
+    s = cc_wave_sum(s);
+    q = cc_wave_sum(q);
+    if (lane == 0) reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
+}
+
+// LayerNorm folding of a Linear layer: w_out[n,k] = fp16(W[n,k] * gamma[k]); c1[n] = sum_k float(w_out[n,k]);
+// c2[n] = sum_k beta[k] * W[n,k] + bias[n].  One workgroup per output row n.
+__global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int N, int K,
+                                                             _Float16* __restrict__ w_out, float* __restrict__ c1,
+                                                             float* __restrict__ c2) {
+    __shared__ float red[8];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = Wt[(int64_t)n * K + k];
+        const _Float16 wf = (_Float16)(w * gamma[k]);
+        w_out[(int64_t)n * K + k] = wf;
+        s1 += (float)wf;
+        s2 = fmaf(beta[k], w, s2);
+    }
+    s1 = cc_wave_sum(s1);
+    s2 = cc_wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        c1[n] = (red[0] + red[1]) + (red[2] + red[3]);
+        c2[n] = (red[4] + red[5]) + (red[6] + red[7]) + (bias ? bias[n] : 0.f);
     }
 }
 
@@ -318,10 +378,19 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
 // ============================================================================ C ABI (single ops)
 extern "C" {
 
+int cc_fold_layernorm_linear_f32(const float* weight, const float* bias, const float* gamma, const float* beta,
+                                 int32_t N, int32_t K, void* w_f16_out, float* c1_out, float* c2_out, void* stream) {
+    if (!weight || !gamma || !beta || !w_f16_out || !c1_out || !c2_out || N <= 0 || K <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), weight, bias, gamma,
+                       beta, N, K, static_cast<_Float16*>(w_f16_out), c1_out, c2_out);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta, void* out,
                      int64_t out_stride, int32_t rows, int32_t W, float eps, int32_t out_f16, void* stream) {
     if (!in || !gamma || !beta || !out || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
-    LnArgs a{in, in_stride, gamma, beta, out, out_stride, rows, W};
+    LnArgs a{in, in_stride, gamma, beta, out, out_stride, rows, W, nullptr, nullptr};
     return cc_launch_layernorm2(a, nullptr, eps, out_f16, static_cast<hipStream_t>(stream));
 }
 
@@ -347,6 +416,13 @@ int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_
         hipLaunchKernelGGL(layernorm_kernel<true>, dim3(total), dim3(256), 0, st, pr, eps);
     else
         hipLaunchKernelGGL(layernorm_kernel<false>, dim3(total), dim3(256), 0, st, pr, eps);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, int rows, int W, hipStream_t st) {
+    if (W & 3) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, rows, W);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

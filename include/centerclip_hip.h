@@ -187,7 +187,22 @@ typedef struct cc_block_weights {
     const float* ln_2_weight;  const float* ln_2_bias;
     const void* c_fc_weight_f16;      /* [4W, W] */   const float* c_fc_bias;       /* [4W] */
     const void* c_proj_weight_f16;    /* [W, 4W] */   const float* c_proj_bias;     /* [W]  */
+    /* ln_1 / ln_2 folded into the Linear layer that consumes them (cc_fold_layernorm_linear_f32):
+     *   LN(h) W^T + b = rstd (h (W*gamma)^T - mu c1) + c2
+     * so the encoders never run a stand-alone LayerNorm pass over the residual stream.           */
+    const void* in_proj_ln_weight_f16; /* fp16(in_proj_weight * ln_1.weight)  [3W, W] */
+    const float* in_proj_ln_c1;        /* [3W] row sums of the folded weight          */
+    const float* in_proj_ln_c2;        /* [3W] in_proj_weight ln_1.bias + in_proj_bias */
+    const void* c_fc_ln_weight_f16;    /* fp16(c_fc.weight * ln_2.weight)     [4W, W] */
+    const float* c_fc_ln_c1;           /* [4W] */
+    const float* c_fc_ln_c2;           /* [4W] */
 } cc_block_weights;
+
+/* Fold a LayerNorm (gamma, beta over K) into the Linear layer y = LN(x) W^T + b that consumes it:
+ * w_f16_out[n,k] = fp16(W[n,k] * gamma[k]); c1_out[n] = sum_k w_f16_out[n,k]; c2_out[n] = sum_k beta[k] W[n,k] + b[n].
+ * weight [N,K] fp32, bias [N] fp32 or NULL.  Fills the *_ln_* fields of cc_block_weights. */
+int cc_fold_layernorm_linear_f32(const float* weight, const float* bias, const float* gamma, const float* beta,
+                                 int32_t N, int32_t K, void* w_f16_out, float* c1_out, float* c2_out, void* stream);
 
 #define CC_MAX_LAYERS 32
 

@@ -40,7 +40,7 @@ def relerr(a, b):
 
 # ------------------------------------------------------------------------------- single ops
 @pytest.mark.parametrize("M,N,K", [(9600, 2304, 768), (2400, 768, 3072), (100, 128, 64), (513, 3072, 768), (77, 512, 2048)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 def test_linear_f16_epilogues(M, N, K, tile):
     from centerclip_amd import ops
     gen = torch.Generator().manual_seed(M + N + K)
@@ -48,6 +48,8 @@ def test_linear_f16_epilogues(M, N, K, tile):
     w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
     bias = torch.randn(N, generator=gen)
     ref = a.double() @ w.double().t() + bias.double()
+    if (tile == 5 and N % 256) or (tile in (1, 3, 6) and N % 128):
+        pytest.skip("tile does not divide N")
     ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
     y = ops.linear_f16(ad, wd, bd, "f32", tile=tile).cpu()
     assert relerr(y, ref) < 2e-4
