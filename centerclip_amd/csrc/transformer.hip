@@ -5,6 +5,7 @@
 // sqrt(64) + mask) v), :326-338 (patch embed + CLS + positional embedding + ln_pre), :448-454
 // (causal mask), :463-464 / :480-484 (ln_post / ln_final + projection of the CLS / EOT row).
 #include "cc_kernels.h"
+#include <cstdlib>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -267,6 +268,135 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
     }
 }
 
+// ---------------------------------------------------------------------------- short sequences (L <= 64)
+// One WAVE per (sequence, head), four independent waves per workgroup, no workgroup barrier:
+//   K fragments are loaded straight from global memory into registers (each is reused by all query tiles
+//   of the wave), V is transposed into a per-wave 8 KB LDS tile [64 d][64 keys] whose 16-byte chunks are
+//   XOR-swizzled by f(d) = (d ^ d>>3) & 7 - conflict-free both for the 2-byte transposing writes (lanes of a
+//   row differ in d>>3) and for the ds_read_b128 operand fetches (16 consecutive d) - and P goes through a
+//   per-wave 2 KB strip.  All global loads of a head (7 V + 8 K + 2 Q per lane) are issued up front.
+// Covers L = 50 (ViT-B/32 and every K = 49 clustered block) and the 32-token text tower.
+#define ATTW_KT 64
+__global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float scale) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4][ATT_D * ATTW_KT + 16 * (ATTW_KT + 8)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = blockIdx.x * 4 + wave;
+    const int units0 = pr.a[0].nseq * pr.a[0].heads;
+    const bool second = unit >= units0;
+    const AttArgs at = second ? pr.a[1] : pr.a[0];
+    const int u = unit - (second ? units0 : 0);
+    if (u >= at.nseq * at.heads) return;                       // wave-uniform; no barriers below
+    const int L = at.L, heads = at.heads, W = at.W;
+    const bool CAUSAL = at.causal != 0;
+    const int seq = u / heads, head = u - seq * heads;
+    const int64_t ld = 3 * (int64_t)W;
+    const _Float16* base = at.qkv + (int64_t)seq * L * ld + head * ATT_D;
+    _Float16* Vt = lds[wave];
+    _Float16* Pw = Vt + ATT_D * ATTW_KT;
+    constexpr int PS = ATTW_KT + 8;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // ---- issue every global load of this head
+    h8 vreg[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {                               // 64 keys x 8 chunks = 512 -> 8 per lane, last is padding
+        const int idx = t * 64 + lane, r = idx >> 3, c = idx & 7;
+        vreg[t] = (r < L) ? *reinterpret_cast<const h8*>(base + (int64_t)r * ld + 2 * W + c * 8) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    h8 kf[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int r = min(kt * 16 + l15, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + W + (ks * 4 + lg) * 8);
+    }
+    // rows 56..63 of V (7 loads cover idx < 448 -> rows < 56): zero them and rows >= L
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int idx = t * 64 + lane, r = idx >> 3, c = idx & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = c * 8 + e;
+            Vt[d * ATTW_KT + ((((r >> 3) ^ ((d ^ (d >> 3)) & 7))) << 3) + (r & 7)] = vreg[t][e];
+        }
+    }
+    {   // keys 56..63 are beyond every supported L (<= 56 rows loaded): zero fill
+        const int d = lane;
+        *reinterpret_cast<h8*>(Vt + d * ATTW_KT + ((7 ^ ((d ^ (d >> 3)) & 7)) << 3)) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    const int qtiles = (L + 15) / 16;
+    for (int qt = 0; qt < qtiles; ++qt) {
+        const int q = qt * 16 + l15;
+        const int qc = min(q, L - 1);
+        h8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)qc * ld + (ks * 4 + lg) * 8);
+        f32x4 s[4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[ks], a, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kt * 16 + lg * 4 + e;
+                const bool ok = key < L && (!CAUSAL || key <= q);
+                a[e] = ok ? a[e] * scale : -3.0e38f;
+                mx = fmaxf(mx, a[e]);
+            }
+            s[kt] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pexp = (s[kt][e] > -1.0e38f) ? __expf(s[kt][e] - mx) : 0.f;
+                s[kt][e] = pexp;
+                sum += pexp;
+            }
+        sum += __shfl_xor(sum, 16, CC_WAVE);
+        sum += __shfl_xor(sum, 32, CC_WAVE);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            h4 ph = {(_Float16)(s[kt][0] * inv), (_Float16)(s[kt][1] * inv), (_Float16)(s[kt][2] * inv),
+                     (_Float16)(s[kt][3] * inv)};
+            *reinterpret_cast<h4*>(Pw + l15 * PS + kt * 16 + lg * 4) = ph;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * PS + kb * 32 + lg * 8);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d = dt * 16 + l15;
+                const h8 vf = *reinterpret_cast<const h8*>(Vt + d * ATTW_KT + (((kb * 4 + lg) ^ ((d ^ (d >> 3)) & 7)) << 3));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < L) {
+            _Float16* dst = at.out + ((int64_t)seq * L + q) * W + head * ATT_D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                *reinterpret_cast<h4*>(dst + dt * 16 + lg * 4) = oh;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ============================================================================ embeddings
 // conv1 as GEMM: A[f*n + (ph*g + pw)][c*p*p + kh*p + kw] = video[f][c][ph*p+kh][pw*p+kw]  (fp16)
 __global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict__ video, _Float16* __restrict__ A,
@@ -439,6 +569,12 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
     pr.a[1] = a1 ? *a1 : a0;
     pr.wgs0 = a0.nseq * a0.heads;
     const int total = pr.wgs0 + (a1 ? a1->nseq * a1->heads : 0);
+    static const bool wave_path = !(getenv("CC_ATT_BLOCK") && getenv("CC_ATT_BLOCK")[0] == '1');   // A/B switch
+    if (wave_path && a0.L <= 56 && (!a1 || a1->L <= 56)) {          // one wave per (sequence, head)
+        hipLaunchKernelGGL(attention_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, st, pr, 0.125f);
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
     size_t smem = att_smem_bytes(a0.L);
     if (a1 && att_smem_bytes(a1->L) > smem) smem = att_smem_bytes(a1->L);
     static size_t configured = 64 * 1024;
