@@ -69,33 +69,35 @@ __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict
 // of each 16-k slice for the t-th MFMA) - A and B use the same permutation, so it is only a
 // fixed re-ordering of the summation.
 #define GT 64
-#define GK 32
-#define GLD 40
+#define GK 64
+#define GLD 72     /* 64 k + 8 pad floats: 72 == 8 (mod 64) words -> rows r, r+8 alias; groups read 16 rows x 16 B = conflict-free in 2 passes */
 
 template <int METRIC>
 __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
                                                         int W, const float* __restrict__ sqn,
                                                         const float* __restrict__ inv, float* __restrict__ draw,
                                                         int* __restrict__ chunkmax, int chunk, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][GT * GLD];
+    extern __shared__ __attribute__((aligned(16))) float gram_lds[];       // [2 buffers][A,B][GT * GLD]
+    auto tile = [&](int buf, int which) { return gram_lds + (buf * 2 + which) * (GT * GLD); };
     const int p = blockIdx.y;
     int t = blockIdx.x, ti = 0, rowlen = ntiles;
     while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
     const int tj = ti + t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 3, lchunk = tid & 7;
-    const float* pa[2];
-    const float* pb[2];
+    const int lrow = tid >> 4, lchunk = tid & 15;            // 16 threads x 16 B cover one 64-float row slice
+    const float* pa[4];
+    const float* pb[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ra = min(ti * GT + lrow + 32 * q, N - 1);
-        const int rb = min(tj * GT + lrow + 32 * q, N - 1);
+    for (int q = 0; q < 4; ++q) {
+        const int ra = min(ti * GT + lrow + 16 * q, N - 1);
+        const int rb = min(tj * GT + lrow + 16 * q, N - 1);
         pa[q] = cc_token_ptr(x, lay, p, ra) + lchunk * 4;
         pb[q] = cc_token_ptr(x, lay, p, rb) + lchunk * 4;
     }
     const int wr = wave >> 1, wc = wave & 1;
     const bool active = !(ti == tj && wr > wc) && (ti * GT + wr * 32 < N) && (tj * GT + wc * 32 < N);
+    const bool diag = (ti == tj);                             // A and B tiles are the same rows: load once
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -103,22 +105,21 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra_[2], rb_[2];
+    float4 ra_[4], rb_[4];
     const int nk = (W + GK - 1) / GK;
     auto gload = [&](int kt) {
-        const int k = kt * GK + lchunk * 4;
-        const bool ok = k < W;
+        const bool ok = kt * GK + lchunk * 4 < W;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             ra_[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!diag) rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * q) * GLD + lchunk * 4]) = ra_[q];
-            *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * q) * GLD + lchunk * 4]) = rb_[q];
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(tile(buf, 0) + (lrow + 16 * q) * GLD + lchunk * 4) = ra_[q];
+            if (!diag) *reinterpret_cast<float4*>(tile(buf, 1) + (lrow + 16 * q) * GLD + lchunk * 4) = rb_[q];
         }
     };
     gload(0);
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
         if (active) {
-            const float* A = &lds[buf][0][(wr * 32 + l15) * GLD + g * 4];
-            const float* Bm = &lds[buf][1][(wc * 32 + l15) * GLD + g * 4];
+            const float* A = tile(buf, 0) + (wr * 32 + l15) * GLD + g * 4;
+            const float* Bm = tile(buf, diag ? 0 : 1) + (wc * 32 + l15) * GLD + g * 4;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < GK / 16; ++ks) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(A + ks * 16);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(A + 16 * GLD + ks * 16);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bm + ks * 16);
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
 // Direct sum_w |x-y|^p in ascending w per pair (exact-zero diagonal like ATen's direct path).
 // MODE 1: p == 1; MODE 0: general p > 0; MODE 2: p == inf.
 #define LLD 36
+#define LPK 32    /* k-slice of the VALU kernel */
 template <int MODE>
 __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N, int W,
                                                       float pw, float* __restrict__ draw, int* __restrict__ chunkmax,
@@ -215,19 +217,19 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
-    const int nk = (W + GK - 1) / GK;
+    const int nk = (W + LPK - 1) / LPK;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool ok = kt * GK + lchunk * 4 < W;
+        const bool ok = kt * LPK + lchunk * 4 < W;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float4 va = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0, 0, 0, 0);
-            const float4 vb = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0, 0, 0, 0);
+            const float4 va = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * LPK) : make_float4(0, 0, 0, 0);
+            const float4 vb = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * LPK) : make_float4(0, 0, 0, 0);
             *reinterpret_cast<float4*>(&lds[0][(lrow + 32 * q) * LLD + lchunk * 4]) = va;
             *reinterpret_cast<float4*>(&lds[1][(lrow + 32 * q) * LLD + lchunk * 4]) = vb;
         }
         __syncthreads();
 #pragma unroll
-        for (int k4 = 0; k4 < GK / 4; ++k4) {
+        for (int k4 = 0; k4 < LPK / 4; ++k4) {
             float4 a[4], b[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(&lds[0][(ty + 16 * r) * LLD + k4 * 4]);
@@ -337,7 +339,18 @@ __device__ __forceinline__ unsigned cc_wave_umax(unsigned v) {
     return max(max(a, b), max(c, d));
 }
 
-template <bool IN_LDS>
+__device__ __forceinline__ unsigned cc_wave_umin(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// NE = compile-time number of 64-token chunks (N <= 64*NE): the KKZ loop is fully unrolled, branch free
+template <bool IN_LDS, int NE>
 __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __restrict__ dist_in, float* dist_rw,
                                                               const float* __restrict__ norms,
                                                               const int* __restrict__ chunkmax, int chunk,
@@ -369,17 +382,42 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         const float mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
         float* dst = IN_LDS ? s.D : (dist_rw + base);
         const int total = N * N;
-        for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-            float v[8];
+        if (IN_LDS && (total & 3) == 0) {                      // 16-byte path (problem base stays 16-byte aligned)
+            const float4* src4 = reinterpret_cast<const float4*>(Dg);
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            const int total4 = total >> 2;
+            for (int i0 = tid; i0 < total4; i0 += 256 * 8) {
+                float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + u * 256;
-                v[u] = idx < total ? Dg[idx] : 0.f;
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * 256;
+                    v[u] = idx < total4 ? src4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * 256;
+                    if (idx < total4) {
+                        if (apply_shift) {
+                            v[u].x = (v[u].x - mx) - 1.0f; v[u].y = (v[u].y - mx) - 1.0f;
+                            v[u].z = (v[u].z - mx) - 1.0f; v[u].w = (v[u].w - mx) - 1.0f;
+                        }
+                        dst4[idx] = v[u];
+                    }
+                }
             }
+        } else {
+            for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + u * 256;
-                if (idx < total) dst[idx] = apply_shift ? (v[u] - mx) - 1.0f : v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * 256;
+                    v[u] = idx < total ? Dg[idx] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * 256;
+                    if (idx < total) dst[idx] = apply_shift ? (v[u] - mx) - 1.0f : v[u];
+                }
             }
         }
         if (!IN_LDS) Dg = dist_rw + base;
@@ -398,44 +436,29 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118).  The running minimum lives in registers as
     // order-preserving uint keys; arg-max = DPP max + ballots (lowest index wins ties).
     if (wave == 0) {
-        unsigned nearest[SEL_MAX_E];
+        unsigned nearest[NE];
         const float* nr = norms + (int64_t)p * N;
-        auto argmax_keys = [&]() -> int {
-            unsigned loc = 0u;
+        unsigned loc = 0u, locn = 0u;                          // lane-local best key and the smallest n attaining it
 #pragma unroll
-            for (int e = 0; e < SEL_MAX_E; ++e)
-                if (e < E) loc = max(loc, nearest[e]);
+        for (int e = 0; e < NE; ++e) {
+            const int n = lane + 64 * e;
+            nearest[e] = (n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
+            if (nearest[e] > loc) { loc = nearest[e]; locn = (unsigned)n; }
+        }
+        for (int i = 0; i < K; ++i) {
+            // arg-max with lowest-index tie break: DPP max of the keys, then DPP min of the candidate indices
             const unsigned mx = cc_wave_umax(loc);
-            int found = 0;
-            bool done = false;
-#pragma unroll
-            for (int e = 0; e < SEL_MAX_E; ++e) {
-                if (e < E && !done) {
-                    const unsigned long long b = __ballot(nearest[e] == mx);
-                    if (b) { found = 64 * e + (__ffsll((long long)b) - 1); done = true; }
-                }
-            }
-            return found;
-        };
-#pragma unroll
-        for (int e = 0; e < SEL_MAX_E; ++e) {
-            const int n = lane + 64 * e;
-            nearest[e] = (e < E && n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
-        }
-        int m = argmax_keys();
-        if (lane == 0) s.med[0] = m;
-#pragma unroll
-        for (int e = 0; e < SEL_MAX_E; ++e) {
-            const int n = lane + 64 * e;
-            nearest[e] = (e < E && n < N) ? cc_float_to_ordered_uint(DREAD(m, n)) : 0u;
-        }
-        for (int i = 1; i < K; ++i) {
-            m = argmax_keys();
+            const int m = (int)cc_wave_umin(loc == mx ? locn : 0xFFFFFFFFu);
             if (lane == 0) s.med[i] = m;
+            loc = 0u; locn = 0u;
 #pragma unroll
-            for (int e = 0; e < SEL_MAX_E; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int n = lane + 64 * e;
-                if (e < E && n < N) nearest[e] = min(nearest[e], cc_float_to_ordered_uint(DREAD(m, n)));
+                if (n < N) {
+                    const unsigned kd = cc_float_to_ordered_uint(DREAD(m, n));
+                    nearest[e] = (i == 0) ? kd : min(nearest[e], kd);
+                    if (nearest[e] > loc) { loc = nearest[e]; locn = (unsigned)n; }
+                }
             }
         }
     }
@@ -678,12 +701,24 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     CC_LAUNCH_CHECK();
     const int nt = (N + GT - 1) / GT;
     dim3 grid(nt * (nt + 1) / 2, P);
+    const size_t gram_smem = (size_t)2 * 2 * GT * GLD * sizeof(float);      // 73,728 B
+    if (metric == CC_METRIC_COSINE || p == 2.0f) {
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gram_dist_kernel<CC_METRIC_COSINE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_smem) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gram_dist_kernel<CC_METRIC_EUCLIDEAN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_smem) != hipSuccess)
+                return CC_ERR_HIP;
+            configured = true;
+        }
+    }
     if (metric == CC_METRIC_COSINE) {
-        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), 0, st, x, lay, N, W, c.sqn, c.inv,
+        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.inv,
                            c.draw, c.chunkmax, chunk, nt);
     } else if (p == 2.0f) {
-        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), 0, st, x, lay, N, W, c.sqn, c.inv,
-                           c.draw, c.chunkmax, chunk, nt);
+        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn,
+                           c.inv, c.draw, c.chunkmax, chunk, nt);
     } else if (p == 1.0f) {
         hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
     } else if (p > 3.0e38f) {
@@ -702,18 +737,27 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
     const bool in_lds = sel_smem_bytes(N, K, true) <= lds_limit;
     const size_t smem = sel_smem_bytes(N, K, in_lds);
     if (smem > lds_limit) return CC_ERR_UNSUPPORTED;
+    const int ne = (N + 63) / 64;
+#define SEL_LAUNCH(INLDS, NEV)                                                                                         \
+    do {                                                                                                               \
+        auto kern = kmedoids_select_kernel<INLDS, NEV>;                                                                \
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
+            return CC_ERR_HIP;                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift,  \
+                           N, K, iter_limit, id_sort, med, assign, iters);                                            \
+    } while (0)
     if (in_lds) {
-        auto kern = kmedoids_select_kernel<true>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return CC_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift, N,
-                           K, iter_limit, id_sort, med, assign, iters);
+        if (ne <= 1) SEL_LAUNCH(true, 1);
+        else if (ne == 2) SEL_LAUNCH(true, 2);
+        else if (ne == 3) SEL_LAUNCH(true, 3);
+        else SEL_LAUNCH(true, 4);
     } else {
-        auto kern = kmedoids_select_kernel<false>;
-        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift, N,
-                           K, iter_limit, id_sort, med, assign, iters);
+        if (ne <= 4) SEL_LAUNCH(false, 4);
+        else if (ne <= 7) SEL_LAUNCH(false, 7);
+        else SEL_LAUNCH(false, SEL_MAX_E);
     }
+#undef SEL_LAUNCH
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
