@@ -90,7 +90,7 @@ def pmc_traffic(kernel):
     None when no counter pass exists for this kernel."""
     import glob
     import re
-    epi = {"c_fc": 1, "in_proj": 0, "c_proj": 2}.get(kernel.split(":")[-1])
+    epi = {"c_fc": 6, "in_proj": 5, "c_proj": 7}.get(kernel.split(":")[-1])
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
     if epi is None or not files:
         return None
@@ -120,8 +120,24 @@ def gemm_roofline(c, device):
         a = torch.randn(M, K, device=device).half()
         w = (torch.randn(N, K, device=device) * K ** -0.5).half()
         bias = torch.randn(N, device=device)
-        out = torch.zeros(M, N, device=device, dtype=torch.float16 if epi.startswith("f16") else torch.float32)
-        ms = event_time_ms(lambda: ops.linear_f16(a, w, bias, epi, out=out), 20)
+        base = name.split("@")[0]
+        if base in ("in_proj", "c_fc"):          # LayerNorm-folded consumer epilogue, statistics in 12 slots
+            hres = torch.randn(M, K, device=device)
+            h16, _ = ops.row_stats(hres)
+            stats = torch.randn(M, 12, 2, device=device).abs()
+            wf, c1, c2 = ops.fold_layernorm_linear(w.float(), bias, torch.ones(K, device=device), torch.zeros(K, device=device))
+            out = torch.empty(M, N, device=device, dtype=torch.float16)
+            fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, out=out, g=(base == "c_fc"):
+                  ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=g, out=out))
+        elif base in ("out_proj", "c_proj"):     # residual epilogue that also emits fp16 rows + partial sums
+            hres = torch.zeros(M, N, device=device)
+            h16b = torch.empty(M, N, device=device, dtype=torch.float16)
+            stb = torch.empty(M * 32 * 2, device=device)
+            fn = lambda a=a, w=w, bias=bias, hres=hres, h16b=h16b, stb=stb: ops.linear_resid_stats_f16(a, w, bias, hres, h16=h16b, stats=stb)
+        else:
+            out = torch.zeros(M, N, device=device, dtype=torch.float32)
+            fn = lambda a=a, w=w, bias=bias, out=out, epi=epi: ops.linear_f16(a, w, bias, epi, out=out)
+        ms = event_time_ms(fn, 20)
         flops = 2.0 * M * N * K
         rows.append(dict(kernel="gemm_f16_kernel:" + name, M=M, N=N, K=K, calls_per_step=calls, avg_us=ms * 1e3,
                          tflops=flops / ms / 1e9, step_share_us=ms * 1e3 * calls))

@@ -400,4 +400,40 @@ int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void*
     return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
 }
 
+/* LayerNorm-folded Linear: y = LN(h) W^T + b evaluated as rstd (h16 Wln^T - mu c1) + c2 (see cc_fold_layernorm_linear_f32).
+ * h16 [M,K] fp16 copy of the rows, stats [M][slots][2] partial (sum, sum of squares) of those fp16 rows. */
+int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
+                     int32_t slots, float eps, void* out_f16, int32_t M, int32_t N, int32_t K, int32_t gelu,
+                     int32_t tile, void* stream) {
+    if (!h_f16 || !w_ln_f16 || !c1 || !c2 || !stats || !out_f16 || slots <= 0 || slots > CC_LN_MAX_SLOTS) return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(h_f16);
+    g.W = static_cast<const _Float16*>(w_ln_f16);
+    g.bias = c2;
+    g.C = out_f16;
+    g.M = M; g.N = N; g.K = K; g.ldc = N;
+    g.ln_stats = stats; g.ln_slots = slots; g.ln_c1 = c1; g.ln_eps = eps;
+    return cc_gemm_dispatch(g, gelu ? EPI_F16_GELU_LN : EPI_F16_LN, tile, static_cast<hipStream_t>(stream));
+}
+
+/* Residual Linear that also emits what the next folded LayerNorm needs: h (fp32, in place) += a W^T + b;
+ * h16 = fp16(h); stats_out [M][*slots_out][2] = per-tile partial (sum, sum of squares) of the fp16 rows. */
+int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
+                              float* stats_out, int32_t* slots_out, int32_t M, int32_t N, int32_t K, int32_t tile,
+                              void* stream) {
+    if (!a_f16 || !w_f16 || !h || !h16_out || !stats_out || !slots_out) return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(a_f16);
+    g.W = static_cast<const _Float16*>(w_f16);
+    g.bias = bias;
+    g.C = h;
+    g.M = M; g.N = N; g.K = K; g.ldc = N;
+    g.c16 = static_cast<_Float16*>(h16_out);
+    g.stats_out = stats_out;
+    int slots[2] = {0, 0};
+    const int rc = cc_gemm_dispatch2(g, nullptr, EPI_F32_RESID_STATS, tile, static_cast<hipStream_t>(stream), slots);
+    *slots_out = slots[0];
+    return rc;
+}
+
 }  // extern "C"

@@ -517,6 +517,11 @@ int cc_fold_layernorm_linear_f32(const float* weight, const float* bias, const f
     return CC_OK;
 }
 
+int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, int32_t rows, int32_t W, void* stream) {
+    if (!h || !h16_out || !stats_out || rows <= 0 || W <= 0) return CC_ERR_INVALID;
+    return cc_launch_row_stats(h, static_cast<_Float16*>(h16_out), stats_out, rows, W, static_cast<hipStream_t>(stream));
+}
+
 int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta, void* out,
                      int64_t out_stride, int32_t rows, int32_t W, float eps, int32_t out_f16, void* stream) {
     if (!in || !gamma || !beta || !out || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;

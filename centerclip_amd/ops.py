@@ -84,3 +84,60 @@ def scaled_dot_nt(a, b, mult=1.0, out=None):
     L.check(L.lib().cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, Bv, E, float(mult), L.ptr(out), out.stride(0),
                                          L.stream_ptr(a.device)), "cc_scaled_dot_nt_f32")
     return out
+
+
+LN_MAX_SLOTS = 32
+
+
+def fold_layernorm_linear(weight, bias, gamma, beta):
+    """-> (w' fp16 [N,K], c1 [N], c2 [N]): LN(x) W^T + b == rstd (x w'^T - mu c1) + c2."""
+    L.require_device(weight, gamma, beta)
+    w = weight.detach().float().contiguous()
+    N, K = w.shape
+    b = bias.detach().float().contiguous() if bias is not None else None
+    wf = torch.empty(N, K, device=w.device, dtype=torch.float16)
+    c1 = torch.empty(N, device=w.device, dtype=torch.float32)
+    c2 = torch.empty(N, device=w.device, dtype=torch.float32)
+    L.check(L.lib().cc_fold_layernorm_linear_f32(L.ptr(w), L.ptr(b), L.ptr(gamma.detach().float().contiguous()),
+                                                 L.ptr(beta.detach().float().contiguous()), N, K, L.ptr(wf), L.ptr(c1),
+                                                 L.ptr(c2), L.stream_ptr(w.device)), "cc_fold_layernorm_linear_f32")
+    return wf, c1, c2
+
+
+def row_stats(h):
+    """h [M,W] fp32 -> (h16, stats [M, 1, 2]: one slot per row)."""
+    L.require_device(h)
+    M, W = h.shape
+    h16 = torch.empty(M, W, device=h.device, dtype=torch.float16)
+    compact = torch.empty(M, 2, device=h.device, dtype=torch.float32)
+    L.check(L.lib().cc_row_stats_f16(L.ptr(h.contiguous()), L.ptr(h16), L.ptr(compact), M, W, L.stream_ptr(h.device)),
+            "cc_row_stats_f16")
+    return h16, compact
+
+
+def linear_ln_f16(h16, w_ln, c1, c2, stats, slots, gelu=False, eps=1e-5, out=None, tile=0):
+    """LayerNorm-folded Linear (stats laid out [M, slots, 2])."""
+    M, K = h16.shape
+    N = w_ln.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=h16.device, dtype=torch.float16)
+    L.check(L.lib().cc_linear_ln_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
+                                     L.ptr(out), M, N, K, int(gelu), tile, L.stream_ptr(h16.device)), "cc_linear_ln_f16")
+    return out
+
+
+def linear_resid_stats_f16(a, w, bias, h, tile=0, h16=None, stats=None):
+    """h += a @ w.T + bias in place; returns (h16, stats [M, slots, 2], slots).  ``h16`` [M,N] fp16 and ``stats``
+    (flat fp32, >= M*32*2) may be preallocated."""
+    import ctypes
+    M, K = a.shape
+    N = w.shape[0]
+    if h16 is None:
+        h16 = torch.empty(M, N, device=a.device, dtype=torch.float16)
+    if stats is None:
+        stats = torch.empty(M * LN_MAX_SLOTS * 2, device=a.device, dtype=torch.float32)
+    slots = ctypes.c_int32(0)
+    L.check(L.lib().cc_linear_resid_stats_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(h), L.ptr(h16), L.ptr(stats),
+                                              ctypes.byref(slots), M, N, K, tile, L.stream_ptr(a.device)),
+            "cc_linear_resid_stats_f16")
+    return h16, stats[:M * slots.value * 2].view(M, slots.value, 2), slots.value

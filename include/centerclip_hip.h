@@ -172,6 +172,20 @@ int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, con
                      void* out, int64_t out_stride, int32_t rows, int32_t W, float eps,
                      int32_t out_f16, void* stream);
 
+/* The three pieces of the folded-LayerNorm pipeline the encoders use instead of stand-alone LayerNorm passes
+ * (replaces ln_1 -> in_proj and ln_2 -> c_fc of modules/clip.py:240,251):
+ *   cc_row_stats_f16          h [rows,W] fp32 -> h16 = fp16(h), stats [rows][1][2] = (sum, sum of squares) of h16
+ *   cc_linear_ln_f16          out(fp16) = [QuickGELU](LN(h) W^T + b), from h16, the folded weight and the stats
+ *   cc_linear_resid_stats_f16 h += a W^T + b (residual), h16 = fp16(h), stats [M][*slots_out][2] (one slot per
+ *                             tile column x wave column; stats buffers must hold 32 slots per row)            */
+int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, int32_t rows, int32_t W, void* stream);
+int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
+                     const float* stats, int32_t slots, float eps, void* out_f16,
+                     int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* stream);
+int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h,
+                              void* h16_out, float* stats_out, int32_t* slots_out,
+                              int32_t M, int32_t N, int32_t K, int32_t tile, void* stream);
+
 /* Multi-head self-attention core of nn.MultiheadAttention (modules/clip.py:220-226):
  * qkv [nseq*L, 3W] fp16 (row = seq*L + token; q | k | v, heads = contiguous 64-wide slices),
  * out [nseq*L, W] fp16 = softmax(q k^T / 8 + mask) v; causal != 0 adds the strict upper

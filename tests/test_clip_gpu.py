@@ -65,6 +65,40 @@ def test_linear_f16_epilogues(M, N, K, tile):
     assert relerr(out.cpu(), ref + resid.double()) < 2e-4
 
 
+@pytest.mark.parametrize("M,W,tile", [(9600, 768, 0), (2400, 768, 0), (512, 512, 0), (300, 768, 1), (300, 768, 4)])
+def test_folded_layernorm_chain(M, W, tile):
+    """residual linear (+fp16 copy + per-tile partial sums) -> LayerNorm-folded linear, against
+    h += a W^T + b;  y = QuickGELU(LN(h) W2^T + b2) in float64."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(M + W)
+    a = torch.randn(M, W, generator=gen).half()
+    w1 = (torch.randn(W, W, generator=gen) * W ** -0.5).half()
+    b1 = torch.randn(W, generator=gen) * 0.1
+    h0 = torch.randn(M, W, generator=gen) * 2 + 0.3
+    gamma, beta = torch.rand(W, generator=gen) + 0.5, torch.randn(W, generator=gen) * 0.2
+    w2 = torch.randn(4 * W, W, generator=gen) * W ** -0.5
+    b2 = torch.randn(4 * W, generator=gen) * 0.1
+    href = h0.double() + a.double() @ w1.double().t() + b1.double()
+    xn = F.layer_norm(href, (W,), gamma.double(), beta.double(), 1e-5)
+    pre = xn @ w2.double().t() + b2.double()
+    yref = pre * torch.sigmoid(1.702 * pre)
+    h = h0.to(DEV).clone()
+    h16, stats, slots = ops.linear_resid_stats_f16(a.to(DEV), w1.to(DEV), b1.to(DEV), h, tile=tile)
+    assert relerr(h.cpu(), href) < 2e-4 and torch.equal(h16, h.half())
+    s = stats.sum(1).double().cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), h16.double().sum(-1).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (h16.double() ** 2).sum(-1).cpu().numpy(), rtol=1e-5)
+    wf, c1, c2 = ops.fold_layernorm_linear(w2.to(DEV), b2.to(DEV), gamma.to(DEV), beta.to(DEV))
+    y = ops.linear_ln_f16(h16, wf, c1, c2, stats.contiguous(), slots, gelu=True).float().cpu()
+    assert relerr(y, yref) < 3e-3
+    pre_hip = ops.linear_ln_f16(h16, wf, c1, c2, stats.contiguous(), slots, gelu=False).float().cpu()
+    assert relerr(pre_hip, pre) < 3e-3
+    # one-slot statistics from cc_row_stats_f16 give the same result
+    h16b, st1 = ops.row_stats(h)
+    y1 = ops.linear_ln_f16(h16b, wf, c1, c2, st1, 1, gelu=True).float().cpu()
+    assert float((y1 - y).abs().max()) <= 4e-3 * float(yref.abs().max())
+
+
 def test_linear_detects_transposed_operands():
     """asymmetric A=I check (a symmetric B would hide a row/col swap)."""
     from centerclip_amd import ops

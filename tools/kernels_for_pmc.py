@@ -6,13 +6,24 @@ import torch
 from centerclip_amd import ops
 from centerclip_amd.cluster import TokenClusterInter
 W = 768
-for name, M, N, K, epi in [("c_fc", 9600, 3072, 768, "f16_gelu"), ("in_proj", 9600, 2304, 768, "f16"), ("c_proj", 9600, 768, 3072, "f32_resid")]:
-    a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+M = 9600
+# the three dominant GEMMs of a block, with the epilogues the encoders really use (LayerNorm folded)
+for name, N, K in [("c_fc", 3072, 768), ("in_proj", 2304, 768)]:
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
     b = torch.randn(N, device="cuda")
-    out = torch.zeros(M, N, device="cuda", dtype=torch.float16 if epi.startswith("f16") else torch.float32)
+    h16, _ = ops.row_stats(torch.randn(M, K, device="cuda"))
+    stats = torch.randn(M, 12, 2, device="cuda").abs()
+    wf, c1, c2 = ops.fold_layernorm_linear(w, b, torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"))
+    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
     for _ in range(5):
-        ops.linear_f16(a, w, b, epi, out=out)
+        ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=(name == "c_fc"), out=out)
     torch.cuda.synchronize()
+a = torch.randn(M, 3072, device="cuda").half(); w = (torch.randn(768, 3072, device="cuda") * 3072 ** -0.5).half()
+b = torch.randn(768, device="cuda"); hres = torch.zeros(M, 768, device="cuda")
+h16b = torch.empty(M, 768, device="cuda", dtype=torch.float16); stb = torch.empty(M * 64, device="cuda")
+for _ in range(5):
+    ops.linear_resid_stats_f16(a, w, b, hres, h16=h16b, stats=stb)
+torch.cuda.synchronize()
 x = torch.randn(16 * 12, 50, W, device="cuda")
 mod = TokenClusterInter(before_cluster_num=49, cluster_num=49, before_block_frames=12, after_block_frames=3,
                         original_frame=12, threshold=1e-6, iter_limit=100, split_size=16, norm_p=2.0)
