@@ -47,6 +47,8 @@ def declare(lib):
     lib.cc_linear_resid_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), i32, i32, i32, i32, vp]
     for name in ("cc_row_stats_f16", "cc_linear_ln_f16", "cc_linear_resid_stats_f16"):
         getattr(lib, name).restype = c.c_int
+    lib.cc_rank_counts_f32.argtypes = [vp, i32, i32, i64, i64, i32, vp, vp]
+    lib.cc_rank_counts_f32.restype = c.c_int
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]

@@ -196,3 +196,44 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
 }
 
 }  // extern "C"
+
+// ============================================================================ N1: retrieval ranks
+// compute_metrics (utils/metrics.py:11-26) sorts every row of -sim and looks the diagonal value up.
+// Equivalent without a sort: for row i with ground-truth column g = diag_offset + i,
+//   c_gt = #{j : sim[i,j] >  sim[i,g]},  c_eq = #{j : sim[i,j] == sim[i,g]}  (>= 1)
+// and the reference's `ind` is the concatenation over rows of range(c_gt, c_gt + c_eq) (np.where returns every
+// position of the sorted row that equals the diagonal value, so ties contribute several entries).
+// One wave per row; element (i, j) lives at sim + i*row_stride + j*col_stride (col_stride != 1 ranks sim^T).
+__global__ __launch_bounds__(256) void rank_counts_kernel(const float* __restrict__ sim, int rows, int cols,
+                                                          int64_t row_stride, int64_t col_stride, int diag_offset,
+                                                          int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const float* row = sim + (int64_t)i * row_stride;
+    const float d = row[(int64_t)(diag_offset + i) * col_stride];
+    int gt = 0, eq = 0;
+    for (int j = lane; j < cols; j += 64) {
+        const float v = row[(int64_t)j * col_stride];
+        gt += (v > d) ? 1 : 0;
+        eq += (v == d) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gt += __shfl_xor(gt, o, CC_WAVE);
+        eq += __shfl_xor(eq, o, CC_WAVE);
+    }
+    if (lane == 0) {
+        counts[2 * i] = gt;
+        counts[2 * i + 1] = eq;
+    }
+}
+
+extern "C" int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
+                                  int32_t diag_offset, int32_t* counts, void* stream) {
+    if (!sim || !counts || rows <= 0 || cols <= 0 || diag_offset < 0 || diag_offset + rows > cols) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
+                       cols, row_stride, col_stride, diag_offset, counts);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}

@@ -300,6 +300,15 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult,
                          float* logits, int32_t ldl, void* stream);
 
+/* N1 - the rank extraction of compute_metrics (utils/metrics.py:11-26) on the device: for row i with
+ * ground-truth column g = diag_offset + i, counts[2i] = #{j: sim[i,j] > sim[i,g]} and counts[2i+1] =
+ * #{j: sim[i,j] == sim[i,g]} (>= 1).  The reference's rank list `ind` is the concatenation over rows of
+ * range(counts[2i], counts[2i] + counts[2i+1]) - R@k / MdR / MnR follow from 2 ints per row instead of a
+ * device->host copy and NumPy sort of the whole matrix.  Element (i,j) = sim[i*row_stride + j*col_stride]
+ * (swap the strides to rank sim^T, i.e. video->text). */
+int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
+                       int32_t diag_offset, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,15 @@ def test_vitb32_full_size_against_fp32_oracle():
     sim = nrm(tfeat) @ nrm(feat.cpu()).t()
     simref = nrm(tref) @ nrm(ref).t()
     assert float((sim - simref).abs().max()) <= 1e-3
+
+
+def test_n1_retrieval_metrics_match_reference(g):
+    """compute_metrics on the device (2 ints per row) == utils/metrics.py:11-26 incl. its tie behaviour."""
+    from centerclip_amd.metrics import compute_metrics
+    sim = torch.from_numpy(g["n1_sim"]).to(DEV)
+    t2v, v2t = compute_metrics(sim), compute_metrics(sim.T)
+    for got, ref, cols in ((t2v, g["n1_t2v"], g["n1_t2v_cols"]), (v2t, g["n1_v2t"], None)):
+        np.testing.assert_allclose([got["R1"], got["R5"], got["R10"], got["MR"], got["MeanR"]], ref, rtol=0, atol=1e-12)
+        if cols is not None:
+            assert got["cols"] == [int(c) for c in cols]
+    assert len(t2v["cols"]) == 41            # the tie with the diagonal yields an extra entry, as in the reference
