@@ -236,11 +236,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("CC_BENCH_SHARE_GPU") == "1":     # dev aid: N ranks on ONE GPU over gloo, to exercise the N>1 code path
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if os.environ.get("CC_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus or world == 1, "launch N>1 through torch.distributed.run"
 
     from centerclip_amd.clip4clip import CLIP4Clip
