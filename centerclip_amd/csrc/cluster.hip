@@ -197,7 +197,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N, int W,
                                                       float pw, float* __restrict__ draw, int* __restrict__ chunkmax,
                                                       int chunk, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float lds[2][GT * LLD];
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GT * LLD];      // [buffer][A,B]
     const int p = blockIdx.y;
     int t = blockIdx.x, ti = 0, rowlen = ntiles;
     while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
@@ -218,23 +218,35 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
     const int nk = (W + LPK - 1) / LPK;
-    for (int kt = 0; kt < nk; ++kt) {
+    float4 ra_[2], rb_[2];
+    auto gload = [&](int kt) {
         const bool ok = kt * LPK + lchunk * 4 < W;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float4 va = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * LPK) : make_float4(0, 0, 0, 0);
-            const float4 vb = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * LPK) : make_float4(0, 0, 0, 0);
-            *reinterpret_cast<float4*>(&lds[0][(lrow + 32 * q) * LLD + lchunk * 4]) = va;
-            *reinterpret_cast<float4*>(&lds[1][(lrow + 32 * q) * LLD + lchunk * 4]) = vb;
+            ra_[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * LPK) : make_float4(0, 0, 0, 0);
+            rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * LPK) : make_float4(0, 0, 0, 0);
         }
-        __syncthreads();
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * q) * LLD + lchunk * 4]) = ra_[q];
+            *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * q) * LLD + lchunk * 4]) = rb_[q];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);           // next slice in flight while this one is consumed
+#pragma unroll 2
         for (int k4 = 0; k4 < LPK / 4; ++k4) {
             float4 a[4], b[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(&lds[0][(ty + 16 * r) * LLD + k4 * 4]);
+            for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(&lds[buf][0][(ty + 16 * r) * LLD + k4 * 4]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&lds[1][(tx + 16 * c) * LLD + k4 * 4]);
+            for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&lds[buf][1][(tx + 16 * c) * LLD + k4 * 4]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -250,6 +262,7 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
                     }
                 }
         }
+        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
     float lmax = -3.0e38f;

@@ -15,6 +15,8 @@
 // bias + residual add -> fp32 in place (out_proj / c_proj), + positional embedding with the
 // patch-row -> token-row remap (conv1 as im2col GEMM, modules/clip.py:282,324-336).
 #include "cc_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -347,8 +349,8 @@ static int pick_tile(const GemmArgs& g) {
     const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
     // 256x256 (one 8-wave workgroup per CU) halves the L2->LDS bytes per flop; it only pays when the
     // tile count fills whole rounds of the 256 CUs
-    if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.85) return 5;
-    if (n128 && mt128 * (g.N / 128) >= 400) return 1;
+    if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.65) return 5;
+    if (n128 && mt128 * (g.N / 128) >= 300) return 1;
     if (n128 && mt64 * (g.N / 128) >= 400) return 3;
     if (mt128 * (g.N / 64) >= 400) return 2;
     return 4;
@@ -359,6 +361,12 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
         tile = pick_tile(g0);
+        {   // tuning aid: CC_TILE_E<epi>_<S|B>=<tile> overrides the choice for small (M < 5000) / big problems
+            char name[32];
+            snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
+            const char* ov = getenv(name);
+            if (ov && ov[0] >= '1' && ov[0] <= '6') tile = ov[0] - '0';
+        }
         if (g1) {                                  // the rider must be divisible by the carrier's BN
             const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
             if (g1->N % bn) tile = (g1->N % 128 == 0 && (tile == 5)) ? 1 : 4;
