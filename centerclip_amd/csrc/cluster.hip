@@ -526,24 +526,82 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     for (int it = 0; it < iter_limit; ++it) {
         assign_step(true);
         __syncthreads();
-        // s_i = sum_{j in cluster(i), ascending j} D[i,j]  (fast_kmeans.py:81, equivalence 2); 4 loads in flight
+        // s_i = sum_j D[i,j] * [a_j == a_i]  (fast_kmeans.py:81-82, equivalence 2).  Non-members contribute exact
+        // zeros in the reference, so only the association of the member terms matters, and that association is
+        // ATen's CPU row sum (SumKernel.cpp, cascade_sum over 8-float vectors): position j feeds accumulator
+        // (j>>3)&3 of lane j&7, sixteen passes of 32 positions are folded into a second-level accumulator, the
+        // left-over vectors go to accumulator 0, the four accumulators of a lane are added in order, and the
+        // scalar tail followed by lanes 0..7 are added last.  Reproducing it keeps tie-breaks between clusters'
+        // candidates identical to the reference on any stored D (duplicate tokens tie exactly).
         for (int i = tid; i < N; i += 256) {
             const unsigned long long* cm = s.cmask + (size_t)s.asg[i] * E;
-            float sum = 0.f;
-            for (int w = 0; w < E; ++w) {
-                unsigned long long m = cm[w];
-                while (m) {
-                    float v[4];
+            float sum;
+            if (N < 8) {                                            // ATen's scalar path: 4 interleaved partials
+                const unsigned m = (unsigned)cm[0];
+                const int n4 = N & ~3;
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool ok = m != 0ull;
-                        const int j = 64 * w + (ok ? (__ffsll((long long)m) - 1) : 0);
-                        m &= m - 1ull;
-                        v[u] = ok ? DREAD(i, j) : 0.f;
-                    }
+                for (int j = 0; j < 4; ++j)
+                    if (j < n4 && ((m >> j) & 1u)) a4[j] += DREAD(i, j);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) sum += v[u];
+                for (int j = 4; j < 7; ++j)
+                    if (j >= n4 && j < N && ((m >> j) & 1u)) a4[0] += DREAD(i, j);
+                if (n4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < N && ((m >> j) & 1u)) a4[0] += DREAD(i, j);
                 }
+                sum = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+            } else {
+                const int vec_end = N & ~7;                         // first position of the scalar tail
+                const int passes = N >> 5;                          // full 4-vector passes (ATen's size_ilp)
+                float acc0[32], acc1[32];
+#pragma unroll
+                for (int b = 0; b < 32; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
+                for (int it = 0; it < passes; ++it) {
+                    const unsigned hm = (unsigned)(cm[it >> 1] >> (32 * (it & 1)));
+                    if (__any(hm != 0u)) {
+                        float d[32];
+                        if (IN_LDS && (N & 3) == 0) {
+                            const float4* r4 = reinterpret_cast<const float4*>(s.D + i * N + 32 * it);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const float4 t = r4[q];
+                                d[4 * q] = t.x; d[4 * q + 1] = t.y; d[4 * q + 2] = t.z; d[4 * q + 3] = t.w;
+                            }
+                        } else if (IN_LDS) {
+#pragma unroll
+                            for (int b = 0; b < 32; ++b) d[b] = s.D[i * N + 32 * it + b];
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 32; ++b)
+                                d[b] = ((hm >> b) & 1u) ? Dg[(int64_t)i * N + 32 * it + b] : 0.f;
+                        }
+#pragma unroll
+                        for (int b = 0; b < 32; ++b) acc0[b] += ((hm >> b) & 1u) ? d[b] : 0.f;
+                    }
+                    if ((it & 15) == 15) {                          // cascade level (level_step = 16 for N < 2^25)
+#pragma unroll
+                        for (int b = 0; b < 32; ++b) { acc1[b] += acc0[b]; acc0[b] = 0.f; }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 32; ++b) acc0[b] += acc1[b];
+                // left-over vectors (-> accumulator 0 of their lane) and the scalar tail, ascending
+                const int rest = passes << 5;
+                const unsigned rm = rest < N ? (unsigned)(cm[rest >> 6] >> (rest & 32)) : 0u;
+                float tail = 0.f;
+#pragma unroll
+                for (int r = 0; r < 31; ++r) {
+                    const int j = rest + r;
+                    if (j < N && ((rm >> r) & 1u)) {
+                        const float v = DREAD(i, j);
+                        if (j < vec_end) acc0[r & 7] += v; else tail += v;
+                    }
+                }
+                sum = tail;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) sum += ((acc0[l] + acc0[8 + l]) + acc0[16 + l]) + acc0[24 + l];
             }
             s.rowsum[i] = sum;
         }

@@ -13,9 +13,9 @@ two independent formulations:
   reference costs.  This is what ``bench.py`` times as ``cpu_baseline``
   (kind "port").
 * ``select_streamlined`` - a per-problem numpy restatement built only from the
-  exact equivalences listed in SURVEY.md §8(a) (running-min KKZ, member-list
-  row sums in ascending index order, fixed-point stop).  It is the executable
-  spec of what the HIP selection kernel does.
+  exact equivalences listed in SURVEY.md §8(a) (running-min KKZ, cluster row
+  sums in the association of ATen's CPU sum -- ``aten_row_sums`` --, fixed-point
+  stop).  It is the executable spec of what the HIP selection kernel does.
 
 Pinning: the reference ships no golden vectors for this path, so
 the oracle is pinned by fixtures generated from the imported reference in the
@@ -174,15 +174,89 @@ def literal_token_cluster(x_lnd, T, T_new, K, distance="euclidean", threshold=1e
 
 
 # ------------------------------------------------------- streamlined (kernel spec)
+def aten_row_sums(M):
+    """Row sums of M [R, n] (fp32) in the association ATen's CPU ``sum`` uses for a
+    contiguous inner reduction -- the arithmetic behind ``torch.sum(sub_matrix,
+    dim=-1)`` at modules/cluster/fast_kmeans.py:82.
+
+    The algorithm is a third-party dependency of the reference (PyTorch,
+    aten/src/ATen/native/cpu/SumKernel.cpp ``cascade_sum``; unchanged from 1.7 --
+    the reference's requirement -- to the 2.10 installed here; ``sum_stub`` is
+    registered up to AVX2, so the vector width is 8 floats on every x86 build).
+    Restated from its published source:
+
+      * n >= 8: view the first (n//8)*8 elements as n//8 vectors of 8 lanes.  Four
+        interleaved vector accumulators (vector v -> accumulator v % 4) run over
+        passes of four vectors; every ``level_step`` = 16 passes accumulator level 0
+        is folded into level 1 (and so on, 4 levels), left-over passes stay in level
+        0, then levels 1..3 are added to level 0.  Vectors beyond the last full pass
+        are added to accumulator 0, then accumulators 1..3 are added to 0 in order.
+        The scalar tail is summed ascending from 0, then lanes 0..7 are added.
+      * n < 8: the same scheme on scalars (4 interleaved partial sums).
+
+    Adding the zeros of masked-out entries is exact, so this also gives the value
+    of the masked sum.  Checked bit-for-bit against torch.sum for n = 1..8225 in
+    tests/test_oracle_cluster.py.
+    """
+    f = np.float32
+    M = np.ascontiguousarray(M, dtype=f)
+    R, n = M.shape
+
+    def multi_row(X):                     # X [R, size, ...] -> sum over axis 1
+        size = X.shape[1]
+        ilp = 4
+        size_ilp = size // ilp
+        shp = (R, ilp) + X.shape[2:]
+        levels = 4
+        lp = max(4, (int(np.ceil(np.log2(size_ilp))) if size_ilp > 1 else 0) // levels)
+        step = 1 << lp
+        mask = step - 1
+        acc = [np.zeros(shp, f) for _ in range(levels)]
+        i = 0
+        while i + step <= size_ilp:
+            for _ in range(step):
+                acc[0] = acc[0] + X[:, i * ilp:(i + 1) * ilp]
+                i += 1
+            for j in range(1, levels):
+                acc[j] = acc[j] + acc[j - 1]
+                acc[j - 1] = np.zeros(shp, f)
+                if (i & (mask << (j * lp))) != 0:
+                    break
+        while i < size_ilp:
+            acc[0] = acc[0] + X[:, i * ilp:(i + 1) * ilp]
+            i += 1
+        for j in range(1, levels):
+            acc[0] = acc[0] + acc[j]
+        part = acc[0]
+        p0 = part[:, 0]
+        for t in range(size_ilp * ilp, size):
+            p0 = p0 + X[:, t]
+        for k in range(1, ilp):
+            p0 = p0 + part[:, k]
+        return p0
+
+    V = 8
+    if n < V:
+        return multi_row(M.reshape(R, n))
+    vs = n // V
+    lanes = multi_row(M[:, :vs * V].reshape(R, vs, V))
+    out = np.zeros(R, f)
+    for t in range(vs * V, n):
+        out = out + M[:, t]
+    for l in range(V):
+        out = out + lanes[:, l]
+    return out
+
+
 def select_streamlined(D, first, K, iter_limit=60, id_sort=True):
     """Per-problem selection from one finished D [N,N] (numpy fp32), using only
     the exact equivalences of SURVEY §8(a):
 
       1. KKZ with a running minimum over rows of D;
-      2. update via member lists: s_i = sum_{j in cluster(i), ascending j} D[i,j]
-         accumulated sequentially in fp32, medoid = member with the smallest
-         s_i (lowest index on ties; an empty cluster yields index 0, as argmin
-         over an all-zero row does in the reference);
+      2. update via cluster membership: s_i = sum_j D[i,j]*[a_j == a_i] in ATen's
+         association (``aten_row_sums``), medoid = member with the smallest s_i
+         (lowest index on ties; an empty cluster yields index 0, as argmin over an
+         all-zero row does in the reference);
       4. stop when the medoid vector is unchanged (fixed point) or at iter_limit;
       6. final sort + re-assignment.
     ``first`` is the first KKZ medoid (argmax of the token L2 norms).
@@ -202,19 +276,13 @@ def select_streamlined(D, first, K, iter_limit=60, id_sort=True):
     for _ in range(iter_limit):
         steps += 1
         assign = np.argmin(D[med], axis=0)          # first k on ties
+        same_cluster = assign[:, None] == assign[None, :]
+        s = aten_row_sums(np.where(same_cluster, D, np.float32(0.0)))
         new = np.zeros(K, dtype=np.int64)
         for k in range(K):
             mem = np.nonzero(assign == k)[0]
-            if mem.size == 0:
-                continue
-            best, best_s = -1, None
-            for i in mem:
-                s = np.float32(0.0)
-                for j in mem:
-                    s = np.float32(s + D[i, j])
-                if best < 0 or s < best_s:
-                    best, best_s = int(i), s
-            new[k] = best
+            if mem.size:
+                new[k] = mem[int(np.argmin(s[mem]))]  # first (lowest index) minimum
         same = np.array_equal(new, med)
         med = new
         if same:

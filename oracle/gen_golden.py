@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by IMPORTING the read-only reference (dev container only).
 
-    python oracle/gen_golden.py [cluster|clip|all]
+    python oracle/gen_golden.py [cluster|dup|clip|all]
 
 The reference (/root/reference, Python/PyTorch) never travels to the GPU box:
 what travels is the data this script writes - inputs (or the integer seeds that
@@ -164,11 +164,37 @@ def gen_cluster():
     print("wrote cluster_golden.npz", sz, "bytes,", len(out), "arrays")
 
 
+def gen_cluster_dup():
+    """Duplicate-token problems (exact ties between non-identical candidates whose row sums round): the
+    reference's selection from a stored D.  Seeds + outputs only -> tests/golden/cluster_dup_golden.npz."""
+    sys.path.insert(0, os.path.join(REF, "modules"))
+    import cluster.fast_kmeans as fk
+    from recipes import DUPLICATE_CASES, duplicate_token_problem
+    t = torch.from_numpy
+    out = {}
+    for tag, (seed, P, nd, N, K, layout) in DUPLICATE_CASES.items():
+        D, X = duplicate_token_problem(seed, P, nd, N, layout)
+        orig = fk.pairwise_distance
+        fk.pairwise_distance = lambda *a_, **k_: t(D).clone()
+        try:
+            a, m = fk.batch_fast_kmedoids(t(X), K, threshold=1e-6, iter_limit=100, id_sort=True)
+            a_ns, m_ns = fk.batch_fast_kmedoids(t(X), K, threshold=1e-6, iter_limit=100, id_sort=False)
+        finally:
+            fk.pairwise_distance = orig
+        out[f"{tag}_assign"], out[f"{tag}_medoids"] = a.numpy().astype(np.int16), m.numpy().astype(np.int16)
+        out[f"{tag}_assign_nosort"], out[f"{tag}_medoids_nosort"] = a_ns.numpy().astype(np.int16), m_ns.numpy().astype(np.int16)
+        print(tag, "done", flush=True)
+    np.savez_compressed(os.path.join(GOLD, "cluster_dup_golden.npz"), **out)
+    print("wrote cluster_dup_golden.npz", os.path.getsize(os.path.join(GOLD, "cluster_dup_golden.npz")), "bytes")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     os.makedirs(GOLD, exist_ok=True)
     if what in ("cluster", "all"):
         gen_cluster()
+    if what in ("dup", "all"):
+        gen_cluster_dup()
     if what in ("clip", "all"):
         from gen_golden_clip import gen_clip
         gen_clip()

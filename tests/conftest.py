@@ -18,3 +18,9 @@ def pytest_configure(config):
 def cluster_golden():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "cluster_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def cluster_dup_golden():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "cluster_dup_golden.npz"))

@@ -296,3 +296,31 @@ def test_n1_retrieval_metrics_match_reference(g):
         if cols is not None:
             assert got["cols"] == [int(c) for c in cols]
     assert len(t2v["cols"]) == 41            # the tie with the diagonal yields an extra entry, as in the reference
+
+
+def test_edge_similarity_shapes_and_masks():
+    """1 x 1 logits, a fully masked clip (denominator 0 -> 1, clip4clip.py:313) and a mask given as int64."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for Bt, Bv, Tn, E in ((1, 1, 1, 64), (3, 2, 5, 512), (65, 67, 3, 512)):
+        t = torch.randn(Bt, 1, E, generator=gen)
+        v = torch.randn(Bv, Tn, E, generator=gen)
+        m = (torch.rand(Bv, Tn, generator=gen) > 0.4).long()
+        m[0] = 0
+        ref = clo.loose_similarity(t, v, m, 0.7)
+        got = ops.loose_similarity(t.squeeze(1).to(DEV), v.to(DEV), m.to(DEV), 0.7).cpu()
+        assert got.shape == (Bt, Bv)
+        mask = torch.isfinite(ref)
+        assert bool(mask[:, 1:].all())
+        np.testing.assert_allclose(got[:, 1:].numpy(), ref[:, 1:].numpy(), rtol=0, atol=3e-5)
+        # the fully masked clip pools to 0 -> 0/0 in both implementations
+        assert bool(torch.isnan(ref[:, 0]).all()) and bool(torch.isnan(got[:, 0]).all())
+
+
+def test_forward_is_deterministic(g):
+    model, T = small_model(g, cluster=True)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    ids = torch.from_numpy(g["t_ids"]).to(DEV)
+    a = model.encode_pair(video, ids, video_frame=T)
+    b = model.encode_pair(video, ids, video_frame=T)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

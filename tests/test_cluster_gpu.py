@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import dyadic, lattice
+from oracle.recipes import DUPLICATE_CASES, duplicate_token_problem, dyadic, lattice
 
 pytestmark = pytest.mark.gpu
 
@@ -231,3 +231,97 @@ def test_pre_norm_equals_clustering_the_normalised_tokens(cl):
     a1, m1 = cl.batch_fast_kmedoids_with_split(X, 9, split_size=2, pre_norm=True, iter_limit=100)
     a2, m2 = cl.batch_fast_kmedoids_with_split(Xn, 9, split_size=2, pre_norm=False, iter_limit=100)
     assert torch.equal(m1, m2) and torch.equal(a1, a2)
+
+
+# ------------------------------------------------------------------------------- edge cases
+def _oracle_indices(X, K, p=2.0, split=16, metric="euclidean"):
+    a, m = co.literal_batch_kmedoids_with_split(torch.from_numpy(X), K, metric, 1e-6, 100, True, p, split, False)
+    return a.numpy(), m.numpy()
+
+
+def _exact_oracle_indices(X, K, split=16):
+    """select_streamlined on the correctly rounded distance (oracle.exact_zero_diag_distance), chunk by chunk.
+    Used where the outcome hinges on single roundings: ATen's CPU sqrt (MKL VML) is not correctly rounded on
+    every host, so the literal oracle's D can differ from the true fp32 value in the last bit there."""
+    A, M = [], []
+    for c0 in range(0, X.shape[0], split):
+        Xc = X[c0:c0 + split]
+        D = co.exact_zero_diag_distance(Xc)
+        for b in range(Xc.shape[0]):
+            first = int(np.argmax(np.sqrt((Xc[b].astype(np.float64) ** 2).sum(-1)).astype(np.float32)))
+            a_s, m_s, _ = co.select_streamlined(D[b], first, K, iter_limit=100)
+            A.append(a_s)
+            M.append(m_s)
+    return np.stack(A), np.stack(M)
+
+
+def test_edge_duplicate_tokens_collide(cl):
+    """Exact duplicates (distance 0 off the diagonal): the self_nearest '-1' on the diagonal is what keeps every
+    medoid in its own cluster (cluster_utils.py:38-41).  Candidates tie in real arithmetic and are separated by
+    the rounding of their fp32 row sums, so this passes only with the reference's summation order."""
+    X = lattice(301, (4, 48, 32))
+    X[:, 24:] = X[:, :24]                       # every token appears twice
+    X[2] = X[2, :1]                             # one problem: ALL tokens identical
+    a, m = cl.batch_fast_kmedoids_with_split(dev(X), 6, threshold=1e-6, iter_limit=100, split_size=16)
+    ao, mo = _exact_oracle_indices(X, 6)
+    assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao)
+
+
+@pytest.mark.parametrize("tag", list(DUPLICATE_CASES))
+def test_p0_duplicate_tokens_from_stored_distance(cl, cluster_dup_golden, tag):
+    """Colliding tokens / permuted rows, selection from a stored D: indices equal the reference's (fixture) and
+    the oracle's.  These cases are decided by how fp32 row sums round (fast_kmeans.py:82 on ATen's CPU sum)."""
+    g = cluster_dup_golden
+    seed, P, nd, N, K, layout = DUPLICATE_CASES[tag]
+    D, X = duplicate_token_problem(seed, P, nd, N, layout)
+    nrm = torch.norm(torch.from_numpy(X), dim=-1).numpy()
+    for sort, sfx in ((True, ""), (False, "_nosort")):
+        a, m = cl.kmedoids_from_distance(dev(D), dev(nrm), K, iter_limit=100, id_sort=sort)
+        assert np.array_equal(m.cpu().numpy(), g[f"{tag}_medoids{sfx}"].astype(np.int64)), (tag, sort)
+        assert np.array_equal(a.cpu().numpy(), g[f"{tag}_assign{sfx}"].astype(np.int64)), (tag, sort)
+    for b in range(P):
+        first = int(np.argmax(nrm[b]))
+        a_s, m_s, _ = co.select_streamlined(D[b], first, K, iter_limit=100)
+        assert np.array_equal(m_s, g[f"{tag}_medoids"][b].astype(np.int64))
+
+
+def test_edge_k1_and_single_problem(cl):
+    X = lattice(302, (1, 70, 16))
+    for K in (1, 2, 70):
+        a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, split_size=4)
+        ao, mo = _oracle_indices(X, K, split=4)
+        assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao)
+
+
+def test_edge_minimal_width_and_sizes(cl):
+    for (P, N, W, K) in ((3, 5, 4, 2), (2, 64, 8, 9), (2, 65, 8, 9), (1, 197, 12, 30), (1, 198, 12, 30)):
+        X = lattice(303 + N, (P, N, W))          # N = 197 is the last size whose D fits in LDS, 198 the first that does not
+        a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, split_size=2)
+        ao, mo = _oracle_indices(X, K, split=2)
+        assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao), (P, N, W, K)
+
+
+def test_edge_maximum_tokens_per_problem(cl):
+    """N = 640 is the largest supported problem (10 x 64-token chunks); N = 641 is refused, not mis-computed."""
+    X = lattice(304, (1, 640, 16))
+    a, m = cl.batch_fast_kmedoids_with_split(dev(X), 12, threshold=1e-6, iter_limit=100, split_size=4)
+    ao, mo = _oracle_indices(X, 12, split=4)
+    assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        cl.batch_fast_kmedoids_with_split(dev(lattice(305, (1, 641, 16))), 12)
+
+
+def test_edge_iteration_limit_is_honoured(cl):
+    """iter_limit = 1 / 2: the state after exactly that many assignment/update rounds, as in the reference."""
+    X = lattice(306, (3, 90, 24))
+    for it in (1, 2):
+        a, m = cl.batch_fast_kmedoids(dev(X), 11, threshold=-1.0, iter_limit=it)
+        ao, mo = co.literal_batch_kmedoids(torch.from_numpy(X), 11, "euclidean", -1.0, it, True, 2.0)
+        assert np.array_equal(m.cpu().numpy(), mo.numpy()) and np.array_equal(a.cpu().numpy(), ao.numpy())
+
+
+def test_run_to_run_determinism(cl):
+    X = dev(np.random.default_rng(5).standard_normal((12, 196, 768)).astype(np.float32))
+    outs = [cl.batch_fast_kmedoids_with_split(X, 49, iter_limit=100, split_size=16) for _ in range(3)]
+    for a, m in outs[1:]:
+        assert torch.equal(m, outs[0][1]) and torch.equal(a, outs[0][0])

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import dyadic, lattice
+from oracle.recipes import DUPLICATE_CASES, duplicate_token_problem, dyadic, lattice
 
 t = torch.from_numpy
 
@@ -80,6 +80,37 @@ def test_p0_update_step_ties(cluster_golden):
         a_s, m_s, _ = co.select_streamlined(D[b], first, 5, iter_limit=50)
         assert np.array_equal(m_s, g["p0_tie_medoids"][b].astype(np.int64))
         assert np.array_equal(a_s, g["p0_tie_assign"][b].astype(np.int64))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 9, 31, 32, 33, 49, 196, 197, 511, 512, 543, 544, 588, 640, 1024, 8225])
+def test_aten_sum_association_restatement(n):
+    """oracle.aten_row_sums restates the association of ATen's CPU sum (the arithmetic of fast_kmeans.py:82);
+    it must equal torch.sum bit for bit, with and without the masked-out zeros of the reference's sub_matrix."""
+    rng = np.random.default_rng(1000 + n)
+    x = (rng.standard_normal((48, n)) * 10 ** rng.uniform(-2, 3, (48, 1))).astype(np.float32)
+    masked = -np.abs(x) * (rng.random((48, n)) < 0.1)
+    for m in (x, masked.astype(np.float32)):
+        ref = t(m).view(2, 3, 8, n).sum(-1).reshape(48).numpy()
+        assert np.array_equal(co.aten_row_sums(m), ref)
+
+
+@pytest.mark.parametrize("tag", list(DUPLICATE_CASES))
+def test_p0_duplicate_tokens(cluster_dup_golden, tag):
+    """Colliding tokens: candidates of one cluster tie exactly in real arithmetic and are separated only by
+    how their fp32 row sums round, so the selection depends on the summation order of fast_kmeans.py:82."""
+    g = cluster_dup_golden
+    seed, P, nd, N, K, layout = DUPLICATE_CASES[tag]
+    D, X = duplicate_token_problem(seed, P, nd, N, layout)
+    for sort, sfx in ((True, ""), (False, "_nosort")):
+        a, m, _ = co.literal_select(t(D), torch.norm(t(X), dim=-1), K, X=t(X), threshold=1e-6, iter_limit=100,
+                                    id_sort=sort)
+        assert np.array_equal(m.numpy(), g[f"{tag}_medoids{sfx}"].astype(np.int64))
+        assert np.array_equal(a.numpy(), g[f"{tag}_assign{sfx}"].astype(np.int64))
+        for b in range(P):
+            first = int(np.argmax(np.linalg.norm(X[b], axis=-1)))
+            a_s, m_s, _ = co.select_streamlined(D[b], first, K, iter_limit=100, id_sort=sort)
+            assert np.array_equal(m_s, g[f"{tag}_medoids{sfx}"][b].astype(np.int64))
+            assert np.array_equal(a_s, g[f"{tag}_assign{sfx}"][b].astype(np.int64))
 
 
 P1 = ["p1_cfg2", "p1_cfg3", "p1_cfg4", "p1_cfg5", "p1_ragged", "p1_k_eq_n", "p1_k1"]
