@@ -309,11 +309,14 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 // Everything here is latency-bound dependent work on a 38-346 K-entry matrix, so the kernel is
 // organised to keep >= 4-8 independent LDS/L2 loads in flight per lane and to avoid LDS
 // crossbar shuffles on the critical path (wave arg-max = 4 DPP steps + readlane, ties resolved
-// to the lowest index with ballots).  Cluster membership is kept as per-cluster bit masks
-// (ballot over 64 consecutive tokens): walking the set bits yields each cluster's members in
-// ascending index order, which is the summation order of the update step.
+// to the lowest index with ballots).  The update step reproduces the association of the reference's
+// row sum (ATen's CPU sum, see sum_rank): cluster membership is kept as per-cluster bit masks in
+// summation-rank space (ballot over 64 consecutive ranks), from which every iteration derives the
+// member list of each cluster in summation order (popcount prefix) together with the tree levels
+// each member closes; a candidate then walks its cluster's list with branch-free level partials
+// and the medoid falls out of a 64-bit LDS min over (key(sum), token).
 //
-// LDS carve (dynamic): [IN_LDS: D N*N f32] rowsum N f32 | med K i32 | cmask K*E u64 | asg N u16
+// LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | cmask K*E u64 | med K i32 | asg, order, mem N u16 | cnt K | off K+1 u16
 #define SEL_MAX_E 10   /* N <= 640 */
 
 // debug hook (not part of the public ABI): per-problem phase timestamps of K2
@@ -323,22 +326,59 @@ __device__ long long* g_sel_prof = nullptr;
         if (prof && tid == 0) prof[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
 
+// Position of token j in the order in which ATen's CPU row sum (SumKernel.cpp cascade_sum, 8-float vectors; the
+// arithmetic of fast_kmeans.py:82) consumes the N terms of a row.  The sum is a fixed tree:
+//   total = ((tail + R_0) + R_1 ... + R_7),  R_l = ((P_0l + P_1l) + P_2l) + P_3l,
+//   P_kl  = sequential sum over passes it of x[32 it + 8 k + l]  (passes 0..15 and 16.. summed apart, then added),
+//   P_0l += the vectors left after the last full pass;  tail = the N % 8 trailing scalars, summed first.
+// Masked-out terms are exact zeros, so walking only a cluster's members in this rank order, with a partial sum per
+// tree level, gives the reference's value bit for bit.  N < 8 is ATen's scalar path: x0, the scalars from 4 on,
+// then x1, x2, x3, strictly left to right.
+__device__ __forceinline__ int sum_rank(int j, int N) {
+    if (N < 8) {
+        const int n4 = N & ~3;
+        if (n4 == 0) return j;
+        return j == 0 ? 0 : (j >= 4 ? j - 3 : (N - 4) + j);
+    }
+    const int vec_end = N & ~7, vs = N >> 3, passes = vs >> 2, nleft = vs & 3;
+    if (j >= vec_end) return j - vec_end;
+    const int l = j & 7, v = j >> 3, k = v & 3, it = v >> 2;
+    int off;
+    if (v >= 4 * passes) off = passes + (v - 4 * passes);
+    else off = (k == 0) ? it : passes + nleft + (k - 1) * passes + it;
+    return (N - vec_end) + l * vs + off;
+}
+
+// mem[] entry: token (bits 0-9) | flags
+#define SEL_F1 0x0400u   /* closes the current run of passes     */
+#define SEL_F2 0x0800u   /* closes the current accumulator (k,l) */
+#define SEL_F3 0x1000u   /* closes the current lane l            */
+#define SEL_TREE 0x2000u /* vector part (not the scalar tail)    */
+#define SEL_LEFT 0x4000u /* left-over vector: joins accumulator 0 */
+__device__ __forceinline__ float sel_and(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
+
 struct SelSmem {
     float* D;
-    float* rowsum;
+    unsigned long long* best;   // per cluster: (ordered key of the smallest row sum) << 32 | token, via ds_min_u64
+    unsigned long long* cmask;  // per cluster: membership bits in summation-rank space
     int* med;
-    unsigned long long* cmask;
-    unsigned short* asg;
+    unsigned short* asg;        // token -> cluster
+    unsigned short* order;      // summation rank -> token (see sum_rank)
+    unsigned short* mem;        // tokens grouped by cluster, each group in summation-rank order
+    unsigned short* cnt;        // members per cluster
+    unsigned short* off;        // K + 1 group offsets into mem
 };
 
 static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
     const int E = (N + 63) / 64;
     size_t b = 0;
     if (in_lds) b += cc_align_up((size_t)N * N * 4, 8);
-    b += cc_align_up((size_t)N * 4, 8);
-    b += cc_align_up((size_t)K * 4, 8);
-    b += (size_t)K * E * 8;
-    b += (size_t)N * 2;
+    b += (size_t)K * 8;                         // best
+    b += (size_t)K * E * 8;                     // cmask
+    b += cc_align_up((size_t)K * 4, 8);         // med
+    b += 3 * cc_align_up((size_t)N * 2, 8);     // asg, order, mem
+    b += cc_align_up((size_t)K * 2, 8);         // cnt
+    b += cc_align_up((size_t)(K + 1) * 2, 8);   // off
     return cc_align_up(b, 16);
 }
 
@@ -378,10 +418,14 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         unsigned char* q = smem_raw;
         s.D = reinterpret_cast<float*>(q);
         if (IN_LDS) q += cc_align_up((size_t)N * N * 4, 8);
-        s.rowsum = reinterpret_cast<float*>(q); q += cc_align_up((size_t)N * 4, 8);
-        s.med = reinterpret_cast<int*>(q); q += cc_align_up((size_t)K * 4, 8);
+        s.best = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * 8;
         s.cmask = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * E * 8;
-        s.asg = reinterpret_cast<unsigned short*>(q);
+        s.med = reinterpret_cast<int*>(q); q += cc_align_up((size_t)K * 4, 8);
+        s.asg = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.order = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.mem = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.cnt = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)K * 2, 8);
+        s.off = reinterpret_cast<unsigned short*>(q);
     }
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -446,6 +490,8 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
 #define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : Dg[(int64_t)(i) * N + (j)])
     SEL_STAMP(1);
 
+    for (int j = tid; j < N; j += 256) s.order[sum_rank(j, N)] = (unsigned short)j;
+
     // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118).  The running minimum lives in registers as
     // order-preserving uint keys; arg-max = DPP max + ballots (lowest index wins ties).
     if (wave == 0) {
@@ -503,137 +549,132 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
                 if (v < best) { best = v; a = k; }
             }
             if (n < N) s.asg[n] = (unsigned short)a;
-            if (build_masks) {
-                // membership bit masks: word w = n / 64 of cluster k  <-  ballot(a == k) over this wave's 64 tokens
-                const int w = (wave + 4 * e);
-                if (w < E) {
-                    const int av = (n < N) ? a : -1;
-                    for (int kb = 0; kb < K; kb += 64) {
-                        unsigned long long mine = 0ull;
-                        const int kend = min(64, K - kb);
-                        for (int kk = 0; kk < kend; ++kk) {
-                            const unsigned long long b = __ballot(av == kb + kk);
-                            if (lane == kk) mine = b;
-                        }
-                        if (lane < kend) s.cmask[(size_t)(kb + lane) * E + w] = mine;
+        }
+        if (build_masks) {
+            // membership bit masks in summation-rank space: bit t of cluster k  <-  token order[t] belongs to k
+            __syncthreads();
+            for (int e = 0; e < 3; ++e) {
+                const int w = wave + 4 * e;
+                if (w >= E) break;                                   // wave-uniform
+                const int t = tid + 256 * e;
+                const int av = (t < N) ? (int)s.asg[s.order[t]] : -1;
+                for (int kb = 0; kb < K; kb += 64) {
+                    unsigned long long mine = 0ull;
+                    const int kend = min(64, K - kb);
+                    for (int kk = 0; kk < kend; ++kk) {
+                        const unsigned long long b = __ballot(av == kb + kk);
+                        if (lane == kk) mine = b;
                     }
+                    if (lane < kend) s.cmask[(size_t)(kb + lane) * E + w] = mine;
                 }
             }
         }
     };
 
     int iters = 0;
+    long long ph0 = 0, ph1 = 0, ph2 = 0;
     for (int it = 0; it < iter_limit; ++it) {
+        long long tq0 = 0, tq1 = 0, tq2 = 0;
+        if (prof) tq0 = (long long)__builtin_readcyclecounter();
         assign_step(true);
         __syncthreads();
-        // s_i = sum_j D[i,j] * [a_j == a_i]  (fast_kmeans.py:81-82, equivalence 2).  Non-members contribute exact
-        // zeros in the reference, so only the association of the member terms matters, and that association is
-        // ATen's CPU row sum (SumKernel.cpp, cascade_sum over 8-float vectors): position j feeds accumulator
-        // (j>>3)&3 of lane j&7, sixteen passes of 32 positions are folded into a second-level accumulator, the
-        // left-over vectors go to accumulator 0, the four accumulators of a lane are added in order, and the
-        // scalar tail followed by lanes 0..7 are added last.  Reproducing it keeps tie-breaks between clusters'
-        // candidates identical to the reference on any stored D (duplicate tokens tie exactly).
-        for (int i = tid; i < N; i += 256) {
-            const unsigned long long* cm = s.cmask + (size_t)s.asg[i] * E;
-            float sum;
-            if (N < 8) {                                            // ATen's scalar path: 4 interleaved partials
-                const unsigned m = (unsigned)cm[0];
-                const int n4 = N & ~3;
-                float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < n4 && ((m >> j) & 1u)) a4[j] += DREAD(i, j);
-#pragma unroll
-                for (int j = 4; j < 7; ++j)
-                    if (j >= n4 && j < N && ((m >> j) & 1u)) a4[0] += DREAD(i, j);
-                if (n4 == 0) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (j < N && ((m >> j) & 1u)) a4[0] += DREAD(i, j);
-                }
-                sum = ((a4[0] + a4[1]) + a4[2]) + a4[3];
-            } else {
-                const int vec_end = N & ~7;                         // first position of the scalar tail
-                const int passes = N >> 5;                          // full 4-vector passes (ATen's size_ilp)
-                float acc0[32], acc1[32];
-#pragma unroll
-                for (int b = 0; b < 32; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
-                for (int it = 0; it < passes; ++it) {
-                    const unsigned hm = (unsigned)(cm[it >> 1] >> (32 * (it & 1)));
-                    if (__any(hm != 0u)) {
-                        float d[32];
-                        if (IN_LDS && (N & 3) == 0) {
-                            const float4* r4 = reinterpret_cast<const float4*>(s.D + i * N + 32 * it);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float4 t = r4[q];
-                                d[4 * q] = t.x; d[4 * q + 1] = t.y; d[4 * q + 2] = t.z; d[4 * q + 3] = t.w;
-                            }
-                        } else if (IN_LDS) {
-#pragma unroll
-                            for (int b = 0; b < 32; ++b) d[b] = s.D[i * N + 32 * it + b];
-                        } else {
-#pragma unroll
-                            for (int b = 0; b < 32; ++b)
-                                d[b] = ((hm >> b) & 1u) ? Dg[(int64_t)i * N + 32 * it + b] : 0.f;
-                        }
-#pragma unroll
-                        for (int b = 0; b < 32; ++b) acc0[b] += ((hm >> b) & 1u) ? d[b] : 0.f;
-                    }
-                    if ((it & 15) == 15) {                          // cascade level (level_step = 16 for N < 2^25)
-#pragma unroll
-                        for (int b = 0; b < 32; ++b) { acc1[b] += acc0[b]; acc0[b] = 0.f; }
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < 32; ++b) acc0[b] += acc1[b];
-                // left-over vectors (-> accumulator 0 of their lane) and the scalar tail, ascending
-                const int rest = passes << 5;
-                const unsigned rm = rest < N ? (unsigned)(cm[rest >> 6] >> (rest & 32)) : 0u;
-                float tail = 0.f;
-#pragma unroll
-                for (int r = 0; r < 31; ++r) {
-                    const int j = rest + r;
-                    if (j < N && ((rm >> r) & 1u)) {
-                        const float v = DREAD(i, j);
-                        if (j < vec_end) acc0[r & 7] += v; else tail += v;
-                    }
-                }
-                sum = tail;
-#pragma unroll
-                for (int l = 0; l < 8; ++l) sum += ((acc0[l] + acc0[8 + l]) + acc0[16 + l]) + acc0[24 + l];
+        if (prof) tq1 = (long long)__builtin_readcyclecounter();
+        // group the tokens by cluster, each group in summation-rank order: counts -> offsets -> scatter
+        for (int k = tid; k < K; k += 256) {
+            const unsigned long long* cm = s.cmask + (size_t)k * E;
+            int n = 0;
+            for (int w = 0; w < E; ++w) n += __popcll(cm[w]);
+            s.cnt[k] = (unsigned short)n;
+            s.best[k] = ~0ull;
+        }
+        __syncthreads();
+        for (int k = tid; k <= K; k += 256) {
+            int o = 0;
+            for (int q = 0; q < k; ++q) o += s.cnt[q];
+            s.off[k] = (unsigned short)o;
+        }
+        __syncthreads();
+        const int vec_end = (N < 8) ? 0 : (N & ~7);            // tokens from here on are the sequential tail
+        const int rest = (N >> 5) << 5;                        // tokens from here to vec_end: left-over vectors
+        // position in ATen's summation tree: lane (bits 4-6) | accumulator (2-3) | run of passes (0-1; 2 = left-over)
+        auto tree_code = [&](int j) {
+            return ((j & 7) << 4) | (j >= rest ? 2 : ((((j >> 3) & 3) << 2) | (j >> 9)));
+        };
+        for (int t = tid; t < N; t += 256) {
+            const int j = s.order[t];
+            const int a = s.asg[j];
+            const unsigned long long* cm = s.cmask + (size_t)a * E;
+            const int wt = t >> 6;
+            unsigned long long below = cm[wt] & ((1ull << (t & 63)) - 1ull);
+            int pos = s.off[a] + __popcll(below);
+            int tp = below ? 64 * wt + 63 - __clzll((long long)below) : -1;   // rank of the previous member
+            for (int w = wt - 1; w >= 0; --w) {
+                const unsigned long long m = cm[w];
+                pos += __popcll(m);
+                if (tp < 0 && m) tp = 64 * w + 63 - __clzll((long long)m);
             }
-            s.rowsum[i] = sum;
+            // entry = token | which tree levels this member closes (vs the previous member) | tree / left-over flags
+            unsigned e = (unsigned)j;
+            if (j < vec_end) {
+                const int jp = tp >= 0 ? (int)s.order[tp] : -1;
+                const int x = (jp < 0 || jp >= vec_end) ? 0x7F : (tree_code(j) ^ tree_code(jp));
+                e |= (x ? SEL_F1 : 0u) | ((x >> 2) ? SEL_F2 : 0u) | ((x >> 4) ? SEL_F3 : 0u) | SEL_TREE |
+                     (j >= rest ? SEL_LEFT : 0u);
+            }
+            s.mem[pos] = (unsigned short)e;
+        }
+        __syncthreads();
+        if (prof) tq2 = (long long)__builtin_readcyclecounter();
+        // s_i = sum_j D[i,j] * [a_j == a_i]  (fast_kmeans.py:81-82, equivalence 2), evaluated over the members of
+        // i's cluster in summation-rank order with one partial sum per level of ATen's tree (see sum_rank):
+        // c = current run of passes, P = accumulator (k,l), R = lane l, F = total.  Closing a level adds it to its
+        // parent; closing an empty level adds an exact zero, so the level logic is branch-free selects.  The
+        // medoid (fast_kmeans.py:82: argmin, lowest index on ties) is a 64-bit LDS min over (key(s_i), i).
+        for (int i = tid; i < N; i += 256) {
+            const int cl = s.asg[i];
+            const int b0 = s.off[cl], b1 = s.off[cl + 1];
+            float c = 0.f, P = 0.f, R = 0.f, F = 0.f;
+            for (int q = b0; q < b1; q += 8) {
+                int e[8];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = (q + u < b1) ? (int)s.mem[q + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                                // padding reads D[i][0], then drops it
+                    const float d = DREAD(i, (e[u] < 0 ? 0 : e[u]) & 0x3FF);
+                    v[u] = e[u] < 0 ? 0.f : d;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    // x & m keeps x or yields +0; x - (x & m) is then +0 or x, both exact
+                    const int ev = e[u] < 0 ? 0 : e[u];                      // padding: no flags, v = 0
+                    const int m1 = -((ev >> 10) & 1), m2 = -((ev >> 11) & 1), m3 = -((ev >> 12) & 1);
+                    const int mt = -((ev >> 13) & 1), ml = -((ev >> 14) & 1);
+                    const float t1 = sel_and(c, m1);  P += t1;  c -= t1;     // new run of passes / accumulator / lane
+                    const float t2 = sel_and(P, m2);  R += t2;  P -= t2;     // new accumulator or lane
+                    const float t3 = sel_and(R, m3);  F += t3;  R -= t3;     // new lane
+                    const float vt = sel_and(v[u], mt);
+                    const float vl = sel_and(vt, ml);
+                    P += vl;                                                 // left-over vector -> accumulator 0
+                    c += vt - vl;
+                    F += v[u] - vt;                                          // tail scalar
+                }
+            }
+            P += c; R += P; F += R;
+            atomicMin(&s.best[cl], ((unsigned long long)cc_float_to_ordered_uint(F) << 32) | (unsigned)i);
         }
         __syncthreads();
         int changed = 0;
-        for (int k = tid; k < K; k += 256) {   // fast_kmeans.py:82: argmin of the row sums, lowest index on ties
-            const unsigned long long* cm = s.cmask + (size_t)k * E;
-            int bi = 0;
-            float best = 0.f;
-            bool have = false;
-            for (int w = 0; w < E; ++w) {
-                unsigned long long m = cm[w];
-                while (m) {
-                    float v[4];
-                    int idx[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool ok = m != 0ull;
-                        idx[u] = ok ? 64 * w + (__ffsll((long long)m) - 1) : -1;
-                        m &= m - 1ull;
-                        v[u] = ok ? s.rowsum[idx[u]] : 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (idx[u] >= 0 && (!have || v[u] < best)) { best = v[u]; bi = idx[u]; have = true; }
-                }
-            }
-            changed |= (bi != s.med[k]);
-            s.med[k] = bi;                      // empty cluster -> 0, as argmin over an all-zero row
+        for (int k = tid; k < K; k += 256) {
+            const unsigned long long b = s.best[k];
+            const int bi = (b == ~0ull) ? 0 : (int)(unsigned)(b & 0xFFFFFFFFull);   // empty cluster -> 0, as argmin
+            changed |= (bi != s.med[k]);                                             // over an all-zero row
+            s.med[k] = bi;
         }
         ++iters;
-        if (!__syncthreads_or(changed)) break;
+        const int any_changed = __syncthreads_or(changed);
+        if (prof) { ph0 += tq1 - tq0; ph1 += tq2 - tq1; ph2 += (long long)__builtin_readcyclecounter() - tq2; }
+        if (!any_changed) break;
     }
     SEL_STAMP(3);
 
@@ -666,7 +707,12 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         for (int n = tid; n < N; n += 256) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
     if (iters_out && tid == 0) iters_out[p] = iters;
     SEL_STAMP(4);
-    if (prof && tid == 0) prof[(int64_t)blockIdx.x * 16 + 5] = iters;
+    if (prof && tid == 0) {
+        prof[(int64_t)blockIdx.x * 16 + 5] = iters;
+        prof[(int64_t)blockIdx.x * 16 + 6] = ph0;
+        prof[(int64_t)blockIdx.x * 16 + 7] = ph1;
+        prof[(int64_t)blockIdx.x * 16 + 8] = ph2;
+    }
 #undef DREAD
 }
 
