@@ -36,8 +36,17 @@ __device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// debug hook (not part of the public ABI): per-workgroup phase timestamps (entry, prologue done, loop done, exit)
+__device__ long long* g_gemm_prof = nullptr;
+#define GEMM_STAMP(slot)                                                                                        \
+    do {                                                                                                        \
+        if (prof && threadIdx.x == 0) prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
+    long long* prof = g_gemm_prof;
+    GEMM_STAMP(0);
     const bool second = (int)blockIdx.x >= pr.tiles0;
     const GemmArgs g = second ? pr.p[1] : pr.p[0];
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
@@ -117,10 +126,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         row_rs = 1.0f / sqrtf(var + g.ln_eps);
     }
     __syncthreads();
+    GEMM_STAMP(1);
     const int l15 = lane & 15, lg = lane >> 4;
+    // Per-column epilogue operands (bias, LN-fold column sums) are fetched into registers while the last k-step's
+    // MFMAs run: issued from inside the epilogue, behind its stores, every fragment would pay its own L2 round trip.
+    constexpr bool RESID = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS);
+    constexpr bool LNFOLD = (EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
+    float4 biasv[NI], c1v[LNFOLD ? NI : 1];
+    auto fetch_epilogue_operands = [&]() {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = col0 + wc * (BN / WN) + j * 16 + lg * 4;
+            biasv[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LNFOLD) c1v[j] = *reinterpret_cast<const float4*>(g.ln_c1 + n);
+        }
+    };
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        else fetch_epilogue_operands();
         const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* lb = la + A_BYTES;
 #pragma unroll
@@ -145,6 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         __syncthreads();
     }
 
+    GEMM_STAMP(2);
     // ---- epilogue: lane holds C[m = .. + l15][n = .. + lg*4 + 0..3]
     constexpr int WTM = BM / WM, WTN = BN / WN;              // wave tile
     constexpr bool OUT_F16 = (EPI == EPI_F16 || EPI == EPI_F16_GELU || EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
@@ -177,15 +202,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 if (FOLD_LN) { const float2 t2 = rowst[wr * WTM + i * 16 + l15]; mu = t2.x; rs = t2.y; }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int n = col0 + wc * WTN + j * 16 + lg * 4;
                     f32x4 v = acc[i][j];
                     if (FOLD_LN) {
-                        const float4 c1 = *reinterpret_cast<const float4*>(g.ln_c1 + n);
+                        const float4 c1 = c1v[LNFOLD ? j : 0];
                         v[0] = rs * (v[0] - mu * c1.x); v[1] = rs * (v[1] - mu * c1.y);
                         v[2] = rs * (v[2] - mu * c1.z); v[3] = rs * (v[3] - mu * c1.w);
                     }
-                    if (g.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+                    {
+                        const float4 bb = biasv[j];
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                     }
                     if (GELU) {
@@ -211,6 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        GEMM_STAMP(3);
         return;
     }
     constexpr bool STATS = (EPI == EPI_F32_RESID_STATS);
@@ -218,26 +243,40 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     constexpr int RHS_MAX = (2 * (A_BYTES + B_BYTES)) / (NWAVES * LDH * 2);
     constexpr int RHS = (RHS_MAX >= WTM) ? WTM : (RHS_MAX >= 64 ? 64 : (RHS_MAX >= 32 ? 32 : 16));
     _Float16* hstg = reinterpret_cast<_Float16*>(smem) + wave * (RHS * LDH);
+    // The fp32 residual rows come from HBM.  They are fetched a group of fragment rows ahead (all loads of a group
+    // in flight together, the next group's issued before this group's stores) - a load issued behind a store to the
+    // same buffer cannot be hoisted by the compiler, and 16-32 serial HBM round trips used to cost more than the
+    // tile's MFMA work.  Group = <= 16 fragments (<= 8 for the 8-wave tiles) to bound the register footprint.
+    constexpr int IG = !RESID ? 1 : (MI * NI <= 16 ? MI : (8 / NI > 0 ? 8 / NI : 1));
+    static_assert(MI % IG == 0, "residual prefetch groups");
+    float4 resv[2][IG][NI];
+    auto fetch_residual = [&](int slot, int grp) {
+#pragma unroll
+        for (int ii = 0; ii < IG; ++ii) {
+            const int m = min(row0 + wr * WTM + (grp * IG + ii) * 16 + l15, g.M - 1);
+            const float* src = reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + col0 + wc * WTN + lg * 4;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) resv[slot][ii][j] = *reinterpret_cast<const float4*>(src + j * 16);
+        }
+    };
+    if (RESID) fetch_residual(0, 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = row0 + wr * WTM + i * 16 + l15;
         float psum = 0.f, psq = 0.f;
+        if (RESID && i % IG == 0 && i + IG < MI) fetch_residual(((i / IG) + 1) & 1, i / IG + 1);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = col0 + wc * WTN + j * 16 + lg * 4;
             f32x4 v = acc[i][j];
-            if (g.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+            {
+                const float4 bb = biasv[j];
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
-            if (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) {
-                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < g.M) {
-                    float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
-                    c = *reinterpret_cast<const float4*>(dst);
-                    c.x += v[0]; c.y += v[1]; c.z += v[2]; c.w += v[3];
-                    *reinterpret_cast<float4*>(dst) = c;
-                }
+            if (RESID) {
+                float4 c = resv[(i / IG) & 1][i % IG][j];
+                c.x += v[0]; c.y += v[1]; c.z += v[2]; c.w += v[3];
+                if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = c;
                 if (STATS) {
                     h4 o = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
                     *reinterpret_cast<h4*>(hstg + ((i * 16 + l15) % RHS) * LDH + j * 16 + lg * 4) = o;
@@ -284,6 +323,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
         }
     }
+    GEMM_STAMP(3);
+}
+
+extern "C" void cc_debug_set_gemm_profile(long long* p) {
+    hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &p, sizeof(p));
 }
 
 namespace {
