@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / GEMM_BK;
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / GEMM_BK);
     stage(0, 0);
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
@@ -141,32 +141,67 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             if (LNFOLD) c1v[j] = *reinterpret_cast<const float4*>(g.ln_c1 + n);
         }
     };
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        else fetch_epilogue_operands();
+    // Main loop, half-shifted: the fragments of k-half 0 of step kt+1 are read while the MFMAs of k-half 1 of step
+    // kt run, and those of k-half 1 while the MFMAs of k-half 0 run, so the one workgroup barrier per step sits
+    // between two MFMA phases whose operands are already in registers (no LDS latency behind the barrier).
+    //   step kt:  read F1(kt) | MFMA F0(kt) | barrier: stage kt+1 landed, buffer kt fully read
+    //             | issue stage kt+2 into buffer kt | read F0(kt+1) | MFMA F1(kt)
+    auto read_frags = [&](int buf, int ks, h8 (&af)[MI], h8 (&bf)[NI]) {
         const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* lb = la + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wr * (BM / WM) + i * 16 + l15;
-                af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = wc * (BN / WN) + j * 16 + l15;
-                bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) {
+            const int r = wr * (BM / WM) + i * 16 + l15;
+            af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
         }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int r = wc * (BN / WN) + j * 16 + l15;
+            bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+        }
+    };
+    auto mma = [&](const h8 (&af)[MI], const h8 (&bf)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
+    // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
+    // plain order is faster (1832 vs 2033) - the co-resident workgroup already fills the LDS-latency gap.
+    constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
+    if (HALF_SHIFTED) {
+        h8 a0[MI], b0[NI], a1[MI], b1[NI];
+        if (nk > 1) stage(1, 1);
+        read_frags(0, 0, a0, b0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int buf = kt & 1;
+            read_frags(buf, 1, a1, b1);
+            mma(a0, b0);
+            __syncthreads();
+            if (kt + 2 < nk) stage(buf, kt + 2);
+            read_frags(buf ^ 1, 0, a0, b0);
+            mma(a1, b1);
+        }
+        read_frags((nk - 1) & 1, 1, a1, b1);
+        mma(a0, b0);
+        __syncthreads();                                      // every wave is done with the staging buffers
+        fetch_epilogue_operands();
+        mma(a1, b1);
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            else fetch_epilogue_operands();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 af[MI], bf[NI];
+                read_frags(buf, ks, af, bf);
+                mma(af, bf);
+            }
+            __syncthreads();
+        }
     }
 
     GEMM_STAMP(2);
@@ -326,8 +361,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     GEMM_STAMP(3);
 }
 
-extern "C" void cc_debug_set_gemm_profile(long long* p) {
-    hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &p, sizeof(p));
+extern "C" int cc_debug_set_gemm_profile(long long* p) {   // debug only; p [workgroups, 4] int64 device memory or NULL
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &p, sizeof(p)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
 
 namespace {
