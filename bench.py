@@ -327,6 +327,13 @@ def main():
                 res["forward_algorithmic_tflops"] = round(gemm_flops * 1.0 / (ms_per_step * 1e-3) / 1e12, 1)
                 res["token_cluster"] = cluster_bench(c, device)
                 res["similarity_10k_x_1k"] = similarity_bench(device)
+                # N3: the same step fed with decoder-layout uint8 frames (normalisation fused into the patch gather)
+                u8 = torch.randint(0, 256, (c["B"], 1, c["T"], 224, 224, 3), dtype=torch.uint8, device=device)
+                ms_u8 = event_time_ms(lambda: model(ids, torch.zeros_like(ids), amask, u8, vmask), 10)
+                ms_f32 = event_time_ms(lambda: model(ids, torch.zeros_like(ids), amask, video, vmask), 10)
+                res["uint8_input"] = {"ms_per_forward_uint8_hwc": round(ms_u8, 3), "ms_per_forward_f32": round(ms_f32, 3),
+                                      "input_bytes_per_clip": {"uint8": c["T"] * 3 * 224 * 224, "f32": c["T"] * 3 * 224 * 224 * 4},
+                                      "launch": "eager"}
         else:
             res["roofline"] = None
         if world == 1 and not a.no_cpu_baseline:

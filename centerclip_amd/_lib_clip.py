@@ -26,6 +26,11 @@ class VitModel(c.Structure):
                 ("cluster_iter_limit", c.c_int32), ("cluster_split_size", c.c_int32), ("cluster_pre_norm", c.c_int32)]
 
 
+class Frames(c.Structure):
+    """cc_frames (include/centerclip_hip.h): format 0 = fp32 CHW (normalised), 1 = uint8 CHW, 2 = uint8 HWC."""
+    _fields_ = [("data", c.c_void_p), ("format", c.c_int32), ("mean", c.c_float * 3), ("std", c.c_float * 3)]
+
+
 class TextModel(c.Structure):
     """struct cc_text_model"""
     _fields_ = [("layers", c.c_int32), ("width", c.c_int32), ("heads", c.c_int32), ("context_length", c.c_int32),
@@ -52,6 +57,11 @@ def declare(lib):
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_vit_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_vit_encode_frames.restype = c.c_int
+    lib.cc_clip_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, c.POINTER(TextModel), vp,
+                                          i32, i32, vp, vp, sz, vp]
+    lib.cc_clip_encode_frames.restype = c.c_int
     lib.cc_token_gather_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.cc_token_gather_f32.restype = c.c_int
     lib.cc_text_workspace_bytes.restype = sz

@@ -15,6 +15,31 @@ from ._lib_clip import BlockWeights, TextModel, VitModel, CC_MAX_LAYERS
 from .cluster import get_cluster_inter
 
 
+# the constants of the reference's loader (dataloaders/decode.py:43-48), applied by the uint8 input path
+PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)
+PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def frames_descriptor(x, mean=PIXEL_MEAN, std=PIXEL_STD):
+    """Tensor -> (cc_frames struct, tensor kept alive).  Float input is what the reference's encode_image takes
+    ([N,3,H,W], already normalised); uint8 input is the decoder's output, [N,3,H,W] or [N,H,W,3], and gets the
+    loader's u8/255 -> (x - mean)/std (dataloaders/transforms.py:19-34,166) inside the patch gather (N3)."""
+    from ._lib_clip import Frames
+    fr = Frames()
+    if x.dtype == torch.uint8:
+        if x.ndim != 4 or (x.shape[1] != 3 and x.shape[-1] != 3):
+            raise ValueError("uint8 frames must be [N,3,H,W] or [N,H,W,3], got %s" % (tuple(x.shape),))
+        x = x.contiguous()
+        fr.format = 1 if x.shape[1] == 3 else 2
+        fr.mean = (ctypes.c_float * 3)(*[float(v) for v in mean])
+        fr.std = (ctypes.c_float * 3)(*[float(v) for v in std])
+    else:
+        x = x.float().contiguous()
+        fr.format = 0
+    fr.data = x.data_ptr()
+    return fr, x
+
+
 class LayerNorm(nn.Module):
     """LayerNorm computed in fp32 whatever the input dtype (modules/clip.py:183-189)."""
 
@@ -186,7 +211,7 @@ class VisualTransformer(nn.Module):
     def encode(self, x, video_frame=-1, want_hidden=False, want_medoids=False, forced_medoids=None):
         """[B*T, 3, H, W] -> (features [B*T_final, output_dim], hidden [B*T_final, L, W] | None)."""
         L.require_device(x)
-        x = x.float().contiguous()
+        fr, x = frames_descriptor(x)
         BT = x.shape[0]
         T = video_frame if video_frame and video_frame > 0 else 1
         has_cluster = any(b.tokencluster_inter is not None for b in self.transformer.resblocks)
@@ -205,9 +230,9 @@ class VisualTransformer(nn.Module):
         ws = L.workspace(lib.cc_vit_workspace_bytes(ctypes.byref(m), B, T), x.device)
         if forced_medoids is not None:
             forced_medoids = forced_medoids.to(device=x.device, dtype=torch.long).contiguous()
-        L.check(lib.cc_vit_encode(ctypes.byref(m), L.ptr(x), B, T, L.ptr(feats), L.ptr(hidden), L.ptr(med),
-                                  L.ptr(forced_medoids), L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
-                "cc_vit_encode")
+        L.check(lib.cc_vit_encode_frames(ctypes.byref(m), ctypes.byref(fr), B, T, L.ptr(feats), L.ptr(hidden),
+                                         L.ptr(med), L.ptr(forced_medoids), L.ptr(ws), ws.numel(),
+                                         L.stream_ptr(x.device)), "cc_vit_encode_frames")
         self.last_medoids = med
         return feats, hidden
 
@@ -294,7 +319,7 @@ class CLIP(nn.Module):
         -> (image features [N', embed_dim], text features [B, embed_dim])"""
         L.require_device(image, text)
         vis = self.visual
-        x = image.float().contiguous()
+        fr, x = frames_descriptor(image)
         ids = text.to(torch.long).contiguous()
         T = video_frame if video_frame and video_frame > 0 else 1
         if not any(b.tokencluster_inter is not None for b in vis.transformer.resblocks):
@@ -307,9 +332,9 @@ class CLIP(nn.Module):
         vfeat = torch.empty(B * frames, self.embed_dim, device=x.device, dtype=torch.float32)
         tfeat = torch.empty(Bt, self.embed_dim, device=x.device, dtype=torch.float32)
         ws = L.workspace(lib.cc_clip_workspace_bytes(ctypes.byref(vm), B, T, ctypes.byref(tm), Bt, Lt), x.device)
-        L.check(lib.cc_clip_encode(ctypes.byref(vm), L.ptr(x), B, T, L.ptr(vfeat), None, ctypes.byref(tm), L.ptr(ids),
-                                   Bt, Lt, L.ptr(tfeat), L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
-                "cc_clip_encode")
+        L.check(lib.cc_clip_encode_frames(ctypes.byref(vm), ctypes.byref(fr), B, T, L.ptr(vfeat), None,
+                                          ctypes.byref(tm), L.ptr(ids), Bt, Lt, L.ptr(tfeat), L.ptr(ws), ws.numel(),
+                                          L.stream_ptr(x.device)), "cc_clip_encode_frames")
         return vfeat, tfeat
 
     def encode_text(self, text, return_hidden=False):

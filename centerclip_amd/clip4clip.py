@@ -49,9 +49,11 @@ class CLIP4Clip(nn.Module):
         if input_ids is not None:
             input_ids = input_ids.view(-1, input_ids.shape[-1])
         if video is not None:
-            video = torch.as_tensor(video).float()
-            b, pair, video_frame, channel, h, w = video.shape
-            video = video.view(-1, channel, h, w)
+            video = torch.as_tensor(video)
+            if video.dtype != torch.uint8:           # uint8 frames go to the patch gather as they are (N3)
+                video = video.float()
+            b, pair, video_frame = video.shape[:3]
+            video = video.reshape((-1,) + tuple(video.shape[3:]))   # [B*T, C, H, W], or [B*T, H, W, C] for uint8 HWC
             video_mask = video_mask.view(-1, video_mask.shape[-1])
             if self.cluster_inter or self.deep_cluster:
                 video_mask = self.get_video_mask_after_cluster(video_mask)
@@ -93,9 +95,9 @@ class CLIP4Clip(nn.Module):
     def get_video_mask_after_cluster(self, video_mask):
         """Mask of a segment = mask of its last frame (clip4clip.py:436-447)."""
         if self.cluster_algo in ['kmediods++', 'pooling', 'sparse_sampling', 'spectral']:
-            inds = torch.arange(self.f_frame_duration - 1, video_mask.shape[-1],
-                                video_mask.shape[-1] // self.final_frames, dtype=torch.long, device=video_mask.device)
-            return video_mask[:, inds]
+            # same columns as the reference's arange(f_frame_duration - 1, T, T // final_frames) index, as a strided
+            # view: no arange / gather kernels in the step
+            return video_mask[:, self.f_frame_duration - 1::video_mask.shape[-1] // self.final_frames]
         return video_mask
 
     def _loose_similarity(self, sequence_output, visual_output, attention_mask, video_mask, gather=False):

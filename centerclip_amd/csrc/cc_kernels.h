@@ -54,7 +54,7 @@ struct AttArgs {
 };
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
-int cc_launch_im2col(const float* video, _Float16* A, int F, int res, int p, hipStream_t st);
+int cc_launch_im2col(const cc_frames& frames, _Float16* A, int F, int res, int p, hipStream_t st);
 int cc_launch_cls_pos(float* h, const float* cls, const float* pos, int F, int Ltok, int W, hipStream_t st);
 int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float* pos, float* h, int* eot, int Bt,
                          int Lt, int W, hipStream_t st);

@@ -204,7 +204,7 @@ bool text_ok(const cc_text_model* m, int Lt) {
 }
 
 // Both towers, block i of the one paired with block i of the other (either may be absent).
-int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, float* vfeat, float* hidden_out,
+int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, float* vfeat, float* hidden_out,
                   int64_t* medoids_out, const int64_t* forced_medoids, const cc_text_model* tm, const int64_t* ids,
                   int Bt, int Lt, float* tfeat, void* ws, size_t ws_bytes, hipStream_t st) {
     VitWs v{};
@@ -222,7 +222,7 @@ int encode_towers(const cc_vit_model* vm, const float* video, int B, int T, floa
         W = vm->width;
         tokens = n;
         // patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
-        rc = cc_launch_im2col(video, v.im2col, F, vm->resolution, vm->patch, st);
+        rc = cc_launch_im2col(*video, v.im2col, F, vm->resolution, vm->patch, st);
         if (rc) return rc;
         GemmArgs ga{};
         ga.A = v.im2col;
@@ -312,13 +312,22 @@ size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T) {
     return carve_vit(m, B, T, nullptr).total;
 }
 
+int cc_vit_encode_frames(const cc_vit_model* m, const cc_frames* frames, int32_t B, int32_t T, float* features,
+                         float* hidden_out, int64_t* medoids_out, const int64_t* forced_medoids, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!m || !frames || !frames->data || !features || !m->blocks || B <= 0 || T <= 0) return CC_ERR_INVALID;
+    if (!vit_ok(m)) return CC_ERR_UNSUPPORTED;
+    return encode_towers(m, frames, B, T, features, hidden_out, medoids_out, forced_medoids, nullptr, nullptr, 0, 0,
+                         nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t T, float* features,
                   float* hidden_out, int64_t* medoids_out, const int64_t* forced_medoids, void* ws, size_t ws_bytes,
                   void* stream) {
-    if (!m || !video || !features || !m->blocks || B <= 0 || T <= 0) return CC_ERR_INVALID;
-    if (!vit_ok(m)) return CC_ERR_UNSUPPORTED;
-    return encode_towers(m, video, B, T, features, hidden_out, medoids_out, forced_medoids, nullptr, nullptr, 0, 0,
-                         nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    cc_frames fr{};
+    fr.data = video;
+    fr.format = CC_FRAMES_F32_CHW;
+    return cc_vit_encode_frames(m, &fr, B, T, features, hidden_out, medoids_out, forced_medoids, ws, ws_bytes, stream);
 }
 
 size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt) {
@@ -340,15 +349,26 @@ size_t cc_clip_workspace_bytes(const cc_vit_model* vm, int32_t B, int32_t T, con
     return cc_vit_workspace_bytes(vm, B, T) + cc_text_workspace_bytes(tm, Bt, Lt);
 }
 
-int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_t T, float* visual_features,
-                   int64_t* medoids_out, const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
-                   float* text_features, void* ws, size_t ws_bytes, void* stream) {
-    if (!vm || !tm || !video || !ids || !visual_features || !text_features || !vm->blocks || !tm->blocks)
+int cc_clip_encode_frames(const cc_vit_model* vm, const cc_frames* frames, int32_t B, int32_t T,
+                          float* visual_features, int64_t* medoids_out, const cc_text_model* tm, const int64_t* ids,
+                          int32_t Bt, int32_t Lt, float* text_features, void* ws, size_t ws_bytes, void* stream) {
+    if (!vm || !tm || !frames || !frames->data || !ids || !visual_features || !text_features || !vm->blocks ||
+        !tm->blocks)
         return CC_ERR_INVALID;
     if (B <= 0 || T <= 0 || Bt <= 0 || Lt <= 0 || Lt > tm->context_length) return CC_ERR_INVALID;
     if (!vit_ok(vm) || !text_ok(tm, Lt)) return CC_ERR_UNSUPPORTED;
-    return encode_towers(vm, video, B, T, visual_features, nullptr, medoids_out, nullptr, tm, ids, Bt, Lt,
+    return encode_towers(vm, frames, B, T, visual_features, nullptr, medoids_out, nullptr, tm, ids, Bt, Lt,
                          text_features, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_t T, float* visual_features,
+                   int64_t* medoids_out, const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
+                   float* text_features, void* ws, size_t ws_bytes, void* stream) {
+    cc_frames fr{};
+    fr.data = video;
+    fr.format = CC_FRAMES_F32_CHW;
+    return cc_clip_encode_frames(vm, &fr, B, T, visual_features, medoids_out, tm, ids, Bt, Lt, text_features, ws,
+                                 ws_bytes, stream);
 }
 
 }  // extern "C"

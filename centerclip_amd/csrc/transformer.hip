@@ -419,6 +419,48 @@ __global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict
     }
 }
 
+// N3: the same patch gather from uint8 frames, with the loader's normalisation fused in.  Per sample exactly the
+// reference's three fp32 operations, in its order: u/255 (transforms.py:166), - mean, / std (torchvision normalize),
+// all IEEE (no reciprocal, no contraction possible between them), so the fp16 patch matrix is bit-identical to the
+// one the fp32 path builds from the loader's output.  HWC = the decoder's layout: a lane reads 8 pixels x 3 bytes.
+template <bool HWC>
+__global__ __launch_bounds__(256) void im2col_u8_f16_kernel(const unsigned char* __restrict__ video,
+                                                            _Float16* __restrict__ A, int F, int res, int p,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int g = res / p, n = g * g, Kc = 3 * p * p;
+    const int64_t total = (int64_t)F * n * Kc / 8;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t e = idx * 8;
+        const int k = (int)(e % Kc);
+        const int64_t row = e / Kc;
+        const int f = (int)(row / n), pi = (int)(row - (int64_t)f * n);
+        const int ph = pi / g, pw = pi - ph * g;
+        const int c = k / (p * p), rem = k - c * p * p, kh = rem / p, kw = rem - kh * p;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const int y = ph * p + kh, x = pw * p + kw;
+        unsigned char u[8];
+        if (HWC) {
+            const unsigned char* src = video + (((int64_t)f * res + y) * res + x) * 3 + c;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = src[3 * q];
+        } else {
+            const unsigned char* src = video + (((int64_t)f * 3 + c) * res + y) * res + x;
+            const uint2 w = *reinterpret_cast<const uint2*>(src);          // x is a multiple of 8, res of 8
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { u[q] = (unsigned char)(w.x >> (8 * q)); u[4 + q] = (unsigned char)(w.y >> (8 * q)); }
+        }
+        h8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v = (float)u[q] / 255.0f;
+            v = v - mean;
+            v = v / sd;
+            o[q] = (_Float16)v;
+        }
+        *reinterpret_cast<h8*>(A + e) = o;
+    }
+}
+
 // h[f][0][:] = class_embedding + positional_embedding[0]      (modules/clip.py:334-336)
 __global__ void cls_pos_kernel(float* __restrict__ h, const float* __restrict__ cls, const float* __restrict__ pos,
                                int F, int Ltok, int W) {
@@ -595,11 +637,26 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
 }
 
 
-int cc_launch_im2col(const float* video, _Float16* A, int F, int res, int p, hipStream_t st) {
-    if ((p & 7) || res % p) return CC_ERR_INVALID;
+int cc_launch_im2col(const cc_frames& fr, _Float16* A, int F, int res, int p, hipStream_t st) {
+    if ((p & 7) || res % p || !fr.data) return CC_ERR_INVALID;
     const int64_t total = (int64_t)F * (res / p) * (res / p) * 3 * p * p / 8;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(im2col_f16_kernel, dim3(blocks), dim3(256), 0, st, video, A, F, res, p);
+    if (fr.format == CC_FRAMES_F32_CHW) {
+        hipLaunchKernelGGL(im2col_f16_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(fr.data), A, F, res, p);
+    } else if (fr.format == CC_FRAMES_U8_CHW || fr.format == CC_FRAMES_U8_HWC) {
+        if (res & 7) return CC_ERR_INVALID;
+        for (int c = 0; c < 3; ++c)
+            if (!(fr.std[c] > 0.f)) return CC_ERR_INVALID;
+        const unsigned char* v = static_cast<const unsigned char*>(fr.data);
+        if (fr.format == CC_FRAMES_U8_HWC)
+            hipLaunchKernelGGL(im2col_u8_f16_kernel<true>, dim3(blocks), dim3(256), 0, st, v, A, F, res, p, fr.mean[0],
+                               fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+        else
+            hipLaunchKernelGGL(im2col_u8_f16_kernel<false>, dim3(blocks), dim3(256), 0, st, v, A, F, res, p, fr.mean[0],
+                               fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+    } else {
+        return CC_ERR_INVALID;
+    }
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -240,6 +240,21 @@ typedef struct cc_vit_model {
     int32_t cluster_iter_limit, cluster_split_size, cluster_pre_norm;
 } cc_vit_model;
 
+/* Frame input descriptor for the *_frames entry points.  The reference's evaluation
+ * loader turns a decoded uint8 frame into the float tensor the ViT eats with three fp32 ops -
+ * x = u8 / 255 (dataloaders/transforms.py:166, GroupToTensorBCHW(div=True)), then x = (x - mean) / std
+ * (transforms.py:19-34 -> torchvision normalize: sub_, div_) with the constants of dataloaders/decode.py:43-48.
+ * Handing over the uint8 frames lets the patch gather do exactly these three IEEE fp32 operations itself
+ * (bit-identical patches), reading 1 byte per sample from HBM (and over PCIe) instead of 4. */
+#define CC_FRAMES_F32_CHW 0   /* [F, 3, res, res] fp32, already normalised (what CLIP.encode_image takes)   */
+#define CC_FRAMES_U8_CHW  1   /* [F, 3, res, res] uint8                                                   */
+#define CC_FRAMES_U8_HWC  2   /* [F, res, res, 3] uint8 (decoder layout, before transforms.py:157 permutes) */
+typedef struct cc_frames {
+    const void* data;
+    int32_t format;           /* CC_FRAMES_*                                         */
+    float mean[3], std[3];    /* per channel; used by the uint8 formats only         */
+} cc_frames;
+
 size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T);
 
 /* CLIP.encode_image(image, video_frame=T) (modules/clip.py:460-469): video [B*T, 3, res, res]
@@ -281,6 +296,17 @@ int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_
                    float* visual_features, int64_t* medoids_out,
                    const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
                    float* text_features, void* ws, size_t ws_bytes, void* stream);
+
+/* cc_vit_encode / cc_clip_encode with the frames given through a cc_frames descriptor (N3): for
+ * CC_FRAMES_F32_CHW identical to the calls above; for the uint8 formats the normalisation of
+ * dataloaders/transforms.py is fused into the patch gather.  Same outputs, same workspace. */
+int cc_vit_encode_frames(const cc_vit_model* m, const cc_frames* frames, int32_t B, int32_t T,
+                         float* features, float* hidden_out, int64_t* medoids_out,
+                         const int64_t* forced_medoids, void* ws, size_t ws_bytes, void* stream);
+int cc_clip_encode_frames(const cc_vit_model* vm, const cc_frames* frames, int32_t B, int32_t T,
+                          float* visual_features, int64_t* medoids_out, const cc_text_model* tm,
+                          const int64_t* ids, int32_t Bt, int32_t Lt, float* text_features,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* S2 - the meanP similarity tail, CLIP4Clip._loose_similarity (modules/clip4clip.py:357-366) with
  * _mean_pooling_for_similarity_visual (:305-316):

@@ -14,6 +14,30 @@ import torch.nn.functional as F
 from . import cluster_oracle as co
 
 
+# constants of the reference's loader, dataloaders/decode.py:43-48
+PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)
+PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def loader_normalize(frames_u8, channels_last=False, mean=PIXEL_MEAN, std=PIXEL_STD):
+    """What the reference's evaluation loader makes of decoded uint8 frames:
+    HWC -> CHW permute (dataloaders/transforms.py:157), ``img.float().div_(255)`` (:166,
+    GroupToTensorBCHW(div=True)), then TensorNormalize (:19-34) = torchvision
+    ``functional.normalize``: ``tensor.sub_(mean[:,None,None]).div_(std[:,None,None])`` with the
+    constants as fp32 tensors.  torchvision is a third-party dependency that is absent from this
+    image (so dataloaders/transforms.py cannot be imported: parity of this row is pinned by
+    this restatement of its published two-line algorithm, checked against plain IEEE numpy
+    arithmetic in tests/test_oracle_clip.py, not by reference-generated fixtures).
+    frames_u8 [N,3,H,W] or [N,H,W,3] uint8 -> [N,3,H,W] fp32."""
+    x = torch.as_tensor(frames_u8)
+    if channels_last:
+        x = x.permute(0, 3, 1, 2)
+    x = x.contiguous().float().div_(255.0)
+    m = torch.as_tensor(mean, dtype=torch.float32)[None, :, None, None]
+    sd = torch.as_tensor(std, dtype=torch.float32)[None, :, None, None]
+    return x.sub_(m).div_(sd)
+
+
 def layer_norm(x, w, b, eps=1e-5):
     """modules/clip.py:183-189: nn.LayerNorm evaluated in fp32."""
     return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps)

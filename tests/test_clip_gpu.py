@@ -317,6 +317,32 @@ def test_edge_similarity_shapes_and_masks():
         np.testing.assert_allclose(got[:, ~dead].numpy(), ref[:, ~dead].numpy(), rtol=0, atol=3e-5)
 
 
+def test_n3_uint8_frames_bit_identical_to_loader_path(g):
+    """N3: uint8 frames (CHW and the decoder's HWC) through the fused normalise + patch gather give the same
+    bits as the reference pipeline loader_normalize -> encode_image, and match the oracle forward."""
+    model, T = small_model(g, cluster=True)
+    res = int(g["video"].shape[-1])
+    rng = np.random.default_rng(11)
+    u_hwc = torch.from_numpy(rng.integers(0, 256, size=(g["video"].shape[0], res, res, 3), dtype=np.uint8))
+    u_chw = u_hwc.permute(0, 3, 1, 2).contiguous()
+    x = clo.loader_normalize(u_hwc, channels_last=True)
+    f_ref, _ = model.visual.encode(x.to(DEV), T)
+    f_chw, _ = model.visual.encode(u_chw.to(DEV), T)
+    f_hwc, _ = model.visual.encode(u_hwc.to(DEV), T)
+    assert torch.equal(f_chw, f_ref) and torch.equal(f_hwc, f_ref)
+    # both towers in one enqueue, uint8 video in the reference's 6-d batch layout
+    ids = torch.from_numpy(g["t_ids"]).to(DEV)
+    v1, t1 = model.encode_pair(x.to(DEV), ids, video_frame=T)
+    v2, t2 = model.encode_pair(u_hwc.to(DEV), ids, video_frame=T)
+    assert torch.equal(v1, v2) and torch.equal(t1, t2)
+    med = model.visual.encode(u_chw.to(DEV), T, want_medoids=True) and model.visual.last_medoids
+    ref = clo.visual_forward(golden_state_dict(g), x, T, cluster_plan={1: (2, 6)}, forced_medoids={1: med.cpu()})
+    f_forced, _ = model.visual.encode(u_chw.to(DEV), T, forced_medoids=med)
+    assert float((nrm(f_forced.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    with pytest.raises(ValueError):
+        model.visual.encode(torch.zeros(4, 5, 64, 64, dtype=torch.uint8, device=DEV), T)
+
+
 def test_forward_is_deterministic(g):
     model, T = small_model(g, cluster=True)
     video = torch.from_numpy(g["video"]).to(DEV)

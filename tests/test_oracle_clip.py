@@ -57,3 +57,19 @@ def test_mask_after_cluster_and_loose_similarity(g):
     seqs = list(torch.from_numpy(g["s_seq"]).split(2)); vis = list(torch.from_numpy(g["s_vis"]).split(3)); ms = list(m3.split(3))
     blocked = clo.similarity_matrix_blocked(seqs, vis, ms, float(g["s_logit_scale"]))
     np.testing.assert_allclose(blocked.numpy(), g["s_logits"], rtol=0, atol=2e-5)
+
+
+def test_n3_loader_normalize_is_three_ieee_ops():
+    """oracle.loader_normalize (the reference loader's u8 -> float, transforms.py:19-34,166) equals the plain IEEE
+    fp32 sequence u/255, -mean, /std bit for bit - the sequence the HIP patch gather performs on uint8 input."""
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 256, size=(3, 16, 24, 3), dtype=np.uint8)
+    u[0, 0, :8, 0] = [0, 1, 2, 127, 128, 254, 255, 77]
+    got = clo.loader_normalize(torch.from_numpy(u), channels_last=True).numpy()
+    mean = np.asarray(clo.PIXEL_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.asarray(clo.PIXEL_STD, dtype=np.float32)[None, :, None, None]
+    x = u.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255.0)
+    want = ((x - mean).astype(np.float32) / std).astype(np.float32)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    got_chw = clo.loader_normalize(torch.from_numpy(np.ascontiguousarray(u.transpose(0, 3, 1, 2)))).numpy()
+    assert np.array_equal(got_chw, want)
