@@ -29,6 +29,13 @@ class TokenLayout(ctypes.Structure):
 _lib = None
 
 
+class ClusterVariant(ctypes.Structure):
+    """cc_cluster_variant (include/centerclip_hip.h): algorithm 0 kmedoids / 1 pooling / 2 sparse_sampling,
+    aggregation 0 medoid / 1 mean."""
+    _fields_ = [("algorithm", ctypes.c_int32), ("aggregation", ctypes.c_int32), ("cluster_embed", ctypes.c_void_p),
+                ("cls_multiplier", ctypes.c_void_p), ("fixed_ids", ctypes.c_void_p)]
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, i64, f32, sz = c.c_void_p, c.c_int32, c.c_int64, c.c_float, c.c_size_t
@@ -44,8 +51,13 @@ def _declare(lib):
     lib.cc_batch_kmedoids_f32.argtypes = [vp, lay, i32, i32, i32, f32, f32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.cc_token_cluster_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, i32,
                                          vp, i64, i64, vp, vp, vp, vp, sz, vp]
+    lib.cc_token_cluster_variant_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, i32,
+                                                 c.POINTER(ClusterVariant), vp, i64, i64, vp, vp, vp, vp, sz, vp]
+    lib.cc_token_aggregate_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, c.POINTER(ClusterVariant), vp,
+                                           i64, i64, vp]
     for name in ("cc_token_norms_f32", "cc_pairwise_distance_f32", "cc_kmedoids_from_dist_f32",
-                 "cc_batch_kmedoids_f32", "cc_token_cluster_f32"):
+                 "cc_batch_kmedoids_f32", "cc_token_cluster_f32", "cc_token_cluster_variant_f32",
+                 "cc_token_aggregate_f32"):
         getattr(lib, name).restype = c.c_int
     return lib
 

@@ -186,11 +186,24 @@ class VisualTransformer(nn.Module):
         m.proj = pk.f32(self.proj)
         m.blocks = ctypes.cast(pk.blocks(self.transformer), ctypes.POINTER(BlockWeights))
         first = None
+        tokens = (self.input_resolution // self.patch_size) ** 2
+        variants = (L.ClusterVariant * CC_MAX_LAYERS)()
+        any_variant = False
+        dev = self.proj.device
         for i, blk in enumerate(self.transformer.resblocks):
             tc = blk.tokencluster_inter
             if tc is not None:
                 m.cluster_frames[i], m.cluster_tokens[i] = tc.after_block_frames, tc.cluster_num
+                if tc.algorithm == 'pooling' and tc.cluster_num != tokens:
+                    raise ValueError("'pooling' keeps the token count: cluster_num_blocks[%d] must be %d" % (i, tokens))
+                variants[i], keep = tc.variant(tc.frame_duration * tokens, dev)     # N2: per-block variant
+                pk.keep.extend(keep)
+                any_variant = any_variant or not tc.is_default_variant
+                tokens = tc.cluster_num
                 first = first or tc
+        if any_variant:
+            pk.keep.append(variants)
+            m.cluster_variants = ctypes.cast(variants, ctypes.c_void_p)
         if first is not None:
             m.cluster_metric = L.METRIC_IDS[first.distance]
             m.cluster_norm_p, m.cluster_threshold = float(first.norm_p), float(first.threshold)

@@ -1,5 +1,9 @@
-"""Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and the kmediods++ /
-aggregation=None branch of TokenClusterInter (:66-352)."""
+"""Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and TokenClusterInter (:66-352) for the
+algorithms 'kmediods++' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
+'sparse_sampling' in eval mode."""
+import ctypes
+
+import numpy as np
 import torch
 
 from .. import _lib as L
@@ -26,6 +30,8 @@ def get_cluster_inter(width, block_id, args=None):
                              id_sort=True, norm_p=args.minkowski_norm_p,
                              aggregation=getattr(args, 'aggregation', None),
                              split_size=4 if args.pretrained_clip_name == 'ViT-B/16' else 16,
+                             cluster_embedding=getattr(args, 'cluster_embedding', False),
+                             adaptive_cls=getattr(args, 'adaptive_cls', False),
                              transformer_width=width, pre_norm=getattr(args, 'pre_norm', False))
 
 
@@ -33,8 +39,10 @@ class TokenClusterInter(torch.nn.Module):
     """Token clustering between transformer blocks: T frames -> T_new segments, the fd*n patch
     tokens of a segment -> K medoid tokens (ascending ids), CLS = mean of the segment's CLS.
 
-    Only the path the shipped scripts use is built (algorithm 'kmediods++', aggregation None,
-    no learnable extras); other options raise NotImplementedError at construction.
+    Built: 'kmediods++' with aggregation None (medoid tokens, the shipped scripts) or any other value (cluster
+    means, cluster.py:291-301), cluster_embedding, adaptive_cls; 'pooling'; 'sparse_sampling' in eval mode.
+    'spectral', the shift algorithms, cluster_frame_embedding (dead code in the reference, :283-285) and
+    mean_residual raise NotImplementedError at construction.
     """
 
     def __init__(self, algorithm='kmediods++', block_id=1, before_cluster_num=49, cluster_num=49,
@@ -46,13 +54,20 @@ class TokenClusterInter(torch.nn.Module):
                  svd_correct_sign=1, pre_norm=False):
         super().__init__()
         assert algorithm in ['kmediods++', 'pooling', 'sparse_sampling', 'spectral', 'temporal_shift', 'token_shift']
-        if algorithm != 'kmediods++':
-            raise NotImplementedError("centerclip_amd builds cluster_algo='kmediods++' only (got %r)" % algorithm)
-        if aggregation not in [None, 'None']:
-            raise NotImplementedError("aggregation=%r is not built (medoid tokens only)" % aggregation)
-        if cluster_embedding or cluster_frame_embedding or adaptive_cls or mean_residual:
-            raise NotImplementedError("cluster_embedding / cluster_frame_embedding / adaptive_cls / mean_residual "
-                                      "are not built")
+        if algorithm not in ('kmediods++', 'pooling', 'sparse_sampling'):
+            raise NotImplementedError("centerclip_amd builds cluster_algo 'kmediods++', 'pooling' and "
+                                      "'sparse_sampling' (got %r)" % algorithm)
+        if cluster_frame_embedding or mean_residual:
+            raise NotImplementedError("cluster_frame_embedding / mean_residual are not built")
+        kmed = algorithm == 'kmediods++'
+        self.cluster_embedding = bool(cluster_embedding) if kmed else False      # cluster.py:154-156
+        self.adaptive_cls = bool(adaptive_cls) if kmed else False
+        scale = transformer_width ** -0.5
+        if self.cluster_embedding:                                                # cluster.py:161-164
+            self.cluster_embed = torch.nn.Parameter(scale * torch.randn(cluster_num, transformer_width))
+        if self.adaptive_cls:                                                     # cluster.py:170-172
+            m = [1 / (before_block_frames // after_block_frames) for _ in range(before_block_frames)]
+            self.cls_multiplier = torch.nn.Parameter(torch.tensor(m).float().reshape(1, before_block_frames, 1, 1))
         assert id_sort, "the reference hard-codes id_sort=True (cluster.py:49)"
         self.algorithm = algorithm
         self.block_id = block_id
@@ -84,12 +99,51 @@ class TokenClusterInter(torch.nn.Module):
         Lt, BT, W = x.shape
         return self._run(x, tok_stride=BT * W, frame_stride=W, BT=BT, Lt=Lt, W=W, frame_major=False), None
 
+    def _sparse_ids(self, N, device):
+        """token_sparse_sampling(cluster_num, N, random_shift=False) (cluster_utils.py:136-170, eval branch):
+        centres of cluster_num equal segments of the N tokens; the same ids for every problem."""
+        if self.training:
+            raise NotImplementedError("sparse_sampling draws random ids in training mode; only eval is built")
+        key = (N, str(device))
+        if getattr(self, "_sparse_key", None) != key:
+            K = self.cluster_num
+            if N > K:
+                tick = N / float(K)
+                offsets = np.array([int(tick / 2.0 + tick * i) for i in range(K)])
+            else:
+                offsets = np.clip(np.arange(0, K), 0, N)
+            self._sparse_key, self._sparse_val = key, torch.from_numpy(offsets).long().to(device)
+        return self._sparse_val
+
+    def variant(self, N, device):
+        """-> (cc_cluster_variant for this module, tensors it points to)."""
+        var = L.ClusterVariant()
+        var.algorithm = {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2}[self.algorithm]
+        var.aggregation = 0 if self.aggregation in [None, 'None'] else 1
+        keep = []
+        if self.cluster_embedding:
+            keep.append(self.cluster_embed.detach().to(device).float().contiguous())
+            var.cluster_embed = keep[-1].data_ptr()
+        if self.adaptive_cls:
+            keep.append(self.cls_multiplier.detach().to(device).float().reshape(-1).contiguous())
+            var.cls_multiplier = keep[-1].data_ptr()
+        if self.algorithm == 'sparse_sampling':
+            keep.append(self._sparse_ids(N, device))
+            var.fixed_ids = keep[-1].data_ptr()
+        return var, keep
+
+    @property
+    def is_default_variant(self):
+        return (self.algorithm == 'kmediods++' and self.aggregation in [None, 'None'] and not self.cluster_embedding
+                and not self.adaptive_cls)
+
     def _run(self, x, tok_stride, frame_stride, BT, Lt, W, frame_major, keep_ids=True):
         L.require_device(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        T, T_new, K = self.before_block_frames, self.after_block_frames, self.cluster_num
+        T, T_new = self.before_block_frames, self.after_block_frames
         B, n = BT // T, Lt - 1
+        K = n if self.algorithm == 'pooling' else self.cluster_num
         lib = L.lib()
         if frame_major:
             out = torch.empty(B * T_new, 1 + K, W, dtype=torch.float32, device=x.device)
@@ -97,13 +151,17 @@ class TokenClusterInter(torch.nn.Module):
         else:
             out = torch.empty(1 + K, B * T_new, W, dtype=torch.float32, device=x.device)
             o_tok, o_frame = B * T_new * W, W
-        medoids = torch.empty(B * T_new, K, dtype=torch.long, device=x.device) if keep_ids else None
         N = self.frame_duration * n
+        var, keep = self.variant(N, x.device)
+        medoids = None
+        if keep_ids and self.algorithm == 'kmediods++':
+            medoids = torch.empty(B * T_new, K, dtype=torch.long, device=x.device)
         ws = L.workspace(lib.cc_cluster_workspace_bytes(B * T_new, N, W, int(bool(self.pre_norm))), x.device)
-        L.check(lib.cc_token_cluster_f32(L.ptr(x), tok_stride, frame_stride, B, T, T_new, n, W, K,
-                                         L.METRIC_IDS[self.distance], float(self.norm_p), float(self.threshold),
-                                         int(self.iter_limit), int(self.split_size), int(bool(self.pre_norm)),
-                                         L.ptr(out), o_tok, o_frame, L.ptr(medoids), None, None,
-                                         L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "cc_token_cluster_f32")
+        L.check(lib.cc_token_cluster_variant_f32(L.ptr(x), tok_stride, frame_stride, B, T, T_new, n, W, K,
+                                                 L.METRIC_IDS[self.distance], float(self.norm_p), float(self.threshold),
+                                                 int(self.iter_limit), int(self.split_size), int(bool(self.pre_norm)),
+                                                 ctypes.byref(var), L.ptr(out), o_tok, o_frame, L.ptr(medoids), None, None,
+                                                 L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
+                "cc_token_cluster_variant_f32")
         self.last_medoids = medoids
         return out

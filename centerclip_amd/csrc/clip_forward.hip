@@ -259,9 +259,21 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             if (vm->cluster_tokens[i] > 0) {        // token cluster before the attention of this block (clip.py:236-242)
                 const int Tn = vm->cluster_frames[i], K = vm->cluster_tokens[i];
                 if (Tn <= 0 || frames % Tn) return CC_ERR_INVALID;
-                if (forced_medoids)
+                const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
+                if (var && var->algorithm == CC_CLUSTER_POOLING && K != tokens) return CC_ERR_INVALID;
+                if (forced_medoids && (!var || (var->algorithm == CC_CLUSTER_KMEDOIDS &&
+                                                var->aggregation == CC_AGGREGATE_MEDOID && !var->cluster_embed &&
+                                                !var->cls_multiplier)))
                     rc = cc_token_gather_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
                                              forced_medoids, hother, W, (int64_t)(K + 1) * W, st);
+                else if (forced_medoids)
+                    rc = CC_ERR_UNSUPPORTED;
+                else if (var)
+                    rc = cc_token_cluster_variant_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                                      vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
+                                                      vm->cluster_iter_limit, vm->cluster_split_size,
+                                                      vm->cluster_pre_norm, var, hother, W, (int64_t)(K + 1) * W,
+                                                      medoids_out, nullptr, nullptr, v.cluster, v.cluster_bytes, st);
                 else
                     rc = cc_token_cluster_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
                                               vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,

@@ -5,7 +5,7 @@
 //      lp_dist_kernel         pairwise Minkowski-p distance, p != 2              (VALU)
 //   K2 kmedoids_select_kernel KKZ init + assign/update iterations + sort,        (latency)
 //                             one workgroup per problem, D resident in LDS when it fits
-//   K3 gather_tokens_kernel   medoid-token gather + per-segment CLS mean          (HBM stream)
+//   K3 reduce_tokens_kernel   medoid-token gather / cluster means / pooling + CLS mean (HBM stream)
 //
 // No host synchronisation anywhere; the [B,K,N,N] temporaries of the reference
 // (modules/cluster/fast_kmeans.py:65,81) are never materialised: the update step walks
@@ -717,41 +717,127 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
 }
 
 // ============================================================================ K3
-// One wave per output token.  Token 0 of segment (b, s) = mean of the fd CLS tokens of its
-// frames (cluster.py:307-308, sequential sum then true division); token 1+k = medoid k of
-// problem p = s*B + b (cluster.py:289,303).
-__global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, int64_t in_tok, int64_t in_frame,
-                                                            int B, int T, int T_new, int n, int W, int K,
-                                                            const long long* __restrict__ medoids,
-                                                            float* __restrict__ out, int64_t out_tok,
-                                                            int64_t out_frame) {
+// Sum over a strided run of rows in the association of ATen's CPU sum over a non-innermost dimension
+// (SumKernel.cpp vectorized_outer_sum -> multi_row_sum): rows are accumulated sequentially, after every 16th row
+// the running sum is folded into a second level, after every 256th that one into a third, and the three levels
+// are added at the end.  Rows that contribute an exact zero (masked-out tokens) can be skipped.
+struct CascadeSum {
+    float4 a0, a1, a2;
+    int chunk;                                                // 16-row chunk a0 belongs to, -1 = none yet
+    __device__ __forceinline__ void init() {
+        a0 = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        chunk = -1;
+    }
+    static __device__ __forceinline__ void acc(float4& d, const float4& v) { d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w; }
+    __device__ __forceinline__ void close_chunk(int next_chunk) {
+        acc(a1, a0);
+        a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((chunk >> 4) != (next_chunk >> 4)) { acc(a2, a1); a1 = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    __device__ __forceinline__ void add(int row, const float4& v) {
+        const int c = row >> 4;
+        if (chunk >= 0 && c != chunk) close_chunk(c);
+        chunk = c;
+        acc(a0, v);
+    }
+    __device__ __forceinline__ float4 total(int rows) {       // rows = length of the reduced dimension
+        if (chunk >= 0 && chunk < (rows >> 4)) {              // the last touched chunk is a complete one
+            const int next = ((chunk >> 4) < (rows >> 8)) ? chunk + 16 : chunk;   // its 256-row group complete too?
+            close_chunk(next);
+        }
+        float4 r = a0;
+        acc(r, a1);
+        acc(r, a2);
+        return r;
+    }
+};
+
+// One wave per output row.  mode 0: K medoid tokens (cluster.py:289; med_stride 0 = the same ids for every problem,
+// 'sparse_sampling' :326-343); mode 1: K cluster means (cluster.py:291-301:
+// sum(res_tmp * mask, dim=1) / sum(mask), empty cluster -> 0/0 = NaN as in the reference); mode 2: 'pooling'
+// (cluster.py:319-324: every token, CLS included, = mean over the segment's frames).  Row 0 of modes 0/1 is the mean
+// of the segment's CLS tokens (cluster.py:307-308), optionally scaled per frame (adaptive_cls, :244-245);
+// cluster_embed [K,W] is added to rows 1..K (:304-305).
+__global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restrict__ x, int64_t in_tok, int64_t in_frame,
+                                                            int B, int T, int T_new, int n, int W, int K, int mode,
+                                                            const long long* __restrict__ medoids, int med_stride,
+                                                            const long long* __restrict__ assign,
+                                                            const float* __restrict__ cluster_embed,
+                                                            const float* __restrict__ cls_mult,
+                                                            float* __restrict__ out, int64_t out_tok, int64_t out_frame) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int rows = B * T_new * (1 + K);
-    if (row >= rows) return;
-    const int seg = row / (1 + K), l = row - seg * (1 + K);
+    const int Lout = (mode == 2) ? 1 + n : 1 + K;
+    if (row >= B * T_new * Lout) return;
+    const int seg = row / Lout, l = row - seg * Lout;
     const int b = seg / T_new, sgm = seg - b * T_new;
-    const int fd = T / T_new;
+    const int fd = T / T_new, N = fd * n;
     float* dst = out + (int64_t)l * out_tok + (int64_t)seg * out_frame;
-    if (l == 0) {
-        const float* src = x + (int64_t)(b * T + sgm * fd) * in_frame;
+    const float* seg0 = x + (int64_t)(b * T + sgm * fd) * in_frame;       // CLS token of the segment's first frame
+    if (l == 0 || mode == 2) {
+        const float* src = seg0 + (int64_t)l * in_tok;
         const float den = (float)fd;
         for (int w = lane * 4; w < W; w += 256) {
-            float4 a = *reinterpret_cast<const float4*>(src + w);
-            for (int f = 1; f < fd; ++f) {
-                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)f * in_frame + w);
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            CascadeSum cs;
+            cs.init();
+            for (int f = 0; f < fd; ++f) {
+                float4 v = *reinterpret_cast<const float4*>(src + (int64_t)f * in_frame + w);
+                if (cls_mult && l == 0 && mode != 2) {
+                    const float m = cls_mult[sgm * fd + f];
+                    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+                }
+                cs.add(f, v);
             }
+            float4 a = cs.total(fd);
             a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
             *reinterpret_cast<float4*>(dst + w) = a;
         }
-    } else {
-        const int p = sgm * B + b;
-        const int j = (int)medoids[(int64_t)p * K + (l - 1)];
+        return;
+    }
+    const int p = sgm * B + b, k = l - 1;
+    const float* emb = cluster_embed ? cluster_embed + (int64_t)k * W : nullptr;
+    if (mode == 0) {
+        const int j = (int)medoids[(int64_t)p * med_stride + k];
         const int f = j / n, i = j - f * n;
-        const float* src = x + (int64_t)(1 + i) * in_tok + (int64_t)(b * T + sgm * fd + f) * in_frame;
-        for (int w = lane * 4; w < W; w += 256)
-            *reinterpret_cast<float4*>(dst + w) = *reinterpret_cast<const float4*>(src + w);
+        const float* src = seg0 + (int64_t)(1 + i) * in_tok + (int64_t)f * in_frame;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + w);
+            if (emb) {
+                const float4 e = *reinterpret_cast<const float4*>(emb + w);
+                v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+            }
+            *reinterpret_cast<float4*>(dst + w) = v;
+        }
+        return;
+    }
+    // mode 1: members of cluster k in ascending token order (64 tokens per ballot)
+    const long long* as = assign + (int64_t)p * N;
+    int count = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) count += __popcll(__ballot(j0 + lane < N && as[j0 + lane] == k));
+    const float den = (float)count;
+    for (int w0 = 0; w0 < W; w0 += 256) {                         // wave-uniform trip count; lanes past W idle
+        const int w = w0 + lane * 4;
+        CascadeSum cs;
+        cs.init();
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            unsigned long long m = __ballot(j0 + lane < N && as[j0 + lane] == k);
+            while (m) {
+                const int j = j0 + __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const int f = j / n, i = j - f * n;
+                if (w < W)
+                    cs.add(j, *reinterpret_cast<const float4*>(seg0 + (int64_t)(1 + i) * in_tok + (int64_t)f * in_frame + w));
+            }
+        }
+        if (w < W) {
+            float4 a = cs.total(N);
+            a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
+            if (emb) {
+                const float4 e = *reinterpret_cast<const float4*>(emb + w);
+                a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+            }
+            *reinterpret_cast<float4*>(dst + w) = a;
+        }
     }
 }
 
@@ -766,6 +852,7 @@ struct ClusterWs {
     float* draw;
     float* xn;
     long long* med;
+    long long* asg;
     size_t total;
 };
 
@@ -783,6 +870,7 @@ ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med) {
     c.inv = static_cast<float*>(take((size_t)P * N * 4));
     c.draw = static_cast<float*>(take((size_t)P * N * N * 4));
     c.med = static_cast<long long*>(take((size_t)P * (size_t)K_for_med * 8));
+    c.asg = static_cast<long long*>(take((size_t)P * N * 8));
     c.xn = pre_norm ? static_cast<float*>(take((size_t)P * N * W * 4)) : nullptr;
     c.total = off;
     return c;
@@ -970,22 +1058,61 @@ int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
     const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL(gather_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, reinterpret_cast<const long long*>(medoids),
-                       out, out_tok_stride, out_frame_stride);
+    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(medoids), K,
+                       (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
+                       out_frame_stride);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
-int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
-                         int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
-                         float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm, float* out,
-                         int64_t out_tok_stride, int64_t out_frame_stride, int64_t* medoids, int64_t* assign,
-                         int32_t* iters, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !out || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                           int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* assign,
+                           const cc_cluster_variant* var, float* out, int64_t out_tok_stride, int64_t out_frame_stride,
+                           void* stream) {
+    if (!x || !out || !assign || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+    if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
+        return CC_ERR_INVALID;
+    const int rows = B * T_new * (1 + K);
+    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 1, (const long long*)nullptr, 0,
+                       reinterpret_cast<const long long*>(assign), var ? var->cluster_embed : nullptr,
+                       var ? var->cls_multiplier : nullptr, out, out_tok_stride, out_frame_stride);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                                 int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
+                                 float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
+                                 const cc_cluster_variant* var, float* out, int64_t out_tok_stride,
+                                 int64_t out_frame_stride, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (!x || !out || !var || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0) return CC_ERR_INVALID;
     if (T % T_new) return CC_ERR_INVALID;
     if ((W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3)) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     const int fd = T / T_new;
+    if (var->algorithm == CC_CLUSTER_POOLING) {                 // no selection: every token = mean over the segment's frames
+        const int rows = B * T_new * (1 + n);
+        hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+                           B, T, T_new, n, W, n, 2, (const long long*)nullptr, 0, (const long long*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, out, out_tok_stride, out_frame_stride);
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
+    if (var->algorithm == CC_CLUSTER_SPARSE_SAMPLING) {         // fixed ids shared by every problem, then gather + CLS mean
+        if (!var->fixed_ids || K <= 0) return CC_ERR_INVALID;
+        const int rows = B * T_new * (1 + K);
+        hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+                           B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(var->fixed_ids), 0,
+                           (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
+                           out_frame_stride);
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
+    if (var->algorithm != CC_CLUSTER_KMEDOIDS || K <= 0) return CC_ERR_INVALID;
+    if (var->aggregation != CC_AGGREGATE_MEDOID && var->aggregation != CC_AGGREGATE_MEAN) return CC_ERR_INVALID;
     cc_token_layout lay;
     lay.B = B; lay.S = T_new; lay.fd = fd; lay.n = n;
     lay.stride_b = (int64_t)T * in_frame_stride;
@@ -997,15 +1124,31 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
     ClusterWs c = carve(ws, P, N, W, pre_norm, N);
     if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
     int64_t* med = medoids ? medoids : reinterpret_cast<int64_t*>(c.med);
+    const bool mean = var->aggregation == CC_AGGREGATE_MEAN;
+    int64_t* asg = assign ? assign : (mean ? reinterpret_cast<int64_t*>(c.asg) : nullptr);
     int rc = cc_batch_kmedoids_f32(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
-                                   pre_norm, med, assign, iters, ws, ws_bytes, stream);
+                                   pre_norm, med, asg, iters, ws, ws_bytes, stream);
     if (rc != CC_OK) return rc;
     const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL(gather_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, reinterpret_cast<const long long*>(med),
-                       out, out_tok_stride, out_frame_stride);
+    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
+                       T, T_new, n, W, K, mean ? 1 : 0, reinterpret_cast<const long long*>(med), K,
+                       reinterpret_cast<const long long*>(asg), var->cluster_embed, var->cls_multiplier, out,
+                       out_tok_stride, out_frame_stride);
     CC_LAUNCH_CHECK();
     return CC_OK;
+}
+
+int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                         int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
+                         float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm, float* out,
+                         int64_t out_tok_stride, int64_t out_frame_stride, int64_t* medoids, int64_t* assign,
+                         int32_t* iters, void* ws, size_t ws_bytes, void* stream) {
+    cc_cluster_variant var{};
+    var.algorithm = CC_CLUSTER_KMEDOIDS;
+    var.aggregation = CC_AGGREGATE_MEDOID;
+    return cc_token_cluster_variant_f32(x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, metric, norm_p, threshold,
+                                        iter_limit, split_size, pre_norm, &var, out, out_tok_stride, out_frame_stride,
+                                        medoids, assign, iters, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -132,6 +132,47 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
                          int64_t* medoids, int64_t* assign, int32_t* iters,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* The other TokenClusterInter variants that share this data layout, modules/cluster/cluster.py:
+ *   algorithm CC_CLUSTER_KMEDOIDS + aggregation CC_AGGREGATE_MEDOID  the shipped path (:289), = cc_token_cluster_f32
+ *   algorithm CC_CLUSTER_KMEDOIDS + aggregation CC_AGGREGATE_MEAN    output token k = mean of the tokens assigned to
+ *                                medoid k (:291-301; an empty cluster yields NaN, as 0/0 does in the reference)
+ *   algorithm CC_CLUSTER_POOLING  every token, CLS included, = mean over the segment's frames (:319-324);
+ *                                K and the k-medoids arguments are ignored, out is [1+n, B*T_new, W]
+ *   cluster_embed  [K, W] fp32 or NULL: learnt embedding added to output tokens 1..K (:304-305)
+ *   cls_multiplier [T] fp32 or NULL: per-frame scale of the CLS token before the segment mean (adaptive_cls, :244-245)
+ * Sums follow the association of the reference's torch.sum / mean over a non-innermost dimension (running sum
+ * folded into a second level every 16 rows), so the outputs are bit-identical to the reference's CPU path.
+ *   algorithm CC_CLUSTER_SPARSE_SAMPLING  eval-mode 'sparse_sampling' (:326-343): fixed_ids [K] int64 (device) are the
+ *                                ids of token_sparse_sampling(K, fd*n, random_shift=False) (cluster_utils.py:136-170),
+ *                                the same for every segment; gather + CLS mean as for medoids */
+#define CC_CLUSTER_KMEDOIDS 0
+#define CC_CLUSTER_POOLING  1
+#define CC_CLUSTER_SPARSE_SAMPLING 2   /* fixed_ids [K]: token_sparse_sampling(K, fd*n, random_shift=False) */
+#define CC_AGGREGATE_MEDOID 0
+#define CC_AGGREGATE_MEAN   1
+typedef struct cc_cluster_variant {
+    int32_t algorithm;
+    int32_t aggregation;
+    const float* cluster_embed;
+    const float* cls_multiplier;
+    const int64_t* fixed_ids;
+} cc_cluster_variant;
+/* The aggregation step of CC_AGGREGATE_MEAN alone, from a given assignment [T_new*B, fd*n] int64 (values 0..K-1;
+ * problem p = s*B + b as everywhere) - the counterpart of cc_token_gather_f32 for cluster means
+ * (cluster.py:291-310).  variant may be NULL; only its cluster_embed / cls_multiplier are used. */
+int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride,
+                           int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                           const int64_t* assign, const cc_cluster_variant* variant,
+                           float* out, int64_t out_tok_stride, int64_t out_frame_stride, void* stream);
+
+int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride,
+                                 int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                                 int32_t metric, float norm_p, float threshold, int32_t iter_limit,
+                                 int32_t split_size, int32_t pre_norm, const cc_cluster_variant* variant,
+                                 float* out, int64_t out_tok_stride, int64_t out_frame_stride,
+                                 int64_t* medoids, int64_t* assign, int32_t* iters,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 
 /*
  * C6 alone - the gather half of TokenClusterInter.forward for given medoid ids:
@@ -238,6 +279,9 @@ typedef struct cc_vit_model {
     int32_t cluster_tokens[CC_MAX_LAYERS];
     int32_t cluster_metric;   float cluster_norm_p;   float cluster_threshold;
     int32_t cluster_iter_limit, cluster_split_size, cluster_pre_norm;
+    /* optional HOST array [layers]: the TokenClusterInter variant of block i (N2); NULL = medoid gather
+     * everywhere.  For CC_CLUSTER_POOLING cluster_tokens[i] must equal the incoming token count. */
+    const struct cc_cluster_variant* cluster_variants;
 } cc_vit_model;
 
 /* Frame input descriptor for the *_frames entry points.  The reference's evaluation

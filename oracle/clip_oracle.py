@@ -77,7 +77,7 @@ def resblock(x, sd, pre, heads, causal):
 def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_medoids=None, return_hidden=False):
     """VisualTransformer.forward + the ln_post/proj tail of CLIP.encode_image
     (clip.py:304-349,460-469).  video [B*T,3,H,W]; cluster_plan {block_index(0-based): (T_new, K)};
-    cluster_cfg dict(distance, threshold, iter_limit, norm_p, split_size, pre_norm).
+    cluster_cfg dict(distance, threshold, iter_limit, norm_p, split_size, pre_norm[, algorithm, aggregation]).
     forced_medoids {block_index: int64 [T_new*B, K]} replaces the k-medoids result (to compare
     embeddings "given identical medoid sets").  Returns features [B*T_final, E]
     (and the hidden state [B*T_final, L, W])."""
@@ -98,6 +98,14 @@ def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_med
             x_lnd = x.permute(1, 0, 2).contiguous()
             if forced_medoids is not None and i in forced_medoids:
                 x_lnd = gather_with_medoids(x_lnd, frames, T_new, forced_medoids[i])
+            elif (cluster_cfg or {}).get("algorithm", "kmediods++") != "kmediods++" or \
+                    (cluster_cfg or {}).get("aggregation") not in [None, "None"]:
+                c = cluster_cfg                                                         # N2 variants
+                x_lnd = co.literal_token_cluster_variant(x_lnd, frames, T_new, K, c.get("algorithm", "kmediods++"),
+                                                         c.get("aggregation"), None, None,
+                                                         c.get("distance", "euclidean"), c.get("threshold", 1e-6),
+                                                         c.get("iter_limit", 100), c.get("norm_p", 2.0),
+                                                         c.get("split_size", 16), c.get("pre_norm", False))
             else:
                 c = cluster_cfg or {}
                 x_lnd = co.literal_token_cluster(x_lnd, frames, T_new, K, c.get("distance", "euclidean"),

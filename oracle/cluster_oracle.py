@@ -173,6 +173,119 @@ def literal_token_cluster(x_lnd, T, T_new, K, distance="euclidean", threshold=1e
     return (out, med, assign) if return_ids else out
 
 
+# --------------------------------------------------------------------------- N2 variants
+def literal_token_cluster_variant(x_lnd, T, T_new, K, algorithm="kmediods++", aggregation=None, cluster_embed=None,
+                                  cls_multiplier=None, distance="euclidean", threshold=1e-6, iter_limit=100,
+                                  norm_p=2.0, split_size=16, pre_norm=False, assign=None, medoids=None):
+    """The other branches of TokenClusterInter.forward (modules/cluster/cluster.py), same ATen op
+    sequence as the reference:
+      kmediods++ + aggregation (:291-301)  token k = sum(res_tmp * mask_k, dim=1) / sum(mask_k)
+      cluster_embed (:304-305), cls_multiplier / adaptive_cls (:244-245)
+      pooling (:319-324), sparse_sampling in eval mode (:326-343 with cluster_utils.py:136-170)
+    ``assign`` / ``medoids`` given: skip the k-medoids and use them (to compare the aggregation
+    "given identical assignment").  Returns [1+K', B*T_new, W]."""
+    L, BT, W = x_lnd.shape
+    n, B, fd = L - 1, BT // T, T // T_new
+    x = x_lnd.permute(1, 0, 2)
+    if algorithm == "pooling":
+        res_x = x.reshape(B, T, L, W)
+        frame_split = [it.mean(dim=1) for it in torch.split(res_x, fd, dim=1)]
+        return torch.stack(frame_split, dim=1).contiguous().reshape(B * T_new, L, W).permute(1, 0, 2).contiguous()
+    all_cls = x[:, 0, :].reshape(B, T, 1, W)
+    if cls_multiplier is not None:
+        all_cls = all_cls * cls_multiplier.reshape(1, T, 1, 1)
+    seg_cls = torch.stack([it.mean(dim=1) for it in torch.split(all_cls, fd, dim=1)], dim=1).reshape(B * T_new, 1, W)
+    res_x = x[:, 1:, :].reshape(B, T, n, W)
+    if algorithm == "sparse_sampling":
+        res_all = []
+        for it in torch.split(res_x, fd, dim=1):
+            it_tmp = it.reshape(B, -1, W)
+            total = it_tmp.shape[1]
+            if total > K:
+                tick = total / float(K)
+                ind = np.array([int(tick / 2.0 + tick * i) for i in range(K)])
+            else:
+                ind = np.clip(np.arange(0, K), 0, total)
+            res_all.append(it_tmp[:, torch.from_numpy(ind).long(), :])
+        x_tmp = torch.stack(res_all, dim=1).contiguous().reshape(B * T_new, K, W)
+        return torch.cat([seg_cls, x_tmp], dim=1).permute(1, 0, 2).contiguous()
+    res_tmp = torch.cat(torch.split(res_x, fd, dim=1), dim=0).contiguous().reshape(B * T_new, -1, W)
+    if assign is None or medoids is None:
+        assign, medoids = literal_batch_kmedoids_with_split(res_tmp, K, distance, threshold, iter_limit, True,
+                                                            norm_p, split_size, pre_norm)
+    if aggregation in [None, "None"]:
+        x_tmp = res_tmp[torch.arange(res_tmp.shape[0]).unsqueeze(-1), medoids, ...]
+    else:
+        parts = []
+        for i in range(K):
+            mask = (assign == i).unsqueeze(-1)
+            parts.append(torch.sum(res_tmp * mask, dim=1, keepdim=True) / torch.sum(mask.float(), dim=1, keepdim=True))
+        x_tmp = torch.cat(parts, dim=1)
+    x_tmp = torch.stack(torch.split(x_tmp, B, dim=0), dim=1).reshape(B * T_new, K, W)
+    if cluster_embed is not None:
+        x_tmp = x_tmp + cluster_embed
+    return torch.cat([seg_cls, x_tmp], dim=1).permute(1, 0, 2).contiguous()
+
+
+def _cascade_rows(X, ilp):
+    """multi_row_sum / row_sum of SumKernel.cpp along axis 0 of X [n, ...]: ``ilp`` interleaved
+    accumulators over the rows (1 = plain sequential), each folded into the next level after every
+    16 of its additions (256, 4096 for the higher levels); levels, then left-over rows, then the
+    interleaved accumulators are added in order."""
+    f = np.float32
+    n = X.shape[0]
+    size = n // ilp
+    levels = 4
+    lp = max(4, (int(np.ceil(np.log2(size))) if size > 1 else 0) // levels)
+    step = 1 << lp
+    mask = step - 1
+    shp = (ilp,) + X.shape[1:]
+    acc = [np.zeros(shp, f) for _ in range(levels)]
+    i = 0
+    while i + step <= size:
+        for _ in range(step):
+            acc[0] = acc[0] + X[i * ilp:(i + 1) * ilp]
+            i += 1
+        for j in range(1, levels):
+            acc[j] = acc[j] + acc[j - 1]
+            acc[j - 1] = np.zeros(shp, f)
+            if (i & (mask << (j * lp))) != 0:
+                break
+    while i < size:
+        acc[0] = acc[0] + X[i * ilp:(i + 1) * ilp]
+        i += 1
+    for j in range(1, levels):
+        acc[0] = acc[0] + acc[j]
+    out = acc[0][0]
+    for t in range(size * ilp, n):
+        out = out + X[t]
+    for k in range(1, ilp):
+        out = out + acc[0][k]
+    return out
+
+
+def aten_outer_sums(M):
+    """Column sums of M [n, C] (fp32) in the association ATen's CPU ``sum`` / ``mean`` uses when the
+    reduced dimension is not the innermost one (SumKernel.cpp ``vectorized_outer_sum``; third-party
+    dependency of the reference, restated from its published source): the columns are taken in
+    groups of 32 (4 vectors of 8; threads split the columns on 32-column boundaries, so this does not
+    depend on the thread count) and summed row after row with the cascade of ``_cascade_rows``
+    (ilp = 1); the columns left after the last full group of 32 go through ``row_sum``, which
+    additionally interleaves 4 accumulators over the rows (ilp = 4).  Every transformer width of
+    the model family is a multiple of 32, so the hot path only ever sees the first form.
+    This is the arithmetic of the segment means (cluster.py:307-308,319-324) and of the cluster
+    means (:296-298); checked bit-for-bit against torch in tests/test_oracle_cluster.py."""
+    M = np.ascontiguousarray(M, dtype=np.float32)
+    C = M.shape[1]
+    full = (C // 32) * 32
+    out = np.empty(C, np.float32)
+    if full:
+        out[:full] = _cascade_rows(M[:, :full], 1)
+    if full < C:
+        out[full:] = _cascade_rows(M[:, full:], 4)
+    return out
+
+
 # ------------------------------------------------------- streamlined (kernel spec)
 def aten_row_sums(M):
     """Row sums of M [R, n] (fp32) in the association ATen's CPU ``sum`` uses for a

@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by IMPORTING the read-only reference (dev container only).
 
-    python oracle/gen_golden.py [cluster|dup|clip|all]
+    python oracle/gen_golden.py [cluster|dup|variants|clip|all]
 
 The reference (/root/reference, Python/PyTorch) never travels to the GPU box:
 what travels is the data this script writes - inputs (or the integer seeds that
@@ -188,6 +188,53 @@ def gen_cluster_dup():
     print("wrote cluster_dup_golden.npz", os.path.getsize(os.path.join(GOLD, "cluster_dup_golden.npz")), "bytes")
 
 
+def gen_cluster_variants():
+    """N2: the other TokenClusterInter branches (aggregation, cluster_embedding, adaptive_cls, pooling,
+    sparse_sampling in eval mode) run by the reference module itself -> tests/golden/cluster_variants_golden.npz.
+    Inputs are regenerated from seeds (recipes.variant_input); stored: outputs, and for the k-medoids cases
+    the assignment / medoids the reference used."""
+    sys.path.insert(0, os.path.join(REF, "modules"))
+    import cluster.cluster as cc
+    import cluster.fast_kmeans as fk
+    from recipes import VARIANT_CASES, variant_input
+    t = torch.from_numpy
+    out = {}
+    for tag, cfg in VARIANT_CASES.items():
+        x, embed, mult = variant_input(cfg)
+        mod = cc.TokenClusterInter(algorithm=cfg["algorithm"], block_id=7, before_cluster_num=cfg["n"],
+                                   cluster_num=cfg["K"], before_block_frames=cfg["T"], after_block_frames=cfg["T_new"],
+                                   original_frame=cfg["T"], distance="euclidean", threshold=1e-6, iter_limit=100,
+                                   id_sort=True, aggregation=cfg["aggregation"], split_size=16, norm_p=2.0,
+                                   cluster_embedding=bool(cfg.get("embed")), adaptive_cls=bool(cfg.get("adaptive")),
+                                   transformer_width=cfg["W"])
+        mod.eval()
+        with torch.no_grad():
+            if embed is not None:
+                mod.cluster_embed.copy_(t(embed))
+            if mult is not None:
+                mod.cls_multiplier.copy_(t(mult).reshape(1, -1, 1, 1))
+            captured = {}
+            orig = cc.batch_fast_kmedoids_with_split
+
+            def spy(*a, **k):
+                r = orig(*a, **k)
+                captured["assign"], captured["medoids"] = r[0].clone(), r[1].clone()
+                return r
+            cc.batch_fast_kmedoids_with_split = spy
+            try:
+                y, res = mod(t(x))
+            finally:
+                cc.batch_fast_kmedoids_with_split = orig
+        assert res is None
+        out[f"{tag}_out"] = y.contiguous().numpy()
+        if captured:
+            out[f"{tag}_assign"] = captured["assign"].numpy().astype(np.int16)
+            out[f"{tag}_medoids"] = captured["medoids"].numpy().astype(np.int16)
+        print(tag, "done", tuple(y.shape), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "cluster_variants_golden.npz"), **out)
+    print("wrote cluster_variants_golden.npz", os.path.getsize(os.path.join(GOLD, "cluster_variants_golden.npz")), "bytes")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     os.makedirs(GOLD, exist_ok=True)
@@ -195,6 +242,8 @@ if __name__ == "__main__":
         gen_cluster()
     if what in ("dup", "all"):
         gen_cluster_dup()
+    if what in ("variants", "all"):
+        gen_cluster_variants()
     if what in ("clip", "all"):
         from gen_golden_clip import gen_clip
         gen_clip()

@@ -80,3 +80,42 @@ def duplicate_token_problem(seed, P, n_distinct, N, layout):
         Ds.append(D)
         Xs.append(xb[idx])
     return np.stack(Ds), np.stack(Xs)
+
+
+def fullmant(seed, shape, scale_bits=20):
+    """Generic-looking fp32 values that are bit-reproducible: integers in (-2^23, 2^23) times 2^-scale_bits.
+    Full 24-bit significands, so sums of them round and expose the order of summation."""
+    r = np.random.default_rng(seed).integers(-(1 << 23) + 1, 1 << 23, size=shape)
+    return (r.astype(np.float32) * np.float32(2.0 ** -scale_bits)).astype(np.float32)
+
+
+# N2 variant fixtures: name -> dict(seed, kind of input, B, T, T_new, n, W, K, algorithm, aggregation, embed, adaptive)
+VARIANT_CASES = {
+    "mean_lattice": dict(seed=91, inp="lattice", B=2, T=12, T_new=4, n=49, W=64, K=20, algorithm="kmediods++", aggregation="mean"),
+    "mean_generic": dict(seed=92, inp="fullmant", B=2, T=12, T_new=3, n=49, W=64, K=12, algorithm="kmediods++", aggregation="mean"),
+    "mean_big_clusters": dict(seed=93, inp="fullmant", B=1, T=8, T_new=1, n=49, W=32, K=3, algorithm="kmediods++", aggregation="mean"),
+    "embed_adaptive": dict(seed=94, inp="lattice", B=2, T=12, T_new=4, n=49, W=64, K=20, algorithm="kmediods++", aggregation=None,
+                           embed=True, adaptive=True),
+    "mean_embed_adaptive": dict(seed=95, inp="lattice", B=2, T=12, T_new=6, n=49, W=32, K=10, algorithm="kmediods++",
+                                aggregation="mean", embed=True, adaptive=True),
+    "pooling_12_3": dict(seed=96, inp="fullmant", B=2, T=12, T_new=3, n=49, W=64, K=49, algorithm="pooling", aggregation=None),
+    "pooling_64_2": dict(seed=97, inp="fullmant", B=1, T=64, T_new=2, n=16, W=32, K=16, algorithm="pooling", aggregation=None),
+    "sparse_12_3": dict(seed=98, inp="fullmant", B=2, T=12, T_new=3, n=49, W=64, K=20, algorithm="sparse_sampling", aggregation=None),
+    "cls_mean_fd32": dict(seed=99, inp="lattice_cls_generic", B=1, T=64, T_new=2, n=16, W=32, K=9, algorithm="kmediods++",
+                          aggregation=None),
+}
+
+
+def variant_input(cfg):
+    """x [1+n, B*T, W] fp32 for a VARIANT_CASES entry (+ cluster_embed [K,W], cls_multiplier [T] when asked)."""
+    L, BT, W = 1 + cfg["n"], cfg["B"] * cfg["T"], cfg["W"]
+    if cfg["inp"] == "lattice":
+        x = lattice(cfg["seed"], (L, BT, W))
+    elif cfg["inp"] == "fullmant":
+        x = fullmant(cfg["seed"], (L, BT, W))
+    else:                                   # lattice patches (robust clustering), generic CLS row
+        x = lattice(cfg["seed"], (L, BT, W))
+        x[0] = fullmant(cfg["seed"] + 1000, (BT, W))
+    embed = fullmant(cfg["seed"] + 2000, (cfg["K"], W), 24) if cfg.get("embed") else None
+    mult = (fullmant(cfg["seed"] + 3000, (cfg["T"],), 24) + np.float32(1.0)) if cfg.get("adaptive") else None
+    return x, embed, mult

@@ -24,3 +24,9 @@ def cluster_golden():
 def cluster_dup_golden():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "cluster_dup_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def cluster_variants_golden():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "cluster_variants_golden.npz"))

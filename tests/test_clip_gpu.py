@@ -343,6 +343,32 @@ def test_n3_uint8_frames_bit_identical_to_loader_path(g):
         model.visual.encode(torch.zeros(4, 5, 64, 64, dtype=torch.uint8, device=DEV), T)
 
 
+@pytest.mark.parametrize("algo,agg", [("pooling", None), ("sparse_sampling", None), ("kmediods++", "mean")])
+def test_n2_variants_inside_the_fused_forward(g, algo, agg):
+    """The per-block cc_cluster_variant array of cc_vit_model: 'pooling' and eval-mode 'sparse_sampling' (no
+    data-dependent selection) agree with the oracle forward; aggregation='mean' runs and is deterministic (its
+    arithmetic is pinned at the operator level in test_cluster_gpu.py)."""
+    from centerclip_amd.clip import build_clip_model
+    T = int(g["cfg"][11])
+    n = (int(g["video"].shape[-1]) // int(g["cfg"][2])) ** 2
+    K = n if algo == "pooling" else 6
+    args = Namespace(cluster_inter=1, cluster_algo=algo, max_frames=T, target_frames_blocks=[4, 2, 2],
+                     cluster_num_blocks=[n, K, K], cluster_distance='euclidean', cluster_threshold=1e-6,
+                     cluster_iter_limit=100, minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=agg,
+                     pre_norm=False)
+    model, _ = build_clip_model(golden_state_dict(g), args=args)
+    model = model.to(DEV).eval()
+    video = torch.from_numpy(g["video"])
+    feat, hidden = model.visual.encode(video.to(DEV), T, want_hidden=True)
+    feat2, _ = model.visual.encode(video.to(DEV), T)
+    assert torch.equal(feat, feat2) and bool(torch.isfinite(feat).all())
+    assert hidden.shape == (video.shape[0] // T * 2, 1 + K, int(g["cfg"][3]))
+    if agg is None:
+        ref = clo.visual_forward(golden_state_dict(g), video, T, cluster_plan={1: (2, K)},
+                                 cluster_cfg=dict(algorithm=algo, aggregation=None))
+        assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+
+
 def test_forward_is_deterministic(g):
     model, T = small_model(g, cluster=True)
     video = torch.from_numpy(g["video"]).to(DEV)

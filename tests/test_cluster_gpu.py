@@ -17,7 +17,8 @@ import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import DUPLICATE_CASES, duplicate_token_problem, dyadic, lattice
+from oracle.recipes import (DUPLICATE_CASES, VARIANT_CASES, duplicate_token_problem, dyadic, fullmant, lattice,
+                            variant_input)
 
 pytestmark = pytest.mark.gpu
 
@@ -325,3 +326,60 @@ def test_run_to_run_determinism(cl):
     outs = [cl.batch_fast_kmedoids_with_split(X, 49, iter_limit=100, split_size=16) for _ in range(3)]
     for a, m in outs[1:]:
         assert torch.equal(m, outs[0][1]) and torch.equal(a, outs[0][0])
+
+
+# ------------------------------------------------------------------------------- N2 variants
+def _variant_module(cl, cfg, embed, mult):
+    mod = cl.TokenClusterInter(algorithm=cfg["algorithm"], block_id=7, before_cluster_num=cfg["n"], cluster_num=cfg["K"],
+                               before_block_frames=cfg["T"], after_block_frames=cfg["T_new"], original_frame=cfg["T"],
+                               distance="euclidean", threshold=1e-6, iter_limit=100, id_sort=True,
+                               aggregation=cfg["aggregation"], split_size=16, norm_p=2.0,
+                               cluster_embedding=embed is not None, adaptive_cls=mult is not None,
+                               transformer_width=cfg["W"]).eval()
+    with torch.no_grad():
+        if embed is not None:
+            mod.cluster_embed.copy_(torch.from_numpy(embed))
+        if mult is not None:
+            mod.cls_multiplier.copy_(torch.from_numpy(mult).reshape(1, -1, 1, 1))
+    return mod.to(DEV)
+
+
+@pytest.mark.parametrize("tag", list(VARIANT_CASES))
+def test_n2_variants_match_reference(cl, cluster_variants_golden, tag):
+    """TokenClusterInter with aggregation / cluster_embedding / adaptive_cls / 'pooling' / 'sparse_sampling':
+    the module output equals the reference module's (fixture) bit for bit.  Inputs whose k-medoids outcome is
+    host-independent (integer lattices, and the algorithms without k-medoids) go through the module; the
+    generic-float k-medoids cases compare the aggregation given the reference's assignment."""
+    import ctypes
+    from centerclip_amd import _lib as L
+    g, cfg = cluster_variants_golden, VARIANT_CASES[tag]
+    x, embed, mult = variant_input(cfg)
+    mod = _variant_module(cl, cfg, embed, mult)
+    want = g[f"{tag}_out"]
+    if cfg["algorithm"] != "kmediods++" or cfg["inp"].startswith("lattice"):
+        y, res = mod(dev(x))
+        assert res is None
+        assert np.array_equal(y.cpu().numpy(), want, equal_nan=True), tag
+        # frame-major layout used inside the fused forward: same values
+        yf = mod.cluster_frame_major(dev(x).permute(1, 0, 2).contiguous())
+        assert np.array_equal(yf.permute(1, 0, 2).cpu().numpy(), want, equal_nan=True)
+    if cfg["aggregation"] is not None:
+        B, T, Tn, n, W, K = (cfg[k] for k in ("B", "T", "T_new", "n", "W", "K"))
+        xd = dev(x)
+        asg = dev(g[f"{tag}_assign"].astype(np.int64))
+        out = torch.empty(1 + K, B * Tn, W, device=DEV)
+        var, keep = mod.variant((T // Tn) * n, xd.device)
+        L.check(L.lib().cc_token_aggregate_f32(L.ptr(xd), B * T * W, W, B, T, Tn, n, W, K, L.ptr(asg), ctypes.byref(var),
+                                               L.ptr(out), B * Tn * W, W, L.stream_ptr(xd.device)), "aggregate")
+        assert np.array_equal(out.cpu().numpy(), want, equal_nan=True), tag
+
+
+def test_n2_unbuilt_variants_fail_loudly(cl):
+    for kw in (dict(algorithm="spectral"), dict(algorithm="token_shift"), dict(mean_residual=True),
+               dict(cluster_frame_embedding=True)):
+        with pytest.raises(NotImplementedError):
+            cl.TokenClusterInter(**kw)
+    mod = cl.TokenClusterInter(algorithm="sparse_sampling", cluster_num=20, before_block_frames=12, after_block_frames=3,
+                               transformer_width=32).to(DEV).train()
+    with pytest.raises(NotImplementedError):
+        mod(dev(lattice(1, (50, 12, 32))))

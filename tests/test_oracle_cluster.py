@@ -13,7 +13,8 @@ import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import DUPLICATE_CASES, duplicate_token_problem, dyadic, lattice
+from oracle.recipes import (DUPLICATE_CASES, VARIANT_CASES, duplicate_token_problem, dyadic, fullmant, lattice,
+                            variant_input)
 
 t = torch.from_numpy
 
@@ -167,3 +168,35 @@ def test_c1_token_cluster_module(cluster_golden, tag):
     y = co.literal_token_cluster(x, T, T_new, K, "euclidean", 1e-6, 100, 2.0, split, False)
     assert tuple(y.shape) == (1 + K, B * T_new, W)
     assert np.array_equal(y.numpy(), g[f"{tag}_out"])
+
+
+# ------------------------------------------------------------------------------- N2 variants
+@pytest.mark.parametrize("tag", list(VARIANT_CASES))
+def test_n2_variant_oracle_reproduces_reference(cluster_variants_golden, tag):
+    """literal_token_cluster_variant == the reference module's output (fixture) for aggregation / cluster_embed /
+    adaptive_cls / pooling / sparse_sampling; the k-medoids cases are evaluated on the reference's own assignment,
+    so generic-float inputs do not depend on this host's cdist rounding."""
+    g, cfg = cluster_variants_golden, VARIANT_CASES[tag]
+    x, embed, mult = variant_input(cfg)
+    kw = {}
+    if f"{tag}_assign" in g.files:
+        kw = dict(assign=t(g[f"{tag}_assign"].astype(np.int64)), medoids=t(g[f"{tag}_medoids"].astype(np.int64)))
+    y = co.literal_token_cluster_variant(t(x), cfg["T"], cfg["T_new"], cfg["K"], cfg["algorithm"], cfg["aggregation"],
+                                         None if embed is None else t(embed), None if mult is None else t(mult), **kw)
+    assert np.array_equal(y.numpy(), g[f"{tag}_out"], equal_nan=True)
+    if cfg["inp"] == "lattice" and kw:            # exact inputs: the oracle's own k-medoids finds the same assignment
+        y2 = co.literal_token_cluster_variant(t(x), cfg["T"], cfg["T_new"], cfg["K"], cfg["algorithm"], cfg["aggregation"],
+                                              None if embed is None else t(embed), None if mult is None else t(mult))
+        assert np.array_equal(y2.numpy(), g[f"{tag}_out"], equal_nan=True)
+
+
+@pytest.mark.parametrize("n,C", [(1, 64), (3, 32), (5, 40), (16, 64), (17, 96), (33, 64), (196, 768), (257, 64), (588, 32),
+                                 (640, 100)])
+def test_aten_outer_sum_association_restatement(n, C):
+    """oracle.aten_outer_sums restates ATen's sum over a non-innermost dimension (segment / cluster means)."""
+    M = fullmant(500 + n, (n, C))
+    masked = M * (np.random.default_rng(n).random((n, 1)) < 0.2)
+    for m in (M, masked.astype(np.float32)):
+        tt = t(m).reshape(1, n, C).repeat(3, 1, 1)
+        assert np.array_equal(co.aten_outer_sums(m), tt.sum(dim=1)[1].numpy())
+        assert np.array_equal(co.aten_outer_sums(m) / np.float32(n), tt.mean(dim=1)[2].numpy())
