@@ -55,6 +55,8 @@ def declare(lib):
         getattr(lib, name).restype = c.c_int
     lib.cc_rank_counts_f32.argtypes = [vp, i32, i32, i64, i64, i32, vp, vp]
     lib.cc_rank_counts_f32.restype = c.c_int
+    lib.cc_rank_counts_cols_f32.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp]
+    lib.cc_rank_counts_cols_f32.restype = c.c_int
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]

@@ -204,36 +204,57 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
 // and the reference's `ind` is the concatenation over rows of range(c_gt, c_gt + c_eq) (np.where returns every
 // position of the sorted row that equals the diagonal value, so ties contribute several entries).
 // One wave per row; element (i, j) lives at sim + i*row_stride + j*col_stride (col_stride != 1 ranks sim^T).
+// gt_cols != nullptr: the ground-truth column of row i is gt_cols[i] (multi-sentence retrieval: several text rows
+// share one video) and a third count is written: #{j < g : sim[i,j] == sim[i,g]}, the position of g among its ties
+// under a stable descending sort.
 __global__ __launch_bounds__(256) void rank_counts_kernel(const float* __restrict__ sim, int rows, int cols,
                                                           int64_t row_stride, int64_t col_stride, int diag_offset,
-                                                          int* __restrict__ counts) {
+                                                          const int* __restrict__ gt_cols, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const float* row = sim + (int64_t)i * row_stride;
-    const float d = row[(int64_t)(diag_offset + i) * col_stride];
-    int gt = 0, eq = 0;
+    const int g = gt_cols ? gt_cols[i] : diag_offset + i;
+    const float d = row[(int64_t)g * col_stride];
+    int gt = 0, eq = 0, before = 0;
     for (int j = lane; j < cols; j += 64) {
         const float v = row[(int64_t)j * col_stride];
         gt += (v > d) ? 1 : 0;
         eq += (v == d) ? 1 : 0;
+        before += (v == d && j < g) ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         gt += __shfl_xor(gt, o, CC_WAVE);
         eq += __shfl_xor(eq, o, CC_WAVE);
+        before += __shfl_xor(before, o, CC_WAVE);
     }
     if (lane == 0) {
-        counts[2 * i] = gt;
-        counts[2 * i + 1] = eq;
+        if (gt_cols) {
+            counts[3 * i] = gt;
+            counts[3 * i + 1] = eq;
+            counts[3 * i + 2] = before;
+        } else {
+            counts[2 * i] = gt;
+            counts[2 * i + 1] = eq;
+        }
     }
+}
+
+extern "C" int cc_rank_counts_cols_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride,
+                                       int64_t col_stride, const int32_t* gt_cols, int32_t* counts3, void* stream) {
+    if (!sim || !counts3 || !gt_cols || rows <= 0 || cols <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
+                       cols, row_stride, col_stride, 0, gt_cols, counts3);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
 }
 
 extern "C" int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
                                   int32_t diag_offset, int32_t* counts, void* stream) {
     if (!sim || !counts || rows <= 0 || cols <= 0 || diag_offset < 0 || diag_offset + rows > cols) return CC_ERR_INVALID;
     hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
-                       cols, row_stride, col_stride, diag_offset, counts);
+                       cols, row_stride, col_stride, diag_offset, (const int*)nullptr, counts);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -1,6 +1,7 @@
-"""Retrieval metrics from a device-resident similarity matrix - mirror of ``utils/metrics.py:11-26``
-(compute_metrics) with the rank extraction done on the GPU (cc_rank_counts_f32): two int32 per row
-travel to the host instead of the whole [Nt, Nv] matrix, and no sort is needed."""
+"""Retrieval metrics from a device-resident similarity matrix - mirror of ``utils/metrics.py`` (compute_metrics
+:11-26, tensor_text_to_video_metrics :38-65, tensor_video_to_text_sim :68-76) with the rank extraction done on
+the GPU (cc_rank_counts_f32 / cc_rank_counts_cols_f32): a few int32 per row travel to the host instead of the whole
+[Nt, Nv] matrix, and no sort is needed."""
 import numpy as np
 import torch
 
@@ -42,3 +43,42 @@ def compute_metrics(x):
         raise TypeError("centerclip_amd.metrics.compute_metrics ranks a device tensor; the reference's NumPy version "
                         "handles host arrays")
     return metrics_from_counts(rank_counts(x))
+
+
+def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10)):
+    """Drop-in for utils.metrics.tensor_text_to_video_metrics (:38-65) on a device tensor.
+    sim_tensor [G, Lmax, C]: group g holds the sentences of video g, padded with -inf rows (main.py:466-476).
+    The reference double-argsorts every row and reads the rank of the ground-truth column off the diagonal; here the
+    rank of sentence (g, l) is #{j: sim[g,l,j] > sim[g,l,g]} plus its position among ties under a stable descending
+    sort (the reference's argsort leaves the order of exact ties open).  Padding rows (non-finite ground truth) are
+    dropped, as in the reference."""
+    if not torch.is_tensor(sim_tensor):
+        raise TypeError("centerclip_amd.metrics ranks device tensors; the reference's version handles host arrays")
+    L.require_device(sim_tensor)
+    x = sim_tensor.float().contiguous()
+    G, Lmax, C = x.shape
+    gt = torch.arange(G, dtype=torch.int32, device=x.device).repeat_interleave(Lmax).contiguous()
+    counts = torch.empty(G * Lmax, 3, dtype=torch.int32, device=x.device)
+    L.check(L.lib().cc_rank_counts_cols_f32(L.ptr(x), G * Lmax, C, C, 1, L.ptr(gt), L.ptr(counts),
+                                            L.stream_ptr(x.device)), "cc_rank_counts_cols_f32")
+    truth = x.reshape(G * Lmax, C).gather(1, gt.long().unsqueeze(1)).squeeze(1)
+    valid = torch.isfinite(truth).cpu().numpy()
+    c = counts.cpu().numpy().astype(np.int64)
+    ranks = (c[:, 0] + c[:, 2])[valid]
+    # the reference divides torch tensors here, i.e. in fp32 (metrics.py:58)
+    res = {"R%d" % k: float(np.float32(np.sum(ranks < k) * 100) / np.float32(len(ranks))) for k in top_k}
+    res["MedianR"] = float(np.sort(ranks + 1)[(len(ranks) - 1) // 2])          # torch.median: the lower middle value
+    res["MeanR"] = float(np.mean(ranks + 1))
+    res["Std_Rank"] = float(np.std(ranks + 1))
+    res["MR"] = res["MedianR"]
+    return res
+
+
+def tensor_video_to_text_sim(sim_tensor):
+    """Drop-in for utils.metrics.tensor_video_to_text_sim (:68-76): NaN -> -inf, max over the sentences of a group,
+    transposed -> [C, G], ready for compute_metrics.  Stays on the device."""
+    L.require_device(sim_tensor)
+    x = sim_tensor.float()
+    x = torch.where(x != x, torch.full_like(x, float("-inf")), x)
+    values, _ = torch.max(x, dim=1, keepdim=True)
+    return torch.squeeze(values).T.contiguous()

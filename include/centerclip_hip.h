@@ -379,6 +379,13 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
 int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
                        int32_t diag_offset, int32_t* counts, void* stream);
 
+/* The same with an explicit ground-truth column per row (gt_cols [rows] int32, device) - the multi-sentence
+ * protocol of tensor_text_to_video_metrics (utils/metrics.py:38-65), where the sentences of one video share its
+ * column.  counts3 [rows,3]: #greater, #equal (>= 1), #equal with a smaller column index (the position of the
+ * ground truth among its ties under a stable descending sort; the reference's argsort leaves that order open). */
+int cc_rank_counts_cols_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
+                            const int32_t* gt_cols, int32_t* counts3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by IMPORTING the read-only reference (dev container only).
 
-    python oracle/gen_golden.py [cluster|dup|variants|clip|all]
+    python oracle/gen_golden.py [cluster|dup|variants|metrics|clip|all]
 
 The reference (/root/reference, Python/PyTorch) never travels to the GPU box:
 what travels is the data this script writes - inputs (or the integer seeds that
@@ -235,6 +235,31 @@ def gen_cluster_variants():
     print("wrote cluster_variants_golden.npz", os.path.getsize(os.path.join(GOLD, "cluster_variants_golden.npz")), "bytes")
 
 
+def gen_metrics_multi():
+    """N1, multi-sentence protocol (main.py:466-480): the reference's tensor_text_to_video_metrics /
+    tensor_video_to_text_sim + compute_metrics on a small ragged problem -> tests/golden/metrics_multi_golden.npz."""
+    from gen_golden_clip import _import_reference
+    rm = _import_reference()[3]
+    rng = np.random.default_rng(12)
+    lens = [3, 1, 5, 2, 4, 1, 2, 5, 3, 1, 2, 4]                      # sentences per video
+    G = len(lens)
+    sim = (rng.integers(-2000, 2000, size=(sum(lens), G)).astype(np.float32) / np.float32(64.0))   # distinct enough, a few ties
+    cut = np.cumsum(lens)
+    max_len = max(lens)
+    blocks = []
+    for s_, e_ in zip([0] + list(cut[:-1]), cut):
+        blocks.append(np.concatenate((sim[s_:e_], np.full((max_len - e_ + s_, G), -np.inf, dtype=np.float32)), axis=0))
+    sim3 = np.stack(blocks, axis=0)
+    tv = rm.tensor_text_to_video_metrics(sim3.copy())
+    v2t_sim = rm.tensor_video_to_text_sim(sim3.copy())
+    vt = rm.compute_metrics(v2t_sim.numpy() if torch.is_tensor(v2t_sim) else v2t_sim)
+    out = {"sim3": sim3, "v2t_sim": np.asarray(v2t_sim),
+           "tv": np.array([tv["R1"], tv["R5"], tv["R10"], tv["MedianR"], tv["MeanR"], tv["Std_Rank"]], dtype=np.float64),
+           "vt": np.array([vt["R1"], vt["R5"], vt["R10"], vt["MR"], vt["MeanR"]], dtype=np.float64)}
+    np.savez_compressed(os.path.join(GOLD, "metrics_multi_golden.npz"), **out)
+    print("wrote metrics_multi_golden.npz", tv, vt)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     os.makedirs(GOLD, exist_ok=True)
@@ -244,6 +269,8 @@ if __name__ == "__main__":
         gen_cluster_dup()
     if what in ("variants", "all"):
         gen_cluster_variants()
+    if what in ("metrics", "all"):
+        gen_metrics_multi()
     if what in ("clip", "all"):
         from gen_golden_clip import gen_clip
         gen_clip()

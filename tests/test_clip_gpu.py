@@ -298,6 +298,21 @@ def test_n1_retrieval_metrics_match_reference(g):
     assert len(t2v["cols"]) == 41            # the tie with the diagonal yields an extra entry, as in the reference
 
 
+def test_n1_multi_sentence_metrics_match_reference():
+    """tensor_text_to_video_metrics / tensor_video_to_text_sim (utils/metrics.py:38-76) on the device == the
+    reference's numbers on a ragged 12-video / 33-sentence problem (fixture from the reference itself)."""
+    from centerclip_amd.metrics import compute_metrics, tensor_text_to_video_metrics, tensor_video_to_text_sim
+    gm = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics_multi_golden.npz"))
+    sim3 = torch.from_numpy(gm["sim3"]).to(DEV)
+    tv = tensor_text_to_video_metrics(sim3)
+    np.testing.assert_allclose([tv["R1"], tv["R5"], tv["R10"], tv["MedianR"], tv["MeanR"], tv["Std_Rank"]], gm["tv"],
+                               rtol=0, atol=1e-12)
+    v2t = tensor_video_to_text_sim(sim3)
+    assert np.array_equal(v2t.cpu().numpy(), gm["v2t_sim"])
+    vt = compute_metrics(v2t)
+    np.testing.assert_allclose([vt["R1"], vt["R5"], vt["R10"], vt["MR"], vt["MeanR"]], gm["vt"], rtol=0, atol=1e-12)
+
+
 def test_edge_similarity_shapes_and_masks():
     """1 x 1 logits, a fully masked clip (denominator 0 -> 1, clip4clip.py:313) and a mask given as int64."""
     from centerclip_amd import ops
