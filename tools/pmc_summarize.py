@@ -14,8 +14,12 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for k, v in acc.items():
         res[k][which + "_raw_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
+OURS = ("gemm_f16_kernel", "kmedoids_select", "gram_dist", "lp_dist", "reduce_tokens", "token_norm", "attention_",
+        "im2col", "dot_nt", "row_stats", "layernorm_kernel", "head_project")
 summary = {}
 for k, v in res.items():
+    if not any(s in k for s in OURS):        # torch's own fill / randn kernels of the driver script are not ours
+        continue
     f = v.get("fetch_raw_per_launch", 0.0) * 1024.0 * 2.0       # x2: gfx950 FETCH_SIZE under-count
     w = v.get("write_raw_per_launch", 0.0) * 1024.0
     summary[k] = dict(launches=v.get("launches", 0), fetch_bytes_per_launch=f, write_bytes_per_launch=w,
