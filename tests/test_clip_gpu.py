@@ -286,6 +286,33 @@ def test_vitb32_full_size_against_fp32_oracle():
     assert float((sim - simref).abs().max()) <= 1e-3
 
 
+def test_vitb32_activitynet_shape_against_fp32_oracle():
+    """BASELINE.json configs[3] shape, one clip: ViT-B/32, 64 frames -> 8 segments at block 7, K=49: 8 problems of
+    N = 392 tokens (the distance matrix does not fit LDS: the global-memory form of the selection kernel).  HIP vs
+    the fp32 CPU oracle given the HIP path's own medoid ids; the ids themselves obey the structural contract."""
+    from centerclip_amd.clip import CLIP
+    torch.manual_seed(1)
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=64,
+                     target_frames_blocks=[64] * 6 + [8] * 6, cluster_num_blocks=[49] * 12,
+                     cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False)
+    model = CLIP(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12, video_frames=64, args=args)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.half().float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    video = torch.randn(64, 3, 224, 224)
+    feat, _ = model.visual.encode(video.to(DEV), 64, want_medoids=True)
+    med = model.visual.last_medoids.cpu()
+    assert feat.shape == (8, 512) and med.shape == (8, 49)
+    assert bool((med[:, 1:] > med[:, :-1]).all()) and int(med.min()) >= 0 and int(med.max()) < 8 * 49
+    ref = clo.visual_forward(sd, video, 64, cluster_plan={6: (8, 49)}, forced_medoids={6: med})
+    d = float((nrm(feat.cpu()) - nrm(ref)).abs().max())
+    print(f"[ViT-B/32 64f] max|delta| normalised embedding = {d:.2e}")
+    assert d <= 1e-3
+
+
 def test_n1_retrieval_metrics_match_reference(g):
     """compute_metrics on the device (2 ints per row) == utils/metrics.py:11-26 incl. its tie behaviour."""
     from centerclip_amd.metrics import compute_metrics
