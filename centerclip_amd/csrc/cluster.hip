@@ -526,6 +526,8 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
 
     // a_n = first argmin_k D[m_k, n]  (fast_kmeans.py:75-76); 8 medoid rows in flight per lane
     auto assign_step = [&](bool build_masks) {
+        if (build_masks)                                             // the masks are rebuilt with LDS atomics below
+            for (int q = tid; q < K * E; q += 256) s.cmask[q] = 0ull;
         for (int e = 0; e < 3; ++e) {
             const int n = tid + 256 * e;
             if (e * 256 >= N) break;                                 // uniform
@@ -551,23 +553,11 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
             if (n < N) s.asg[n] = (unsigned short)a;
         }
         if (build_masks) {
-            // membership bit masks in summation-rank space: bit t of cluster k  <-  token order[t] belongs to k
+            // membership bit masks in summation-rank space: bit t of cluster k  <-  token order[t] belongs to k.
+            // One ds_or_b64 per token (OR commutes: deterministic) instead of K ballots per wave.
             __syncthreads();
-            for (int e = 0; e < 3; ++e) {
-                const int w = wave + 4 * e;
-                if (w >= E) break;                                   // wave-uniform
-                const int t = tid + 256 * e;
-                const int av = (t < N) ? (int)s.asg[s.order[t]] : -1;
-                for (int kb = 0; kb < K; kb += 64) {
-                    unsigned long long mine = 0ull;
-                    const int kend = min(64, K - kb);
-                    for (int kk = 0; kk < kend; ++kk) {
-                        const unsigned long long b = __ballot(av == kb + kk);
-                        if (lane == kk) mine = b;
-                    }
-                    if (lane < kend) s.cmask[(size_t)(kb + lane) * E + w] = mine;
-                }
-            }
+            for (int t = tid; t < N; t += 256)
+                atomicOr(&s.cmask[(size_t)s.asg[s.order[t]] * E + (t >> 6)], 1ull << (t & 63));
         }
     };
 
@@ -588,10 +578,20 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
             s.best[k] = ~0ull;
         }
         __syncthreads();
-        for (int k = tid; k <= K; k += 256) {
-            int o = 0;
-            for (int q = 0; q < k; ++q) o += s.cnt[q];
-            s.off[k] = (unsigned short)o;
+        if (wave == 0) {                                       // exclusive prefix sum of the counts: wave scan, 64 at a time
+            int carry = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int v = (base + lane < K) ? (int)s.cnt[base + lane] : 0;
+                int incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                if (base + lane < K) s.off[base + lane] = (unsigned short)(carry + incl - v);
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) s.off[K] = (unsigned short)carry;
         }
         __syncthreads();
         const int vec_end = (N < 8) ? 0 : (N & ~7);            // tokens from here on are the sequential tail
