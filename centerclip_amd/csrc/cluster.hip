@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
     const int wr = wave >> 1, wc = wave & 1;
     const bool active = !(ti == tj && wr > wc) && (ti * GT + wr * 32 < N) && (tj * GT + wc * 32 < N);
     const bool diag = (ti == tj);                             // A and B tiles are the same rows: load once
+    // 16x16 fragments of this wave's 32x32 block that lie entirely in the padding, or (diagonal block) strictly below
+    // the diagonal, are not computed (wave-uniform): the mirrored store of fragment (0,1) covers (1,0)
+    const int wrow0 = ti * GT + wr * 32, wcol0 = tj * GT + wc * 32;
+    const bool dblock = diag && wr == wc;
+    const bool f01 = wcol0 + 16 < N, f10 = (wrow0 + 16 < N) && !dblock, f11 = (wrow0 + 16 < N) && (wcol0 + 16 < N);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b0[tt], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b1[tt], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b0[tt], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b1[tt], acc[1][1], 0, 0, 0);
+                    if (f01) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b1[tt], acc[0][1], 0, 0, 0);
+                    if (f10) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b0[tt], acc[1][0], 0, 0, 0);
+                    if (f11) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b1[tt], acc[1][1], 0, 0, 0);
                 }
             }
         }
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
             for (int fn = 0; fn < 2; ++fn) {
+                if ((fm == 0 && fn == 1 && !f01) || (fm == 1 && fn == 0 && !f10) || (fm == 1 && fn == 1 && !f11)) continue;
                 const int j = tj * GT + wc * 32 + fn * 16 + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
                         }
                         lmax = fmaxf(lmax, d);
                         Dp[(int64_t)i * N + j] = d;
-                        if (mirror) Dp[(int64_t)j * N + i] = d;
+                        if (mirror || (dblock && fm == 0 && fn == 1)) Dp[(int64_t)j * N + i] = d;
                     }
                 }
             }
@@ -497,29 +503,40 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     if (wave == 0) {
         unsigned nearest[NE];
         const float* nr = norms + (int64_t)p * N;
-        unsigned loc = 0u, locn = 0u;                          // lane-local best key and the smallest n attaining it
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int n = lane + 64 * e;
             nearest[e] = (n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
-            if (nearest[e] > loc) { loc = nearest[e]; locn = (unsigned)n; }
         }
+        long long kq0 = 0, kq1 = 0;
         for (int i = 0; i < K; ++i) {
-            // arg-max with lowest-index tie break: DPP max of the keys, then DPP min of the candidate indices
+            long long ks0 = 0, ks1 = 0;
+            if (prof) ks0 = (long long)__builtin_readcyclecounter();
+            // arg-max with lowest-index tie break: DPP max of the keys, then one ballot per 64-token chunk - the first
+            // chunk with a lane at the maximum holds the smallest index (all scalar work: s_ff1 on the ballot)
+            unsigned loc = nearest[0];
+#pragma unroll
+            for (int e = 1; e < NE; ++e) loc = max(loc, nearest[e]);
             const unsigned mx = cc_wave_umax(loc);
-            const int m = (int)cc_wave_umin(loc == mx ? locn : 0xFFFFFFFFu);
+            int m = -1;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const unsigned long long b = __ballot(nearest[e] == mx);
+                if (m < 0 && b) m = 64 * e + __ffsll((long long)b) - 1;
+            }
             if (lane == 0) s.med[i] = m;
-            loc = 0u; locn = 0u;
+            if (prof) ks1 = (long long)__builtin_readcyclecounter();
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const int n = lane + 64 * e;
                 if (n < N) {
                     const unsigned kd = cc_float_to_ordered_uint(DREAD(m, n));
                     nearest[e] = (i == 0) ? kd : min(nearest[e], kd);
-                    if (nearest[e] > loc) { loc = nearest[e]; locn = (unsigned)n; }
                 }
             }
+            if (prof) { kq0 += ks1 - ks0; kq1 += (long long)__builtin_readcyclecounter() - ks1; }
         }
+        if (prof && lane == 0) { prof[(int64_t)blockIdx.x * 16 + 9] = kq0; prof[(int64_t)blockIdx.x * 16 + 10] = kq1; }
     }
     __syncthreads();
     SEL_STAMP(2);
