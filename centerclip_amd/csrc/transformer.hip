@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long long* __rest
 
 // out[r][e0:e0+64] = LN(h[row_of(r)]) @ proj[W, E]   (fp32 throughout).  grid = (E/64, R): every
 // workgroup re-normalises its row (W floats, cheap) and produces 64 outputs; the 256 threads are
-// 4 k-slices x 64 outputs, proj reads are coalesced over the output index.
+// 16 k-slices x 16 lanes x 4 outputs, proj reads are 16-byte loads coalesced over the output index.
 //   row_of(r) = r*row_mul + (row_idx ? row_idx[r] : 0)
 __global__ __launch_bounds__(256) void head_project_kernel(const float* __restrict__ h, int row_mul,
                                                            const int* __restrict__ row_idx,
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
                                                            int W, int E, float eps) {
     __shared__ float xn[1024];
     __shared__ float red[8];
-    __shared__ float part[4][64];
+    __shared__ __attribute__((aligned(16))) float part[16][64];
     const int r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = h + ((int64_t)r * row_mul + (row_idx ? row_idx[r] : 0)) * W;
     float s = 0.f;
@@ -558,24 +558,40 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + eps);
     for (int w = tid; w < W; w += 256) xn[w] = (xn[w] - mean) * rstd * gamma[w] + beta[w];
     __syncthreads();
-    const int e = blockIdx.x * 64 + lane;
-    const int wq = (W + 3) / 4, w0 = wave * wq, w1 = min(W, w0 + wq);
-    float acc = 0.f;
-    if (e < E) {
+    // 16 k-slices (4 waves x 4 lane groups) x 16 lanes x 4 outputs: 16-byte proj loads, 8 in flight per lane, so the
+    // dependent-load chain is W / 16 / 8 batches long (it was W / 4 / 8 with one output per lane)
+    const int eg = lane & 15, ks = wave * 4 + (lane >> 4);
+    const int e = blockIdx.x * 64 + eg * 4;
+    const int wq = (W + 15) / 16, w0 = ks * wq, w1 = min(W, w0 + wq);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < E) {                                              // E % 4 == 0 (checked by the launcher)
         const float* pp = proj + e;
         int w = w0;
-        for (; w + 8 <= w1; w += 8) {            // 8 independent loads in flight per lane
-            float pv[8];
+        for (; w + 8 <= w1; w += 8) {
+            float4 pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = pp[(int64_t)(w + u) * E];
+            for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const float4*>(pp + (int64_t)(w + u) * E);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(xn[w + u], pv[u], acc);
+            for (int u = 0; u < 8; ++u) {
+                const float x = xn[w + u];
+                acc.x = fmaf(x, pv[u].x, acc.x); acc.y = fmaf(x, pv[u].y, acc.y);
+                acc.z = fmaf(x, pv[u].z, acc.z); acc.w = fmaf(x, pv[u].w, acc.w);
+            }
         }
-        for (; w < w1; ++w) acc = fmaf(xn[w], pp[(int64_t)w * E], acc);
+        for (; w < w1; ++w) {
+            const float4 pv = *reinterpret_cast<const float4*>(pp + (int64_t)w * E);
+            const float x = xn[w];
+            acc.x = fmaf(x, pv.x, acc.x); acc.y = fmaf(x, pv.y, acc.y); acc.z = fmaf(x, pv.z, acc.z); acc.w = fmaf(x, pv.w, acc.w);
+        }
     }
-    part[wave][lane] = acc;
+    *reinterpret_cast<float4*>(&part[ks][eg * 4]) = acc;
     __syncthreads();
-    if (wave == 0 && e < E) out[(int64_t)r * E + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (tid < 64 && blockIdx.x * 64 + tid < E) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][tid];       // fixed order: deterministic
+        out[(int64_t)r * E + blockIdx.x * 64 + tid] = t;
+    }
 }
 
 // ============================================================================ C ABI (single ops)
@@ -707,7 +723,7 @@ int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float
 
 int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, const float* gamma, const float* beta,
                            const float* proj, float* out, int R, int W, int E, hipStream_t st) {
-    if (W > 1024) return CC_ERR_UNSUPPORTED;
+    if (W > 1024 || (E & 3)) return CC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, R), dim3(256), 0, st, h, row_mul, row_idx, gamma, beta, proj, out, W, E, 1e-5f);
     CC_LAUNCH_CHECK();
     return CC_OK;
