@@ -160,12 +160,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
         }
     };
+    // Co-resident 4-wave workgroups: raising the wave priority over its MFMA block keeps the other workgroup's VMEM /
+    // LDS instructions from being issued between them (measured: 1832 -> 1713-1763 cycles per k-step for the 128-wide
+    // tiles; the single-workgroup 256x256 tile loses 7 % with it, so it is keyed on the loop form below).
+    constexpr bool MMA_PRIO = !((NWAVES == 8) || (BM == 64 && BN == 64));
     auto mma = [&](const h8 (&af)[MI], const h8 (&bf)[NI]) {
+        if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
