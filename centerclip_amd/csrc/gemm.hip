@@ -200,11 +200,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             const int buf = kt & 1;
             if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
             else fetch_epilogue_operands();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                h8 af[MI], bf[NI];
-                read_frags(buf, ks, af, bf);
-                mma(af, bf);
+            {
+                h8 a0[MI], b0[NI], a1[MI], b1[NI];
+                read_frags(buf, 0, a0, b0);
+                read_frags(buf, 1, a1, b1);                   // the second k-half's reads fly under the first half's MFMAs
+                mma(a0, b0);
+                mma(a1, b1);
             }
             __syncthreads();
         }
