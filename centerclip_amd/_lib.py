@@ -75,11 +75,12 @@ def lib():
     """Load the shared library once; raise if it has not been built (python -m centerclip_amd.build)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("CENTERCLIP_HIP_LIB", LIB_PATH)    # dev aid: A/B two builds in one GPU session
+        if not os.path.exists(path):
             raise CenterClipHipError(
                 "libcenterclip_hip.so not found at %s - build it with `python -m centerclip_amd.build` "
-                "(the HIP library is the only execution path; there is no CPU fallback)" % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
+                "(the HIP library is the only execution path; there is no CPU fallback)" % path)
+        handle = ctypes.CDLL(path)
         _declare(handle)
         _declare_optional(handle)
         _lib = handle

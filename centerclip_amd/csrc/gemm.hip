@@ -185,10 +185,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             const int buf = kt & 1;
             read_frags(buf, 1, a1, b1);
             mma(a0, b0);
+            // one fragment read per group of MFMAs: the reads of the next k-half trickle in under this half's MFMAs
+#pragma unroll
+            for (int q = 0; q < MI + NI; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);   // MFMAs
+            }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (kt + 2 < nk) stage(buf, kt + 2);
             read_frags(buf ^ 1, 0, a0, b0);
             mma(a1, b1);
+#pragma unroll
+            for (int q = 0; q < MI + NI; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         read_frags((nk - 1) & 1, 1, a1, b1);
         mma(a0, b0);
