@@ -165,13 +165,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // tiles; the single-workgroup 256x256 tile loses 7 % with it, so it is keyed on the loop form below).
     constexpr bool MMA_PRIO = !((NWAVES == 8) || (BM == 64 && BN == 64));
     auto mma = [&](const h8 (&af)[MI], const h8 (&bf)[NI]) {
-        if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
@@ -215,10 +213,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             else fetch_epilogue_operands();
             {
                 h8 a0[MI], b0[NI], a1[MI], b1[NI];
+                if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);  // (s_setprio ends a scheduling region: keep it outside)
                 read_frags(buf, 0, a0, b0);
-                read_frags(buf, 1, a1, b1);                   // the second k-half's reads fly under the first half's MFMAs
+                read_frags(buf, 1, a1, b1);
                 mma(a0, b0);
                 mma(a1, b1);
+                // order: the first k-half's reads, then the second half's reads one per MFMA group of the first half
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+                for (int q = 0; q < MI + NI; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
         }
