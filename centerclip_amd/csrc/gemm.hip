@@ -43,6 +43,11 @@ __device__ long long* g_gemm_prof = nullptr;
         if (prof && threadIdx.x == 0) prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {          // lane exchange inside a 16-lane DPP row (bit pattern)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     long long* prof = g_gemm_prof;
@@ -302,88 +307,86 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         return;
     }
     constexpr bool STATS = (EPI == EPI_F32_RESID_STATS);
-    constexpr int LDH = WTN + 8;                                  // staged fp16 row (halfs)
-    constexpr int RHS_MAX = (2 * (A_BYTES + B_BYTES)) / (NWAVES * LDH * 2);
-    constexpr int RHS = (RHS_MAX >= WTM) ? WTM : (RHS_MAX >= 64 ? 64 : (RHS_MAX >= 32 ? 32 : 16));
-    _Float16* hstg = reinterpret_cast<_Float16*>(smem) + wave * (RHS * LDH);
-    // The fp32 residual rows come from HBM.  They are fetched a group of fragment rows ahead (all loads of a group
-    // in flight together, the next group's issued before this group's stores) - a load issued behind a store to the
-    // same buffer cannot be hoisted by the compiler, and 16-32 serial HBM round trips used to cost more than the
-    // tile's MFMA work.  Group = <= 16 fragments (<= 8 for the 8-wave tiles) to bound the register footprint.
-    constexpr int IG = !RESID ? 1 : (MI * NI <= 16 ? MI : (8 / NI > 0 ? 8 / NI : 1));
-    static_assert(MI % IG == 0, "residual prefetch groups");
-    float4 resv[2][IG][NI];
-    auto fetch_residual = [&](int slot, int grp) {
+    // fp32 outputs go through a per-wave LDS strip too: a 16-row fragment group is written in accumulator layout
+    // (16 rows x 16 B per lane) and read back row-major, so that every global access of this epilogue - residual
+    // read, fp32 write, fp16 copy - covers a whole wave-tile row (WTN x 4 B = 256 B for the 128-wide tiles) instead of
+    // 64-byte pieces of 16 different rows, and a row's LN statistics reduce over one DPP row of lanes.
+    constexpr int LDF = WTN + 4;                                  // floats per staged row (272-byte rows for WTN = 64)
+    constexpr int LPRF = WTN / 4;                                 // lanes per row, 16 B each (16 or 8)
+    constexpr int RPP = 64 / LPRF, PASSES = 16 / RPP;             // rows per access, accesses per 16-row group
+    static_assert(LPRF == 16 || LPRF == 8, "fp32 epilogue geometry");
+    static_assert(NWAVES * 16 * LDF * 4 <= 2 * (A_BYTES + B_BYTES), "fp32 epilogue strip fits the staging buffers");
+    float* fstg = reinterpret_cast<float*>(smem) + wave * (16 * LDF);
+    const int er = lane / LPRF, ec = (lane % LPRF) * 4;           // this lane's row (within a pass) and column
+    const int ncol = col0 + wc * WTN + ec;
+    auto out_row = [&](int i, int ps) { return row0 + wr * WTM + i * 16 + ps * RPP + er; };
+    // The fp32 residual rows come from HBM: they are fetched one fragment-row group ahead (issued before this
+    // group's stores - a load behind a store to the same buffer cannot be hoisted by the compiler).
+    float4 resv[2][PASSES];
+    auto fetch_residual = [&](int slot, int i) {
 #pragma unroll
-        for (int ii = 0; ii < IG; ++ii) {
-            const int m = min(row0 + wr * WTM + (grp * IG + ii) * 16 + l15, g.M - 1);
-            const float* src = reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + col0 + wc * WTN + lg * 4;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) resv[slot][ii][j] = *reinterpret_cast<const float4*>(src + j * 16);
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int m = min(out_row(i, ps), g.M - 1);
+            resv[slot][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + ncol);
         }
     };
     if (RESID) fetch_residual(0, 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = row0 + wr * WTM + i * 16 + l15;
-        float psum = 0.f, psq = 0.f;
-        if (RESID && i % IG == 0 && i + IG < MI) fetch_residual(((i / IG) + 1) & 1, i / IG + 1);
+        if (RESID && i + 1 < MI) fetch_residual((i + 1) & 1, i + 1);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = col0 + wc * WTN + j * 16 + lg * 4;
-            f32x4 v = acc[i][j];
-            {
-                const float4 bb = biasv[j];
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
+            const float4 bb = biasv[j];
+            *reinterpret_cast<float4*>(fstg + l15 * LDF + j * 16 + lg * 4) =
+                make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the strip is private to this wave
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int m = out_row(i, ps);
+            float4 v = *reinterpret_cast<const float4*>(fstg + (ps * RPP + er) * LDF + ec);
             if (RESID) {
-                float4 c = resv[(i / IG) & 1][i % IG][j];
-                c.x += v[0]; c.y += v[1]; c.z += v[2]; c.w += v[3];
-                if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = c;
+                const float4 c = resv[i & 1][ps];
+                v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
                 if (STATS) {
-                    h4 o = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
-                    *reinterpret_cast<h4*>(hstg + ((i * 16 + l15) % RHS) * LDH + j * 16 + lg * 4) = o;
+                    const h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    if (m < g.M) *reinterpret_cast<h4*>(g.c16 + (int64_t)m * g.ldc + ncol) = o;
                     // statistics of what the consumer will actually multiply: the fp16-rounded row
                     const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-                    psum += (q0 + q1) + (q2 + q3);
-                    psq += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                    float psum = (q0 + q1) + (q2 + q3);
+                    float psq = (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                    // the LPRF lanes of a row sit in one DPP row: quad swaps, half mirror (8 lanes), mirror (16 lanes)
+                    psum += dpp_f32<0xB1>(psum);
+                    psq += dpp_f32<0xB1>(psq);
+                    psum += dpp_f32<0x4E>(psum);
+                    psq += dpp_f32<0x4E>(psq);
+                    psum += dpp_f32<0x141>(psum);
+                    psq += dpp_f32<0x141>(psq);
+                    if (LPRF == 16) {
+                        psum += dpp_f32<0x140>(psum);
+                        psq += dpp_f32<0x140>(psq);
+                    }
+                    if ((lane % LPRF) == 0 && m < g.M) {          // one slot per (tile column, wave column)
+                        const int slot = tn * WN + wc;
+                        reinterpret_cast<float2*>(g.stats_out)[(int64_t)m * (g.tiles_n * WN) + slot] = make_float2(psum, psq);
+                    }
                 }
             } else if (m < g.M) {
                 if (EPI == EPI_F32_PATCH) {
                     const int f = m / g.patch_n, tok = m - f * g.patch_n + 1;
-                    const float4 pe = *reinterpret_cast<const float4*>(g.pos + (int64_t)tok * g.N + n);
-                    float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + n;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+                    const float4 pe = *reinterpret_cast<const float4*>(g.pos + (int64_t)tok * g.N + ncol);
+                    float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + ncol;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
                 } else {
-                    float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
                 }
             }
         }
-        if (STATS) {
-            // this wave's partial over its WTN columns: combine the 4 lane groups, one slot per (tile column, wave column)
-            psum += __shfl_xor(psum, 16, 64); psq += __shfl_xor(psq, 16, 64);
-            psum += __shfl_xor(psum, 32, 64); psq += __shfl_xor(psq, 32, 64);
-            if (lg == 0 && m < g.M) {
-                const int slot = tn * WN + wc;
-                reinterpret_cast<float2*>(g.stats_out)[(int64_t)m * (g.tiles_n * WN) + slot] = make_float2(psum, psq);
-            }
-            // flush the staged fp16 rows of this RHS-row group as 16-byte x (WTN/8)-lane row segments
-            if (((i + 1) * 16) % RHS == 0) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                constexpr int LPR = WTN / 8, RPI = 64 / LPR;
-                const int lr = lane / LPR, lc = (lane % LPR) * 8;
-                const int h0 = (i + 1) * 16 - RHS;
-#pragma unroll
-                for (int r0 = 0; r0 < RHS; r0 += RPI) {
-                    const int mm = row0 + wr * WTM + h0 + r0 + lr;
-                    const h8 val = *reinterpret_cast<const h8*>(hstg + (r0 + lr) * LDH + lc);
-                    if (mm < g.M) *reinterpret_cast<h8*>(g.c16 + (int64_t)mm * g.ldc + col0 + wc * WTN + lc) = val;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
+        if (i + 1 < MI) {                                         // the strip is rewritten by the next group
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
         }
     }
     GEMM_STAMP(3);
