@@ -181,30 +181,75 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // plain order is faster (1832 vs 2033) - the co-resident workgroup already fills the LDS-latency gap.
     constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
     if (HALF_SHIFTED) {
+        // Every MFMA phase is written as MI groups of one fragment row (NI MFMAs), and the other work of the phase -
+        // the fragment reads of the next k-half and, after the barrier, the LDS-DMA loads of the stage after next - is
+        // dealt out over those groups in source order with a scheduling fence after each group: the issue cost of the
+        // loads and reads hides under MFMA execution instead of preceding the block (in lockstep with the sibling wave
+        // of the SIMD) or trailing it (straight into the barrier's wait).
+        auto read_a = [&](int buf, int ks, int i, h8 (&af)[MI]) {
+            const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
+            const int r = wr * (BM / WM) + i * 16 + l15;
+            af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+        };
+        auto read_b = [&](int buf, int ks, int j, h8 (&bf)[NI]) {
+            const unsigned char* lb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
+            const int r = wc * (BN / WN) + j * 16 + l15;
+            bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+        };
+        auto stage_piece = [&](int buf, int kt, int q) {        // q-th of the A_LOADS + B_LOADS pieces of a stage
+            unsigned char* base = smem + buf * (A_BYTES + B_BYTES);
+            if (q < A_LOADS) glds16(asrc[q] + kt * GEMM_BK, reinterpret_cast<_Float16*>(base) + (q * NWAVES + wave) * 512);
+            else glds16(bsrc[q - A_LOADS] + kt * GEMM_BK,
+                        reinterpret_cast<_Float16*>(base + A_BYTES) + ((q - A_LOADS) * NWAVES + wave) * 512);
+        };
+        auto mma_row = [&](int i, const h8 (&af)[MI], const h8 (&bf)[NI]) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        };
+        constexpr int NLOAD = A_LOADS + B_LOADS, LPG = (NLOAD + MI - 1) / MI;   // LDS-DMA pieces per group
+        constexpr int BPG = (NI + MI - 1) / MI;                                 // B-fragment reads per group
         h8 a0[MI], b0[NI], a1[MI], b1[NI];
         if (nk > 1) stage(1, 1);
         read_frags(0, 0, a0, b0);
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            const int buf = kt & 1;
-            read_frags(buf, 1, a1, b1);
-            mma(a0, b0);
-            // one fragment read per group of MFMAs: the reads of the next k-half trickle in under this half's MFMAs
+        // phase 1 of step kt: MFMAs of k-half 0, reads of k-half 1
+        auto phase1 = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < MI + NI; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);   // MFMAs
+            for (int i = 0; i < MI; ++i) {
+                mma_row(i, a0, b0);       // (MFMAs first: the wait for this phase's operands must not cover new reads)
+#pragma unroll
+                for (int q = 0; q < BPG; ++q)
+                    if (i * BPG + q < NI) read_b(buf, 1, i * BPG + q, b1);
+                read_a(buf, 1, i, a1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        // phase 2: MFMAs of k-half 1, reads of k-half 0 of the next step (other buffer), loads of the stage after next
+        auto phase2 = [&](int buf, int kt, bool with_stage) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (with_stage) {
+#pragma unroll
+                    for (int q = 0; q < LPG; ++q)
+                        if (i * LPG + q < NLOAD) stage_piece(buf, kt + 2, i * LPG + q);
+                }
+                mma_row(i, a1, b1);
+#pragma unroll
+                for (int q = 0; q < BPG; ++q)
+                    if (i * BPG + q < NI) read_b(buf ^ 1, 0, i * BPG + q, b0);
+                read_a(buf ^ 1, 0, i, a0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) {                           // steady state: a stage to load in every step
+            phase1(kt & 1);
             __syncthreads();
-            if (kt + 2 < nk) stage(buf, kt + 2);
-            read_frags(buf ^ 1, 0, a0, b0);
-            mma(a1, b1);
-#pragma unroll
-            for (int q = 0; q < MI + NI; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            phase2(kt & 1, kt, true);
+        }
+        for (; kt + 1 < nk; ++kt) {                           // second-to-last step: nothing left to load
+            phase1(kt & 1);
+            __syncthreads();
+            phase2(kt & 1, kt, false);
         }
         read_frags((nk - 1) & 1, 1, a1, b1);
         mma(a0, b0);
