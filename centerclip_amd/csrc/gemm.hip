@@ -176,6 +176,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             for (int j = 0; j < NI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     };
+    auto read_a = [&](int buf, int ks, int i, h8 (&af)[MI]) {
+        const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
+        const int r = wr * (BM / WM) + i * 16 + l15;
+        af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+    };
+    auto read_b = [&](int buf, int ks, int j, h8 (&bf)[NI]) {
+        const unsigned char* lb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
+        const int r = wc * (BN / WN) + j * 16 + l15;
+        bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+    };
+    auto stage_piece = [&](int buf, int kt, int q) {        // q-th of the A_LOADS + B_LOADS pieces of a stage
+        unsigned char* base = smem + buf * (A_BYTES + B_BYTES);
+        if (q < A_LOADS) glds16(asrc[q] + kt * GEMM_BK, reinterpret_cast<_Float16*>(base) + (q * NWAVES + wave) * 512);
+        else glds16(bsrc[q - A_LOADS] + kt * GEMM_BK,
+                    reinterpret_cast<_Float16*>(base + A_BYTES) + ((q - A_LOADS) * NWAVES + wave) * 512);
+    };
+    auto mma_row = [&](int i, const h8 (&af)[MI], const h8 (&bf)[NI]) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
     // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
     // plain order is faster (1832 vs 2033) - the co-resident workgroup already fills the LDS-latency gap.
@@ -186,26 +206,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         // dealt out over those groups in source order with a scheduling fence after each group: the issue cost of the
         // loads and reads hides under MFMA execution instead of preceding the block (in lockstep with the sibling wave
         // of the SIMD) or trailing it (straight into the barrier's wait).
-        auto read_a = [&](int buf, int ks, int i, h8 (&af)[MI]) {
-            const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
-            const int r = wr * (BM / WM) + i * 16 + l15;
-            af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
-        };
-        auto read_b = [&](int buf, int ks, int j, h8 (&bf)[NI]) {
-            const unsigned char* lb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
-            const int r = wc * (BN / WN) + j * 16 + l15;
-            bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
-        };
-        auto stage_piece = [&](int buf, int kt, int q) {        // q-th of the A_LOADS + B_LOADS pieces of a stage
-            unsigned char* base = smem + buf * (A_BYTES + B_BYTES);
-            if (q < A_LOADS) glds16(asrc[q] + kt * GEMM_BK, reinterpret_cast<_Float16*>(base) + (q * NWAVES + wave) * 512);
-            else glds16(bsrc[q - A_LOADS] + kt * GEMM_BK,
-                        reinterpret_cast<_Float16*>(base + A_BYTES) + ((q - A_LOADS) * NWAVES + wave) * 512);
-        };
-        auto mma_row = [&](int i, const h8 (&af)[MI], const h8 (&bf)[NI]) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        };
         constexpr int NLOAD = A_LOADS + B_LOADS, LPG = (NLOAD + MI - 1) / MI;   // LDS-DMA pieces per group
         constexpr int BPG = (NI + MI - 1) / MI;                                 // B-fragment reads per group
         h8 a0[MI], b0[NI], a1[MI], b1[NI];
@@ -257,29 +257,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         fetch_epilogue_operands();
         mma(a1, b1);
     } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-            else fetch_epilogue_operands();
-            {
-                h8 a0[MI], b0[NI], a1[MI], b1[NI];
-                if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);  // (s_setprio ends a scheduling region: keep it outside)
-                read_frags(buf, 0, a0, b0);
-                read_frags(buf, 1, a1, b1);
-                mma(a0, b0);
-                mma(a1, b1);
-                // order: the first k-half's reads, then the second half's reads one per MFMA group of the first half
-                __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+        // Two co-resident workgroups per CU: the plain order (this step's reads, then its MFMAs) with the same group
+        // structure - the second k-half's reads and the next stage's LDS-DMA loads are dealt out between the fragment
+        // rows of the first half's MFMAs; the wave priority is raised over the whole compute region.
+        constexpr int NLOAD = A_LOADS + B_LOADS, LPG = (NLOAD + MI - 1) / MI, BPG = (NI + MI - 1) / MI;
+        auto step = [&](int buf, int kt, bool with_stage) {
+            h8 a0[MI], b0[NI], a1[MI], b1[NI];
+            if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);      // (s_setprio ends a scheduling region: keep it outside)
+            read_frags(buf, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < MI + NI; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (MI + NI), 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int i = 0; i < MI; ++i) {
+                mma_row(i, a0, b0);
+                if (with_stage) {
+#pragma unroll
+                    for (int q = 0; q < LPG; ++q)
+                        if (i * LPG + q < NLOAD) stage_piece(buf ^ 1, kt + 1, i * LPG + q);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
-                if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int q = 0; q < BPG; ++q)
+                    if (i * BPG + q < NI) read_b(buf, 1, i * BPG + q, b1);
+                read_a(buf, 1, i, a1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            mma(a1, b1);
+            if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
-        }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        fetch_epilogue_operands();
+        step((nk - 1) & 1, nk - 1, false);
     }
 
     GEMM_STAMP(2);
