@@ -63,6 +63,81 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
     }
 }
 
+// Small batches (a forward step's own Bt x Bv logits): the three launches above are latency-bound (5 + 7 + 14 us for
+// 16 x 16), so one workgroup per video does the whole tail: wave 0 pools / normalises the video exactly as
+// video_pool_kernel does, parks it in LDS, then the four waves normalise one text each and take the dot product.
+__global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float* __restrict__ text,
+                                                                     const float* __restrict__ visual,
+                                                                     const long long* __restrict__ mask,
+                                                                     float* __restrict__ logits, int ldl,
+                                                                     float* __restrict__ pooled_out, int Bt, int Bv,
+                                                                     int Tn, int E, float mult) {
+    __shared__ float vp[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x;
+    constexpr int MAXE = 16;                      // E <= 1024
+    if (wave == 0) {
+        float acc[MAXE];
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) acc[q] = 0.f;
+        float cnt = 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            const float* src = visual + ((int64_t)v * Tn + t) * E;
+            float x[MAXE];
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const int e = lane + 64 * q;
+                x[q] = e < E ? src[e] : 0.f;
+                s = fmaf(x[q], x[q], s);
+            }
+            const float nrm = sqrtf(cc_wave_sum(s));
+            const float mk = (float)mask[(int64_t)v * Tn + t];
+            cnt += mk;
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
+        }
+        if (cnt == 0.f) cnt = 1.f;                // "avoid zero divide", clip4clip.py:313
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            acc[q] = acc[q] / cnt;
+            s = fmaf(acc[q], acc[q], s);
+        }
+        const float nrm = sqrtf(cc_wave_sum(s));
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            if (e < E) {
+                const float p = acc[q] / nrm;
+                vp[e] = p;
+                if (pooled_out) pooled_out[(int64_t)v * E + e] = p;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = wave; t < Bt; t += 4) {
+        const float* src = text + (int64_t)t * E;
+        float x[MAXE];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            x[q] = e < E ? src[e] : 0.f;
+            s = fmaf(x[q], x[q], s);
+        }
+        const float nrm = sqrtf(cc_wave_sum(s));
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            if (e < E) d = fmaf(x[q] / nrm, vp[e], d);
+        }
+        d = cc_wave_sum(d);
+        if (lane == 0) logits[(int64_t)t * ldl + v] = mult * d;
+    }
+}
+
 // C[i][j] = mult * sum_k A[i][k] B[j][k]; 64x64 tile per workgroup, exact-fp32 MFMA (16x16x4),
 // same LDS layout as the Gram kernel of cluster.hip.
 #define ST 64
@@ -185,6 +260,13 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
     if (!text || !visual || !video_mask || !logits) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_similarity_workspace_bytes(Bt, Bv, E)) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((long)Bt * Bv <= 4096 && E <= 1024 && Bt > 0 && Bv > 0) {      // one launch for a step's own logits
+        hipLaunchKernelGGL(loose_similarity_small_kernel, dim3(Bv), dim3(256), 0, st, text, visual,
+                           reinterpret_cast<const long long*>(video_mask), logits, ldl, pooled_out, Bt, Bv, Tn, E,
+                           expf(logit_scale));
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
     float* tn = static_cast<float*>(ws);
     float* vp = pooled_out ? pooled_out
                            : reinterpret_cast<float*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
