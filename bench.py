@@ -256,8 +256,10 @@ def main():
     ids, amask, video, vmask = synthetic_batch(c, device, seed=100 + rank)
     logit_mult = float(torch.tensor(float(sd["logit_scale"])).exp())
 
+    token_type = torch.zeros_like(ids)                   # an input of the reference signature (unused by the path)
+
     def step():
-        out = model(ids, torch.zeros_like(ids), amask, video, vmask)
+        out = model(ids, token_type, amask, video, vmask)
         seq, vis = out["sequence_output"], out["visual_output"]
         vm = model.get_video_mask_after_cluster(vmask.view(-1, vmask.shape[-1]))
         if world > 1:
