@@ -258,29 +258,35 @@ def main():
 
     token_type = torch.zeros_like(ids)                   # an input of the reference signature (unused by the path)
 
-    def step():
+    def towers():
         out = model(ids, token_type, amask, video, vmask)
-        seq, vis = out["sequence_output"], out["visual_output"]
         vm = model.get_video_mask_after_cluster(vmask.view(-1, vmask.shape[-1]))
+        return out["sequence_output"], out["visual_output"], vm.to(torch.long).contiguous()
+
+    def tail(seq, vis, vm):
         if world > 1:
             # exchange step: one packed all-gather of (video features, mask), then this rank's row block
             vis_all, vm_all = ccdist.all_gather(vis, vm)
             return ops.loose_similarity(seq.squeeze(1), vis_all, vm_all, float(sd["logit_scale"]))
-        return model.get_similarity_logits(seq, vis, amask, vmask)[0]
+        return ops.loose_similarity(seq.squeeze(1), vis, vm, float(sd["logit_scale"]))
+
+    def step():
+        return tail(*towers())
 
     graph = None
     with torch.no_grad():
         for _ in range(max(a.warmup, 1)):
             logits = step()
         torch.cuda.synchronize()
-        if not a.no_graph and world == 1:
-            # capture one whole step (both towers as parallel branches, cluster op, similarity) into a
-            # hipGraph: removes ~190 host launches per step from the critical path.  Inputs stay resident,
-            # so a replay IS one pass of the hot path over the batch.
+        if not a.no_graph:
+            # capture into a hipGraph: removes ~190 host launches per step from the critical path.  Inputs stay
+            # resident, so a replay IS one pass of the hot path over the batch.  1 GPU: the whole step; N GPUs: both
+            # towers (the RCCL all-gather and the similarity tail that follows it are launched eagerly after it).
             try:
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
-                    logits = step()
+                # thread_local: the RCCL watchdog thread of an initialised process group may query events meanwhile
+                with torch.cuda.graph(gph, capture_error_mode="thread_local" if world > 1 else "global"):
+                    captured = step() if world == 1 else towers()
                 gph.replay()
                 torch.cuda.synchronize()
                 graph = gph
@@ -288,7 +294,12 @@ def main():
                 sys.stderr.write("graph capture failed (%s); timing eager launches\n" % exc)
                 graph = None
                 torch.cuda.synchronize()
-        run = graph.replay if graph is not None else step
+        if graph is None:
+            run = step
+        elif world == 1:
+            run = lambda: (graph.replay(), captured)[1]
+        else:
+            run = lambda: (graph.replay(), tail(*captured))[1]
         for _ in range(a.warmup):
             run()
         torch.cuda.synchronize()
@@ -318,7 +329,7 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 MFMA operands, fp32 accumulate/residual/LN/softmax; cluster + similarity fp32",
                "data": "synthetic (N(0,1) frames, random token ids, random-init weights with CLIP init statistics rounded through fp16)",
-               "launch": "hipGraph replay" if graph is not None else "eager launches",
+               "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (towers) + eager all-gather / similarity") if graph is not None else "eager launches",
                "config": {"workload": c["name"], "global_batch": c["B"] * world, "parallelism": "dp%d (clips sharded, packed RCCL feature all-gather)" % world if world > 1 else "single GPU"}}
         if world == 1 and not a.no_extras:
             with torch.no_grad():
