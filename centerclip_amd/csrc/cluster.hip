@@ -76,11 +76,16 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
                                                         int W, const float* __restrict__ sqn,
                                                         const float* __restrict__ inv, float* __restrict__ draw,
-                                                        int* __restrict__ chunkmax, int chunk, int ntiles) {
+                                                        int* __restrict__ chunkmax, int chunk, int ntiles, int nprob) {
     extern __shared__ __attribute__((aligned(16))) float gram_lds[];       // [2 buffers][A,B][GT * GLD]
     auto tile = [&](int buf, int which) { return gram_lds + (buf * 2 + which) * (GT * GLD); };
-    const int p = blockIdx.y;
-    int t = blockIdx.x, ti = 0, rowlen = ntiles;
+    // Workgroup b runs on XCD b % 8, each with its own L2: all tiles of a problem are given to ONE XCD (problem
+    // p -> XCD p % 8), so a problem's tokens are fetched into one L2 once instead of into up to 8 of them (PMC: the Gram
+    // kernel fetched 116 MB for 28.9 MB of tokens with the tile-major order).
+    const int tiles_pp = ntiles * (ntiles + 1) / 2;
+    const int p = ((int)blockIdx.x >> 3) / tiles_pp * 8 + ((int)blockIdx.x & 7);
+    if (p >= nprob) return;
+    int t = ((int)blockIdx.x >> 3) % tiles_pp, ti = 0, rowlen = ntiles;
     while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
     const int tj = ti + t;
 
@@ -202,10 +207,15 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
 template <int MODE>
 __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N, int W,
                                                       float pw, float* __restrict__ draw, int* __restrict__ chunkmax,
-                                                      int chunk, int ntiles) {
+                                                      int chunk, int ntiles, int nprob) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GT * LLD];      // [buffer][A,B]
-    const int p = blockIdx.y;
-    int t = blockIdx.x, ti = 0, rowlen = ntiles;
+    // Workgroup b runs on XCD b % 8, each with its own L2: all tiles of a problem are given to ONE XCD (problem
+    // p -> XCD p % 8), so a problem's tokens are fetched into one L2 once instead of into up to 8 of them (PMC: the Gram
+    // kernel fetched 116 MB for 28.9 MB of tokens with the tile-major order).
+    const int tiles_pp = ntiles * (ntiles + 1) / 2;
+    const int p = ((int)blockIdx.x >> 3) / tiles_pp * 8 + ((int)blockIdx.x & 7);
+    if (p >= nprob) return;
+    int t = ((int)blockIdx.x >> 3) % tiles_pp, ti = 0, rowlen = ntiles;
     while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
     const int tj = ti + t;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -922,7 +932,7 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
                        (float*)nullptr, c.chunkmax, nchunks);
     CC_LAUNCH_CHECK();
     const int nt = (N + GT - 1) / GT;
-    dim3 grid(nt * (nt + 1) / 2, P);
+    dim3 grid((unsigned)(((P + 7) / 8) * 8 * (nt * (nt + 1) / 2)));       // 1-D: problem p on XCD p % 8
     const size_t gram_smem = (size_t)2 * 2 * GT * GLD * sizeof(float);      // 73,728 B
     if (metric == CC_METRIC_COSINE || p == 2.0f) {
         static bool configured = false;
@@ -937,16 +947,16 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     }
     if (metric == CC_METRIC_COSINE) {
         hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.inv,
-                           c.draw, c.chunkmax, chunk, nt);
+                           c.draw, c.chunkmax, chunk, nt, P);
     } else if (p == 2.0f) {
         hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn,
-                           c.inv, c.draw, c.chunkmax, chunk, nt);
+                           c.inv, c.draw, c.chunkmax, chunk, nt, P);
     } else if (p == 1.0f) {
-        hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+        hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
     } else if (p > 3.0e38f) {
-        hipLaunchKernelGGL(lp_dist_kernel<2>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+        hipLaunchKernelGGL(lp_dist_kernel<2>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
     } else {
-        hipLaunchKernelGGL(lp_dist_kernel<0>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt);
+        hipLaunchKernelGGL(lp_dist_kernel<0>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
     }
     CC_LAUNCH_CHECK();
     return CC_OK;
