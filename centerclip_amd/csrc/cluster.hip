@@ -26,9 +26,13 @@ __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict
     if (blockIdx.x == 0 && chunkmax)
         for (int c = threadIdx.x; c < nchunks; c += 256) chunkmax[c] = (int)0x80000000;
     const int lane = threadIdx.x & 63;
-    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= P * N) return;
-    const int p = tok / N, j = tok - p * N;
+    // problem p on XCD p % 8 (workgroup b runs on XCD b % 8), the mapping of the distance kernels that follow: the
+    // tokens this pass pulls into an XCD's L2 are the ones its Gram tiles read next
+    const int bpp = (N + 3) >> 2;                                      // workgroups per problem (4 tokens each)
+    const int p = ((int)blockIdx.x >> 3) / bpp * 8 + ((int)blockIdx.x & 7);
+    const int j = (((int)blockIdx.x >> 3) % bpp) * 4 + (threadIdx.x >> 6);
+    if (p >= P || j >= N) return;
+    const int tok = p * N + j;
     const float* src = cc_token_ptr(x, lay, p, j);
     float acc = 0.f;
     for (int w = lane * 4; w < W; w += 256) {
@@ -921,7 +925,7 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
                  const ClusterWs& c, hipStream_t st) {
     const int P = lay.B * lay.S, N = lay.fd * lay.n;
     const int nchunks = (P + chunk - 1) / chunk;
-    const int nb = (P * N + 3) / 4;
+    const int nb = ((P + 7) / 8) * 8 * ((N + 3) / 4);                  // token_norm_kernel: problem p on XCD p % 8
     if (pre_norm) {
         hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv, c.xn,
                            (int*)nullptr, 0);
@@ -1015,7 +1019,7 @@ int cc_token_norms_f32(const float* x, const cc_token_layout* lay, int32_t W, fl
     const int P = lay->B * lay->S, N = lay->fd * lay->n;
     ClusterWs c = carve(ws, P, N, W, 0, N);
     if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
-    hipLaunchKernelGGL(token_norm_kernel, dim3((P * N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, *lay,
+    hipLaunchKernelGGL(token_norm_kernel, dim3(((P + 7) / 8) * 8 * ((N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, *lay,
                        P, N, W, c.sqn, norms, c.inv, (float*)nullptr, (int*)nullptr, 0);
     CC_LAUNCH_CHECK();
     return CC_OK;
