@@ -48,9 +48,11 @@ def test_linear_f16_epilogues(M, N, K, tile):
     w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
     bias = torch.randn(N, generator=gen)
     ref = a.double() @ w.double().t() + bias.double()
-    if (tile == 5 and N % 256) or (tile in (1, 3, 6) and N % 128):
-        pytest.skip("tile does not divide N")
     ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    if (tile == 5 and N % 256) or (tile in (1, 3, 6) and N % 128):
+        with pytest.raises(RuntimeError, match="invalid"):      # a forced tile that does not divide N is refused
+            ops.linear_f16(ad, wd, bd, "f32", tile=tile)
+        return
     y = ops.linear_f16(ad, wd, bd, "f32", tile=tile).cpu()
     assert relerr(y, ref) < 2e-4
     y = ops.linear_f16(ad, wd, None, "f32", tile=tile).cpu()
