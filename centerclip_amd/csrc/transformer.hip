@@ -586,11 +586,11 @@ __global__ __launch_bounds__(256) void head_project_kernel(const float* __restri
     }
     *reinterpret_cast<float4*>(&part[ks][eg * 4]) = acc;
     __syncthreads();
-    if (tid < 64 && blockIdx.x * 64 + tid < E) {
+    if (tid < 64 && (int)blockIdx.x * 64 + tid < E) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += part[q][tid];       // fixed order: deterministic
-        out[(int64_t)r * E + blockIdx.x * 64 + tid] = t;
+        out[(int64_t)r * E + (int)blockIdx.x * 64 + tid] = t;
     }
 }
 
