@@ -61,6 +61,11 @@ __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict
     }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float cc_dpp_f32(float x) {       // lane exchange inside a 16-lane DPP row (bit pattern)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
 // ============================================================================ K1
 // 64x64 tile of the Gram matrix of one problem per 256-thread workgroup (4 waves, 32x32 per
 // wave, 2x2 v_mfma_f32_16x16x4_f32 accumulators).  Only tiles with tj >= ti are launched;
@@ -78,10 +83,12 @@ __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict
 
 template <int METRIC>
 __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
-                                                        int W, const float* __restrict__ sqn,
-                                                        const float* __restrict__ inv, float* __restrict__ draw,
-                                                        int* __restrict__ chunkmax, int chunk, int ntiles, int nprob) {
-    extern __shared__ __attribute__((aligned(16))) float gram_lds[];       // [2 buffers][A,B][GT * GLD]
+                                                        int W, float* sqn, float* nrm, float* inv, int own_norms,
+                                                        float* __restrict__ draw, int* __restrict__ chunkmax, int chunk,
+                                                        int ntiles, int nprob) {
+    // own_norms: the row norms come out of this kernel (sum of squares of the rows it stages anyway; the diagonal
+    // tiles publish sqn / nrm / inv for the selection kernel) instead of a separate pass over the tokens (K0).
+    extern __shared__ __attribute__((aligned(16))) float gram_lds[];       // [2 buffers][A,B][GT * GLD] + 2 x GT norms
     auto tile = [&](int buf, int which) { return gram_lds + (buf * 2 + which) * (GT * GLD); };
     // Workgroup b runs on XCD b % 8, each with its own L2: all tiles of a problem are given to ONE XCD (problem
     // p -> XCD p % 8), so a problem's tokens are fetched into one L2 once instead of into up to 8 of them (PMC: the Gram
@@ -129,11 +136,20 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
             if (!diag) rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    float na[4] = {0.f, 0.f, 0.f, 0.f}, nb[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the rows' sums of squares
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             *reinterpret_cast<float4*>(tile(buf, 0) + (lrow + 16 * q) * GLD + lchunk * 4) = ra_[q];
             if (!diag) *reinterpret_cast<float4*>(tile(buf, 1) + (lrow + 16 * q) * GLD + lchunk * 4) = rb_[q];
+            if (own_norms) {
+                na[q] = fmaf(ra_[q].x, ra_[q].x, na[q]); na[q] = fmaf(ra_[q].y, ra_[q].y, na[q]);
+                na[q] = fmaf(ra_[q].z, ra_[q].z, na[q]); na[q] = fmaf(ra_[q].w, ra_[q].w, na[q]);
+                if (!diag) {
+                    nb[q] = fmaf(rb_[q].x, rb_[q].x, nb[q]); nb[q] = fmaf(rb_[q].y, rb_[q].y, nb[q]);
+                    nb[q] = fmaf(rb_[q].z, rb_[q].z, nb[q]); nb[q] = fmaf(rb_[q].w, rb_[q].w, nb[q]);
+                }
+            }
         }
     };
     gload(0);
@@ -165,6 +181,31 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         __syncthreads();
     }
 
+    float* lsq = gram_lds + 2 * 2 * GT * GLD;                 // [2][GT]: sum of squares of the A rows, of the B rows
+    if (own_norms) {
+        // the 16 threads of a row (lchunk) sit in one DPP row: quad swaps, half mirror, mirror
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = na[q], b = nb[q];
+            a += cc_dpp_f32<0xB1>(a); b += cc_dpp_f32<0xB1>(b);
+            a += cc_dpp_f32<0x4E>(a); b += cc_dpp_f32<0x4E>(b);
+            a += cc_dpp_f32<0x141>(a); b += cc_dpp_f32<0x141>(b);
+            a += cc_dpp_f32<0x140>(a); b += cc_dpp_f32<0x140>(b);
+            if (lchunk == 0) {
+                const int r = lrow + 16 * q;
+                lsq[r] = a;
+                lsq[GT + r] = diag ? a : b;
+                const int row = ti * GT + r;
+                if (diag && row < N) {                         // every row block has its diagonal tile: publish once
+                    const float n = sqrtf(a);
+                    sqn[(int64_t)p * N + row] = a;
+                    nrm[(int64_t)p * N + row] = n;
+                    inv[(int64_t)p * N + row] = 1.0f / (n + 1e-6f);
+                }
+            }
+        }
+        __syncthreads();
+    }
     // epilogue: distance, chunk max, direct + mirrored store
     float lmax = -3.0e38f;
     if (active) {
@@ -183,12 +224,15 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
                     const int i = ti * GT + wr * 32 + fm * 16 + g * 4 + r;
                     if (i < N && j < N) {
                         const float gij = acc[fm][fn][r];
+                        const float sqi = own_norms ? lsq[i - ti * GT] : sq[i], sqj = own_norms ? lsq[GT + j - tj * GT] : sq[j];
                         float d;
                         if (METRIC == CC_METRIC_EUCLIDEAN) {
-                            const float d2 = (sq[i] + sq[j]) - 2.0f * gij;
+                            const float d2 = (sqi + sqj) - 2.0f * gij;
                             d = (i == j) ? 0.0f : sqrtf(fmaxf(d2, 0.0f));
                         } else {
-                            d = 1.0f - (gij * iv[i]) * iv[j];
+                            const float ivi = own_norms ? 1.0f / (sqrtf(sqi) + 1e-6f) : iv[i];
+                            const float ivj = own_norms ? 1.0f / (sqrtf(sqj) + 1e-6f) : iv[j];
+                            d = 1.0f - (gij * ivi) * ivj;
                         }
                         lmax = fmaxf(lmax, d);
                         Dp[(int64_t)i * N + j] = d;
@@ -932,12 +976,19 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
         x = c.xn;
         lay = contiguous_layout(P, N, W);
     }
-    hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv,
-                       (float*)nullptr, c.chunkmax, nchunks);
-    CC_LAUNCH_CHECK();
+    // the Gram kernels produce the row norms themselves (of the pre-normalised copy when pre_norm made one above);
+    // the Minkowski kernels (no Gram) keep the separate norm pass
+    const bool own_norms = (metric == CC_METRIC_COSINE || p == 2.0f);
+    if (own_norms) {
+        if (hipMemsetAsync(c.chunkmax, 0x80, (size_t)nchunks * sizeof(int), st) != hipSuccess) return CC_ERR_HIP;   // keys << any distance
+    } else {
+        hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv,
+                           (float*)nullptr, c.chunkmax, nchunks);
+        CC_LAUNCH_CHECK();
+    }
     const int nt = (N + GT - 1) / GT;
     dim3 grid((unsigned)(((P + 7) / 8) * 8 * (nt * (nt + 1) / 2)));       // 1-D: problem p on XCD p % 8
-    const size_t gram_smem = (size_t)2 * 2 * GT * GLD * sizeof(float);      // 73,728 B
+    const size_t gram_smem = (size_t)(2 * 2 * GT * GLD + 2 * GT) * sizeof(float);      // 74,240 B
     if (metric == CC_METRIC_COSINE || p == 2.0f) {
         static bool configured = false;
         if (!configured) {
@@ -950,11 +1001,11 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
         }
     }
     if (metric == CC_METRIC_COSINE) {
-        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.inv,
-                           c.draw, c.chunkmax, chunk, nt, P);
+        hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.nrm,
+                           c.inv, own_norms ? 1 : 0, c.draw, c.chunkmax, chunk, nt, P);
     } else if (p == 2.0f) {
         hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn,
-                           c.inv, c.draw, c.chunkmax, chunk, nt, P);
+                           c.nrm, c.inv, own_norms ? 1 : 0, c.draw, c.chunkmax, chunk, nt, P);
     } else if (p == 1.0f) {
         hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
     } else if (p > 3.0e38f) {
