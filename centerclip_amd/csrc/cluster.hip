@@ -281,6 +281,14 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    // 16x16 blocks (r, c) of the tile that lie in the padding, or - in a diagonal tile - strictly below the diagonal,
+    // are skipped; the mirrored store of block (c, r) covers them
+    unsigned live = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ti * GT + 16 * r < N && tj * GT + 16 * c < N && !(ti == tj && r > c)) live |= 1u << (4 * r + c);
     const int nk = (W + LPK - 1) / LPK;
     float4 ra_[2], rb_[2];
     auto gload = [&](int kt) {
@@ -315,6 +323,7 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    if (!((live >> (4 * r + c)) & 1u)) continue;      // padded or below-diagonal 16x16 block (uniform)
                     const float d0 = fabsf(a[r].x - b[c].x), d1 = fabsf(a[r].y - b[c].y);
                     const float d2 = fabsf(a[r].z - b[c].z), d3 = fabsf(a[r].w - b[c].w);
                     if (MODE == 1) {
@@ -336,12 +345,12 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = ti * GT + ty + 16 * r, j = tj * GT + tx + 16 * c;
-            if (i < N && j < N) {
+            if (((live >> (4 * r + c)) & 1u) && i < N && j < N) {
                 float d = acc[r][c];
                 if (MODE == 0) d = powf(d, 1.0f / pw);
                 lmax = fmaxf(lmax, d);
                 Dp[(int64_t)i * N + j] = d;
-                if (tj > ti) Dp[(int64_t)j * N + i] = d;
+                if (tj > ti || c > r) Dp[(int64_t)j * N + i] = d;
             }
         }
     if (chunkmax) {
