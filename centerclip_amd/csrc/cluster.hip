@@ -390,7 +390,8 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 // and the medoid falls out of a 64-bit LDS min over (key(sum), token).
 //
 // LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | cmask K*E u64 | med K i32 | asg, order, mem N u16 | cnt K | off K+1 u16
-#define SEL_MAX_E 10   /* N <= 640 */
+#define SEL_MAX_E 16   /* N <= 1023: ATen's row sum folds its accumulators once (pass 16) below 1024 terms */
+#define SEL_MAX_N 1023
 
 // debug hook (not part of the public ABI): per-problem phase timestamps of K2
 __device__ long long* g_sel_prof = nullptr;
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     auto assign_step = [&](bool build_masks) {
         if (build_masks)                                             // the masks are rebuilt with LDS atomics below
             for (int q = tid; q < K * E; q += 256) s.cmask[q] = 0ull;
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const int n = tid + 256 * e;
             if (e * 256 >= N) break;                                 // uniform
             const int nn = min(n, N - 1);
@@ -763,9 +764,9 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     SEL_STAMP(3);
 
     if (id_sort) {                              // fast_kmeans.py:90-94
-        int mine[3], rank[3];
+        int mine[4], rank[4];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const int k = tid + 256 * e;
             mine[e] = 0; rank[e] = 0;
             if (k < K) {
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 3; ++e)
+        for (int e = 0; e < 4; ++e)
             if (tid + 256 * e < K) s.med[rank[e]] = mine[e];
         __syncthreads();
         if (assign_out) assign_step(false);
@@ -1051,6 +1052,7 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
     } else {
         if (ne <= 4) SEL_LAUNCH(false, 4);
         else if (ne <= 7) SEL_LAUNCH(false, 7);
+        else if (ne <= 10) SEL_LAUNCH(false, 10);
         else SEL_LAUNCH(false, SEL_MAX_E);
     }
 #undef SEL_LAUNCH
@@ -1115,7 +1117,7 @@ int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, 
                               void* ws, size_t ws_bytes, void* stream) {
     (void)ws; (void)ws_bytes;
     if (!dist || !norms || !medoids || P <= 0 || N <= 0 || K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
-    if (N > 64 * SEL_MAX_E || N > 65535) return CC_ERR_UNSUPPORTED;
+    if (N > SEL_MAX_N) return CC_ERR_UNSUPPORTED;
     return run_select(dist, nullptr, norms, nullptr, 1, 0, P, N, K, iter_limit, id_sort,
                       reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters,
                       static_cast<hipStream_t>(stream));
@@ -1131,7 +1133,7 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
     if (K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
     if (metric != CC_METRIC_EUCLIDEAN && metric != CC_METRIC_COSINE) return CC_ERR_UNSUPPORTED;
     if (!p_supported(metric, norm_p)) return CC_ERR_UNSUPPORTED;
-    if (N > 64 * SEL_MAX_E) return CC_ERR_UNSUPPORTED;
+    if (N > SEL_MAX_N) return CC_ERR_UNSUPPORTED;
     if (split_size <= 0 || split_size > P) split_size = P;
     ClusterWs c = carve(ws, P, N, W, pre_norm, N);
     if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;

@@ -39,6 +39,10 @@ DUPLICATE_CASES = {
     "perm_n640": (85, 2, 0, 640, 1, "permrows"),
     "perm_n6": (86, 6, 0, 6, 1, "permrows"),
     "perm_n196_k2": (87, 3, 0, 196, 2, "permrows"),
+    # beyond 640 tokens (ViT-B/16 with 4 frames per segment = 784; the supported maximum 1023)
+    "perm_n784": (88, 1, 0, 784, 1, "permrows"),
+    "perm_n1023": (89, 1, 0, 1023, 1, "permrows"),
+    "dup_n1000": (90, 1, 250, 1000, 20, "tile"),
 }
 
 

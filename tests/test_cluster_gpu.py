@@ -303,13 +303,16 @@ def test_edge_minimal_width_and_sizes(cl):
 
 
 def test_edge_maximum_tokens_per_problem(cl):
-    """N = 640 is the largest supported problem (10 x 64-token chunks); N = 641 is refused, not mis-computed."""
-    X = lattice(304, (1, 640, 16))
-    a, m = cl.batch_fast_kmedoids_with_split(dev(X), 12, threshold=1e-6, iter_limit=100, split_size=4)
-    ao, mo = _oracle_indices(X, 12, split=4)
-    assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao)
+    """N = 1023 is the largest supported problem (ATen's row sum folds its accumulators once below 1024 terms, which
+    is what the selection kernel reproduces); N = 784 is ViT-B/16 with 4 frames per segment; N = 1024 is refused, not
+    mis-computed."""
+    for N, K in ((640, 12), (784, 100), (1023, 30)):
+        X = lattice(304 + N, (1, N, 16))
+        a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, split_size=4)
+        ao, mo = _exact_oracle_indices(X, K, split=4)
+        assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao), N
     with pytest.raises(RuntimeError, match="unsupported"):
-        cl.batch_fast_kmedoids_with_split(dev(lattice(305, (1, 641, 16))), 12)
+        cl.batch_fast_kmedoids_with_split(dev(lattice(305, (1, 1024, 16))), 12)
 
 
 def test_edge_iteration_limit_is_honoured(cl):
