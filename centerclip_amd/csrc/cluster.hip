@@ -509,8 +509,11 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     SEL_STAMP(0);
 
     // ---- stage D: (d - chunk_max) - 1, then the diagonal - 1 (cluster_utils.py:35-41); 8 loads in flight
-    if (IN_LDS || apply_shift) {
-        const float mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
+    // (when D stays in global memory the shift is applied on the fly by DREAD instead: a read-modify-write pass over
+    // the N x N matrix used to be a quarter of this kernel at N = 392-588)
+    const float shift_mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
+    if (IN_LDS) {
+        const float mx = shift_mx;
         float* dst = IN_LDS ? s.D : (dist_rw + base);
         const int total = N * N;
         if (IN_LDS && (total & 3) == 0) {                      // 16-byte path (problem base stays 16-byte aligned)
@@ -561,7 +564,15 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         }
         __syncthreads();
     }
-#define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : Dg[(int64_t)(i) * N + (j)])
+    auto dread_global = [&](int i, int j) {                  // same operations, same order as the staging pass
+        float d = Dg[(int64_t)i * N + j];
+        if (apply_shift) {
+            d = (d - shift_mx) - 1.0f;
+            if (i == j) d -= 1.0f;
+        }
+        return d;
+    };
+#define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : dread_global((i), (j)))
     SEL_STAMP(1);
 
     for (int j = tid; j < N; j += 256) s.order[sum_rank(j, N)] = (unsigned short)j;
