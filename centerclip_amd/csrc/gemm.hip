@@ -260,7 +260,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         // Two co-resident workgroups per CU: the plain order (this step's reads, then its MFMAs) with the same group
         // structure - the second k-half's reads and the next stage's LDS-DMA loads are dealt out between the fragment
         // rows of the first half's MFMAs; the wave priority is raised over the whole compute region.
-        constexpr int NLOAD = A_LOADS + B_LOADS, LPG = (NLOAD + MI - 1) / MI, BPG = (NI + MI - 1) / MI;
+        // (all LDS-DMA pieces go behind the FIRST fragment row: they have to land by this step's barrier, and
+        // 2.196 vs 2.208 ms per step against dealing them out over the four rows)
+        constexpr int NLOAD = A_LOADS + B_LOADS, LPG = NLOAD, BPG = (NI + MI - 1) / MI;
         auto step = [&](int buf, int kt, bool with_stage) {
             h8 a0[MI], b0[NI], a1[MI], b1[NI];
             if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);      // (s_setprio ends a scheduling region: keep it outside)
