@@ -312,9 +312,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             __syncthreads();
         }
         _Float16* stg = reinterpret_cast<_Float16*>(smem + STATS_BYTES) + wave * (RH * LDO);
-        constexpr int LPR = WTN / 8;                          // lanes per row (16 B each)
+        constexpr int LPR_ACT = WTN / 8;                      // lanes that carry a row (16 B each)
+        constexpr int LPR = LPR_ACT <= 4 ? 4 : (LPR_ACT <= 8 ? 8 : 16);   // lane slots per row (48-wide wave tiles: 6 of 8)
         constexpr int RPI = 64 / LPR;                         // rows per store instruction
         const int lr = lane / LPR, lc = (lane % LPR) * 8;
+        const bool lane_on = (LPR == LPR_ACT) || (lane % LPR) < LPR_ACT;
         _Float16* Cb = reinterpret_cast<_Float16*>(g.C);
 #pragma unroll
         for (int h0 = 0; h0 < WTM; h0 += RH) {
@@ -349,8 +351,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
             for (int r0 = 0; r0 < RH; r0 += RPI) {
                 const int m = row0 + wr * WTM + h0 + r0 + lr;
-                const h8 v = *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
-                if (m < g.M) *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = v;
+                if (lane_on && m < g.M)
+                    *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) =
+                        *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
             }
             if (h0 + RH < WTM) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     constexpr int LDF = WTN + 4;                                  // floats per staged row (272-byte rows for WTN = 64)
     constexpr int LPRF = WTN / 4;                                 // lanes per row, 16 B each (16 or 8)
     constexpr int RPP = 64 / LPRF, PASSES = 16 / RPP;             // rows per access, accesses per 16-row group
-    static_assert(LPRF == 16 || LPRF == 8, "fp32 epilogue geometry");
+    static_assert(OUT_F16 || LPRF == 16 || LPRF == 8, "fp32 epilogue geometry");
     static_assert(NWAVES * 16 * LDF * 4 <= 2 * (A_BYTES + B_BYTES), "fp32 epilogue strip fits the staging buffers");
     float* fstg = reinterpret_cast<float*>(smem) + wave * (16 * LDF);
     const int er = lane / LPRF, ec = (lane % LPRF) * 4;           // this lane's row (within a pass) and column
@@ -499,13 +502,44 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     }
 }
 
+// tiles whose wave tile is 48 columns wide exist for the fp16-output epilogues only
+template <int BM, int BN, int WM, int WN>
+int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
+    GemmPair pr{};
+    g0.tiles_m = (g0.M + BM - 1) / BM;
+    g0.tiles_n = g0.N / BN;
+    pr.p[0] = g0;
+    pr.tiles0 = g0.tiles_m * g0.tiles_n;
+    int total = pr.tiles0;
+    if (g1) {
+        pr.p[1] = *g1;
+        pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
+        pr.p[1].tiles_n = g1->N / BN;
+        total += pr.p[1].tiles_m * pr.p[1].tiles_n;
+    } else {
+        pr.p[1] = g0;
+    }
+    switch (epi) {
+        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16>(pr, total, st);
+        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(pr, total, st);
+        case EPI_F16_LN: return launch_one<BM, BN, WM, WN, EPI_F16_LN>(pr, total, st);
+        case EPI_F16_GELU_LN: return launch_one<BM, BN, WM, WN, EPI_F16_GELU_LN>(pr, total, st);
+        default: return CC_ERR_INVALID;
+    }
+}
+
 }  // namespace
 
 static bool gemm_shape_ok(const GemmArgs& g) {
     return g.M > 0 && g.N > 0 && g.K > 0 && (g.K % GEMM_BK) == 0 && (g.N % 64) == 0;
 }
 
-static int pick_tile(const GemmArgs& g) {
+static bool epi_is_f16(int epi) {
+    return epi == EPI_F16 || epi == EPI_F16_GELU || epi == EPI_F16_LN || epi == EPI_F16_GELU_LN;
+}
+static int tile_bn(int tile) { return tile == 5 ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
+
+static int pick_tile(const GemmArgs& g, int epi) {
     // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
     // >= ~1.5 workgroups per CU; below that trade tile efficiency for parallelism.
     const long mt128 = (g.M + 127) / 128, mt64 = (g.M + 63) / 64;
@@ -513,30 +547,41 @@ static int pick_tile(const GemmArgs& g) {
     const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
     // 256x256 (one 8-wave workgroup per CU) halves the L2->LDS bytes per flop; it only pays when the
     // tile count fills whole rounds of the 256 CUs
-    if ((g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.65) return 5;
+    const bool ok256 = (g.N % 256) == 0 && t256 >= 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.65;
+    // 256x192: the same 8-wave kernel with 48-column wave tiles.  Where the 256x256 grid leaves the last round of the
+    // 256 CUs mostly idle (in_proj, N = 2304: 342 tiles = 1.34 rounds) the narrower tile fills the same number of rounds
+    // with 3/4 of the work per round (456 tiles = 1.78 rounds).
+    if (epi_is_f16(epi) && (g.N % 192) == 0) {
+        const long t192 = (long)((g.M + 255) / 256) * (g.N / 192);
+        const long r192 = (t192 + 255) / 256 * 192, r256 = ok256 ? (t256 + 255) / 256 * 256 : 0;
+        if (t192 >= 256 && (double)t192 / (double)((t192 + 255) / 256 * 256) >= 0.65 && (!ok256 || r192 * 10 < r256 * 9))
+            return 7;
+    }
+    if (ok256) return 5;
     if (n128 && mt128 * (g.N / 128) >= 300) return 1;
     if (n128 && mt64 * (g.N / 128) >= 400) return 3;
     if (mt128 * (g.N / 64) >= 400) return 2;
     return 4;
 }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128 (8 waves)
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
+// 7 only for the fp16-output epilogues)
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
-        tile = pick_tile(g0);
+        tile = pick_tile(g0, epi);
         {   // tuning aid: CC_TILE_E<epi>_<S|B>=<tile> overrides the choice for small (M < 5000) / big problems
             char name[32];
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
-            if (ov && ov[0] >= '1' && ov[0] <= '6') tile = ov[0] - '0';
+            if (ov && ov[0] >= '1' && ov[0] <= '7') tile = ov[0] - '0';
         }
         if (g1) {                                  // the rider must be divisible by the carrier's BN
-            const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
-            if (g1->N % bn) tile = (g1->N % 128 == 0 && (tile == 5)) ? 1 : 4;
+            if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7)) ? 1 : 4;
         }
     }
-    const int bn = (tile == 5) ? 256 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64;
+    if (tile == 7 && !epi_is_f16(epi)) return CC_ERR_INVALID;
+    const int bn = tile_bn(tile);
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
     if (slots_out) {
         const int wn = (tile == 5) ? 4 : 2;
@@ -551,6 +596,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         case 4: return launch_tile<64, 64, 2, 2>(g0, g1, epi, st);
         case 5: return launch_tile<256, 256, 2, 4>(g0, g1, epi, st);
         case 6: return launch_tile<256, 128, 4, 2>(g0, g1, epi, st);
+        case 7: return launch_tile_f16<256, 192, 2, 4>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
 }

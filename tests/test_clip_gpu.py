@@ -67,6 +67,43 @@ def test_linear_f16_epilogues(M, N, K, tile):
     assert relerr(out.cpu(), ref + resid.double()) < 2e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(9600, 2304, 768), (300, 192, 64), (1000, 1536, 512), (257, 768, 3072)])
+def test_linear_f16_tile_256x192(M, N, K):
+    """tile 7 (256 x 192, 48-column wave tiles) exists for the fp16-output epilogues only; the auto choice picks it for
+    in_proj at M = 9,600 and must agree with the forced 256 x 256 / 128 x 128 results bit for bit (same k order)."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(7 * M + N + K)
+    a = (torch.randn(M, K, generator=gen)).half()
+    w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
+    bias = torch.randn(N, generator=gen)
+    ref = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    y = ops.linear_f16(ad, wd, bd, "f16", tile=7)
+    assert relerr(y.float().cpu(), ref) < 2e-3
+    assert torch.equal(y, ops.linear_f16(ad, wd, bd, "f16", tile=4))
+    assert torch.equal(y, ops.linear_f16(ad, wd, bd, "f16", tile=0))
+    y = ops.linear_f16(ad, wd, bd, "f16_gelu", tile=7)
+    assert relerr(y.float().cpu(), ref * torch.sigmoid(1.702 * ref)) < 2e-3
+    assert torch.equal(y, ops.linear_f16(ad, wd, bd, "f16_gelu", tile=4))
+    for epi in ("f32", "f32_resid"):
+        with pytest.raises(RuntimeError, match="invalid"):
+            ops.linear_f16(ad, wd, bd, epi, out=torch.zeros(M, N, device=DEV), tile=7)
+    with pytest.raises(RuntimeError, match="invalid"):
+        ops.linear_f16(ad[:, :64].contiguous(), wd[:128, :64].contiguous(), None, "f16", tile=7)     # 128 % 192
+    # folded LayerNorm through the same tile
+    h = torch.randn(M, K, generator=gen) * 2 + 0.3
+    gamma, beta = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.2
+    w2 = torch.randn(N, K, generator=gen) * K ** -0.5
+    pre = F.layer_norm(h.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w2.double().t() + bias.double()
+    h16, st1 = ops.row_stats(h.to(DEV))
+    wf, c1, c2 = ops.fold_layernorm_linear(w2.to(DEV), bd, gamma.to(DEV), beta.to(DEV))
+    y7 = ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=False, tile=7)
+    assert relerr(y7.float().cpu(), pre) < 3e-3
+    assert torch.equal(y7, ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=False, tile=4))
+    y7 = ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=True, tile=7)
+    assert torch.equal(y7, ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=True, tile=4))
+
+
 @pytest.mark.parametrize("M,W,tile", [(9600, 768, 0), (2400, 768, 0), (512, 512, 0), (300, 768, 1), (300, 768, 4)])
 def test_folded_layernorm_chain(M, W, tile):
     """residual linear (+fp16 copy + per-tile partial sums) -> LayerNorm-folded linear, against
