@@ -44,6 +44,14 @@ struct LnArgs {
     int rows, W;
     _Float16* out16;     // optional (fp32-output variant): fp16 copy of the output rows, row stride W
     float* stats;        // optional: [rows][2] (sum, sum of squares) of the OUTPUT rows (one slot)
+    const float* cls;    // optional (ln_pre): rows with row % cls_period == 0 take cls + pos0 as their input
+    const float* pos0;
+    int cls_period;
+};
+struct TextEmbedArgs {
+    const long long* ids; const float* tok_emb; const float* pos; float* h; int* eot; int Bt, Lt, W;
+    _Float16* h16;       // optional: fp16 copy of the rows + their (sum, sum of squares) [rows][2]
+    float* stats;
 };
 // fp16 copy + (sum, sumsq) of fp32 rows (one wave per row); rows contiguous with stride W
 int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, int rows, int W, hipStream_t st);
@@ -55,8 +63,28 @@ struct AttArgs {
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
 int cc_launch_im2col(const cc_frames& frames, _Float16* A, int F, int res, int p, hipStream_t st);
-int cc_launch_cls_pos(float* h, const float* cls, const float* pos, int F, int Ltok, int W, hipStream_t st);
-int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float* pos, float* h, int* eot, int Bt,
-                         int Lt, int W, hipStream_t st);
+int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st);
+// ln_pre (args as cc_launch_layernorm2, fp32 output) and the text embedding in one launch
+int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hipStream_t st);
+struct HeadArgs {        // out[r] = LN(h[r*row_mul + (row_idx ? row_idx[r] : 0)]) @ proj[W, E]
+    const float* h; int row_mul; const int* row_idx; const float* gamma; const float* beta; const float* proj;
+    float* out; int R, W, E;
+};
+int cc_launch_head_project2(const HeadArgs& a0, const HeadArgs* a1, hipStream_t st);
 int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, const float* gamma, const float* beta,
                            const float* proj, float* out, int R, int W, int E, hipStream_t st);
+
+// cluster.hip: cc_token_gather_f32 / cc_token_cluster_variant_f32 with by-products for the next block's folded ln_1
+// (row_h16 [rows][W] fp16 copy of the dense output rows, row_stats [rows][2] their (sum, sum of squares))
+extern "C" {
+int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                         int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
+                         int64_t out_tok_stride, int64_t out_frame_stride, _Float16* row_h16, float* row_stats,
+                         void* stream);
+int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                                  int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
+                                  float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
+                                  const cc_cluster_variant* var, float* out, int64_t out_tok_stride,
+                                  int64_t out_frame_stride, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
+                                  size_t ws_bytes, _Float16* row_h16, float* row_stats, void* stream);
+}

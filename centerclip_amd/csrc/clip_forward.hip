@@ -233,21 +233,23 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         ga.patch_n = n;
         rc = cc_gemm_dispatch(ga, EPI_F32_PATCH, 0, st);
         if (rc) return rc;
-        rc = cc_launch_cls_pos(v.h, vm->class_embedding, vm->positional_embedding, F, n + 1, W, st);
-        if (rc) return rc;
-        {   // ln_pre in place (fp32) + fp16 copy + row statistics for block 1's folded ln_1
-            LnArgs a{v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, v.h16, v.st0};
-            rc = cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st);
-            if (rc) return rc;
-        }
         h = v.h;
         hother = v.h2;
     }
-    if (tm) {
-        rc = cc_launch_text_embed(reinterpret_cast<const long long*>(ids), tm->token_embedding,
-                                  tm->positional_embedding, t.h, t.eot, Bt, Lt, tm->width, st);
-        if (rc) return rc;
-        rc = cc_launch_row_stats(t.h, t.h16, t.st0, Bt * Lt, tm->width, st);
+    {   // ln_pre in place (fp32; the CLS rows = class_embedding + positional_embedding[0] are formed inside) + fp16 copy +
+        // row statistics for block 1's folded ln_1, and the text embedding with the same by-products - one launch
+        LnArgs a{};
+        TextEmbedArgs te{};
+        if (vm) {
+            const int n = tokens, F = B * T;
+            a = LnArgs{v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, v.h16, v.st0,
+                       vm->class_embedding, vm->positional_embedding, n + 1};
+        }
+        if (tm)
+            te = TextEmbedArgs{reinterpret_cast<const long long*>(ids), tm->token_embedding, tm->positional_embedding,
+                               t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0};
+        rc = (vm && tm) ? cc_launch_pre_stage(a, te, 1e-5f, st)
+                        : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;
     }
     const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
@@ -261,31 +263,28 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                 if (Tn <= 0 || frames % Tn) return CC_ERR_INVALID;
                 const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
                 if (var && var->algorithm == CC_CLUSTER_POOLING && K != tokens) return CC_ERR_INVALID;
+                // (the gather / aggregation launch also writes the fp16 copy + row statistics of the new rows)
+                cc_cluster_variant dflt{};
+                dflt.algorithm = CC_CLUSTER_KMEDOIDS;
+                dflt.aggregation = CC_AGGREGATE_MEDOID;
                 if (forced_medoids && (!var || (var->algorithm == CC_CLUSTER_KMEDOIDS &&
                                                 var->aggregation == CC_AGGREGATE_MEDOID && !var->cluster_embed &&
                                                 !var->cls_multiplier)))
-                    rc = cc_token_gather_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                             forced_medoids, hother, W, (int64_t)(K + 1) * W, st);
+                    rc = cc_token_gather_rows(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                              forced_medoids, hother, W, (int64_t)(K + 1) * W, v.h16, v.st0, st);
                 else if (forced_medoids)
                     rc = CC_ERR_UNSUPPORTED;
-                else if (var)
-                    rc = cc_token_cluster_variant_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                                      vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
-                                                      vm->cluster_iter_limit, vm->cluster_split_size,
-                                                      vm->cluster_pre_norm, var, hother, W, (int64_t)(K + 1) * W,
-                                                      medoids_out, nullptr, nullptr, v.cluster, v.cluster_bytes, st);
                 else
-                    rc = cc_token_cluster_f32(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                              vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
-                                              vm->cluster_iter_limit, vm->cluster_split_size, vm->cluster_pre_norm,
-                                              hother, W, (int64_t)(K + 1) * W, medoids_out, nullptr, nullptr,
-                                              v.cluster, v.cluster_bytes, st);
+                    rc = cc_token_cluster_variant_rows(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                                       vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
+                                                       vm->cluster_iter_limit, vm->cluster_split_size,
+                                                       vm->cluster_pre_norm, var ? var : &dflt, hother, W,
+                                                       (int64_t)(K + 1) * W, medoids_out, nullptr, nullptr, v.cluster,
+                                                       v.cluster_bytes, v.h16, v.st0, st);
                 if (rc) return rc;
                 float* tmp = h; h = hother; hother = tmp;
                 frames = Tn;
                 tokens = K;
-                rc = cc_launch_row_stats(h, v.h16, v.st0, B * frames * (tokens + 1), W, st);
-                if (rc) return rc;
                 cv.slots0 = 1;
             }
             cv.h = h; cv.h16 = v.h16; cv.st0 = v.st0; cv.st1 = v.st1; cv.qkv = v.qkv; cv.att = v.att; cv.u = v.u;
@@ -299,19 +298,16 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                             ht ? &ct : nullptr, st);
         if (rc) return rc;
     }
-    if (vm) {       // ln_post + proj on the CLS rows only (clip.py:463-464)
-        rc = cc_launch_head_project(h, tokens + 1, nullptr, vm->ln_post_weight, vm->ln_post_bias, vm->proj, vfeat,
-                                    B * frames, W, vm->embed_dim, st);
-        if (rc) return rc;
-        if (hidden_out && hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
-                                         hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return CC_ERR_HIP;
-    }
-    if (tm) {       // ln_final + text_projection on the EOT rows only (clip.py:480-484)
-        rc = cc_launch_head_project(t.h, Lt, t.eot, tm->ln_final_weight, tm->ln_final_bias, tm->text_projection,
-                                    tfeat, Bt, tm->width, tm->embed_dim, st);
-        if (rc) return rc;
-    }
+    // ln_post + proj on the CLS rows only (clip.py:463-464); ln_final + text_projection on the EOT rows only
+    // (clip.py:480-484) - one launch for both heads
+    HeadArgs hv{}, ht{};
+    if (vm) hv = HeadArgs{h, tokens + 1, nullptr, vm->ln_post_weight, vm->ln_post_bias, vm->proj, vfeat, B * frames, W, vm->embed_dim};
+    if (tm) ht = HeadArgs{t.h, Lt, t.eot, tm->ln_final_weight, tm->ln_final_bias, tm->text_projection, tfeat, Bt, tm->width, tm->embed_dim};
+    rc = cc_launch_head_project2(vm ? hv : ht, (vm && tm) ? &ht : nullptr, st);
+    if (rc) return rc;
+    if (vm && hidden_out && hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
+                                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CC_ERR_HIP;
     return CC_OK;
 }
 

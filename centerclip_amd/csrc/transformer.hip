@@ -22,20 +22,22 @@ struct LnPair {
 };
 
 template <bool OUT_F16>
-__global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
-    const bool second = (int)blockIdx.x >= pr.blocks0;
-    const LnArgs a = second ? pr.a[1] : pr.a[0];
+__device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane, float eps) {
     const int W = a.W;
-    const int lane = threadIdx.x & 63;
-    const int row = ((int)blockIdx.x - (second ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
     const float* src = a.in + (int64_t)row * a.in_stride;
+    // ln_pre: the CLS row of every frame is class_embedding + positional_embedding[0] (modules/clip.py:334-336), formed
+    // here instead of by a pass of its own (cls_period = tokens per frame; the input row is never read)
+    const bool cls_row = a.cls && (row % a.cls_period) == 0;
     float4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int w = lane * 4 + t * 256;
-        v[t] = (w < W) ? *reinterpret_cast<const float4*>(src + w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w >= W) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (cls_row) {
+            const float4 c = *reinterpret_cast<const float4*>(a.cls + w), p0 = *reinterpret_cast<const float4*>(a.pos0 + w);
+            v[t] = make_float4(c.x + p0.x, c.y + p0.y, c.z + p0.z, c.w + p0.w);
+        } else v[t] = *reinterpret_cast<const float4*>(src + w);
         s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
     }
     const float mean = cc_wave_sum(s) / (float)W;
@@ -79,6 +81,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
         osq = cc_wave_sum(osq);
         if (lane == 0) reinterpret_cast<float2*>(a.stats)[row] = make_float2(osum, osq);
     }
+}
+
+template <bool OUT_F16>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
+    const bool second = (int)blockIdx.x >= pr.blocks0;
+    const LnArgs& a = second ? pr.a[1] : pr.a[0];
+    const int row = ((int)blockIdx.x - (second ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    layernorm_row<OUT_F16>(a, row, threadIdx.x & 63, eps);
 }
 
 // fp16 copy + (sum, sum of squares of the fp16-rounded values) of contiguous fp32 rows; one wave per row
@@ -492,30 +503,33 @@ __global__ __launch_bounds__(256) void im2col_u8_f16_kernel(const unsigned char*
     }
 }
 
-// h[f][0][:] = class_embedding + positional_embedding[0]      (modules/clip.py:334-336)
-__global__ void cls_pos_kernel(float* __restrict__ h, const float* __restrict__ cls, const float* __restrict__ pos,
-                               int F, int Ltok, int W) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= F * W) return;
-    const int f = idx / W, w = idx - f * W;
-    h[(int64_t)f * Ltok * W + w] = cls[w] + pos[w];
-}
-
 // text: h[b*Lt + t] = token_embedding[ids[b,t]] + positional_embedding[t]; eot[b] = first argmax ids[b,:]
-__global__ __launch_bounds__(256) void text_embed_kernel(const long long* __restrict__ ids,
-                                                         const float* __restrict__ tok_emb,
-                                                         const float* __restrict__ pos, float* __restrict__ h,
-                                                         int* __restrict__ eot, int Bt, int Lt, int W) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Bt * Lt) return;
+// (optionally also the fp16 copy of the row and its (sum, sum of squares), exactly as row_stats_kernel forms them)
+__device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, int lane) {
+    const long long* ids = e.ids;
+    const int Lt = e.Lt, W = e.W;
+    int* eot = e.eot;
     const int b = row / Lt, t = row - b * Lt;
     const long long id = ids[row];
-    const float* src = tok_emb + (int64_t)id * W;
+    const float* src = e.tok_emb + (int64_t)id * W;
+    float s = 0.f, q = 0.f;
     for (int w = lane * 4; w < W; w += 256) {
         const float4 a = *reinterpret_cast<const float4*>(src + w);
-        const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)t * W + w);
-        *reinterpret_cast<float4*>(h + (int64_t)row * W + w) = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+        const float4 pe = *reinterpret_cast<const float4*>(e.pos + (int64_t)t * W + w);
+        const float4 v = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+        *reinterpret_cast<float4*>(e.h + (int64_t)row * W + w) = v;
+        if (e.h16) {
+            h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<h4*>(e.h16 + (int64_t)row * W + w) = o;
+            const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+            s += (q0 + q1) + (q2 + q3);
+            q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+        }
+    }
+    if (e.h16) {
+        s = cc_wave_sum(s);
+        q = cc_wave_sum(q);
+        if (lane == 0) reinterpret_cast<float2*>(e.stats)[row] = make_float2(s, q);
     }
     if (t == 0) {      // one wave scans the row for the first maximum id (modules/clip.py:484)
         unsigned long long key = 0ull;
@@ -529,20 +543,48 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long long* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void text_embed_kernel(TextEmbedArgs e) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < e.Bt * e.Lt) text_embed_row(e, row, threadIdx.x & 63);
+}
+
+// The stage in front of the first blocks of both towers in ONE launch: ln_pre of the visual rows (in place, CLS rows
+// formed on the fly, + fp16 copy + row statistics) in workgroups [0, blocks_ln), the text embedding rows behind them.
+__global__ __launch_bounds__(256) void pre_stage_kernel(LnArgs ln, TextEmbedArgs te, int blocks_ln, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < blocks_ln) {
+        const int row = blockIdx.x * 4 + wave;
+        if (row < ln.rows) layernorm_row<false>(ln, row, lane, eps);
+    } else {
+        const int row = ((int)blockIdx.x - blocks_ln) * 4 + wave;
+        if (row < te.Bt * te.Lt) text_embed_row(te, row, lane);
+    }
+}
+
 // out[r][e0:e0+64] = LN(h[row_of(r)]) @ proj[W, E]   (fp32 throughout).  grid = (E/64, R): every
 // workgroup re-normalises its row (W floats, cheap) and produces 64 outputs; the 256 threads are
 // 16 k-slices x 16 lanes x 4 outputs, proj reads are 16-byte loads coalesced over the output index.
 //   row_of(r) = r*row_mul + (row_idx ? row_idx[r] : 0)
-__global__ __launch_bounds__(256) void head_project_kernel(const float* __restrict__ h, int row_mul,
-                                                           const int* __restrict__ row_idx,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           const float* __restrict__ proj, float* __restrict__ out,
-                                                           int W, int E, float eps) {
+// Up to two heads per launch (rows [0, p[0].R) of the grid's y axis -> p[0], the rest -> p[1]): the visual CLS rows
+// and the text EOT rows of the fused forward.
+struct HeadPair {
+    HeadArgs p[2];
+};
+__global__ __launch_bounds__(256) void head_project_kernel(HeadPair hp, float eps) {
     __shared__ float xn[1024];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float part[16][64];
-    const int r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool second = (int)blockIdx.y >= hp.p[0].R;
+    const HeadArgs& a = second ? hp.p[1] : hp.p[0];
+    const float* __restrict__ h = a.h;
+    const int* __restrict__ row_idx = a.row_idx;
+    const float* __restrict__ gamma = a.gamma;
+    const float* __restrict__ beta = a.beta;
+    const float* __restrict__ proj = a.proj;
+    float* __restrict__ out = a.out;
+    const int row_mul = a.row_mul, W = a.W, E = a.E;
+    if ((int)blockIdx.x * 64 >= E) return;                    // the two heads may differ in E (grid x covers the larger)
+    const int r = (int)blockIdx.y - (second ? hp.p[0].R : 0), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = h + ((int64_t)r * row_mul + (row_idx ? row_idx[r] : 0)) * W;
     float s = 0.f;
     for (int w = tid; w < W; w += 256) { const float v = src[w]; xn[w] = v; s += v; }
@@ -708,23 +750,35 @@ int cc_launch_im2col(const cc_frames& fr, _Float16* A, int F, int res, int p, hi
     return CC_OK;
 }
 
-int cc_launch_cls_pos(float* h, const float* cls, const float* pos, int F, int Ltok, int W, hipStream_t st) {
-    hipLaunchKernelGGL(cls_pos_kernel, dim3((F * W + 255) / 256), dim3(256), 0, st, h, cls, pos, F, Ltok, W);
+int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st) {
+    if ((e.W & 3) || (e.h16 && !e.stats)) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(text_embed_kernel, dim3((e.Bt * e.Lt + 3) / 4), dim3(256), 0, st, e);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
-int cc_launch_text_embed(const long long* ids, const float* tok_emb, const float* pos, float* h, int* eot, int Bt,
-                         int Lt, int W, hipStream_t st) {
-    hipLaunchKernelGGL(text_embed_kernel, dim3((Bt * Lt + 3) / 4), dim3(256), 0, st, ids, tok_emb, pos, h, eot, Bt, Lt, W);
+int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hipStream_t st) {
+    if (ln.W > 1024 || (ln.W & 3) || (te.W & 3) || (te.h16 && !te.stats) || (ln.cls && (!ln.pos0 || ln.cls_period <= 0)))
+        return CC_ERR_INVALID;
+    const int blocks_ln = (ln.rows + 3) / 4;
+    hipLaunchKernelGGL(pre_stage_kernel, dim3(blocks_ln + (te.Bt * te.Lt + 3) / 4), dim3(256), 0, st, ln, te, blocks_ln, eps);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_launch_head_project2(const HeadArgs& a0, const HeadArgs* a1, hipStream_t st) {
+    if (a0.W > 1024 || (a0.E & 3) || (a1 && (a1->W > 1024 || (a1->E & 3)))) return CC_ERR_UNSUPPORTED;
+    HeadPair hp{};
+    hp.p[0] = a0;
+    hp.p[1] = a1 ? *a1 : a0;
+    const int E = (a1 && a1->E > a0.E) ? a1->E : a0.E;
+    hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, a0.R + (a1 ? a1->R : 0)), dim3(256), 0, st, hp, 1e-5f);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
 int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, const float* gamma, const float* beta,
                            const float* proj, float* out, int R, int W, int E, hipStream_t st) {
-    if (W > 1024 || (E & 3)) return CC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, R), dim3(256), 0, st, h, row_mul, row_idx, gamma, beta, proj, out, W, E, 1e-5f);
-    CC_LAUNCH_CHECK();
-    return CC_OK;
+    const HeadArgs a{h, row_mul, row_idx, gamma, beta, proj, out, R, W, E};
+    return cc_launch_head_project2(a, nullptr, st);
 }
