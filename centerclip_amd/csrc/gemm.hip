@@ -575,6 +575,9 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
             if (ov && ov[0] >= '1' && ov[0] <= '7') tile = ov[0] - '0';
+            snprintf(name, sizeof(name), "CC_TILE_E%d_%c_K%d", epi, g0.M < 5000 ? 'S' : 'B', g0.K);   // one shape only
+            ov = getenv(name);
+            if (ov && ov[0] >= '1' && ov[0] <= '7') tile = ov[0] - '0';
         }
         if (g1) {                                  // the rider must be divisible by the carrier's BN
             if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7)) ? 1 : 4;
