@@ -352,6 +352,33 @@ def test_vitb32_activitynet_shape_against_fp32_oracle():
     assert d <= 1e-3
 
 
+def test_vitb16_shape_against_fp32_oracle():
+    """BASELINE.json configs[4] shape, one clip: ViT-B/16 (196 tokens per frame, L = 197: the long-sequence attention
+    kernel), 12 frames -> 4 segments at block 7, K = 100: 4 problems of N = 588 tokens.  HIP vs the fp32 CPU oracle given
+    the HIP path's own medoid ids."""
+    from centerclip_amd.clip import CLIP
+    torch.manual_seed(2)
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=12,
+                     target_frames_blocks=[12] * 6 + [4] * 6, cluster_num_blocks=[100] * 12,
+                     cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/16', aggregation=None, pre_norm=False)
+    model = CLIP(512, 224, 12, 768, 16, 77, 49408, 512, 8, 12, video_frames=12, args=args)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.half().float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    video = torch.randn(12, 3, 224, 224)
+    feat, _ = model.visual.encode(video.to(DEV), 12, want_medoids=True)
+    med = model.visual.last_medoids.cpu()
+    assert feat.shape == (4, 512) and med.shape == (4, 100)
+    assert bool((med[:, 1:] > med[:, :-1]).all()) and int(med.min()) >= 0 and int(med.max()) < 3 * 196
+    ref = clo.visual_forward(sd, video, 12, cluster_plan={6: (4, 100)}, forced_medoids={6: med})
+    d = float((nrm(feat.cpu()) - nrm(ref)).abs().max())
+    print(f"[ViT-B/16 12f] max|delta| normalised embedding = {d:.2e}")
+    assert d <= 1e-3
+
+
 def test_n1_retrieval_metrics_match_reference(g):
     """compute_metrics on the device (2 ints per row) == utils/metrics.py:11-26 incl. its tie behaviour."""
     from centerclip_amd.metrics import compute_metrics
