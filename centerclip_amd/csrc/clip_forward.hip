@@ -7,6 +7,7 @@
 // Reference call stack: CLIP.encode_image -> VisualTransformer.forward -> Transformer ->
 // ResidualAttentionBlock.forward (modules/clip.py:460-469, 304-349, 256-269, 228-253).
 #include "cc_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -96,6 +97,19 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
     const int Wa = c0->W, Wb = c1 ? c1->W : 0;
     int rc;
     int slots[2];
+    // experiment knob: CC_UNPAIR bit mask (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj) - the clustered visual blocks launch
+    // those phases separately for the two towers
+    static const int unpair_mask = [] { const char* e = getenv("CC_UNPAIR"); return e ? atoi(e) : 0; }();
+    const int unpair = (c1 && M0 < 5000) ? unpair_mask : 0;
+    auto dispatch = [&](GemmArgs& g0, GemmArgs& g1, int epi, int bit, int* sl) {
+        if (!(unpair & bit)) return cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, epi, 0, st, sl);
+        int s0[2] = {0, 0}, s1[2] = {0, 0};
+        int r = cc_gemm_dispatch2(g0, nullptr, epi, 0, st, sl ? s0 : nullptr);
+        if (r) return r;
+        r = cc_gemm_dispatch2(g1, nullptr, epi, 0, st, sl ? s1 : nullptr);
+        if (sl) { sl[0] = s0[0]; sl[1] = s1[0]; }
+        return r;
+    };
     auto base = [&](const BlockCtx* c, int M, const _Float16* A, const void* Wt, const float* bias, void* C, int N, int K) {
         GemmArgs g{};
         g.A = A; g.W = static_cast<const _Float16*>(Wt); g.bias = bias; g.C = C;
@@ -113,7 +127,7 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
             g1 = base(c1, M1, c1->h16, w1->in_proj_ln_weight_f16, w1->in_proj_ln_c2, c1->qkv, 3 * Wb, Wb);
             g1.ln_stats = c1->st0; g1.ln_slots = c1->slots0; g1.ln_c1 = w1->in_proj_ln_c1;
         }
-        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F16_LN, 0, st);
+        rc = dispatch(g0, g1, EPI_F16_LN, 1, nullptr);
         if (rc) return rc;
     }
     {
@@ -132,7 +146,7 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
             g1 = base(c1, M1, c1->att, w1->out_proj_weight_f16, w1->out_proj_bias, c1->h, Wb, Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st1;
         }
-        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F32_RESID_STATS, 0, st, slots);
+        rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 2, slots);
         if (rc) return rc;
         c0->slots1 = slots[0];
         if (c1) c1->slots1 = slots[1];
@@ -146,7 +160,7 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
             g1 = base(c1, M1, c1->h16, w1->c_fc_ln_weight_f16, w1->c_fc_ln_c2, c1->u, 4 * Wb, Wb);
             g1.ln_stats = c1->st1; g1.ln_slots = c1->slots1; g1.ln_c1 = w1->c_fc_ln_c1;
         }
-        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F16_GELU_LN, 0, st);
+        rc = dispatch(g0, g1, EPI_F16_GELU_LN, 4, nullptr);
         if (rc) return rc;
     }
     // ---- x = x + c_proj(u)   [+ fp16 copy and row statistics for the next block's ln_1]
@@ -158,7 +172,7 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
             g1 = base(c1, M1, c1->u, w1->c_proj_weight_f16, w1->c_proj_bias, c1->h, Wb, 4 * Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st0;
         }
-        rc = cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, EPI_F32_RESID_STATS, 0, st, slots);
+        rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 8, slots);
         if (rc) return rc;
         c0->slots0 = slots[0];
         if (c1) c1->slots0 = slots[1];

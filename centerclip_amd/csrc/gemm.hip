@@ -48,7 +48,7 @@ __device__ __forceinline__ float dpp_f32(float x) {          // lane exchange in
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     long long* prof = g_gemm_prof;
     GEMM_STAMP(0);
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const GemmArgs g = second ? pr.p[1] : pr.p[0];
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
-    constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int CH = BK / 8;                               // 16-byte chunks per staged row (8 or 16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * (A_BYTES + B_BYTES)
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
@@ -81,27 +82,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
 
-    // ---- staging addresses: LDS chunk idx -> (row r, chunk position cp); source chunk = cp ^ (r & 7)
-    constexpr int A_LOADS = BM * 8 / THREADS, B_LOADS = BN * 8 / THREADS;
+    // ---- staging addresses: LDS chunk idx -> (row r, chunk position cp); source chunk = cp ^ (r & (CH - 1))
+    constexpr int A_LOADS = BM * CH / THREADS, B_LOADS = BN * CH / THREADS;
     const _Float16* asrc[A_LOADS];
     const _Float16* bsrc[B_LOADS];
 #pragma unroll
     for (int q = 0; q < A_LOADS; ++q) {
-        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
+        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
         asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8;
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
-        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx >> 3, c = (idx & 7) ^ (r & 7);
+        const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
         bsrc[q] = g.W + (int64_t)(col0 + r) * g.K + c * 8;
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
         _Float16* lb = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES) + A_BYTES);
 #pragma unroll
-        for (int q = 0; q < A_LOADS; ++q) glds16(asrc[q] + kt * GEMM_BK, la + (q * NWAVES + wave) * 512);
+        for (int q = 0; q < A_LOADS; ++q) glds16(asrc[q] + kt * BK, la + (q * NWAVES + wave) * 512);
 #pragma unroll
-        for (int q = 0; q < B_LOADS; ++q) glds16(bsrc[q] + kt * GEMM_BK, lb + (q * NWAVES + wave) * 512);
+        for (int q = 0; q < B_LOADS; ++q) glds16(bsrc[q] + kt * BK, lb + (q * NWAVES + wave) * 512);
     };
 
     f32x4 acc[MI][NI];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = __builtin_amdgcn_readfirstlane(g.K / GEMM_BK);
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
     stage(0, 0);
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
@@ -157,12 +158,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = wr * (BM / WM) + i * 16 + l15;
-            af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            af[i] = *reinterpret_cast<const h8*>(la + r * (BK * 2) + (((ks * 4 + lg) ^ (r & (CH - 1))) << 4));
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int r = wc * (BN / WN) + j * 16 + l15;
-            bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            bf[j] = *reinterpret_cast<const h8*>(lb + r * (BK * 2) + (((ks * 4 + lg) ^ (r & (CH - 1))) << 4));
         }
     };
     // Co-resident 4-wave workgroups: raising the wave priority over its MFMA block keeps the other workgroup's VMEM /
@@ -179,17 +180,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     auto read_a = [&](int buf, int ks, int i, h8 (&af)[MI]) {
         const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
         const int r = wr * (BM / WM) + i * 16 + l15;
-        af[i] = *reinterpret_cast<const h8*>(la + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+        af[i] = *reinterpret_cast<const h8*>(la + r * (BK * 2) + (((ks * 4 + lg) ^ (r & (CH - 1))) << 4));
     };
     auto read_b = [&](int buf, int ks, int j, h8 (&bf)[NI]) {
         const unsigned char* lb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
         const int r = wc * (BN / WN) + j * 16 + l15;
-        bf[j] = *reinterpret_cast<const h8*>(lb + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+        bf[j] = *reinterpret_cast<const h8*>(lb + r * (BK * 2) + (((ks * 4 + lg) ^ (r & (CH - 1))) << 4));
     };
     auto stage_piece = [&](int buf, int kt, int q) {        // q-th of the A_LOADS + B_LOADS pieces of a stage
         unsigned char* base = smem + buf * (A_BYTES + B_BYTES);
-        if (q < A_LOADS) glds16(asrc[q] + kt * GEMM_BK, reinterpret_cast<_Float16*>(base) + (q * NWAVES + wave) * 512);
-        else glds16(bsrc[q - A_LOADS] + kt * GEMM_BK,
+        if (q < A_LOADS) glds16(asrc[q] + kt * BK, reinterpret_cast<_Float16*>(base) + (q * NWAVES + wave) * 512);
+        else glds16(bsrc[q - A_LOADS] + kt * BK,
                     reinterpret_cast<_Float16*>(base + A_BYTES) + ((q - A_LOADS) * NWAVES + wave) * 512);
     };
     auto mma_row = [&](int i, const h8 (&af)[MI], const h8 (&bf)[NI]) {
@@ -200,7 +201,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
     // plain order is faster (1832 vs 2033) - the co-resident workgroup already fills the LDS-latency gap.
     constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
-    if (HALF_SHIFTED) {
+    if constexpr (BK > GEMM_BK) {
+        // Deep k-step (BK = 128, the 64x64 tile only): the small tile is bound by the latency of the LDS-DMA round trip,
+        // one per k-step and workgroup (~900 cycles for 8 MFMAs per wave at BK = 64) - twice the bytes per stage halves
+        // the number of round trips of a long-K problem.  KS sub-steps of 32 k: the fragments of sub-step s+1 are read
+        // while the MFMAs of sub-step s run; the next stage's loads are all issued behind the first reads.
+        constexpr int KS = BK / 32, NLOAD = A_LOADS + B_LOADS;
+        auto step = [&](int buf, int kt, bool with_stage) {
+            h8 af[2][MI], bf[2][NI];
+            read_frags(buf, 0, af[0], bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) read_frags(buf, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+                if (ks == 0 && with_stage) {
+#pragma unroll
+                    for (int q = 0; q < NLOAD; ++q) stage_piece(buf ^ 1, kt + 1, q);
+                }
+                mma(af[ks & 1], bf[ks & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        fetch_epilogue_operands();
+        step((nk - 1) & 1, nk - 1, false);
+    } else if (HALF_SHIFTED) {
         // Every MFMA phase is written as MI groups of one fragment row (NI MFMAs), and the other work of the phase -
         // the fragment reads of the next k-half and, after the barrier, the LDS-DMA loads of the stage after next - is
         // dealt out over those groups in source order with a scheduling fence after each group: the issue cost of the
@@ -455,10 +481,10 @@ extern "C" int cc_debug_set_gemm_profile(long long* p) {   // debug only; p [wor
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
-    constexpr size_t smem = 2 * (size_t)(BM + BN) * GEMM_BK * 2;
-    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI>;
+    constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
+    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK>;
     if (smem > 64 * 1024) {
         static bool configured = false;      // per instantiation; benign race (idempotent call)
         if (!configured) {
@@ -473,7 +499,7 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     return CC_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = GEMM_BK>
 int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     GemmPair pr{};
     g0.tiles_m = (g0.M + BM - 1) / BM;
@@ -490,14 +516,14 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1] = g0;
     }
     switch (epi) {
-        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16>(pr, total, st);
-        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(pr, total, st);
-        case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID>(pr, total, st);
-        case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH>(pr, total, st);
-        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(pr, total, st);
-        case EPI_F16_LN: return launch_one<BM, BN, WM, WN, EPI_F16_LN>(pr, total, st);
-        case EPI_F16_GELU_LN: return launch_one<BM, BN, WM, WN, EPI_F16_GELU_LN>(pr, total, st);
-        case EPI_F32_RESID_STATS: return launch_one<BM, BN, WM, WN, EPI_F32_RESID_STATS>(pr, total, st);
+        case EPI_F16: return launch_one<BM, BN, WM, WN, EPI_F16, BK>(pr, total, st);
+        case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU, BK>(pr, total, st);
+        case EPI_F32_RESID: return launch_one<BM, BN, WM, WN, EPI_F32_RESID, BK>(pr, total, st);
+        case EPI_F32_PATCH: return launch_one<BM, BN, WM, WN, EPI_F32_PATCH, BK>(pr, total, st);
+        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32, BK>(pr, total, st);
+        case EPI_F16_LN: return launch_one<BM, BN, WM, WN, EPI_F16_LN, BK>(pr, total, st);
+        case EPI_F16_GELU_LN: return launch_one<BM, BN, WM, WN, EPI_F16_GELU_LN, BK>(pr, total, st);
+        case EPI_F32_RESID_STATS: return launch_one<BM, BN, WM, WN, EPI_F32_RESID_STATS, BK>(pr, total, st);
         default: return CC_ERR_INVALID;
     }
 }
@@ -538,6 +564,7 @@ static bool epi_is_f16(int epi) {
     return epi == EPI_F16 || epi == EPI_F16_GELU || epi == EPI_F16_LN || epi == EPI_F16_GELU_LN;
 }
 static int tile_bn(int tile) { return tile == 5 ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
+static int tile_bk(int tile) { return tile == 8 ? 128 : GEMM_BK; }
 
 static int pick_tile(const GemmArgs& g, int epi) {
     // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
@@ -561,11 +588,13 @@ static int pick_tile(const GemmArgs& g, int epi) {
     if (n128 && mt128 * (g.N / 128) >= 300) return 1;
     if (n128 && mt64 * (g.N / 128) >= 400) return 3;
     if (mt128 * (g.N / 64) >= 400) return 2;
-    return 4;
+    // long-K problems on the small tile: 128-deep k-steps (c_proj of the clustered blocks 25.5 -> 21.2 us alone,
+    // 2.158 vs 2.166 ms per step; the short-K out_proj loses with it)
+    return (g.K % 128 == 0 && g.K >= 2048) ? 8 : 4;
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
-// 7 only for the fp16-output epilogues)
+// 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0)
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
@@ -574,16 +603,18 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             char name[32];
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
-            if (ov && ov[0] >= '1' && ov[0] <= '7') tile = ov[0] - '0';
+            if (ov && ov[0] >= '1' && ov[0] <= '8') tile = ov[0] - '0';
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c_K%d", epi, g0.M < 5000 ? 'S' : 'B', g0.K);   // one shape only
             ov = getenv(name);
-            if (ov && ov[0] >= '1' && ov[0] <= '7') tile = ov[0] - '0';
+            if (ov && ov[0] >= '1' && ov[0] <= '8') tile = ov[0] - '0';
         }
         if (g1) {                                  // the rider must be divisible by the carrier's BN
             if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7)) ? 1 : 4;
+            if (g1->K % tile_bk(tile)) tile = 4;
         }
     }
     if (tile == 7 && !epi_is_f16(epi)) return CC_ERR_INVALID;
+    if ((g0.K % tile_bk(tile)) || (g1 && (g1->K % tile_bk(tile)))) return CC_ERR_INVALID;
     const int bn = tile_bn(tile);
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
     if (slots_out) {
@@ -600,6 +631,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         case 5: return launch_tile<256, 256, 2, 4>(g0, g1, epi, st);
         case 6: return launch_tile<256, 128, 4, 2>(g0, g1, epi, st);
         case 7: return launch_tile_f16<256, 192, 2, 4>(g0, g1, epi, st);
+        case 8: return launch_tile<64, 64, 2, 2, 128>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
 }
