@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
 // Covers L = 50 (ViT-B/32 and every K = 49 clustered block) and the 32-token text tower.
 #define ATTW_KT 64
 __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float scale) {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[4][ATT_D * ATTW_KT + 16 * (ATTW_KT + 8)];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4][ATT_D * ATTW_KT + 2 * 16 * (ATTW_KT + 8)];   // V^T + two P strips
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = blockIdx.x * 4 + wave;
     const int units0 = pr.a[0].nseq * pr.a[0].heads;
@@ -321,6 +321,16 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + W + (ks * 4 + lg) * 8);
     }
+    // the query fragments of all (at most 4) query tiles too: behind the loop's own loads every tile would wait a
+    // full L2 round trip with fewer than 3 waves per SIMD to cover it
+    const int qtiles = (L + 15) / 16;
+    h8 qf[4][2];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int qc = min(qt * 16 + l15, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const h8*>(base + (int64_t)qc * ld + (ks * 4 + lg) * 8);
+    }
     // rows 56..63 of V (7 loads cover idx < 448 -> rows < 56): zero them and rows >= L
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
@@ -338,20 +348,18 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    const int qtiles = (L + 15) / 16;
-    for (int qt = 0; qt < qtiles; ++qt) {
-        const int q = qt * 16 + l15;
-        const int qc = min(q, L - 1);
-        h8 qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)qc * ld + (ks * 4 + lg) * 8);
+    for (int qt = 0; qt < 4; ++qt) {
+        if (qt >= qtiles) break;                              // wave-uniform
+        const int q = qt * 16 + l15;
+        _Float16* Pq = Pw + (qt & 1) * (16 * PS);             // alternate strips: tile qt+1 need not wait for tile qt's reads
         f32x4 s[4];
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[ks], a, 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[qt][ks], a, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = kt * 16 + lg * 4 + e;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
         for (int kt = 0; kt < 4; ++kt) {
             h4 ph = {(_Float16)(s[kt][0] * inv), (_Float16)(s[kt][1] * inv), (_Float16)(s[kt][2] * inv),
                      (_Float16)(s[kt][3] * inv)};
-            *reinterpret_cast<h4*>(Pw + l15 * PS + kt * 16 + lg * 4) = ph;
+            *reinterpret_cast<h4*>(Pq + l15 * PS + kt * 16 + lg * 4) = ph;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * PS + kb * 32 + lg * 8);
+            const h8 pf = *reinterpret_cast<const h8*>(Pq + l15 * PS + kb * 32 + lg * 8);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + l15;
