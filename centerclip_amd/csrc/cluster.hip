@@ -126,39 +126,51 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra_[4], rb_[4];
+    // The tokens come from HBM (first touch) and a k-step's MFMAs are short: with the next slice loaded only one step
+    // ahead every step waited most of a memory round trip.  GD register stages: slice kt + GD is requested at the top of
+    // step kt into the stage slice kt just left (it went to LDS at the end of step kt - 1).
+    constexpr int GD = 3;
+    float4 ra_[GD][4], rb_[GD][4];
     const int nk = (W + GK - 1) / GK;
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, int st) {
         const bool ok = kt * GK + lchunk * 4 < W;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ra_[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!diag) rb_[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra_[st][q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!diag) rb_[st][q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * GK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     float na[4] = {0.f, 0.f, 0.f, 0.f}, nb[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the rows' sums of squares
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int st) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4*>(tile(buf, 0) + (lrow + 16 * q) * GLD + lchunk * 4) = ra_[q];
-            if (!diag) *reinterpret_cast<float4*>(tile(buf, 1) + (lrow + 16 * q) * GLD + lchunk * 4) = rb_[q];
+            const float4 va = ra_[st][q], vb = rb_[st][q];
+            *reinterpret_cast<float4*>(tile(buf, 0) + (lrow + 16 * q) * GLD + lchunk * 4) = va;
+            if (!diag) *reinterpret_cast<float4*>(tile(buf, 1) + (lrow + 16 * q) * GLD + lchunk * 4) = vb;
             if (own_norms) {
-                na[q] = fmaf(ra_[q].x, ra_[q].x, na[q]); na[q] = fmaf(ra_[q].y, ra_[q].y, na[q]);
-                na[q] = fmaf(ra_[q].z, ra_[q].z, na[q]); na[q] = fmaf(ra_[q].w, ra_[q].w, na[q]);
+                na[q] = fmaf(va.x, va.x, na[q]); na[q] = fmaf(va.y, va.y, na[q]);
+                na[q] = fmaf(va.z, va.z, na[q]); na[q] = fmaf(va.w, va.w, na[q]);
                 if (!diag) {
-                    nb[q] = fmaf(rb_[q].x, rb_[q].x, nb[q]); nb[q] = fmaf(rb_[q].y, rb_[q].y, nb[q]);
-                    nb[q] = fmaf(rb_[q].z, rb_[q].z, nb[q]); nb[q] = fmaf(rb_[q].w, rb_[q].w, nb[q]);
+                    nb[q] = fmaf(vb.x, vb.x, nb[q]); nb[q] = fmaf(vb.y, vb.y, nb[q]);
+                    nb[q] = fmaf(vb.z, vb.z, nb[q]); nb[q] = fmaf(vb.w, vb.w, nb[q]);
                 }
             }
         }
     };
-    gload(0);
-    lstore(0);
+    gload(0, 0);
+#pragma unroll
+    for (int u = 1; u < GD; ++u)
+        if (u < nk) gload(u, u);
+    lstore(0, 0);
     __syncthreads();
     const int g = lane >> 4, l15 = lane & 15;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt0 = 0; kt0 < nk; kt0 += GD) {
+#pragma unroll
+      for (int u = 0; u < GD; ++u) {
+        const int kt = kt0 + u;
+        if (kt >= nk) break;
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + GD < nk) gload(kt + GD, u);
         if (active) {
             const float* A = tile(buf, 0) + (wr * 32 + l15) * GLD + g * 4;
             const float* Bm = tile(buf, diag ? 0 : 1) + (wc * 32 + l15) * GLD + g * 4;
@@ -177,8 +189,9 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
                 }
             }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) lstore(buf ^ 1, (u + 1) % GD);
         __syncthreads();
+      }
     }
 
     float* lsq = gram_lds + 2 * 2 * GT * GLD;                 // [2][GT]: sum of squares of the A rows, of the B rows
