@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
         return None
     data = json.load(open(files[-1]))
     for name, v in data.items():
-        if re.search(r"gemm_f16_kernel<.*, %d>" % epi, name):
+        if re.search(r"gemm_f16_kernel<\d+, \d+, \d+, \d+, %d(, \d+)?>" % epi, name):     # <BM, BN, WM, WN, EPI[, BK]>
             return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch_bytes": round(v["fetch_bytes_per_launch"]),
                     "write_bytes": round(v["write_bytes_per_launch"]), "source": os.path.basename(files[-1])}
     return None
