@@ -232,9 +232,13 @@ def cpu_baseline(c, state_dict):
     t1 = run(1, 1)
     n = int(max(1, min(c["B"], round(12.0 / max(t1, 1e-3)))))
     t = run(n, 2)
-    return dict(value=round(n / t, 3), unit="clips/s", cores=used, kind="port",
-                sample="%d clip(s) x 12 frames + %d caption(s) through oracle/clip_oracle.py (fp32, literal k-medoids), "
-                       "%.1f s of CPU work; single clip %.2f s" % (n, n, t, t1))
+    batches = 1
+    while t < 10.0 and batches < 8:                      # a bounded sample of ~10-30 s: whole batches of the workload
+        t += run(n, 2 + batches)
+        batches += 1
+    return dict(value=round(n * batches / t, 3), unit="clips/s", cores=used, kind="port",
+                sample="%d batch(es) of %d clip(s) x 12 frames + %d caption(s) through oracle/clip_oracle.py (fp32, literal "
+                       "k-medoids), %.1f s of CPU work; single clip %.2f s" % (batches, n, n, t, t1))
 
 
 def cpu_baseline_cluster(c):
