@@ -292,7 +292,7 @@ def main():
     def towers():
         out = model(ids, token_type, amask, video, vmask)
         vm = model.get_video_mask_after_cluster(vmask.view(-1, vmask.shape[-1]))
-        return out["sequence_output"], out["visual_output"], vm.to(torch.long).contiguous()
+        return out["sequence_output"], out["visual_output"], vm.to(torch.long) if world == 1 else vm.to(torch.long).contiguous()
 
     def tail(seq, vis, vm):
         if world > 1:

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 // visual [Bv, Tn, E], mask [Bv, Tn] int64 -> pooled [Bv, E]   (one wave per video)
 __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
-                                                         const long long* __restrict__ mask,
+                                                         const long long* __restrict__ mask, int64_t mrs, int64_t mcs,
                                                          float* __restrict__ pooled, int Bv, int Tn, int E) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
             s = fmaf(x[q], x[q], s);
         }
         const float nrm = sqrtf(cc_wave_sum(s));
-        const float mk = (float)mask[(int64_t)v * Tn + t];
+        const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];   // element strides: a strided view is fine
         cnt += mk;
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
 // video_pool_kernel does, parks it in LDS, then the four waves normalise one text each and take the dot product.
 __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float* __restrict__ text,
                                                                      const float* __restrict__ visual,
-                                                                     const long long* __restrict__ mask,
-                                                                     float* __restrict__ logits, int ldl,
+                                                                     const long long* __restrict__ mask, int64_t mrs,
+                                                                     int64_t mcs, float* __restrict__ logits, int ldl,
                                                                      float* __restrict__ pooled_out, int Bt, int Bv,
                                                                      int Tn, int E, float mult) {
     __shared__ float vp[1024];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
                 s = fmaf(x[q], x[q], s);
             }
             const float nrm = sqrtf(cc_wave_sum(s));
-            const float mk = (float)mask[(int64_t)v * Tn + t];
+            const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];   // element strides: a strided view is fine
             cnt += mk;
 #pragma unroll
             for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
@@ -234,14 +234,19 @@ size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E) {
     return cc_align_up((size_t)Bt * E * 4, 256) + cc_align_up((size_t)Bv * E * 4, 256);
 }
 
-int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
-                                float* pooled, void* stream) {
+static int video_pool_launch(const float* visual, const int64_t* video_mask, int64_t mrs, int64_t mcs, int32_t Bv,
+                             int32_t Tn, int32_t E, float* pooled, void* stream) {
     if (!visual || !video_mask || !pooled || Bv <= 0 || Tn <= 0 || E <= 0) return CC_ERR_INVALID;
     if (E > 1024) return CC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(video_pool_kernel, dim3((Bv + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), visual,
-                       reinterpret_cast<const long long*>(video_mask), pooled, Bv, Tn, E);
+                       reinterpret_cast<const long long*>(video_mask), mrs, mcs, pooled, Bv, Tn, E);
     CC_LAUNCH_CHECK();
     return CC_OK;
+}
+
+int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
+                                float* pooled, void* stream) {
+    return video_pool_launch(visual, video_mask, Tn, 1, Bv, Tn, E, pooled, stream);
 }
 
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult, float* logits,
@@ -254,16 +259,17 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
     return CC_OK;
 }
 
-int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t Bt, int32_t Bv,
-                            int32_t Tn, int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out,
-                            void* ws, size_t ws_bytes, void* stream) {
+int cc_loose_similarity_strided_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                    int64_t mask_row_stride, int64_t mask_col_stride, int32_t Bt, int32_t Bv, int32_t Tn,
+                                    int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out, void* ws,
+                                    size_t ws_bytes, void* stream) {
     if (!text || !visual || !video_mask || !logits) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_similarity_workspace_bytes(Bt, Bv, E)) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((long)Bt * Bv <= 4096 && E <= 1024 && Bt > 0 && Bv > 0) {      // one launch for a step's own logits
         hipLaunchKernelGGL(loose_similarity_small_kernel, dim3(Bv), dim3(256), 0, st, text, visual,
-                           reinterpret_cast<const long long*>(video_mask), logits, ldl, pooled_out, Bt, Bv, Tn, E,
-                           expf(logit_scale));
+                           reinterpret_cast<const long long*>(video_mask), mask_row_stride, mask_col_stride, logits, ldl,
+                           pooled_out, Bt, Bv, Tn, E, expf(logit_scale));
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
@@ -272,9 +278,16 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
                            : reinterpret_cast<float*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, tn, Bt, E);
     CC_LAUNCH_CHECK();
-    int rc = cc_video_pool_normalize_f32(visual, video_mask, Bv, Tn, E, vp, stream);
+    int rc = video_pool_launch(visual, video_mask, mask_row_stride, mask_col_stride, Bv, Tn, E, vp, stream);
     if (rc) return rc;
     return cc_scaled_dot_nt_f32(tn, vp, Bt, Bv, E, expf(logit_scale), logits, ldl, stream);
+}
+
+int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t Bt, int32_t Bv,
+                            int32_t Tn, int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return cc_loose_similarity_strided_f32(text, visual, video_mask, Tn, 1, Bt, Bv, Tn, E, logit_scale, logits, ldl,
+                                           pooled_out, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

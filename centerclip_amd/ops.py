@@ -49,16 +49,18 @@ def loose_similarity(text, visual, video_mask, logit_scale, return_pooled=False)
     L.require_device(text, visual, video_mask)
     text = text.float().contiguous()
     visual = visual.float().contiguous()
-    mask = video_mask.to(torch.long).contiguous()
+    mask = video_mask.to(torch.long)          # a strided int64 view (every fd-th frame of the frame mask) is used as is
     Bt, E = text.shape
     Bv, Tn, _ = visual.shape
+    assert mask.shape == (Bv, Tn)
     lib = L.lib()
     logits = torch.empty(Bt, Bv, device=text.device, dtype=torch.float32)
     pooled = torch.empty(Bv, E, device=text.device, dtype=torch.float32) if return_pooled else None
     ws = L.workspace(lib.cc_similarity_workspace_bytes(Bt, Bv, E), text.device)
-    L.check(lib.cc_loose_similarity_f32(L.ptr(text), L.ptr(visual), L.ptr(mask), Bt, Bv, Tn, E, float(logit_scale),
-                                        L.ptr(logits), Bv, L.ptr(pooled), L.ptr(ws), ws.numel(),
-                                        L.stream_ptr(text.device)), "cc_loose_similarity_f32")
+    L.check(lib.cc_loose_similarity_strided_f32(L.ptr(text), L.ptr(visual), L.ptr(mask), mask.stride(0), mask.stride(1),
+                                                Bt, Bv, Tn, E, float(logit_scale), L.ptr(logits), Bv, L.ptr(pooled),
+                                                L.ptr(ws), ws.numel(), L.stream_ptr(text.device)),
+            "cc_loose_similarity_strided_f32")
     return (logits, pooled) if return_pooled else logits
 
 

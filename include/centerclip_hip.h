@@ -365,6 +365,13 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
                             int32_t Bt, int32_t Bv, int32_t Tn, int32_t E, float logit_scale,
                             float* logits, int32_t ldl, float* pooled_out,
                             void* ws, size_t ws_bytes, void* stream);
+/* The same with the mask addressed through element strides (mask[v, t] = video_mask[v*row_stride + t*col_stride]):
+ * the segment mask after clustering is every fd-th column of the frame mask (clip4clip.py:436-447), taken as a strided
+ * view instead of a gathered copy. */
+int cc_loose_similarity_strided_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                    int64_t mask_row_stride, int64_t mask_col_stride, int32_t Bt, int32_t Bv,
+                                    int32_t Tn, int32_t E, float logit_scale, float* logits, int32_t ldl,
+                                    float* pooled_out, void* ws, size_t ws_bytes, void* stream);
 /* logits[Bt,Bv] = mult * a[Bt,E] b[Bv,E]^T for already-normalised rows (the sharded eval
  * similarity matrix, main.py:502-534, computed in one launch per row block). */
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult,

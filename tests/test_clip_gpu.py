@@ -425,6 +425,28 @@ def test_edge_similarity_shapes_and_masks():
         np.testing.assert_allclose(got[:, ~dead].numpy(), ref[:, ~dead].numpy(), rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize("Bt,Bv", [(5, 7), (80, 70)])          # one-launch tail / pooled + MFMA path
+def test_similarity_takes_the_segment_mask_as_a_strided_view(Bt, Bv):
+    """The mask after clustering is every fd-th column of the frame mask (clip4clip.py:436-447): the similarity entry reads it
+    through strides - same logits as with a gathered copy, and the NaN pattern of fully masked clips is kept."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(Bt * 100 + Bv)
+    T, Tn, E = 12, 3, 512
+    text = torch.randn(Bt, E, generator=gen).to(DEV)
+    vis = torch.randn(Bv, Tn, E, generator=gen).to(DEV)
+    frame_mask = (torch.rand(Bv, T, generator=gen) > 0.3).long()
+    frame_mask[0] = 0                                             # a fully masked clip
+    frame_mask = frame_mask.to(DEV)
+    view = frame_mask[:, T // Tn - 1::T // Tn]
+    assert not view.is_contiguous() and view.shape == (Bv, Tn)
+    a = ops.loose_similarity(text, vis, view, 0.7)
+    b = ops.loose_similarity(text, vis, view.contiguous(), 0.7)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    ref = clo.loose_similarity(text.cpu().view(Bt, 1, E), vis.cpu(), view.cpu().contiguous(), 0.7)
+    ok = ~torch.isnan(ref)
+    assert float((a.cpu()[ok] - ref[ok]).abs().max()) <= 1e-3 * float(torch.tensor(0.7).exp())
+
+
 def test_n3_uint8_frames_bit_identical_to_loader_path(g):
     """N3: uint8 frames (CHW and the decoder's HWC) through the fused normalise + patch gather give the same
     bits as the reference pipeline loader_normalize -> encode_image, and match the oracle forward."""
