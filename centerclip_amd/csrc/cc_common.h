@@ -38,6 +38,11 @@ __device__ __forceinline__ float cc_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, CC_WAVE));
     return v;
 }
+__device__ __forceinline__ int cc_wave_imax(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, CC_WAVE));
+    return v;
+}
 __device__ __forceinline__ unsigned long long cc_wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -17,14 +17,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ============================================================================ K0
 // One wave per token.  sqn = sum x^2 (fp32), nrm = sqrtf(sqn), inv = 1/(nrm + 1e-6).
 // If xn != nullptr also writes the pre-normalised token x/(nrm+1e-6) to a contiguous
-// [P,N,W] buffer (fast_kmeans.py:21-22).  Block 0 also resets the chunk-max keys.
+// [P,N,W] buffer (fast_kmeans.py:21-22).
 __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict__ x, cc_token_layout lay,
                                                          int P, int N, int W, float* __restrict__ sqn,
                                                          float* __restrict__ nrm, float* __restrict__ inv,
                                                          float* __restrict__ xn, int* __restrict__ chunkmax,
                                                          int nchunks) {
-    if (blockIdx.x == 0 && chunkmax)
-        for (int c = threadIdx.x; c < nchunks; c += 256) chunkmax[c] = (int)0x80000000;
+    (void)chunkmax; (void)nchunks;                           // (the chunk maxima are per-tile slots now: nothing to reset)
     const int lane = threadIdx.x & 63;
     // problem p on XCD p % 8 (workgroup b runs on XCD b % 8), the mapping of the distance kernels that follow: the
     // tokens this pass pulls into an XCD's L2 are the ones its Gram tiles read next
@@ -255,8 +254,11 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
             }
     }
     if (chunkmax) {
-        lmax = cc_wave_max(lmax);
-        if (lane == 0 && active) atomicMax(&chunkmax[p / chunk], cc_float_to_ordered_int(lmax));
+        // one slot per (problem, tile, wave), written unconditionally (idle waves: the key below every distance): the
+        // selection kernel reduces the slots of its chunk - no reset pass before this kernel, no atomics
+        lmax = cc_wave_max(active ? lmax : -3.0e38f);
+        if (lane == 0)
+            chunkmax[((int64_t)p * tiles_pp + (((int)blockIdx.x >> 3) % tiles_pp)) * 4 + wave] = cc_float_to_ordered_int(lmax);
     }
 }
 
@@ -368,8 +370,23 @@ __global__ __launch_bounds__(256) void lp_dist_kernel(const float* __restrict__ 
         }
     if (chunkmax) {
         lmax = cc_wave_max(lmax);
-        if (lane == 0 && lmax > -1.0e38f) atomicMax(&chunkmax[p / chunk], cc_float_to_ordered_int(lmax));
+        if (lane == 0)
+            chunkmax[((int64_t)p * tiles_pp + (((int)blockIdx.x >> 3) % tiles_pp)) * 4 + (tid >> 6)] = cc_float_to_ordered_int(lmax);
     }
+}
+
+// chunkmax[c] = max over the per-(problem, tile, wave) slots of the problems of chunk c (stand-alone distance path; the
+// fused path reduces the slots inside the selection kernel).  One workgroup per chunk.
+__global__ __launch_bounds__(256) void chunk_max_reduce_kernel(const int* __restrict__ slots, int slots_pp, int P, int chunk,
+                                                               int* __restrict__ chunkmax) {
+    __shared__ int red[4];
+    const int c = blockIdx.x, p0 = c * chunk, p1 = min(P, p0 + chunk);
+    int m = (int)0x80000000;
+    for (int64_t q = (int64_t)p0 * slots_pp + threadIdx.x; q < (int64_t)p1 * slots_pp; q += 256) m = max(m, slots[q]);
+    m = cc_wave_imax(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) chunkmax[c] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
 // Applies the all_negative shift / self_nearest diagonal to a raw distance tensor
@@ -493,7 +510,7 @@ __device__ __forceinline__ unsigned cc_wave_umin(unsigned v) {
 template <bool IN_LDS, int NE>
 __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __restrict__ dist_in, float* dist_rw,
                                                               const float* __restrict__ norms,
-                                                              const int* __restrict__ chunkmax, int chunk,
+                                                              const int* __restrict__ chunkmax, int slots_pp, int chunk,
                                                               int apply_shift, int N, int K, int iter_limit,
                                                               int id_sort, long long* __restrict__ medoids_out,
                                                               long long* __restrict__ assign_out,
@@ -524,7 +541,20 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     // ---- stage D: (d - chunk_max) - 1, then the diagonal - 1 (cluster_utils.py:35-41); 8 loads in flight
     // (when D stays in global memory the shift is applied on the fly by DREAD instead: a read-modify-write pass over
     // the N x N matrix used to be a quarter of this kernel at N = 392-588)
-    const float shift_mx = apply_shift ? cc_ordered_int_to_float(chunkmax[p / chunk]) : 0.f;
+    // torch.max(dis) over the problems of this problem's chunk (cluster_utils.py:36, fast_kmeans.py:127-135): the
+    // distance kernel left one maximum per (problem, tile, wave)
+    float shift_mx = 0.f;
+    if (apply_shift) {
+        int* red = reinterpret_cast<int*>(smem_raw);
+        const int c0 = (p / chunk) * chunk, c1 = min((int)gridDim.x, c0 + chunk);
+        int m = (int)0x80000000;
+        for (int64_t q = (int64_t)c0 * slots_pp + tid; q < (int64_t)c1 * slots_pp; q += 256) m = max(m, chunkmax[q]);
+        m = cc_wave_imax(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        shift_mx = cc_ordered_int_to_float(max(max(red[0], red[1]), max(red[2], red[3])));
+        __syncthreads();                                       // red[] is the start of the staged D / of best[]
+    }
     if (IN_LDS) {
         const float mx = shift_mx;
         float* dst = IN_LDS ? s.D : (dist_rw + base);
@@ -979,6 +1009,8 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
 namespace {
 
 struct ClusterWs {
+    int* tilemax;
+    int slots_pp;
     int* chunkmax;
     float* sqn;
     float* nrm;
@@ -998,7 +1030,12 @@ ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med) {
         off += cc_align_up(bytes, 256);
         return ptr;
     };
-    c.chunkmax = static_cast<int*>(take((size_t)P * 4));
+    {   // per-(problem, tile, wave) maxima of the distance kernel + the reduced per-chunk values (stand-alone path)
+        const size_t nt = (size_t)(N + GT - 1) / GT;
+        c.slots_pp = (int)(nt * (nt + 1) / 2 * 4);
+        c.tilemax = static_cast<int*>(take((size_t)P * c.slots_pp * 4));
+        c.chunkmax = static_cast<int*>(take((size_t)P * 4));
+    }
     c.sqn = static_cast<float*>(take((size_t)P * N * 4));
     c.nrm = static_cast<float*>(take((size_t)P * N * 4));
     c.inv = static_cast<float*>(take((size_t)P * N * 4));
@@ -1027,7 +1064,6 @@ cc_token_layout contiguous_layout(int P, int N, int W) {
 int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p, int chunk, int pre_norm,
                  const ClusterWs& c, hipStream_t st) {
     const int P = lay.B * lay.S, N = lay.fd * lay.n;
-    const int nchunks = (P + chunk - 1) / chunk;
     const int nb = ((P + 7) / 8) * 8 * ((N + 3) / 4);                  // token_norm_kernel: problem p on XCD p % 8
     if (pre_norm) {
         hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv, c.xn,
@@ -1038,11 +1074,9 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     // the Gram kernels produce the row norms themselves (of the pre-normalised copy when pre_norm made one above);
     // the Minkowski kernels (no Gram) keep the separate norm pass
     const bool own_norms = (metric == CC_METRIC_COSINE || p == 2.0f);
-    if (own_norms) {
-        if (hipMemsetAsync(c.chunkmax, 0x80, (size_t)nchunks * sizeof(int), st) != hipSuccess) return CC_ERR_HIP;   // keys << any distance
-    } else {
+    if (!own_norms) {
         hipLaunchKernelGGL(token_norm_kernel, dim3(nb), dim3(256), 0, st, x, lay, P, N, W, c.sqn, c.nrm, c.inv,
-                           (float*)nullptr, c.chunkmax, nchunks);
+                           (float*)nullptr, (int*)nullptr, 0);
         CC_LAUNCH_CHECK();
     }
     const int nt = (N + GT - 1) / GT;
@@ -1061,22 +1095,22 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     }
     if (metric == CC_METRIC_COSINE) {
         hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_COSINE>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.nrm,
-                           c.inv, own_norms ? 1 : 0, c.draw, c.chunkmax, chunk, nt, P);
+                           c.inv, own_norms ? 1 : 0, c.draw, c.tilemax, chunk, nt, P);
     } else if (p == 2.0f) {
         hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_EUCLIDEAN>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn,
-                           c.nrm, c.inv, own_norms ? 1 : 0, c.draw, c.chunkmax, chunk, nt, P);
+                           c.nrm, c.inv, own_norms ? 1 : 0, c.draw, c.tilemax, chunk, nt, P);
     } else if (p == 1.0f) {
-        hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
+        hipLaunchKernelGGL(lp_dist_kernel<1>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.tilemax, chunk, nt, P);
     } else if (p > 3.0e38f) {
-        hipLaunchKernelGGL(lp_dist_kernel<2>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
+        hipLaunchKernelGGL(lp_dist_kernel<2>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.tilemax, chunk, nt, P);
     } else {
-        hipLaunchKernelGGL(lp_dist_kernel<0>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.chunkmax, chunk, nt, P);
+        hipLaunchKernelGGL(lp_dist_kernel<0>, grid, dim3(256), 0, st, x, lay, N, W, p, c.draw, c.tilemax, chunk, nt, P);
     }
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
-int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int chunk,
+int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int slots_pp, int chunk,
                int apply_shift, int P, int N, int K, int iter_limit, int id_sort, long long* med, long long* assign,
                int* iters, hipStream_t st) {
     const size_t lds_limit = 160 * 1024;
@@ -1090,7 +1124,7 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
         if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return CC_ERR_HIP;                                                                                         \
-        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, chunk, apply_shift,  \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, slots_pp, chunk, apply_shift, \
                            N, K, iter_limit, id_sort, med, assign, iters);                                            \
     } while (0)
     if (in_lds) {
@@ -1154,6 +1188,11 @@ int cc_pairwise_distance_f32(const float* x, const cc_token_layout* lay, int32_t
     if (all_negative || self_nearest) {
         const int64_t total = (int64_t)P * N * N;
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (all_negative) {
+            hipLaunchKernelGGL(chunk_max_reduce_kernel, dim3((P + chunk - 1) / chunk), dim3(256), 0, st, c.tilemax, c.slots_pp,
+                               P, chunk, c.chunkmax);
+            CC_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(shift_dist_kernel, dim3(blocks), dim3(256), 0, st, dist, P, N, c.chunkmax, chunk,
                            all_negative, self_nearest);
         CC_LAUNCH_CHECK();
@@ -1167,7 +1206,7 @@ int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, 
     (void)ws; (void)ws_bytes;
     if (!dist || !norms || !medoids || P <= 0 || N <= 0 || K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
     if (N > SEL_MAX_N) return CC_ERR_UNSUPPORTED;
-    return run_select(dist, nullptr, norms, nullptr, 1, 0, P, N, K, iter_limit, id_sort,
+    return run_select(dist, nullptr, norms, nullptr, 0, 1, 0, P, N, K, iter_limit, id_sort,
                       reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters,
                       static_cast<hipStream_t>(stream));
 }
@@ -1189,7 +1228,7 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = run_distance(x, *lay, W, metric, norm_p, split_size, pre_norm, c, st);
     if (rc != CC_OK) return rc;
-    return run_select(c.draw, c.draw, c.nrm, c.chunkmax, split_size, 1, P, N, K, iter_limit, id_sort,
+    return run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, iter_limit, id_sort,
                       reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st);
 }
 
