@@ -84,6 +84,27 @@ def event_time_ms(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
+def graph_time_ms(fn, launches=20, replays=4):
+    """Average duration of one launch of `fn`: `launches` of them captured into one hipGraph, replayed with HIP events
+    around the replays on the launch stream - the same way the step itself is issued, so the interval holds the kernels
+    and the graph's own launch-to-launch gaps, not the host's eager launch cadence.  Falls back to eager launches."""
+    try:
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(launches):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        return event_time_ms(g.replay, replays, warm=1) / launches
+    except Exception as exc:                   # noqa: BLE001
+        sys.stderr.write("graph timing failed (%s); timing eager launches\n" % exc)
+        torch.cuda.synchronize()
+        return event_time_ms(fn, launches)
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/pmc.sh -> profiles/*traffic_pmc.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE);
@@ -103,8 +124,8 @@ def pmc_traffic(kernel):
 
 
 def gemm_roofline(c, device):
-    """Time every distinct GEMM of one step alone (HIP events on the launch stream, back-to-back
-    launches) and return the dominant one.  Algorithmic flops = 2*M*N*K."""
+    """Time every distinct GEMM of one step alone (HIP events on the launch stream around replays of a hipGraph of
+    back-to-back launches) and return the dominant one.  Algorithmic flops = 2*M*N*K."""
     from centerclip_amd import ops
     W, B, T = c["width"], c["B"], c["T"]
     L0, L1 = 50, c["K"] + 1
@@ -137,7 +158,7 @@ def gemm_roofline(c, device):
         else:
             out = torch.zeros(M, N, device=device, dtype=torch.float32)
             fn = lambda a=a, w=w, bias=bias, out=out, epi=epi: ops.linear_f16(a, w, bias, epi, out=out)
-        ms = event_time_ms(fn, 20)
+        ms = graph_time_ms(fn)
         flops = 2.0 * M * N * K
         rows.append(dict(kernel="gemm_f16_kernel:" + name, M=M, N=N, K=K, calls_per_step=calls, avg_us=ms * 1e3,
                          tflops=flops / ms / 1e9, step_share_us=ms * 1e3 * calls))
