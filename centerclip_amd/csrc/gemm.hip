@@ -15,6 +15,8 @@
 // bias + residual add -> fp32 in place (out_proj / c_proj), + positional embedding with the
 // patch-row -> token-row remap (conv1 as im2col GEMM, modules/clip.py:282,324-336).
 #include "cc_kernels.h"
+#include <cstring>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 
@@ -599,7 +601,14 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
         tile = pick_tile(g0, epi);
-        {   // tuning aid: CC_TILE_E<epi>_<S|B>=<tile> overrides the choice for small (M < 5000) / big problems
+        // tuning aid: CC_TILE_E<epi>_<S|B>[_K<k>]=<tile> overrides the choice for small (M < 5000) / big problems; the
+        // environment is scanned once, the per-launch look-ups only happen when such a variable exists
+        static const bool any_override = [] {
+            for (char** e = environ; e && *e; ++e)
+                if (!strncmp(*e, "CC_TILE_", 8)) return true;
+            return false;
+        }();
+        if (any_override) {
             char name[32];
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
