@@ -315,6 +315,49 @@ def test_edge_maximum_tokens_per_problem(cl):
         cl.batch_fast_kmedoids_with_split(dev(lattice(305, (1, 1024, 16))), 12)
 
 
+def _sweep_cases():
+    """32 seeded (P, N, W, K, split) draws: problem counts that are not multiples of the XCD count or of the split size, N
+    around the 64-token chunk / 8-float vector / 197-token LDS boundaries, K from 1 to N."""
+    rng = np.random.default_rng(20260928)
+    edge_n = [2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 191, 192, 196, 197, 198, 255, 256, 257, 300]
+    out = []
+    for c in range(32):
+        N = int(edge_n[c]) if c < len(edge_n) else int(rng.integers(2, 301))
+        P = int(rng.integers(1, 21))
+        W = int(rng.integers(1, 25)) * 4
+        K = int(rng.integers(1, min(N, 40) + 1)) if c % 5 else min(N, 40)
+        split = int(rng.choice([1, 3, 4, 16]))
+        out.append((c, P, N, W, K, split))
+    return out
+
+
+@pytest.mark.parametrize("c,P,N,W,K,split", _sweep_cases())
+def test_random_shape_sweep_matches_oracle(cl, c, P, N, W, K, split):
+    """Seeded sweep over problem shapes on lattice tokens (exactly representable distances, parity level P1): medoids and
+    assignment equal the oracle's, bit for bit, for every draw."""
+    X = lattice(7000 + c, (P, N, W))
+    if split > 1:
+        a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, split_size=split)
+    else:
+        a, m = cl.batch_fast_kmedoids(dev(X), K, threshold=1e-6, iter_limit=100)
+        split = max(P, 1)
+    ao, mo = _exact_oracle_indices(X, K, split=split)
+    assert np.array_equal(m.cpu().numpy(), mo), (P, N, W, K, split)
+    assert np.array_equal(a.cpu().numpy(), ao), (P, N, W, K, split)
+
+
+@pytest.mark.parametrize("c,P,N,W,K,split", [t for t in _sweep_cases() if t[0] % 3 == 0])
+def test_random_shape_sweep_l1_matches_oracle(cl, c, P, N, W, K, split):
+    """The same draws with the shipped MSR-VTT setting norm_p = 1 on dyadic tokens (parity level P2: |x - y| sums are exact
+    in fp32 there, so the direct Minkowski kernel and ATen's cdist agree bit for bit)."""
+    X = dyadic(7100 + c, (P, N, W))
+    split = max(split, 2)
+    a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, norm_p=1.0, split_size=split)
+    ao, mo = _oracle_indices(X, K, p=1.0, split=split)
+    assert np.array_equal(m.cpu().numpy(), mo), (P, N, W, K, split)
+    assert np.array_equal(a.cpu().numpy(), ao), (P, N, W, K, split)
+
+
 def test_edge_iteration_limit_is_honoured(cl):
     """iter_limit = 1 / 2: the state after exactly that many assignment/update rounds, as in the reference."""
     X = lattice(306, (3, 90, 24))
