@@ -891,12 +891,55 @@ struct CascadeSum {
     }
 };
 
+// Sum over the rows for one float4 of columns, in the association ATen uses for THAT column (vectorized_outer_sum):
+// columns inside the last full group of 32 -> the plain cascade above; columns behind it (only when W % 32 != 0, which no
+// width of the model family has) -> row_sum: four cascades interleaved over the rows (row r -> cascade r % 4 at position
+// r / 4), then cascade 0, the up to three left-over rows in order, cascades 1..3.
+template <bool LEFT>
+struct OuterSum {
+    CascadeSum s0;
+    CascadeSum s1, s2, s3;                                    // (dead unless LEFT)
+    float4 l0, l1, l2;
+    bool ilp;
+    int rows4;
+    __device__ __forceinline__ void init(bool left_columns, int rows) {
+        s0.init();
+        ilp = LEFT && left_columns;
+        rows4 = (rows >> 2) << 2;
+        if (LEFT) {
+            s1.init(); s2.init(); s3.init();
+            l0 = l1 = l2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void add(int row, const float4& v) {
+        if (!LEFT || !ilp) { s0.add(row, v); return; }
+        if (row >= rows4) {                                   // left-over rows: kept apart, added one by one in total()
+            const int t = row - rows4;
+            if (t == 0) l0 = v; else if (t == 1) l1 = v; else l2 = v;
+            return;
+        }
+        const int a = row & 3, r = row >> 2;
+        if (a == 0) s0.add(r, v); else if (a == 1) s1.add(r, v); else if (a == 2) s2.add(r, v); else s3.add(r, v);
+    }
+    __device__ __forceinline__ float4 total(int rows) {
+        if (!LEFT || !ilp) return s0.total(rows);
+        const int size = rows >> 2;
+        float4 r = s0.total(size);
+        CascadeSum::acc(r, l0); CascadeSum::acc(r, l1); CascadeSum::acc(r, l2);       // absent rows are exact zeros
+        float4 t = s1.total(size); CascadeSum::acc(r, t);
+        t = s2.total(size); CascadeSum::acc(r, t);
+        t = s3.total(size); CascadeSum::acc(r, t);
+        return r;
+    }
+};
+
 // One wave per output row.  mode 0: K medoid tokens (cluster.py:289; med_stride 0 = the same ids for every problem,
 // 'sparse_sampling' :326-343); mode 1: K cluster means (cluster.py:291-301:
 // sum(res_tmp * mask, dim=1) / sum(mask), empty cluster -> 0/0 = NaN as in the reference); mode 2: 'pooling'
 // (cluster.py:319-324: every token, CLS included, = mean over the segment's frames).  Row 0 of modes 0/1 is the mean
 // of the segment's CLS tokens (cluster.py:307-308), optionally scaled per frame (adaptive_cls, :244-245);
 // cluster_embed [K,W] is added to rows 1..K (:304-305).
+template <bool LEFT>
 __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restrict__ x, int64_t in_tok, int64_t in_frame,
                                                             int B, int T, int T_new, int n, int W, int K, int mode,
                                                             const long long* __restrict__ medoids, int med_stride,
@@ -936,8 +979,8 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
         const float* src = seg0 + (int64_t)l * in_tok;
         const float den = (float)fd;
         for (int w = lane * 4; w < W; w += 256) {
-            CascadeSum cs;
-            cs.init();
+            OuterSum<LEFT> cs;
+            cs.init(w >= (W & ~31), fd);
             for (int f = 0; f < fd; ++f) {
                 float4 v = *reinterpret_cast<const float4*>(src + (int64_t)f * in_frame + w);
                 if (cls_mult && l == 0 && mode != 2) {
@@ -979,8 +1022,8 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
     const float den = (float)count;
     for (int w0 = 0; w0 < W; w0 += 256) {                         // wave-uniform trip count; lanes past W idle
         const int w = w0 + lane * 4;
-        CascadeSum cs;
-        cs.init();
+        OuterSum<LEFT> cs;
+        cs.init(w >= (W & ~31), N);
         for (int j0 = 0; j0 < N; j0 += 64) {
             unsigned long long m = __ballot(j0 + lane < N && as[j0 + lane] == k);
             while (m) {
@@ -1247,7 +1290,7 @@ int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
     const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(medoids), K,
                        (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
                        out_frame_stride, row_h16, row_stats);
@@ -1272,7 +1315,7 @@ int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_fra
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
     const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 1, (const long long*)nullptr, 0,
                        reinterpret_cast<const long long*>(assign), var ? var->cluster_embed : nullptr,
                        var ? var->cls_multiplier : nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats);
@@ -1296,7 +1339,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     const int fd = T / T_new;
     if (var->algorithm == CC_CLUSTER_POOLING) {                 // no selection: every token = mean over the segment's frames
         const int rows = B * T_new * (1 + n);
-        hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+        hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, n, 2, (const long long*)nullptr, 0, (const long long*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats);
         CC_LAUNCH_CHECK();
@@ -1305,7 +1348,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     if (var->algorithm == CC_CLUSTER_SPARSE_SAMPLING) {         // fixed ids shared by every problem, then gather + CLS mean
         if (!var->fixed_ids || K <= 0) return CC_ERR_INVALID;
         const int rows = B * T_new * (1 + K);
-        hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+        hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(var->fixed_ids), 0,
                            (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
                            out_frame_stride, row_h16, row_stats);
@@ -1331,7 +1374,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
                                    pre_norm, med, asg, iters, ws, ws_bytes, stream);
     if (rc != CC_OK) return rc;
     const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL(reduce_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
+    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
                        T, T_new, n, W, K, mean ? 1 : 0, reinterpret_cast<const long long*>(med), K,
                        reinterpret_cast<const long long*>(asg), var->cluster_embed, var->cls_multiplier, out,
                        out_tok_stride, out_frame_stride, row_h16, row_stats);

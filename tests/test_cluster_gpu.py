@@ -170,6 +170,84 @@ def test_c1_token_cluster_module(cl, cluster_golden, tag):
     assert med.shape == (B * T_new, K) and (np.diff(med, axis=1) > 0).all()
 
 
+def _module_sweep_cases():
+    rng = np.random.default_rng(20260929)
+    out = []
+    for c in range(14):
+        T_new = int(rng.choice([1, 2, 3, 4]))
+        fd = int(rng.choice([1, 2, 3, 4, 6]))
+        g = int(rng.choice([2, 3, 4, 7]))
+        n, T = g * g, T_new * fd
+        B = int(rng.integers(1, 6))
+        W = int(rng.integers(1, 13)) * 8
+        K = int(rng.integers(1, min(fd * n, 30) + 1))
+        if fd == 1 and K >= n:                      # the module only exists when frames or tokens shrink (cluster.py:32-34)
+            K = n - 1
+        out.append((c, B, T, T_new, n, W, K, int(rng.choice([2, 4, 16]))))
+    return out
+
+
+@pytest.mark.parametrize("c,B,T,T_new,n,W,K,split", _module_sweep_cases())
+def test_c1_module_shape_sweep_matches_oracle(cl, c, B, T, T_new, n, W, K, split):
+    """Seeded sweep over (B, T, T_new, n, W, K): regrouping of frames into segments, clustering, medoid gather, CLS mean and
+    restack give the literal oracle's output tensor bit for bit (lattice patches, generic CLS rows)."""
+    x = lattice(7200 + c, (1 + n, B * T, W))
+    x[0] = fullmant(7300 + c, (B * T, W))
+    mod = cl.TokenClusterInter(algorithm="kmediods++", block_id=7, before_cluster_num=n, cluster_num=K,
+                               before_block_frames=T, after_block_frames=T_new, original_frame=T,
+                               distance="euclidean", threshold=1e-6, iter_limit=100, id_sort=True,
+                               aggregation=None, split_size=split, norm_p=2.0, transformer_width=W)
+    y, res = mod(dev(x))
+    # expected tensor: the oracle's regrouping / gather / CLS mean (cluster.py:239-260,289,303-310) around the medoids of
+    # select_streamlined on the correctly rounded distances (see _exact_oracle_indices for why not ATen's sqrt here)
+    fd = T // T_new
+    tokens, cls = co.regroup_segments(torch.from_numpy(x), T, T_new)
+    _, med = _exact_oracle_indices(tokens.numpy(), K, split=split)
+    P = tokens.shape[0]
+    picked = tokens[torch.arange(P).unsqueeze(-1), torch.from_numpy(med)]
+    picked = picked.reshape(T_new, B, K, W).permute(1, 0, 2, 3).reshape(B * T_new, K, W)
+    seg_cls = torch.stack([c_.mean(dim=1) for c_ in torch.split(cls, fd, dim=1)], dim=1)
+    ref = torch.cat([seg_cls.reshape(B * T_new, 1, W), picked], dim=1).permute(1, 0, 2).contiguous()
+    assert res is None and tuple(y.shape) == (1 + K, B * T_new, W)
+    assert np.array_equal(mod.last_medoids.cpu().numpy() if mod.last_medoids is not None else med, med)
+    assert np.array_equal(y.cpu().numpy(), ref.numpy()), (B, T, T_new, n, W, K, split)
+
+
+@pytest.mark.parametrize("c,B,T,T_new,n,W,K,split", _module_sweep_cases())
+def test_n2_mean_and_pooling_shape_sweep(cl, c, B, T, T_new, n, W, K, split):
+    """The same draws through the cluster-mean aggregation (given the oracle's assignment) and through 'pooling', on generic
+    floats: exact equality needs ATen's association of the sum over tokens / frames for EVERY column - the cascade for the
+    columns inside full groups of 32 and the four-way interleaved row_sum behind them (widths that are not multiples of 32)."""
+    import ctypes
+    from centerclip_amd import _lib as L
+    x = fullmant(7400 + c, (1 + n, B * T, W))
+    xt = torch.from_numpy(x)
+    fd = T // T_new
+    # pooling: every token = mean over the segment's frames
+    mod = cl.TokenClusterInter(algorithm="pooling", block_id=7, before_cluster_num=n, cluster_num=n,
+                               before_block_frames=T, after_block_frames=T_new, original_frame=T,
+                               transformer_width=W).to(DEV).eval()
+    if fd > 1:
+        y, _ = mod(dev(x))
+        ref = co.literal_token_cluster_variant(xt, T, T_new, n, algorithm="pooling")
+        assert np.array_equal(y.cpu().numpy(), ref.numpy()), ("pooling", B, T, T_new, n, W)
+    # cluster means given an assignment (a seeded random one: every cluster size from empty to large occurs)
+    rng = np.random.default_rng(7500 + c)
+    asg = rng.integers(0, K, size=(B * T_new, fd * n)).astype(np.int64)
+    med = np.zeros((B * T_new, K), np.int64)
+    ref = co.literal_token_cluster_variant(xt, T, T_new, K, aggregation="mean", assign=torch.from_numpy(asg),
+                                           medoids=torch.from_numpy(med))
+    agg = cl.TokenClusterInter(algorithm="kmediods++", block_id=7, before_cluster_num=n, cluster_num=K,
+                               before_block_frames=T, after_block_frames=T_new, original_frame=T, aggregation="mean",
+                               transformer_width=W).to(DEV).eval()
+    xd = dev(x)
+    out = torch.empty(1 + K, B * T_new, W, device=DEV)
+    var, keep = agg.variant(fd * n, xd.device)
+    L.check(L.lib().cc_token_aggregate_f32(L.ptr(xd), B * T * W, W, B, T, T_new, n, W, K, L.ptr(dev(asg)), ctypes.byref(var),
+                                           L.ptr(out), B * T_new * W, W, L.stream_ptr(xd.device)), "aggregate")
+    assert np.array_equal(out.cpu().numpy(), ref.numpy(), equal_nan=True), ("mean", B, T, T_new, n, W, K)
+
+
 # ------------------------------------------------------------------------------- P3 + properties
 def _objective(D, med, assign):
     P = D.shape[0]
