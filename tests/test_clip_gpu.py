@@ -178,6 +178,59 @@ def test_attention(nseq, L, heads, causal):
     assert float((y.double() - ref).abs().max()) < 4e-3 * float(ref.abs().max())
 
 
+def _attention_sweep():
+    rng = np.random.default_rng(20260930)
+    edge_l = [1, 2, 15, 16, 17, 31, 32, 33, 48, 49, 50, 55, 56, 57, 63, 64, 65, 100, 128, 129, 197, 255, 256]
+    return [(int(rng.integers(1, 9)), int(L), int(rng.integers(1, 5)), bool(rng.integers(0, 2))) for L in edge_l]
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", _attention_sweep())
+def test_attention_length_sweep(nseq, L, heads, causal):
+    """Sequence lengths around the 16-row query tiles, the 56-token switch between the wave and the workgroup kernel and
+    the 256-token limit, with and without the causal mask."""
+    test_attention(nseq, L, heads, causal)
+
+
+def _gemm_sweep():
+    rng = np.random.default_rng(20261001)
+    out = []
+    for c in range(28):
+        M = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 1000, 2400]))
+        N = int(rng.integers(1, 17)) * 64
+        K = int(rng.integers(1, 17)) * 64
+        epi = str(rng.choice(["f16", "f16_gelu", "f32", "f32_resid"]))
+        tiles = [t for t in (1, 2, 3, 4, 5, 6, 7, 8) if N % {1: 128, 2: 64, 3: 128, 4: 64, 5: 256, 6: 128, 7: 192, 8: 64}[t] == 0
+                 and (t != 7 or epi.startswith("f16")) and (t != 8 or K % 128 == 0)]
+        out.append((c, M, N, K, epi, int(rng.choice(tiles))))
+    return out
+
+
+@pytest.mark.parametrize("c,M,N,K,epi,tile", _gemm_sweep())
+def test_linear_f16_shape_sweep(c, M, N, K, epi, tile):
+    """Seeded sweep over (M, N, K, epilogue, tile): ragged last row tiles, single-tile problems, every tile shape the
+    dispatcher can be forced to; the automatic choice must give the forced tile's result (same k order) bit for bit."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(9000 + c)
+    a = torch.randn(M, K, generator=gen).half()
+    w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
+    bias = torch.randn(N, generator=gen)
+    ref = a.double() @ w.double().t() + bias.double()
+    resid = torch.randn(M, N, generator=gen)
+    outs = []
+    for t in (tile, 0):
+        if epi == "f32_resid":
+            out = resid.to(DEV).clone()
+            ops.linear_f16(a.to(DEV), w.to(DEV), bias.to(DEV), epi, out=out, tile=t)
+            want, tol = ref + resid.double(), 2e-4
+        else:
+            out = ops.linear_f16(a.to(DEV), w.to(DEV), bias.to(DEV), epi, tile=t)
+            want = ref * torch.sigmoid(1.702 * ref) if epi == "f16_gelu" else ref
+            tol = 2e-4 if epi == "f32" else 2e-3
+        assert relerr(out.float().cpu(), want) < tol, (M, N, K, epi, t)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]), (M, N, K, epi, tile)
+
+
 # ------------------------------------------------------------------------------- small model vs reference goldens
 def small_model(g, cluster):
     from centerclip_amd.clip import build_clip_model
@@ -377,6 +430,38 @@ def test_vitb16_shape_against_fp32_oracle():
     d = float((nrm(feat.cpu()) - nrm(ref)).abs().max())
     print(f"[ViT-B/16 12f] max|delta| normalised embedding = {d:.2e}")
     assert d <= 1e-3
+
+
+def _similarity_sweep():
+    rng = np.random.default_rng(20261002)
+    return [(c, int(rng.integers(1, 130)), int(rng.integers(1, 130)), int(rng.integers(1, 9)), int(rng.choice([64, 128, 512, 1024])))
+            for c in range(16)]
+
+
+@pytest.mark.parametrize("c,Bt,Bv,Tn,E", _similarity_sweep())
+def test_similarity_and_rank_shape_sweep(c, Bt, Bv, Tn, E):
+    """Seeded sweep over (Bt, Bv, T_new, E): both forms of the meanP similarity (one-launch tail for Bt x Bv <= 4096, pooled
+    + exact-fp32 MFMA GEMM above) against the oracle within 1e-3 of the logit scale, random masks with fully masked clips;
+    then the rank counts of the result against a NumPy count, exactly."""
+    from centerclip_amd import ops
+    from centerclip_amd.metrics import rank_counts
+    gen = torch.Generator().manual_seed(9100 + c)
+    text, vis = torch.randn(Bt, E, generator=gen), torch.randn(Bv, Tn, E, generator=gen)
+    mask = (torch.rand(Bv, Tn, generator=gen) > 0.25).long()
+    if Bv > 2:
+        mask[1] = 0
+    logits = ops.loose_similarity(text.to(DEV), vis.to(DEV), mask.to(DEV), 1.3)
+    ref = clo.loose_similarity(text.view(Bt, 1, E), vis, mask, 1.3)
+    got = logits.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    assert float((got[ok] - ref[ok]).abs().max()) <= 1e-3 * float(torch.tensor(1.3).exp())
+    sim = torch.nan_to_num(logits, nan=-1e30)
+    R = min(Bt, Bv)
+    counts = rank_counts(sim[:R].contiguous()).cpu().numpy()
+    sn = sim[:R].cpu().numpy()
+    d = sn[np.arange(R), np.arange(R)]
+    assert np.array_equal(counts[:, 0], (sn > d[:, None]).sum(1)) and np.array_equal(counts[:, 1], (sn == d[:, None]).sum(1))
 
 
 def test_n1_retrieval_metrics_match_reference(g):
