@@ -405,6 +405,65 @@ def test_vitb32_activitynet_shape_against_fp32_oracle():
     assert d <= 1e-3
 
 
+def _model_sweep():
+    rng = np.random.default_rng(20261003)
+    out = []
+    for c in range(8):
+        heads = int(rng.integers(1, 4))
+        layers = int(rng.integers(2, 5))
+        patch, res = (16, 64) if rng.integers(0, 2) else (32, 96)
+        n = (res // patch) ** 2
+        T_new = int(rng.choice([1, 2, 3]))
+        fd = int(rng.choice([1, 2, 4]))
+        K = int(rng.integers(1, min(fd * n, 12) + 1))
+        if fd == 1 and K >= n:
+            K = n - 1
+        cblock = int(rng.integers(2, layers + 1))            # 1-based block whose input is clustered (block 1 cannot be:
+        #                                                      its 'tokens before' is cluster_num_blocks[0] itself, cluster.py:26-27)
+        theads = int(rng.integers(1, 3))
+        out.append((c, heads, layers, patch, res, T_new * fd, T_new, K, cblock, theads, int(rng.integers(2, 5)),
+                    int(rng.integers(4, 21)), int(rng.integers(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("c,heads,layers,patch,res,T,T_new,K,cblock,theads,tlayers,Lt,B", _model_sweep())
+def test_small_model_sweep_against_fp32_oracle(c, heads, layers, patch, res, T, T_new, K, cblock, theads, tlayers, Lt, B):
+    """Seeded sweep over tiny CLIP configurations (widths 64-192, 2-4 blocks, 16- and 32-pixel patches, the cluster block
+    anywhere, text towers shorter and longer than the visual one so the paired launches run out on either side): both
+    towers through the fused forward vs the plain fp32 oracle given the HIP path's own medoids, <= 1e-3 on the
+    normalised embeddings."""
+    from centerclip_amd.clip import CLIP
+    torch.manual_seed(100 + c)
+    W, Wt, n = heads * 64, theads * 64, (res // patch) ** 2
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=T,
+                     target_frames_blocks=[T] * (cblock - 1) + [T_new] * (layers - cblock + 1),
+                     cluster_num_blocks=[n] * (cblock - 1) + [K] * (layers - cblock + 1),
+                     cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/%d' % patch, aggregation=None, pre_norm=False)
+    model = CLIP(64, res, layers, W, patch, 24, 1000, Wt, theads, tlayers, video_frames=T, args=args)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.copy_(prm.half().float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    video = torch.randn(B * T, 3, res, res)
+    feat, _ = model.visual.encode(video.to(DEV), T, want_medoids=True)
+    med = model.visual.last_medoids.cpu()
+    assert feat.shape == (B * T_new, 64) and med.shape == (B * T_new, K)
+    ref = clo.visual_forward(sd, video, T, cluster_plan={cblock - 1: (T_new, K)}, forced_medoids={cblock - 1: med})
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    ids = torch.zeros(B, Lt, dtype=torch.long)
+    for b in range(B):
+        ln = min(Lt, 3 + b)
+        ids[b, 0], ids[b, ln - 1] = 998, 999
+        ids[b, 1:ln - 1] = torch.randint(1, 997, (max(ln - 2, 0),))
+    tfeat = model.encode_text(ids.to(DEV)).cpu()
+    assert float((nrm(tfeat) - nrm(clo.text_forward(sd, ids))).abs().max()) <= 1e-3
+    # the paired encode of both towers gives the separate encodes' values
+    both_v, both_t = model.encode_pair(video.to(DEV), ids.to(DEV), video_frame=T)
+    assert torch.equal(both_v.cpu(), feat.cpu()) and torch.equal(both_t.cpu(), tfeat)
+
+
 def test_vitb16_shape_against_fp32_oracle():
     """BASELINE.json configs[4] shape, one clip: ViT-B/16 (196 tokens per frame, L = 197: the long-sequence attention
     kernel), 12 frames -> 4 segments at block 7, K = 100: 4 problems of N = 588 tokens.  HIP vs the fp32 CPU oracle given
