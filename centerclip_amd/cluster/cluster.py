@@ -31,7 +31,8 @@ def get_cluster_inter(width, block_id, args=None):
                              aggregation=getattr(args, 'aggregation', None),
                              split_size=4 if args.pretrained_clip_name == 'ViT-B/16' else 16,
                              cluster_embedding=getattr(args, 'cluster_embedding', False),
-                             adaptive_cls=getattr(args, 'adaptive_cls', False),
+                             cluster_frame_embedding=getattr(args, 'cluster_frame_embedding', False),
+                             adaptive_cls=False,          # hard-coded in the reference too (cluster.py:59)
                              transformer_width=width, pre_norm=getattr(args, 'pre_norm', False))
 
 
@@ -41,8 +42,10 @@ class TokenClusterInter(torch.nn.Module):
 
     Built: 'kmediods++' with aggregation None (medoid tokens, the shipped scripts) or any other value (cluster
     means, cluster.py:291-301), cluster_embedding, adaptive_cls; 'pooling'; 'sparse_sampling' in eval mode.
-    'spectral', the shift algorithms, cluster_frame_embedding (dead code in the reference, :283-285) and
-    mean_residual raise NotImplementedError at construction.
+    cluster_frame_embedding is accepted the way the reference treats it: the parameter exists (checkpoints that carry
+    `cluster_frame_embed` load) and the forward does not use it (its use is commented out, :283-285).
+    'spectral', the shift algorithms and mean_residual (not reachable from the reference's arguments) raise
+    NotImplementedError at construction.
     """
 
     def __init__(self, algorithm='kmediods++', block_id=1, before_cluster_num=49, cluster_num=49,
@@ -57,14 +60,17 @@ class TokenClusterInter(torch.nn.Module):
         if algorithm not in ('kmediods++', 'pooling', 'sparse_sampling'):
             raise NotImplementedError("centerclip_amd builds cluster_algo 'kmediods++', 'pooling' and "
                                       "'sparse_sampling' (got %r)" % algorithm)
-        if cluster_frame_embedding or mean_residual:
-            raise NotImplementedError("cluster_frame_embedding / mean_residual are not built")
+        if mean_residual:
+            raise NotImplementedError("mean_residual is not built")
         kmed = algorithm == 'kmediods++'
         self.cluster_embedding = bool(cluster_embedding) if kmed else False      # cluster.py:154-156
         self.adaptive_cls = bool(adaptive_cls) if kmed else False
         scale = transformer_width ** -0.5
         if self.cluster_embedding:                                                # cluster.py:161-164
             self.cluster_embed = torch.nn.Parameter(scale * torch.randn(cluster_num, transformer_width))
+        if bool(cluster_frame_embedding) and kmed:                                # cluster.py:155,167-169 (unused in forward)
+            self.cluster_frame_embed = torch.nn.Parameter(
+                scale * torch.randn(before_block_frames // after_block_frames, transformer_width).unsqueeze(1))
         if self.adaptive_cls:                                                     # cluster.py:170-172
             m = [1 / (before_block_frames // after_block_frames) for _ in range(before_block_frames)]
             self.cls_multiplier = torch.nn.Parameter(torch.tensor(m).float().reshape(1, before_block_frames, 1, 1))

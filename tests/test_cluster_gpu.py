@@ -498,9 +498,20 @@ def test_n2_variants_match_reference(cl, cluster_variants_golden, tag):
         assert np.array_equal(out.cpu().numpy(), want, equal_nan=True), tag
 
 
+def test_cluster_frame_embedding_is_a_parameter_the_forward_ignores(cl):
+    """As in the reference (cluster.py:155,167-169 create it, :283-285 - its use - is commented out): checkpoints that
+    carry `cluster_frame_embed` load, and the output equals the plain module's."""
+    kw = dict(algorithm="kmediods++", before_cluster_num=16, cluster_num=5, before_block_frames=6, after_block_frames=2,
+              original_frame=6, transformer_width=32, split_size=4)
+    plain = cl.TokenClusterInter(**kw).to(DEV).eval()
+    withfe = cl.TokenClusterInter(cluster_frame_embedding=True, **kw).to(DEV).eval()
+    assert tuple(withfe.cluster_frame_embed.shape) == (3, 1, 32) and "cluster_frame_embed" in withfe.state_dict()
+    x = dev(lattice(411, (17, 12, 32)))
+    assert torch.equal(plain(x)[0], withfe(x)[0])
+
+
 def test_n2_unbuilt_variants_fail_loudly(cl):
-    for kw in (dict(algorithm="spectral"), dict(algorithm="token_shift"), dict(mean_residual=True),
-               dict(cluster_frame_embedding=True)):
+    for kw in (dict(algorithm="spectral"), dict(algorithm="token_shift"), dict(mean_residual=True)):
         with pytest.raises(NotImplementedError):
             cl.TokenClusterInter(**kw)
     mod = cl.TokenClusterInter(algorithm="sparse_sampling", cluster_num=20, before_block_frames=12, after_block_frames=3,
