@@ -33,6 +33,7 @@ struct GemmArgs {
 struct GemmPair {
     GemmArgs p[2];
     int tiles0;          // workgroups [0, tiles0) -> p[0], the rest -> p[1]
+    int rider_prio;      // raise the wave priority of p[1]'s workgroups
 };
 
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st);

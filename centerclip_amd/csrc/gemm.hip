@@ -114,6 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
+    // The rider's tiles are the ones that spill into a second round when the carrier alone fills the slots (the
+    // clustered blocks): served first by the CU's arbiters they free their slots sooner for the tiles still queued.
+    const bool rider_first = second && pr.rider_prio;
+    if (rider_first) __builtin_amdgcn_s_setprio(2);
     stage(0, 0);
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         constexpr int NLOAD = A_LOADS + B_LOADS, LPG = NLOAD, BPG = (NI + MI - 1) / MI;
         auto step = [&](int buf, int kt, bool with_stage) {
             h8 a0[MI], b0[NI], a1[MI], b1[NI];
-            if (MMA_PRIO) __builtin_amdgcn_s_setprio(1);      // (s_setprio ends a scheduling region: keep it outside)
+            if (MMA_PRIO) {                                   // (s_setprio ends a scheduling region: keep it outside)
+                if (rider_first) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+            }
             read_frags(buf, 0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             mma(a1, b1);
-            if (MMA_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (MMA_PRIO) {
+                if (rider_first) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+            }
             __syncthreads();
         };
         for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
@@ -514,6 +522,10 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
         pr.p[1].tiles_n = g1->N / BN;
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
+        // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
+        // (2.172 vs 2.182 ms per step over 5 A/B rounds; CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+        static const int rp = [] { const char* e = getenv("CC_RIDER_PRIO"); return e ? atoi(e) : 1; }();
+        pr.rider_prio = (rp == 2) || (rp == 1 && g0.M < 5000);
     } else {
         pr.p[1] = g0;
     }
@@ -544,6 +556,10 @@ int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
         pr.p[1].tiles_n = g1->N / BN;
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
+        // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
+        // (2.172 vs 2.182 ms per step over 5 A/B rounds; CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+        static const int rp = [] { const char* e = getenv("CC_RIDER_PRIO"); return e ? atoi(e) : 1; }();
+        pr.rider_prio = (rp == 2) || (rp == 1 && g0.M < 5000);
     } else {
         pr.p[1] = g0;
     }
