@@ -1,25 +1,36 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark of the CenterCLIP retrieval hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): clips/sec (ViT-B/32, 12 frames) - plus token-cluster Mtokens/s and
-pairwise-similarities/s as extra fields.  Workload at N=1 = BASELINE.json configs[1]
-("MSR-VTT-shaped synthetic: ViT-B/32, 12 frames, 3 segments, k=49 medoids, batch 16").
+N > 1 without WORLD_SIZE in the environment: this script launches itself under torch.distributed.run with N ranks (one
+per GPU, RCCL) and refuses - exit code 2 - when fewer than N GPUs are visible.  Launched by torch.distributed.run it
+checks WORLD_SIZE == N.
+
+Metric (BASELINE.json): clips/sec (ViT-B/32, 12 frames) + token-cluster Mtokens/s, and pairwise-similarities/s as an
+extra field.  Workload = BASELINE.json configs[1] ("MSR-VTT-shaped synthetic: ViT-B/32, 12 frames, 3 segments, k=49
+medoids, batch 16") per GPU.
 
 One step = one pass of the hot path over one batch that is already resident in HBM:
-  video [16,1,12,3,224,224] fp32 + ids [16,32]  ->  CLIP4Clip.forward (text tower, ViT with the
-  token-cluster op in block 7)  ->  [N>1: packed RCCL all-gather of the features]  ->
-  get_similarity_logits (this rank's row block of the [G*16, G*16] logits).
+  video [16,1,12,3,224,224] fp32 + ids [16,32]  ->  CLIP4Clip.forward (text tower, ViT with the token-cluster op in
+  block 7)  ->  [N>1: ONE RCCL all-gather of the preallocated feature records]  ->  get_similarity_logits (this rank's
+  row block of the [G*16, G*16] logits).
 Weak scaling: every rank owns its own 16 clips; value = all ranks' clips / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
-dominant kernel (measured live with HIP events on the launch stream) and `cpu_baseline` (the
-oracle = plain-PyTorch CPU port of the reference path, timed on this host on a bounded sample).
+Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides, repeated until >= --min-seconds of timed work have run (DVFS steady state; the first window alone is ~40 ms).
+`ms_per_step` / `value` are the MEDIAN window (max over ranks per window); the first window is reported next to it.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the kernel symbol with the
+largest share of the step (measured live with HIP events on the launch stream) and `cpu_baseline` (the oracle = the
+plain-PyTorch CPU restatement of the reference path, timed on this host on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from argparse import Namespace
@@ -31,10 +42,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # HBM3E spec peak
 
 CFG2 = dict(name="cfg2 MSR-VTT-shaped: ViT-B/32 224^2, 12 frames -> 3 segments @block 7, K=49, batch 16, 32 words",
             B=16, T=12, T_new=3, K=49, cluster_block=7, words=32, patch=32, res=224, width=768, layers=12)
+# cluster-op shapes of the other BASELINE.json configs: reported as µs/call + Mtokens/s
+CLUSTER_SHAPES = {"cfg2": dict(B=16, T=12, T_new=3, n=49, K=49, split=16),
+                  "cfg4 ActivityNet-shaped (per GPU)": dict(B=8, T=64, T_new=8, n=49, K=49, split=16),
+                  "cfg5 ViT-B/16": dict(B=16, T=12, T_new=4, n=196, K=100, split=4)}
 
 
 def task_config(c):
@@ -105,101 +121,124 @@ def graph_time_ms(fn, launches=20, replays=4):
         return event_time_ms(fn, launches)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (tools/pmc.sh -> profiles/*traffic_pmc.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE);
-    None when no counter pass exists for this kernel."""
+TILES = {1: (128, 128, 2, 2, 64), 2: (128, 64, 2, 2, 64), 3: (64, 128, 2, 2, 64), 4: (64, 64, 2, 2, 64),
+         5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128)}
+
+
+def kernel_symbol(M, N, K, epi):
+    """Name of the gemm_f16_kernel instantiation a stand-alone launch of this shape runs on (as rocprofv3 prints it)."""
+    from centerclip_amd import _lib as L
+    t = L.lib().cc_linear_tile_for(M, N, K, epi)
+    bm, bn, wm, wn, bk = TILES[t]
+    return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
+
+
+def pmc_traffic(symbol):
+    """HBM bytes per launch of a kernel symbol from the COMMITTED rocprofv3 PMC passes (tools/pmc.sh ->
+    profiles/*traffic_pmc.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  Not measured in this run;
+    None when no counter pass exists for the symbol."""
     import glob
-    import re
-    epi = {"c_fc": 6, "in_proj": 5, "c_proj": 7}.get(kernel.split(":")[-1])
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
-    if epi is None or not files:
+    if not files:
         return None
     data = json.load(open(files[-1]))
+    key = symbol.replace(" ", "")
     for name, v in data.items():
-        if re.search(r"gemm_f16_kernel<\d+, \d+, \d+, \d+, %d(, \d+)?>" % epi, name):     # <BM, BN, WM, WN, EPI[, BK]>
+        if key in name.replace(" ", ""):
             return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch_bytes": round(v["fetch_bytes_per_launch"]),
-                    "write_bytes": round(v["write_bytes_per_launch"]), "source": os.path.basename(files[-1])}
+                    "write_bytes": round(v["write_bytes_per_launch"]),
+                    "source": "committed profile profiles/%s (PMC pass of an earlier run, not measured here)" % os.path.basename(files[-1])}
     return None
 
 
 def gemm_roofline(c, device):
     """Time every distinct GEMM of one step alone (HIP events on the launch stream around replays of a hipGraph of
-    back-to-back launches) and return the dominant one.  Algorithmic flops = 2*M*N*K."""
+    back-to-back launches), group them by kernel symbol and return the symbol with the largest share of the step as the
+    dominant kernel.  Algorithmic flops = 2*M*N*K."""
     from centerclip_amd import ops
     W, B, T = c["width"], c["B"], c["T"]
     L0, L1 = 50, c["K"] + 1
     M0, M1 = B * T * L0, B * c["T_new"] * L1
     n0, n1 = c["cluster_block"] - 1, 13 - c["cluster_block"]
-    shapes = [("patch_embed", B * T * 49, W, 3 * 32 * 32, "f32", 1),
-              ("in_proj", M0, 3 * W, W, "f16", n0), ("out_proj", M0, W, W, "f32_resid", n0),
-              ("c_fc", M0, 4 * W, W, "f16_gelu", n0), ("c_proj", M0, W, 4 * W, "f32_resid", n0),
-              ("in_proj@clustered", M1, 3 * W, W, "f16", n1), ("out_proj@clustered", M1, W, W, "f32_resid", n1),
-              ("c_fc@clustered", M1, 4 * W, W, "f16_gelu", n1), ("c_proj@clustered", M1, W, 4 * W, "f32_resid", n1)]
+    # (name, M, N, K, epilogue id, calls per step)
+    shapes = [("patch_embed", B * T * 49, W, 3 * 32 * 32, 3, 1),
+              ("in_proj", M0, 3 * W, W, 5, n0), ("out_proj", M0, W, W, 7, n0),
+              ("c_fc", M0, 4 * W, W, 6, n0), ("c_proj", M0, W, 4 * W, 7, n0),
+              ("in_proj@clustered", M1, 3 * W, W, 5, n1), ("out_proj@clustered", M1, W, W, 7, n1),
+              ("c_fc@clustered", M1, 4 * W, W, 6, n1), ("c_proj@clustered", M1, W, 4 * W, 7, n1)]
     rows = []
     for name, M, N, K, epi, calls in shapes:
         a = torch.randn(M, K, device=device).half()
         w = (torch.randn(N, K, device=device) * K ** -0.5).half()
         bias = torch.randn(N, device=device)
-        base = name.split("@")[0]
-        if base in ("in_proj", "c_fc"):          # LayerNorm-folded consumer epilogue, statistics in 12 slots
+        if epi in (5, 6):                        # LayerNorm-folded consumer epilogue, statistics in 12 slots
             hres = torch.randn(M, K, device=device)
-            h16, _ = ops.row_stats(hres)
+            h16, _, _ = ops.row_stats(hres)
             stats = torch.randn(M, 12, 2, device=device).abs()
             wf, c1, c2 = ops.fold_layernorm_linear(w.float(), bias, torch.ones(K, device=device), torch.zeros(K, device=device))
-            out = torch.empty(M, N, device=device, dtype=torch.float16)
-            fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, out=out, g=(base == "c_fc"):
-                  ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=g, out=out))
-        elif base in ("out_proj", "c_proj"):     # residual epilogue that also emits fp16 rows + partial sums
+            fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, g=(epi == 6):
+                  ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=g))
+        elif epi == 7:                           # residual epilogue that also emits centred fp16 rows + partial sums
             hres = torch.zeros(M, N, device=device)
             h16b = torch.empty(M, N, device=device, dtype=torch.float16)
             stb = torch.empty(M * 32 * 2, device=device)
-            fn = lambda a=a, w=w, bias=bias, hres=hres, h16b=h16b, stb=stb: ops.linear_resid_stats_f16(a, w, bias, hres, h16=h16b, stats=stb)
-        else:
+            _, st_in, sh_in = ops.row_stats(torch.randn(M, N, device=device))
+            sh_out = torch.empty(M, device=device)
+            fn = (lambda a=a, w=w, bias=bias, hres=hres, h16b=h16b, stb=stb, st_in=st_in, sh_in=sh_in, sh_out=sh_out:
+                  ops.linear_resid_stats_f16(a, w, bias, hres, h16=h16b, stats=stb, shift_in=sh_in,
+                                             stats_in=st_in.view(-1, 1, 2), shift_out=sh_out))
+        else:                                    # the patch GEMM's shape with the plain fp32 epilogue
             out = torch.zeros(M, N, device=device, dtype=torch.float32)
-            fn = lambda a=a, w=w, bias=bias, out=out, epi=epi: ops.linear_f16(a, w, bias, epi, out=out)
+            fn = lambda a=a, w=w, bias=bias, out=out: ops.linear_f16(a, w, bias, "f32", out=out)
         ms = graph_time_ms(fn)
         flops = 2.0 * M * N * K
-        rows.append(dict(kernel="gemm_f16_kernel:" + name, M=M, N=N, K=K, calls_per_step=calls, avg_us=ms * 1e3,
-                         tflops=flops / ms / 1e9, step_share_us=ms * 1e3 * calls))
-    # dominant kernel = largest share of the step.  c_fc and c_proj tie within a few per cent (same flops); c_fc is taken
-    # then, because its kernel instantiation (<256,256,2,4,6>) serves this one shape only, so the rocprofv3 per-kernel
-    # average under profiles/ is directly comparable (c_proj shares <128,128,2,2,7> with out_proj).
-    top = max(r["step_share_us"] for r in rows)
-    dom = next((r for r in rows if r["kernel"].endswith(":c_fc") and r["step_share_us"] >= 0.95 * top), None) or \
-        max(rows, key=lambda r: r["step_share_us"])
-    tr = pmc_traffic(dom["kernel"])
-    roof = dict(bound="mfma", kernel=dom["kernel"], achieved=round(dom["tflops"], 1), peak=MFMA_F16_PEAK_TFLOPS,
-                unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_F16_PEAK_TFLOPS, 4),
-                traffic=tr["hbm_bytes_per_launch"] if tr else None, traffic_unit="bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
-                traffic_detail=tr, avg_launch_us=round(dom["avg_us"], 2),
-                algorithmic_flops_per_launch=2.0 * dom["M"] * dom["N"] * dom["K"],
-                algorithmic_bytes_per_launch=2.0 * (dom["M"] * dom["K"] + dom["N"] * dom["K"] + dom["M"] * dom["N"]))
+        rows.append(dict(kernel=kernel_symbol(M, N, K, 4 if epi == 3 else epi), role=name, M=M, N=N, K=K, calls_per_step=calls,
+                         avg_us=ms * 1e3, tflops=flops / ms / 1e9, step_share_us=ms * 1e3 * calls))
+    # dominant kernel = the SYMBOL with the largest total time in the step (several shapes may share an instantiation)
+    by_sym = {}
+    for r in rows:
+        s = by_sym.setdefault(r["kernel"], dict(us=0.0, flops=0.0, launches=0, roles=[]))
+        s["us"] += r["step_share_us"]
+        s["flops"] += 2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"]
+        s["launches"] += r["calls_per_step"]
+        s["roles"].append(r["role"])
+    sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
+    tf = dom["flops"] / dom["us"] / 1e6
+    tr = pmc_traffic(sym)
+    roof = dict(bound="mfma", kernel=sym, roles=dom["roles"], achieved=round(tf, 1), peak=MFMA_F16_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                traffic=tr["hbm_bytes_per_launch"] if tr else None,
+                traffic_unit="bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE), from a committed profile - not measured in this run",
+                traffic_detail=tr, avg_launch_us=round(dom["us"] / dom["launches"], 2),
+                algorithmic_flops_per_launch=dom["flops"] / dom["launches"],
+                step_share_us=round(dom["us"], 1),
+                by_symbol={k: dict(roles=v["roles"], step_share_us=round(v["us"], 1),
+                                   tflops=round(v["flops"] / v["us"] / 1e6, 1),
+                                   frac=round(v["flops"] / v["us"] / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)) for k, v in by_sym.items()})
     gemm_us = sum(r["step_share_us"] for r in rows)
     gemm_flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"] for r in rows)
     return roof, rows, gemm_us, gemm_flops
 
 
-def cluster_bench(c, device):
-    """token-cluster Mtokens/s: the op alone on cfg-2 shaped activations (P=48 problems of 196 tokens)."""
+def cluster_bench(c, device, iters=30):
+    """token-cluster Mtokens/s: the op alone on frame-major activations of one config's shape."""
     from centerclip_amd.cluster import TokenClusterInter
-    B, T, Tn, K, W = c["B"], c["T"], c["T_new"], c["K"], c["width"]
-    x = torch.randn(B * T, 50, W, device=device)
-    mod = TokenClusterInter(before_cluster_num=49, cluster_num=K, before_block_frames=T, after_block_frames=Tn,
-                            original_frame=T, threshold=1e-6, iter_limit=100, split_size=16, norm_p=2.0)
-    ms = event_time_ms(lambda: mod.cluster_frame_major(x), 30)
-    P, N = B * Tn, (T // Tn) * 49
+    B, T, Tn, K, n = c["B"], c["T"], c["T_new"], c["K"], c["n"]
+    W = 768
+    x = torch.randn(B * T, 1 + n, W, device=device)
+    mod = TokenClusterInter(before_cluster_num=n, cluster_num=K, before_block_frames=T, after_block_frames=Tn,
+                            original_frame=T, threshold=1e-6, iter_limit=100, split_size=c["split"], norm_p=2.0)
+    ms = event_time_ms(lambda: mod.cluster_frame_major(x), iters)
+    P, N = B * Tn, (T // Tn) * n
     tokens = P * N
     alg_bytes = P * N * W * 4 + P * K * W * 4 + P * K * 8
-    return dict(mtokens_per_s=round(tokens / ms / 1e3, 2), us_per_call=round(ms * 1e3, 1),
+    return dict(mtokens_per_s=round(tokens / ms / 1e3, 2), us_per_call=round(ms * 1e3, 1), problems=P, tokens_per_problem=N,
                 roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=cluster_pmc_traffic(),
-                              traffic_unit="bytes per call, sum over K1-K3 (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
-                              algorithmic_bytes_per_launch=alg_bytes))
+                              frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=alg_bytes))
 
 
 def cluster_pmc_traffic():
-    """HBM bytes of one token-cluster call = sum over its four kernels, from the committed PMC passes (None if absent)."""
+    """HBM bytes of one cfg-2 token-cluster call = sum over its kernels, from the committed PMC passes (None if absent)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
     if not files:
@@ -215,17 +254,33 @@ def cluster_pmc_traffic():
     return round(total) if seen == 3 else None
 
 
-def similarity_bench(device):
-    """pairwise-similarities/s: 10k texts x 1k videos (3 segments each), pooling + exact-fp32 MFMA NT GEMM."""
-    from centerclip_amd import ops
+def similarity_bench(device, world=1):
+    """pairwise-similarities/s: 10k texts x 1k videos (3 segments each): pooling + exact-fp32 MFMA NT GEMM.  world > 1:
+    rows sharded over ranks (dist.sharded_similarity with the HIP kernel), time = max over ranks."""
+    from centerclip_amd import ops, dist as ccdist
     Nt, Nv, Tn, E = 10000, 1000, 3, 512
-    t = torch.randn(Nt, E, device=device)
-    v = torch.randn(Nv, Tn, E, device=device)
+    g = torch.Generator().manual_seed(11)
+    t = torch.randn(Nt, E, generator=g).to(device)
+    v = torch.randn(Nv, Tn, E, generator=g).to(device)
     m = torch.ones(Nv, Tn, dtype=torch.long, device=device)
-    ms = event_time_ms(lambda: ops.loose_similarity(t, v, m, 1.0), 20)
+    if world == 1:
+        ms = event_time_ms(lambda: ops.loose_similarity(t, v, m, 1.0), 20)
+    else:
+        t0, t1 = ccdist.shard_rows(Nt)
+        v0, v1 = ccdist.shard_rows(Nv)
+        tl = ops.normalize_rows(t[t0:t1])
+
+        def run():
+            pooled = ops.video_pool_normalize(v[v0:v1], m[v0:v1])          # this rank's videos
+            return ccdist.sharded_similarity(tl, pooled, Nv, 2.718281828)   # all-gather of [Nv, E] + local NT GEMM
+        ms = event_time_ms(run, 10)
+        tt = torch.tensor([ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt)
     flops = 2.0 * Nt * Nv * E
     return dict(pairs_per_s=round(Nt * Nv / ms * 1e3, 0), us_per_call=round(ms * 1e3, 1),
-                tflops_fp32=round(flops / ms / 1e9, 2), frac_of_fp32_mfma_peak=round(flops / ms / 1e9 / 157.3, 4))
+                tflops_fp32=round(flops / ms / 1e9, 2), frac_of_fp32_mfma_peak=round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS / world, 4),
+                sharding="rows over %d ranks, videos all-gathered (%.1f MB)" % (world, Nv * E * 4 / 1e6) if world > 1 else "single GPU")
 
 
 def cpu_baseline(c, state_dict):
@@ -273,72 +328,98 @@ def cpu_baseline_cluster(c):
                 sample="one call on [48,196,768] fp32, %.2f s" % t)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start N ranks on this node."""
+    share = os.environ.get("CC_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < a.gpus and not share:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible - refusing to report a %d-GPU number from fewer "
+                         "devices\n" % (a.gpus, ndev, a.gpus))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="keep timing K-step windows until this much timed work ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a captured hipGraph replay")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cluster / similarity side measurements")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d: launch it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    if os.environ.get("CC_BENCH_SHARE_GPU") == "1":     # dev aid: N ranks on ONE GPU over gloo, to exercise the N>1 code path
+    share = os.environ.get("CC_BENCH_SHARE_GPU") == "1"   # dev aid: N ranks on ONE GPU over gloo, to exercise the N>1 code path
+    if share:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("CC_BENCH_SHARE_GPU") == "1":
+        if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    assert world == a.gpus or world == 1, "launch N>1 through torch.distributed.run"
 
     from centerclip_amd.clip4clip import CLIP4Clip
-    from centerclip_amd import dist as ccdist, ops
+    from centerclip_amd import dist as ccdist
     c = CFG2
     sd = random_state_dict(c, seed=0)                    # same weights on every rank
     model = CLIP4Clip.from_state_dict(dict(sd), task_config(c)).to(device).eval()
     ids, amask, video, vmask = synthetic_batch(c, device, seed=100 + rank)
-    logit_mult = float(torch.tensor(float(sd["logit_scale"])).exp())
-
     token_type = torch.zeros_like(ids)                   # an input of the reference signature (unused by the path)
+    scale = float(sd["logit_scale"])
+    sink = ccdist.PackedFeatures(c["B"], c["T_new"], 512, device, world) if world > 1 else None
 
-    def towers():
+    def step1():                                         # single GPU: the reference's call sequence (main.py:444,518)
         out = model(ids, token_type, amask, video, vmask)
-        vm = model.get_video_mask_after_cluster(vmask.view(-1, vmask.shape[-1]))
-        return out["sequence_output"], out["visual_output"], vm.to(torch.long) if world == 1 else vm.to(torch.long).contiguous()
+        logits, *_ = model.get_similarity_logits(out["sequence_output"], out["visual_output"], amask, vmask)
+        return logits
 
-    def tail(seq, vis, vm):
-        if world > 1:
-            # exchange step: one packed all-gather of (video features, mask), then this rank's row block
-            vis_all, vm_all = ccdist.all_gather(vis, vm)
-            return ops.loose_similarity(seq.squeeze(1), vis_all, vm_all, float(sd["logit_scale"]))
-        return ops.loose_similarity(seq.squeeze(1), vis, vm, float(sd["logit_scale"]))
+    def towers_n():                                      # N GPUs: both towers write into the preallocated record
+        model.encode_into(sink, ids, video, vmask)
 
-    def step():
-        return tail(*towers())
+    def tail_n():                                        # exchange step (ONE all-gather) + this rank's row block
+        sink.gather()
+        return sink.logits(sink.seq, scale)
 
     graph = None
     with torch.no_grad():
         for _ in range(max(a.warmup, 1)):
-            logits = step()
+            if world == 1:
+                logits = step1()
+            else:
+                towers_n()
+                logits = tail_n()
         torch.cuda.synchronize()
         if not a.no_graph:
-            # capture into a hipGraph: removes ~190 host launches per step from the critical path.  Inputs stay
+            # capture into a hipGraph: removes ~70 host launches per step from the critical path.  Inputs stay
             # resident, so a replay IS one pass of the hot path over the batch.  1 GPU: the whole step; N GPUs: both
-            # towers (the RCCL all-gather and the similarity tail that follows it are launched eagerly after it).
+            # towers (the RCCL all-gather and the similarity launch that follows it are issued eagerly after it).
             try:
                 gph = torch.cuda.CUDAGraph()
                 # thread_local: the RCCL watchdog thread of an initialised process group may query events meanwhile
                 with torch.cuda.graph(gph, capture_error_mode="thread_local" if world > 1 else "global"):
-                    captured = step() if world == 1 else towers()
+                    captured = step1() if world == 1 else towers_n()
                 gph.replay()
                 torch.cuda.synchronize()
                 graph = gph
@@ -346,33 +427,60 @@ def main():
                 sys.stderr.write("graph capture failed (%s); timing eager launches\n" % exc)
                 graph = None
                 torch.cuda.synchronize()
-        if graph is None:
-            run = step
-        elif world == 1:
-            run = lambda: (graph.replay(), captured)[1]
+        if world == 1:
+            run = step1 if graph is None else (lambda: (graph.replay(), captured)[1])
+        elif graph is None:
+            run = lambda: (towers_n(), tail_n())[1]
         else:
-            run = lambda: (graph.replay(), tail(*captured))[1]
+            run = lambda: (graph.replay(), tail_n())[1]
         for _ in range(a.warmup):
             run()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out_ = run()
-            if out_ is not None:
-                logits = out_
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+        windows = []
+        total = 0.0
+        while True:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                out_ = run()
+                if out_ is not None:
+                    logits = out_
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:                    # max over ranks (also keeps every rank on the same number of windows)
+                tt = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt)
+            windows.append(el)
+            total += el
+            if total >= a.min_seconds or len(windows) >= 400:
+                break
     assert logits.shape == (c["B"], c["B"] * world) and bool(torch.isfinite(logits).all())
+    elapsed = statistics.median(windows)
+
+    extras = {}
+    if not a.no_extras:
+        with torch.no_grad():
+            tc = {name: cluster_bench(s, device, iters=30 if name == "cfg2" else 10) for name, s in CLUSTER_SHAPES.items()}
+            if world > 1:                    # replicated op: the node's rate is the sum of the ranks' rates
+                for name in tc:
+                    tt = torch.tensor([tc[name]["mtokens_per_s"]], device=device, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                    tc[name]["mtokens_per_s_all_ranks"] = round(float(tt), 2)
+            extras["token_cluster"] = tc
+            extras["similarity_10k_x_1k"] = similarity_bench(device, world)
+            if world > 1:
+                ms = event_time_ms(sink.gather, 50)
+                tt = torch.tensor([ms], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                extras["feature_all_gather"] = dict(bytes_per_rank=sink.rec, bytes_gathered=sink.bytes_per_gather,
+                                                    us_per_call=round(float(tt) * 1e3, 1),
+                                                    backend=dist.get_backend(), collectives_per_step=1)
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -381,8 +489,21 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 MFMA operands, fp32 accumulate/residual/LN/softmax; cluster + similarity fp32",
                "data": "synthetic (N(0,1) frames, random token ids, random-init weights with CLIP init statistics rounded through fp16)",
+               "timing": {"windows": len(windows), "steps_per_window": a.steps, "statistic": "median window (max over ranks per window)",
+                          "first_window_ms_per_step": round(windows[0] / a.steps * 1e3, 3),
+                          "min_window_ms_per_step": round(min(windows) / a.steps * 1e3, 3),
+                          "max_window_ms_per_step": round(max(windows) / a.steps * 1e3, 3),
+                          "timed_seconds": round(total, 3)},
                "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (towers) + eager all-gather / similarity") if graph is not None else "eager launches",
-               "config": {"workload": c["name"], "global_batch": c["B"] * world, "parallelism": "dp%d (clips sharded, packed RCCL feature all-gather)" % world if world > 1 else "single GPU"}}
+               "config": {"workload": c["name"], "global_batch": c["B"] * world,
+                          "parallelism": "dp%d (clips sharded, one RCCL all-gather of preallocated feature records)" % world if world > 1 else "single GPU"}}
+        res.update(extras)
+        if "token_cluster" in res:
+            res["token_cluster"]["cfg2"]["roofline"]["traffic"] = cluster_pmc_traffic()
+            res["token_cluster"]["cfg2"]["roofline"]["traffic_unit"] = ("bytes per call, sum over K1-K3 (PMC: 2*FETCH_SIZE + "
+                                                                         "WRITE_SIZE), from a committed profile - not measured in this run")
+            res["token_cluster_mtokens_per_s"] = res["token_cluster"]["cfg2"].get("mtokens_per_s_all_ranks",
+                                                                                  res["token_cluster"]["cfg2"]["mtokens_per_s"])
         if world == 1 and not a.no_extras:
             with torch.no_grad():
                 roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device)
@@ -390,8 +511,6 @@ def main():
                 res["gemm_breakdown"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
                 res["gemm_time_share_of_step"] = round(gemm_us / (ms_per_step * 1e3), 3)
                 res["forward_algorithmic_tflops"] = round(gemm_flops * 1.0 / (ms_per_step * 1e-3) / 1e12, 1)
-                res["token_cluster"] = cluster_bench(c, device)
-                res["similarity_10k_x_1k"] = similarity_bench(device)
                 # N3: the same step fed with decoder-layout uint8 frames (normalisation fused into the patch gather)
                 u8 = torch.randint(0, 256, (c["B"], 1, c["T"], 224, 224, 3), dtype=torch.uint8, device=device)
                 ms_u8 = event_time_ms(lambda: model(ids, torch.zeros_like(ids), amask, u8, vmask), 10)

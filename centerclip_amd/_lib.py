@@ -107,14 +107,21 @@ def stream_ptr(device=None):
 
 
 _workspaces = {}
+_retired = []      # outgrown workspaces stay allocated: a hipGraph captured earlier may still hold their addresses
 
 
 def workspace(nbytes, device):
-    """Caller-owned scratch for the C ABI: one growing uint8 buffer per (device, stream)."""
+    """Caller-owned scratch for the C ABI: one growing uint8 buffer per (device, stream).  A buffer that is outgrown is
+    retired, never freed - a captured hipGraph replays with the addresses it was captured with, and the caching
+    allocator must not hand that memory to another tensor (growth is geometric, so the retired total stays below the
+    live buffer's size)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _retired.append(buf)
+        grow = 0 if buf is None else buf.numel() * 3 // 2
+        buf = torch.empty(max(int(nbytes), grow, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf

@@ -48,9 +48,26 @@ def declare(lib):
     lib.cc_attention_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.cc_fold_layernorm_linear_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.cc_fold_layernorm_linear_f32.restype = c.c_int
-    lib.cc_row_stats_f16.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.cc_row_stats_f16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.cc_linear_ln_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp]
-    lib.cc_linear_resid_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), i32, i32, i32, i32, vp]
+    lib.cc_linear_resid_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), vp, vp, i32, vp, i32, i32, i32, i32, vp]
+    lib.cc_linear_tile_for.argtypes = [i32, i32, i32, i32]
+    lib.cc_linear_tile_for.restype = c.c_int
+    lib.cc_linear_resid_stats_slots.argtypes = [i32, i32, i32, i32]
+    lib.cc_linear_resid_stats_slots.restype = c.c_int
+    lib.cc_attention_strided_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i64, i64, vp]
+    lib.cc_attention_strided_f16.restype = c.c_int
+    lib.cc_text_encode_hidden.argtypes = [c.POINTER(TextModel), vp, i32, i32, vp, vp, vp, sz, vp]
+    lib.cc_text_encode_hidden.restype = c.c_int
+    lib.cc_head_project_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.cc_head_project_f32.restype = c.c_int
+    lib.cc_contrastive_loss_f32.argtypes = [vp, i32, i64, i64, vp, vp, sz, vp]
+    lib.cc_contrastive_loss_f32.restype = c.c_int
+    lib.cc_normalize_rows_f32.argtypes = [vp, vp, i32, i32, vp]
+    lib.cc_normalize_rows_f32.restype = c.c_int
+    lib.cc_loose_similarity_grouped_f32.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, f32, vp, i32,
+                                                    vp, vp, sz, vp]
+    lib.cc_loose_similarity_grouped_f32.restype = c.c_int
     for name in ("cc_row_stats_f16", "cc_linear_ln_f16", "cc_linear_resid_stats_f16"):
         getattr(lib, name).restype = c.c_int
     lib.cc_rank_counts_f32.argtypes = [vp, i32, i32, i64, i64, i32, vp, vp]
@@ -62,8 +79,8 @@ def declare(lib):
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_vit_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_vit_encode_frames.restype = c.c_int
-    lib.cc_clip_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, c.POINTER(TextModel), vp,
-                                          i32, i32, vp, vp, sz, vp]
+    lib.cc_clip_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, vp,
+                                          c.POINTER(TextModel), vp, i32, i32, vp, vp, sz, vp]
     lib.cc_clip_encode_frames.restype = c.c_int
     lib.cc_token_gather_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.cc_token_gather_f32.restype = c.c_int

@@ -3,14 +3,22 @@ same class / method names, forward signatures and state-dict keys (SURVEY.md §8
 the HIP encoders of libcenterclip_hip.so through the C ABI.  No PyTorch compute fallback.
 
 Built: VisualTransformer (ViT-B/32, ViT-B/16, linear_patch '2d'), the text Transformer,
-CLIP.encode_image / encode_text, build_clip_model.  Not built (out of the hot path, SURVEY §2.1
-#2): ModifiedResNet, linear_patch='3d', weight download, return_hidden=True.
+ResidualAttentionBlock.forward / Transformer.forward on LND activations (composed from the op-level
+entry points), CLIP.encode_image / encode_text (incl. return_hidden=True), CLIP.forward,
+build_clip_model, load_clip_state_dict (local files).  Not built (out of the hot path, SURVEY §2.1
+#2): ModifiedResNet, linear_patch='3d', weight download.
+
+All compute goes through ``torch.ops.centerclip.*`` (torch_ops.py).
 """
 import ctypes
 import torch
 from torch import nn
 
+import os
+
 from . import _lib as L
+from . import ops
+from . import torch_ops as T
 from ._lib_clip import BlockWeights, TextModel, VitModel, CC_MAX_LAYERS
 from .cluster import get_cluster_inter
 
@@ -50,7 +58,6 @@ class LayerNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
-        from . import ops
         y = ops.layernorm(x.float().contiguous(), self.weight.float(), self.bias.float(), self.eps)
         return y.type(x.dtype)
 
@@ -66,8 +73,13 @@ class _Attn(nn.Module):
 
 
 class ResidualAttentionBlock(nn.Module):
-    """Parameters of one block under the reference's names (clip.py:197-217); the compute runs
-    inside the fused encoders.  ``tokencluster_inter`` is decided per block by get_cluster_inter."""
+    """One block under the reference's parameter names (clip.py:197-217).  Inside the fused encoders
+    (VisualTransformer.encode, CLIP.encode_text / encode_pair) the compute of all blocks runs from one enqueue;
+    ``forward`` is the block-level drop-in of clip.py:228-253 on the reference's LND activations, composed from the same
+    op-level entry points (folded LayerNorm -> in_proj, attention, out_proj + residual, folded LayerNorm -> c_fc +
+    QuickGELU, c_proj + residual).  ``attn_mask`` follows the reference: None for the visual tower, the (callable)
+    causal mask builder for the text tower - the kernels take it as a causal flag.
+    ``tokencluster_inter`` is decided per block by get_cluster_inter."""
 
     def __init__(self, d_model, n_head, attn_mask=None, block_id=1, args=None):
         super().__init__()
@@ -79,6 +91,43 @@ class ResidualAttentionBlock(nn.Module):
         self.n_head = n_head
         self.block_id = block_id
         self.tokencluster_inter = get_cluster_inter(d_model, block_id, args)
+        self._fold = None
+
+    def _folded(self):
+        """fp16 operands + LayerNorm-folded weights of this block, rebuilt when a parameter changes."""
+        key = _Pack.signature(self)
+        if self._fold is None or self._fold[0] != key:
+            f16 = lambda t: t.detach().to(torch.float16).contiguous()
+            f32 = lambda t: t.detach().float().contiguous()
+            in_w, in_c1, in_c2 = ops.fold_layernorm_linear(self.attn.in_proj_weight, self.attn.in_proj_bias,
+                                                           self.ln_1.weight, self.ln_1.bias)
+            fc_w, fc_c1, fc_c2 = ops.fold_layernorm_linear(self.mlp["c_fc"].weight, self.mlp["c_fc"].bias,
+                                                           self.ln_2.weight, self.ln_2.bias)
+            self._fold = (key, dict(in_w=in_w, in_c1=in_c1, in_c2=in_c2, fc_w=fc_w, fc_c1=fc_c1, fc_c2=fc_c2,
+                                    out_w=f16(self.attn.out_proj.weight), out_b=f32(self.attn.out_proj.bias),
+                                    proj_w=f16(self.mlp["c_proj"].weight), proj_b=f32(self.mlp["c_proj"].bias)))
+        return self._fold[1]
+
+    def forward(self, x_tuple):
+        """(x [L, N, W] LND, video_frame, cluster_loss) -> same tuple   (clip.py:228-253)"""
+        x, video_frame, cluster_loss = x_tuple
+        L.require_device(x)
+        if self.tokencluster_inter is not None:                 # place 1, before the self-attention (clip.py:236-242)
+            x, res_x = self.tokencluster_inter(x)
+            if res_x is not None:
+                raise NotImplementedError("mean_residual is not built")
+        Lq, N, W = x.shape
+        M = Lq * N
+        w = self._folded()
+        h = x.float().contiguous().view(M, W).clone()           # the residual stream (updated in place below)
+        h16, st, sh = ops.row_stats(h)
+        qkv = ops.linear_ln_f16(h16, w["in_w"], w["in_c1"], w["in_c2"], st, 1, eps=self.ln_1.eps)
+        att = ops.attention_f16(qkv, N, Lq, self.n_head, causal=self.attn_mask is not None, seq_rows=1, tok_rows=N)
+        h16, st1, slots1, _ = ops.linear_resid_stats_f16(att, w["out_w"], w["out_b"], h, shift_in=sh,
+                                                         stats_in=st.view(M, 1, 2))
+        u = ops.linear_ln_f16(h16, w["fc_w"], w["fc_c1"], w["fc_c2"], st1, slots1, gelu=True, eps=self.ln_2.eps)
+        ops.linear_f16(u, w["proj_w"], w["proj_b"], "f32_resid", out=h)
+        return (h.view(Lq, N, W).type(x.dtype), video_frame, cluster_loss)
 
 
 class Transformer(nn.Module):
@@ -87,6 +136,12 @@ class Transformer(nn.Module):
         self.width, self.layers, self.heads = width, layers, heads
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask, i + 1, args)
                                          for i in range(layers)])
+
+    def forward(self, x, video_frame=-1, visual=False):
+        """x [L, N, W] (LND) through the blocks one by one (clip.py:264-269); visual=True returns the whole tuple."""
+        cluster_loss = torch.zeros([], device=x.device)
+        out = self.resblocks((x, video_frame, cluster_loss))
+        return out if visual else out[0]
 
 
 class _Pack:
@@ -97,6 +152,7 @@ class _Pack:
         self.key = None
         self.keep = []
         self.struct = None
+        self.handle = None
 
     @staticmethod
     def signature(module):
@@ -171,10 +227,13 @@ class VisualTransformer(nn.Module):
 
     # -- C-ABI model struct -----------------------------------------------------------------
     def _model(self):
+        """-> handle of the packed cc_vit_model in the torch_ops registry (rebuilt when a parameter changes)."""
         sig = _Pack.signature(self)
         pk = self._pack
         if pk.key == sig:
-            return pk.struct
+            return pk.handle
+        if pk.handle is not None:
+            T.release_model(pk.handle)
         pk.keep, pk.key = [], sig
         m = VitModel()
         m.layers, m.width, m.heads = self.transformer.layers, self.width, self.heads
@@ -210,7 +269,20 @@ class VisualTransformer(nn.Module):
             m.cluster_iter_limit, m.cluster_split_size = int(first.iter_limit), int(first.split_size)
             m.cluster_pre_norm = int(bool(first.pre_norm))
         pk.struct = m
-        return m
+        meta = dict(embed_dim=self.output_dim, width=self.width, final=self._final_meta)
+        pk.handle = T.register_model(m, meta, pk)
+        return pk.handle
+
+    def _final_meta(self, video_frame):
+        """(frames per clip, tokens incl. CLS) after all cluster blocks and (segments, K) of the LAST k-medoids block (the
+        one whose ids cc_vit_encode reports) or None."""
+        frames, ltok = self.final_shape(video_frame)
+        med = None
+        for blk in self.transformer.resblocks:
+            tc = blk.tokencluster_inter
+            if tc is not None and tc.algorithm == 'kmediods++':
+                med = (tc.after_block_frames, tc.cluster_num)
+        return frames, ltok, med
 
     def final_shape(self, video_frame):
         """(frames, tokens incl. CLS) per clip after all cluster blocks."""
@@ -222,35 +294,29 @@ class VisualTransformer(nn.Module):
         return frames, tokens + 1
 
     def encode(self, x, video_frame=-1, want_hidden=False, want_medoids=False, forced_medoids=None):
-        """[B*T, 3, H, W] -> (features [B*T_final, output_dim], hidden [B*T_final, L, W] | None)."""
+        """[B*T, 3, H, W] -> (features [B*T_final, output_dim], hidden [B*T_final, L, W] | None).  With want_medoids the
+        ids of the LAST k-medoids block ([T_new*B, K] of that block) are left in ``last_medoids``."""
         L.require_device(x)
-        fr, x = frames_descriptor(x)
+        if x.dtype != torch.uint8:
+            x = x.float()
+        x = x.contiguous()
         BT = x.shape[0]
-        T = video_frame if video_frame and video_frame > 0 else 1
+        T_ = video_frame if video_frame and video_frame > 0 else 1
         has_cluster = any(b.tokencluster_inter is not None for b in self.transformer.resblocks)
         if not has_cluster:
-            T = 1
-        assert BT % T == 0
-        B = BT // T
-        m = self._model()
-        lib = L.lib()
-        frames, ltok = self.final_shape(T)
-        feats = torch.empty(B * frames, self.output_dim, device=x.device, dtype=torch.float32)
-        hidden = torch.empty(B * frames, ltok, self.width, device=x.device, dtype=torch.float32) if want_hidden else None
-        med = None
-        if want_medoids and has_cluster:
-            med = torch.empty(B * frames, ltok - 1, device=x.device, dtype=torch.long)
-        ws = L.workspace(lib.cc_vit_workspace_bytes(ctypes.byref(m), B, T), x.device)
+            T_ = 1
+        assert BT % T_ == 0
         if forced_medoids is not None:
             forced_medoids = forced_medoids.to(device=x.device, dtype=torch.long).contiguous()
-        L.check(lib.cc_vit_encode_frames(ctypes.byref(m), ctypes.byref(fr), B, T, L.ptr(feats), L.ptr(hidden),
-                                         L.ptr(med), L.ptr(forced_medoids), L.ptr(ws), ws.numel(),
-                                         L.stream_ptr(x.device)), "cc_vit_encode_frames")
-        self.last_medoids = med
-        return feats, hidden
+        feats, hidden, med = torch.ops.centerclip.vit_encode(x, self._model(), BT // T_, T_, bool(want_hidden),
+                                                             bool(want_medoids and has_cluster), forced_medoids)
+        self.last_medoids = med if med.numel() else None
+        return feats, (hidden if want_hidden else None)
 
     def forward(self, x, video_frame=-1):
-        """-> (hidden [N', L', W] before ln_post, cluster_loss)   (clip.py:304-349)"""
+        """-> (hidden [N', L', W] before ln_post, cluster_loss)   (clip.py:304-349).  Runs the fused encoder (the
+        reference's self.transformer(x, video_frame, visual=True) call is inside it); the block-by-block form is
+        Transformer.forward."""
         _, hidden = self.encode(x, video_frame, want_hidden=True)
         return hidden, torch.zeros([], device=x.device)
 
@@ -302,9 +368,13 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.dtype
 
     def encode_image(self, image, return_hidden=False, video_frame=-1):
-        """-> (x [N', embed_dim], cluster_loss)   (clip.py:460-469)"""
+        """-> (x [N', embed_dim], cluster_loss), or (x, hidden [N', L', embed_dim]) with return_hidden (clip.py:460-469:
+        hidden = ln_post(h) @ proj on every token, x = its CLS row)."""
         if return_hidden:
-            raise NotImplementedError("return_hidden=True is not built (only the CLS row is projected)")
+            _, h = self.visual.encode(image, video_frame, want_hidden=True)
+            hidden = ops.head_project(h, self.visual.ln_post.weight, self.visual.ln_post.bias, self.visual.proj)
+            hidden = hidden.view(h.shape[0], h.shape[1], -1)
+            return hidden[:, 0, :], hidden
         feats, _ = self.visual.encode(image, video_frame)
         return feats, torch.zeros([], device=image.device)
 
@@ -314,7 +384,9 @@ class CLIP(nn.Module):
                                          self.positional_embedding.data_ptr(), self.text_projection.data_ptr()),)
         pk = self._text_pack
         if pk.key == sig:
-            return pk.struct
+            return pk.handle
+        if pk.handle is not None:
+            T.release_model(pk.handle)
         pk.keep, pk.key = [], sig
         m = TextModel()
         m.layers, m.width, m.heads = self.transformer.layers, self.transformer.width, self.transformer.heads
@@ -324,46 +396,75 @@ class CLIP(nn.Module):
         m.text_projection = pk.f32(self.text_projection)
         m.blocks = ctypes.cast(pk.blocks(self.transformer), ctypes.POINTER(BlockWeights))
         pk.struct = m
-        return m
+        pk.handle = T.register_model(m, dict(embed_dim=self.embed_dim, width=self.transformer.width), pk)
+        return pk.handle
 
-    def encode_pair(self, image, text, video_frame=-1):
+    def encode_pair(self, image, text, video_frame=-1, out=None):
         """encode_image + encode_text of one CLIP4Clip.forward call in a single enqueue (cc_clip_encode):
         block i of the text tower shares its launches with block i of the ViT.
-        -> (image features [N', embed_dim], text features [B, embed_dim])"""
+        -> (image features [N', embed_dim], text features [B, embed_dim]); ``out`` = preallocated (vfeat, tfeat)."""
         L.require_device(image, text)
         vis = self.visual
-        fr, x = frames_descriptor(image)
+        if image.dtype != torch.uint8:
+            image = image.float()
+        image = image.contiguous()
         ids = text.to(torch.long).contiguous()
-        T = video_frame if video_frame and video_frame > 0 else 1
+        T_ = video_frame if video_frame and video_frame > 0 else 1
         if not any(b.tokencluster_inter is not None for b in vis.transformer.resblocks):
-            T = 1
-        B = x.shape[0] // T
-        Bt, Lt = ids.shape
-        vm, tm = vis._model(), self._text_model()
-        frames, _ = vis.final_shape(T)
-        lib = L.lib()
-        vfeat = torch.empty(B * frames, self.embed_dim, device=x.device, dtype=torch.float32)
-        tfeat = torch.empty(Bt, self.embed_dim, device=x.device, dtype=torch.float32)
-        ws = L.workspace(lib.cc_clip_workspace_bytes(ctypes.byref(vm), B, T, ctypes.byref(tm), Bt, Lt), x.device)
-        L.check(lib.cc_clip_encode_frames(ctypes.byref(vm), ctypes.byref(fr), B, T, L.ptr(vfeat), None,
-                                          ctypes.byref(tm), L.ptr(ids), Bt, Lt, L.ptr(tfeat), L.ptr(ws), ws.numel(),
-                                          L.stream_ptr(x.device)), "cc_clip_encode_frames")
-        return vfeat, tfeat
+            T_ = 1
+        B = image.shape[0] // T_
+        forced = getattr(vis, "forced_medoids", None)       # test hook ("given identical medoid sets", SURVEY §8c)
+        keep = getattr(vis, "keep_medoids", False)
+        if out is None and forced is None and not keep:
+            return torch.ops.centerclip.clip_encode(image, ids, vis._model(), self._text_model(), B, T_)
+        h = vis._model()
+        frames, _, med_shape = vis._final_meta(T_)
+        if out is None:
+            out = (torch.empty(B * frames, self.embed_dim, device=image.device, dtype=torch.float32),
+                   torch.empty(ids.shape[0], self.embed_dim, device=image.device, dtype=torch.float32))
+        med = torch.empty(B * med_shape[0], med_shape[1], device=image.device, dtype=torch.long) if (keep and med_shape) else None
+        if forced is not None:
+            forced = forced.to(device=image.device, dtype=torch.long).contiguous()
+        torch.ops.centerclip.clip_encode_out(image, ids, h, self._text_model(), B, T_, out[0], out[1], med, forced)
+        vis.last_medoids = med
+        return out
 
     def encode_text(self, text, return_hidden=False):
-        """ids [B, n_ctx] -> [B, embed_dim]: EOT row of ln_final(x) @ text_projection (clip.py:471-496)."""
-        if return_hidden:
-            raise NotImplementedError("return_hidden=True is not built")
+        """ids [B, n_ctx] -> [B, embed_dim]: EOT row of ln_final(x) @ text_projection (clip.py:471-496); with
+        return_hidden also hidden [B, n_ctx, embed_dim] = ln_final(x) @ text_projection on every token."""
         L.require_device(text)
         ids = text.to(torch.long).contiguous()
-        Bt, Lt = ids.shape
-        m = self._text_model()
-        lib = L.lib()
-        out = torch.empty(Bt, self.embed_dim, device=ids.device, dtype=torch.float32)
-        ws = L.workspace(lib.cc_text_workspace_bytes(ctypes.byref(m), Bt, Lt), ids.device)
-        L.check(lib.cc_text_encode(ctypes.byref(m), L.ptr(ids), Bt, Lt, L.ptr(out), L.ptr(ws), ws.numel(),
-                                   L.stream_ptr(ids.device)), "cc_text_encode")
-        return out
+        feats, h = torch.ops.centerclip.text_encode(ids, self._text_model(), bool(return_hidden))
+        if return_hidden:
+            hidden = ops.head_project(h, self.ln_final.weight, self.ln_final.bias, self.text_projection)
+            return feats, hidden.view(h.shape[0], h.shape[1], -1)
+        return feats
+
+    def forward(self, image, text):
+        """-> (logits_per_image, logits_per_text)   (clip.py:498-512)"""
+        image_features, _ = self.encode_image(image)
+        text_features = self.encode_text(text)
+        img, txt = ops.normalize_rows(image_features), ops.normalize_rows(text_features)
+        mult = T.logit_multiplier(self.logit_scale.detach())
+        return ops.scaled_dot_nt(img, txt, mult), ops.scaled_dot_nt(txt, img, mult)
+
+
+_PT_NAME = {"ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt"}      # clip.py:29-36 (ViT entries)
+
+
+def load_clip_state_dict(pretrained_clip_name="ViT-B/32", pretrained_dir=os.path.expanduser("~/models/pretrained")):
+    """The local-file half of modules/clip.py:load_clip_state_dict: <pretrained_dir>/ViT-B-32.pt as a TorchScript
+    archive (the OpenAI release format) or a plain state dict.  Nothing is downloaded (no network on the target boxes):
+    a missing file raises."""
+    if pretrained_clip_name not in _PT_NAME:
+        raise NotImplementedError("only the ViT checkpoints are supported, got %r" % (pretrained_clip_name,))
+    model_path = os.path.join(pretrained_dir, _PT_NAME[pretrained_clip_name])
+    if not os.path.exists(model_path):
+        raise FileNotFoundError("%s not found (weight download is not built; place the checkpoint there)" % model_path)
+    try:
+        return torch.jit.load(model_path, map_location="cpu").eval().state_dict()
+    except RuntimeError:
+        return torch.load(model_path, map_location="cpu")
 
 
 def build_clip_model(state_dict, convert_fp16=True, linear_patch='2d', cut_top_layer=0, load_state_dict=True,

@@ -1,17 +1,21 @@
 """MI355X-native mirror of the retrieval path of ``modules/clip4clip.py`` (meanP / loose_type):
-CLIP4Clip.forward (eval branch), get_sequence_output, get_visual_output, get_similarity_logits,
-get_video_mask_after_cluster - same signatures and return conventions.
+CLIP4Clip.from_pretrained (local checkpoint), forward, get_sequence_output, get_visual_output,
+get_similarity_logits, _loose_similarity, get_video_mask_after_cluster - same signatures and return conventions
+(SURVEY.md §8b, rows S1/S2).  All compute goes through ``torch.ops.centerclip.*``.
 
-Not built: the training branch (loss, DDP), seqTransf / tightTransf heads,
-from_pretrained's weight-download plumbing.  ``CLIP4Clip.from_state_dict`` replaces it.
+Training mode returns the reference's loss VALUES (feature all-gather -> logits -> symmetric CrossEn,
+clip4clip.py:245-262) without a backward - gradients / the optimiser are out of scope.
+Not built: seqTransf / tightTransf heads, weight download.
 """
 import torch
 from torch import nn
 
 from . import _lib as L
 from . import ops
-from .clip import build_clip_model
+from . import torch_ops as T
+from .clip import build_clip_model, load_clip_state_dict
 from .dist import all_gather
+from .losses import symmetric_contrastive_loss
 
 
 class CLIP4Clip(nn.Module):
@@ -40,14 +44,36 @@ class CLIP4Clip(nn.Module):
         """Build from an OpenAI-CLIP style state dict (keys without the 'clip.' prefix)."""
         return cls(clip_state_dict, task_config)
 
+    @classmethod
+    def from_pretrained(cls, cross_model_name=None, state_dict=None, cache_dir=None, type_vocab_size=2, *inputs,
+                        **kwargs):
+        """modules/clip4clip.py:27-123 for the built configuration (meanP, linear_patch '2d'): the CLIP weights come
+        from <task_config.pretrained_dir>/ViT-B-32.pt (or ViT-B-16.pt), a fine-tuned ``state_dict`` (keys prefixed
+        'clip.') overrides them, ``temperature_new`` > 1 replaces logit_scale.  ``cross_model_name`` / ``cache_dir`` /
+        ``type_vocab_size`` configure the cross encoder, which only the tightTransf head uses: accepted, unused."""
+        task_config = kwargs['task_config']
+        if state_dict is None:
+            state_dict = {}
+        name = getattr(task_config, 'pretrained_clip_name', "ViT-B/32")
+        clip_state_dict = load_clip_state_dict(name, pretrained_dir=task_config.pretrained_dir)
+        model = cls(clip_state_dict, task_config)
+        override = {k[len("clip."):]: v for k, v in state_dict.items() if k.startswith("clip.")}
+        if override:
+            model.clip.load_state_dict(override, strict=False)
+        if getattr(task_config, "temperature_new", 0.0) > 1.0:
+            model.clip.logit_scale.data.fill_(task_config.temperature_new)
+        return model
+
     # ------------------------------------------------------------------ forward (clip4clip.py:199-263)
     def forward(self, input_ids=None, token_type_ids=None, attention_mask=None, video=None, video_mask=None,
                 pre_visual_pooling=False):
-        if self.training:
-            raise NotImplementedError("the training branch (loss + DDP) is out of scope; call .eval()")
         output_dict = {'sequence_output': None, 'visual_output': None, 'loss': None}
+        sequence_output = visual_output = None
+        cluster_loss = None
         if input_ids is not None:
             input_ids = input_ids.view(-1, input_ids.shape[-1])
+            if attention_mask is not None:
+                attention_mask = attention_mask.view(-1, attention_mask.shape[-1])
         if video is not None:
             video = torch.as_tensor(video)
             if video.dtype != torch.uint8:           # uint8 frames go to the patch gather as they are (N3)
@@ -60,17 +86,46 @@ class CLIP4Clip(nn.Module):
         if input_ids is not None and video is not None:
             # both towers in one enqueue: the text tower's blocks share their launches with the ViT's
             vfeat, tfeat = self.clip.encode_pair(video, input_ids, video_frame=video_frame)
-            output_dict['sequence_output'] = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
+            sequence_output = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
             visual_output = vfeat.view(video_mask.size(0), -1, vfeat.size(-1))
+            cluster_loss = torch.zeros([], device=vfeat.device)
         elif input_ids is not None:
-            output_dict['sequence_output'] = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
+            sequence_output = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
         elif video is not None:
-            visual_output, _ = self.get_visual_output(video, video_mask, video_frame=video_frame)
+            visual_output, cluster_loss = self.get_visual_output(video, video_mask, video_frame=video_frame)
+        output_dict['sequence_output'] = sequence_output
         if video is not None:
-            if self.pre_visual_pooling:
-                visual_output = ops.video_pool_normalize(visual_output, video_mask)
-            output_dict['visual_output'] = visual_output
+            if self.training or not self.pre_visual_pooling:
+                output_dict['visual_output'] = visual_output
+            else:                                    # clip4clip.py:238-243: normalise, masked mean, normalise
+                output_dict['visual_output'] = ops.video_pool_normalize(visual_output, video_mask)
+        if self.training:
+            # loss values of the reference's training branch (clip4clip.py:245-262); forward only
+            with torch.no_grad():
+                sim_matrix, *_tmp = self.get_similarity_logits(sequence_output, visual_output, attention_mask,
+                                                               video_mask, shaped=True)
+                sim_loss, _, _ = symmetric_contrastive_loss(sim_matrix)
+            output_dict['loss'] = sim_loss + cluster_loss
+            output_dict['cluster_loss'] = cluster_loss
+            output_dict['sim_loss'] = sim_loss
         return output_dict
+
+    def encode_into(self, sink, input_ids, video, video_mask):
+        """The multi-GPU step's producer: forward()'s two towers with the features written straight into a
+        dist.PackedFeatures record (sink.vis / sink.seq; the segment mask is copied into sink.mask), so that the exchange
+        of clip4clip.py:351-355 is ONE all_gather_into_tensor of preallocated buffers with no packing step."""
+        input_ids = input_ids.view(-1, input_ids.shape[-1])
+        video = torch.as_tensor(video)
+        if video.dtype != torch.uint8:
+            video = video.float()
+        video_frame = video.shape[2]
+        video = video.reshape((-1,) + tuple(video.shape[3:]))
+        video_mask = video_mask.view(-1, video_mask.shape[-1])
+        if self.cluster_inter or self.deep_cluster:
+            video_mask = self.get_video_mask_after_cluster(video_mask)
+        self.clip.encode_pair(video, input_ids, video_frame=video_frame, out=(sink.vis, sink.seq))
+        sink.mask.copy_(video_mask)
+        return sink
 
     def _logit_scale_value(self):
         """Python float of clip.logit_scale, cached per parameter version (no device->host sync per call)."""
@@ -100,24 +155,25 @@ class CLIP4Clip(nn.Module):
             return video_mask[:, self.f_frame_duration - 1::video_mask.shape[-1] // self.final_frames]
         return video_mask
 
-    def _loose_similarity(self, sequence_output, visual_output, attention_mask, video_mask, gather=False):
-        """exp(logit_scale) * t_hat @ v_bar^T   (clip4clip.py:324-367).  gather=True reproduces the
-        training-time feature all-gather (one packed RCCL all-gather instead of three + barrier)."""
+    def _loose_similarity(self, sequence_output, visual_output, attention_mask, video_mask):
+        """exp(logit_scale) * t_hat @ v_bar^T   (clip4clip.py:324-367).  In training mode the features of all ranks are
+        gathered first (:351-355) - one packed RCCL all-gather instead of three + a barrier."""
         sequence_output, visual_output = sequence_output.contiguous(), visual_output.contiguous()
-        if gather:
-            visual_output, video_mask, sequence_output = all_gather(visual_output, video_mask, sequence_output)
+        if self.training:
+            visual_output, video_mask, sequence_output = all_gather(visual_output, video_mask.contiguous(),
+                                                                    sequence_output)
         text = sequence_output.squeeze(1)
         scale = self._logit_scale_value()
-        if visual_output.ndim == 2:      # already pooled + normalised (pre_visual_pooling)
-            L.require_device(text)
-            tn = ops.scaled_dot_nt(text / text.norm(dim=-1, keepdim=True), visual_output, mult=float(torch.tensor(scale).exp()))
-            return tn
+        if visual_output.ndim == 2:      # already pooled + normalised (eval with pre_visual_pooling, :357)
+            L.require_device(text, visual_output)
+            return ops.scaled_dot_nt(ops.normalize_rows(text), visual_output, mult=T.logit_multiplier(scale))
         return ops.loose_similarity(text, visual_output, video_mask, scale)
 
     def get_similarity_logits(self, sequence_output, visual_output, attention_mask, video_mask, shaped=False):
         """-> (logits [Bt, Bv], ())   (clip4clip.py:412-434)"""
         if shaped is False:
-            attention_mask = attention_mask.view(-1, attention_mask.shape[-1])
+            if attention_mask is not None:
+                attention_mask = attention_mask.view(-1, attention_mask.shape[-1])
             video_mask = video_mask.view(-1, video_mask.shape[-1])
         if visual_output.ndim == 3 and video_mask.shape[1] != visual_output.shape[1]:
             video_mask = self.get_video_mask_after_cluster(video_mask)

@@ -1,12 +1,11 @@
 """Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and TokenClusterInter (:66-352) for the
 algorithms 'kmediods++' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
 'sparse_sampling' in eval mode."""
-import ctypes
-
 import numpy as np
 import torch
 
 from .. import _lib as L
+from .. import torch_ops  # noqa: F401  (registers torch.ops.centerclip)
 
 
 def get_cluster_inter(width, block_id, args=None):
@@ -147,27 +146,17 @@ class TokenClusterInter(torch.nn.Module):
         L.require_device(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        T, T_new = self.before_block_frames, self.after_block_frames
-        B, n = BT // T, Lt - 1
+        n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
-        lib = L.lib()
-        if frame_major:
-            out = torch.empty(B * T_new, 1 + K, W, dtype=torch.float32, device=x.device)
-            o_tok, o_frame = W, (1 + K) * W
-        else:
-            out = torch.empty(1 + K, B * T_new, W, dtype=torch.float32, device=x.device)
-            o_tok, o_frame = B * T_new * W, W
         N = self.frame_duration * n
         var, keep = self.variant(N, x.device)
-        medoids = None
-        if keep_ids and self.algorithm == 'kmediods++':
-            medoids = torch.empty(B * T_new, K, dtype=torch.long, device=x.device)
-        ws = L.workspace(lib.cc_cluster_workspace_bytes(B * T_new, N, W, int(bool(self.pre_norm))), x.device)
-        L.check(lib.cc_token_cluster_variant_f32(L.ptr(x), tok_stride, frame_stride, B, T, T_new, n, W, K,
-                                                 L.METRIC_IDS[self.distance], float(self.norm_p), float(self.threshold),
-                                                 int(self.iter_limit), int(self.split_size), int(bool(self.pre_norm)),
-                                                 ctypes.byref(var), L.ptr(out), o_tok, o_frame, L.ptr(medoids), None, None,
-                                                 L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
-                "cc_token_cluster_variant_f32")
-        self.last_medoids = medoids
+        out, medoids = torch.ops.centerclip.token_cluster(
+            x, bool(frame_major), self.before_block_frames, self.after_block_frames, K, L.METRIC_IDS[self.distance],
+            float(self.norm_p), float(self.threshold), int(self.iter_limit), int(self.split_size), bool(self.pre_norm),
+            int(var.algorithm), int(var.aggregation),
+            keep[0] if self.cluster_embedding else None,
+            keep[1 if self.cluster_embedding else 0] if self.adaptive_cls else None,
+            keep[-1] if self.algorithm == 'sparse_sampling' else None,
+            bool(keep_ids and self.algorithm == 'kmediods++'))
+        self.last_medoids = medoids if medoids.numel() else None
         return out

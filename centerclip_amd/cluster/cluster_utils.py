@@ -1,13 +1,8 @@
 """Mirror of modules/cluster/cluster_utils.py:8-43 (pairwise_distance) and :78-118 (KKZ_init)."""
-import ctypes
-
 import torch
 
 from .. import _lib as L
-
-
-def _contiguous_layout(P, N, W):
-    return L.TokenLayout(P, 1, 1, N, N * W, 0, 0, W)
+from .. import torch_ops  # noqa: F401  (registers torch.ops.centerclip)
 
 
 def _as_batch(x):
@@ -32,15 +27,7 @@ def pairwise_distance(data1, data2, metric='euclidean', self_nearest=True, all_n
         raise NotImplementedError("centerclip_amd.pairwise_distance computes self-distances only (data2 must be data1)")
     L.require_device(data1)
     x, squeeze = _as_batch(data1.float().contiguous())
-    P, N, W = x.shape
-    lay = _contiguous_layout(P, N, W)
-    dist = torch.empty(P, N, N, dtype=torch.float32, device=x.device)
-    lib = L.lib()
-    nbytes = lib.cc_cluster_workspace_bytes(P, N, W, 0)
-    ws = L.workspace(nbytes, x.device)
-    L.check(lib.cc_pairwise_distance_f32(L.ptr(x), ctypes.byref(lay), W, L.METRIC_IDS[metric], float(p),
-                                         int(bool(all_negative)), int(bool(self_nearest)), P, L.ptr(dist), None,
-                                         L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "cc_pairwise_distance_f32")
+    dist = torch.ops.centerclip.pairwise_distance(x, L.METRIC_IDS[metric], float(p), bool(all_negative), bool(self_nearest))
     return dist[0] if squeeze else dist
 
 
@@ -61,15 +48,6 @@ def KKZ_init(X, distance_matrix, K, batch=False):
     if not batch:
         x, d = x.unsqueeze(0), d.transpose(-2, -1).unsqueeze(0)
     d = d.contiguous()
-    P, N, W = x.shape
-    lay = _contiguous_layout(P, N, W)
-    lib = L.lib()
-    norms = torch.empty(P, N, dtype=torch.float32, device=x.device)
-    medoids = torch.empty(P, K, dtype=torch.long, device=x.device)
-    ws = L.workspace(lib.cc_cluster_workspace_bytes(P, N, W, 0), x.device)
-    st = L.stream_ptr(x.device)
-    L.check(lib.cc_token_norms_f32(L.ptr(x), ctypes.byref(lay), W, L.ptr(norms), L.ptr(ws), ws.numel(), st),
-            "cc_token_norms_f32")
-    L.check(lib.cc_kmedoids_from_dist_f32(L.ptr(d), L.ptr(norms), P, N, K, 0, 0, L.ptr(medoids), None, None,
-                                          L.ptr(ws), ws.numel(), st), "cc_kmedoids_from_dist_f32")
+    norms = torch.ops.centerclip.token_norms(x)
+    _assign, medoids, _iters = torch.ops.centerclip.kmedoids_from_dist(d, norms, int(K), 0, False)
     return medoids if batch else medoids[0]

@@ -26,6 +26,14 @@ struct GemmArgs {
     float ln_eps;
     float* stats_out;        // RESID_STATS: [M][tiles_n * WN][2]
     _Float16* c16;           // RESID_STATS: fp16 copy of the updated rows (row stride ldc)
+    // RESID_STATS row centring: the fp16 copy is fp16(h - c_row) and the statistics are those of the centred copy
+    // (LayerNorm is invariant to a per-row shift, so the consuming *_LN GEMM needs no change); c_row = the row mean one
+    // sublayer ago = shift_in[m] + mean of the centred copy the previous sublayer wrote (its partial sums
+    // shift_stats [M][shift_slots][2]); written to shift_out [M].  All null: c_row = 0.
+    const float* shift_in;
+    const float* shift_stats;
+    int shift_slots;
+    float* shift_out;
 };
 
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
@@ -43,23 +51,27 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
 struct LnArgs {
     const float* in; int64_t in_stride; const float* gamma; const float* beta; void* out; int64_t out_stride;
     int rows, W;
-    _Float16* out16;     // optional (fp32-output variant): fp16 copy of the output rows, row stride W
-    float* stats;        // optional: [rows][2] (sum, sum of squares) of the OUTPUT rows (one slot)
+    _Float16* out16;     // optional (fp32-output variant): fp16 copy of the output rows MINUS their mean, row stride W
+    float* stats;        // optional: [rows][2] (sum, sum of squares) of that centred fp16 copy (one slot)
+    float* shift;        // optional: [rows] the mean that was subtracted
     const float* cls;    // optional (ln_pre): rows with row % cls_period == 0 take cls + pos0 as their input
     const float* pos0;
     int cls_period;
 };
 struct TextEmbedArgs {
     const long long* ids; const float* tok_emb; const float* pos; float* h; int* eot; int Bt, Lt, W;
-    _Float16* h16;       // optional: fp16 copy of the rows + their (sum, sum of squares) [rows][2]
+    _Float16* h16;       // optional: centred fp16 copy of the rows + its (sum, sum of squares) [rows][2] + the row means
     float* stats;
+    float* shift;
 };
 // fp16 copy + (sum, sumsq) of fp32 rows (one wave per row); rows contiguous with stride W
-int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, int rows, int W, hipStream_t st);
+int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, float* shift, int rows, int W, hipStream_t st);
 int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_f16, hipStream_t st);
 
 struct AttArgs {
     const _Float16* qkv; _Float16* out; int nseq, L, heads, W, causal;
+    // row of (sequence s, token t) in qkv / out = s*seq_rows + t*tok_rows; 0, 0 = frame-major (seq_rows = L, tok_rows = 1)
+    int64_t seq_rows, tok_rows;
 };
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
@@ -81,11 +93,11 @@ extern "C" {
 int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                          int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
                          int64_t out_tok_stride, int64_t out_frame_stride, _Float16* row_h16, float* row_stats,
-                         void* stream);
+                         float* row_shift, void* stream);
 int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                                   int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
                                   float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
                                   const cc_cluster_variant* var, float* out, int64_t out_tok_stride,
                                   int64_t out_frame_stride, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
-                                  size_t ws_bytes, _Float16* row_h16, float* row_stats, void* stream);
+                                  size_t ws_bytes, _Float16* row_h16, float* row_stats, float* row_shift, void* stream);
 }

@@ -30,6 +30,8 @@ struct VitWs {
     _Float16* h16;   // fp16 copy of the residual stream (GEMM A operand; LayerNorm is folded into the GEMM)
     float* st0;      // partial (sum, sumsq) of the rows entering in_proj  [M][CC_LN_MAX_SLOTS][2]
     float* st1;      // ... entering c_fc
+    float* sh0;      // per-row constant the fp16 copy entering in_proj was centred on  [M]
+    float* sh1;      // ... entering c_fc
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
@@ -49,6 +51,8 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
     v.h16 = c.take<_Float16>(M0 * W);
     v.st0 = c.take<float>(M0 * CC_LN_MAX_SLOTS * 2);
     v.st1 = c.take<float>(M0 * CC_LN_MAX_SLOTS * 2);
+    v.sh0 = c.take<float>(M0);
+    v.sh1 = c.take<float>(M0);
     v.qkv = c.take<_Float16>(M0 * 3 * W);
     v.att = c.take<_Float16>(M0 * W);
     v.u = c.take<_Float16>(M0 * 4 * W);
@@ -77,6 +81,8 @@ struct BlockCtx {          // one tower's activations for the current block
     _Float16* h16;
     float* st0;
     float* st1;
+    float* sh0;
+    float* sh1;
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
@@ -97,9 +103,13 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
     const int Wa = c0->W, Wb = c1 ? c1->W : 0;
     int rc;
     int slots[2];
-    // experiment knob: CC_UNPAIR bit mask (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj) - the clustered visual blocks launch
+    // experiment knob (development builds, -DCC_DEV_KNOBS): CC_UNPAIR bit mask (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj) - the clustered visual blocks launch
     // those phases separately for the two towers
+#ifdef CC_DEV_KNOBS
     static const int unpair_mask = [] { const char* e = getenv("CC_UNPAIR"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int unpair_mask = 0;
+#endif
     const int unpair = (c1 && M0 < 5000) ? unpair_mask : 0;
     auto dispatch = [&](GemmArgs& g0, GemmArgs& g1, int epi, int bit, int* sl) {
         if (!(unpair & bit)) return cc_gemm_dispatch2(g0, c1 ? &g1 : nullptr, epi, 0, st, sl);
@@ -141,10 +151,12 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
     {
         GemmArgs g0 = base(c0, M0, c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa);
         g0.c16 = c0->h16; g0.stats_out = c0->st1;
+        g0.shift_in = c0->sh0; g0.shift_stats = c0->st0; g0.shift_slots = c0->slots0; g0.shift_out = c0->sh1;
         GemmArgs g1{};
         if (c1) {
             g1 = base(c1, M1, c1->att, w1->out_proj_weight_f16, w1->out_proj_bias, c1->h, Wb, Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st1;
+            g1.shift_in = c1->sh0; g1.shift_stats = c1->st0; g1.shift_slots = c1->slots0; g1.shift_out = c1->sh1;
         }
         rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 2, slots);
         if (rc) return rc;
@@ -167,10 +179,12 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
     {
         GemmArgs g0 = base(c0, M0, c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa);
         g0.c16 = c0->h16; g0.stats_out = c0->st0;
+        g0.shift_in = c0->sh1; g0.shift_stats = c0->st1; g0.shift_slots = c0->slots1; g0.shift_out = c0->sh0;
         GemmArgs g1{};
         if (c1) {
             g1 = base(c1, M1, c1->u, w1->c_proj_weight_f16, w1->c_proj_bias, c1->h, Wb, 4 * Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st0;
+            g1.shift_in = c1->sh1; g1.shift_stats = c1->st1; g1.shift_slots = c1->slots1; g1.shift_out = c1->sh0;
         }
         rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 8, slots);
         if (rc) return rc;
@@ -185,6 +199,8 @@ struct TextWs {
     _Float16* h16;
     float* st0;
     float* st1;
+    float* sh0;
+    float* sh1;
     _Float16* qkv;
     _Float16* att;
     _Float16* u;
@@ -200,6 +216,8 @@ TextWs carve_text(const cc_text_model* m, int Bt, int Lt, void* ws) {
     t.h16 = c.take<_Float16>(M * W);
     t.st0 = c.take<float>(M * CC_LN_MAX_SLOTS * 2);
     t.st1 = c.take<float>(M * CC_LN_MAX_SLOTS * 2);
+    t.sh0 = c.take<float>(M);
+    t.sh1 = c.take<float>(M);
     t.qkv = c.take<_Float16>(M * 3 * W);
     t.att = c.take<_Float16>(M * W);
     t.u = c.take<_Float16>(M * 4 * W);
@@ -220,7 +238,7 @@ bool text_ok(const cc_text_model* m, int Lt) {
 // Both towers, block i of the one paired with block i of the other (either may be absent).
 int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, float* vfeat, float* hidden_out,
                   int64_t* medoids_out, const int64_t* forced_medoids, const cc_text_model* tm, const int64_t* ids,
-                  int Bt, int Lt, float* tfeat, void* ws, size_t ws_bytes, hipStream_t st) {
+                  int Bt, int Lt, float* tfeat, float* text_hidden_out, void* ws, size_t ws_bytes, hipStream_t st) {
     VitWs v{};
     TextWs t{};
     size_t off = 0;
@@ -256,17 +274,27 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         TextEmbedArgs te{};
         if (vm) {
             const int n = tokens, F = B * T;
-            a = LnArgs{v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, v.h16, v.st0,
+            a = LnArgs{v.h, W, vm->ln_pre_weight, vm->ln_pre_bias, v.h, W, F * (n + 1), W, v.h16, v.st0, v.sh0,
                        vm->class_embedding, vm->positional_embedding, n + 1};
         }
         if (tm)
             te = TextEmbedArgs{reinterpret_cast<const long long*>(ids), tm->token_embedding, tm->positional_embedding,
-                               t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0};
+                               t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0, t.sh0};
         rc = (vm && tm) ? cc_launch_pre_stage(a, te, 1e-5f, st)
                         : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;
     }
     const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
+    // medoids_out receives the ids of the LAST k-medoids block only (it is sized for that block); forced_medoids is a
+    // single id tensor, so it is only meaningful for plans with one cluster block
+    int last_kmed = -1, cluster_blocks = 0;
+    for (int i = 0; i < vl; ++i)
+        if (vm->cluster_tokens[i] > 0) {
+            ++cluster_blocks;
+            const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
+            if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS) last_kmed = i;
+        }
+    if (forced_medoids && cluster_blocks > 1) return CC_ERR_UNSUPPORTED;
     BlockCtx cv{}, ct{};
     cv.slots0 = ct.slots0 = 1;
     for (int i = 0; i < (vl > tl ? vl : tl); ++i) {
@@ -285,7 +313,7 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                                                 var->aggregation == CC_AGGREGATE_MEDOID && !var->cluster_embed &&
                                                 !var->cls_multiplier)))
                     rc = cc_token_gather_rows(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                              forced_medoids, hother, W, (int64_t)(K + 1) * W, v.h16, v.st0, st);
+                                              forced_medoids, hother, W, (int64_t)(K + 1) * W, v.h16, v.st0, v.sh0, st);
                 else if (forced_medoids)
                     rc = CC_ERR_UNSUPPORTED;
                 else
@@ -293,19 +321,22 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                                                        vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
                                                        vm->cluster_iter_limit, vm->cluster_split_size,
                                                        vm->cluster_pre_norm, var ? var : &dflt, hother, W,
-                                                       (int64_t)(K + 1) * W, medoids_out, nullptr, nullptr, v.cluster,
-                                                       v.cluster_bytes, v.h16, v.st0, st);
+                                                       (int64_t)(K + 1) * W, i == last_kmed ? medoids_out : nullptr,
+                                                       nullptr, nullptr, v.cluster, v.cluster_bytes, v.h16, v.st0,
+                                                       v.sh0, st);
                 if (rc) return rc;
                 float* tmp = h; h = hother; hother = tmp;
                 frames = Tn;
                 tokens = K;
                 cv.slots0 = 1;
             }
-            cv.h = h; cv.h16 = v.h16; cv.st0 = v.st0; cv.st1 = v.st1; cv.qkv = v.qkv; cv.att = v.att; cv.u = v.u;
+            cv.h = h; cv.h16 = v.h16; cv.st0 = v.st0; cv.st1 = v.st1; cv.sh0 = v.sh0; cv.sh1 = v.sh1;
+            cv.qkv = v.qkv; cv.att = v.att; cv.u = v.u;
             cv.nseq = B * frames; cv.L = tokens + 1; cv.W = W; cv.heads = vm->heads; cv.causal = 0;
         }
         if (ht) {
-            ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
+            ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.sh0 = t.sh0; ct.sh1 = t.sh1;
+            ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
             ct.nseq = Bt; ct.L = Lt; ct.W = tm->width; ct.heads = tm->heads; ct.causal = 1;
         }
         rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[i] : nullptr,
@@ -321,6 +352,9 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     if (rc) return rc;
     if (vm && hidden_out && hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
                                            hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CC_ERR_HIP;
+    if (tm && text_hidden_out && hipMemcpyAsync(text_hidden_out, t.h, (size_t)Bt * Lt * tm->width * sizeof(float),
+                                                hipMemcpyDeviceToDevice, st) != hipSuccess)
         return CC_ERR_HIP;
     return CC_OK;
 }
@@ -340,7 +374,7 @@ int cc_vit_encode_frames(const cc_vit_model* m, const cc_frames* frames, int32_t
     if (!m || !frames || !frames->data || !features || !m->blocks || B <= 0 || T <= 0) return CC_ERR_INVALID;
     if (!vit_ok(m)) return CC_ERR_UNSUPPORTED;
     return encode_towers(m, frames, B, T, features, hidden_out, medoids_out, forced_medoids, nullptr, nullptr, 0, 0,
-                         nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
+                         nullptr, nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t T, float* features,
@@ -357,13 +391,24 @@ size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt) {
     return carve_text(m, Bt, Lt, nullptr).total;
 }
 
-int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt, float* features, void* ws,
-                   size_t ws_bytes, void* stream) {
+int cc_text_encode_hidden(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt, float* features,
+                          float* hidden_out, void* ws, size_t ws_bytes, void* stream) {
     if (!m || !ids || !features || !m->blocks || Bt <= 0 || Lt <= 0) return CC_ERR_INVALID;
     if (Lt > m->context_length) return CC_ERR_INVALID;
     if (!text_ok(m, Lt)) return CC_ERR_UNSUPPORTED;
-    return encode_towers(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m, ids, Bt, Lt, features, ws,
-                         ws_bytes, static_cast<hipStream_t>(stream));
+    return encode_towers(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m, ids, Bt, Lt, features, hidden_out,
+                         ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt, float* features, void* ws,
+                   size_t ws_bytes, void* stream) {
+    return cc_text_encode_hidden(m, ids, Bt, Lt, features, nullptr, ws, ws_bytes, stream);
+}
+
+int cc_head_project_f32(const float* h, int32_t row_mul, const int32_t* row_idx, const float* gamma, const float* beta,
+                        const float* proj, float* out, int32_t R, int32_t W, int32_t E, void* stream) {
+    if (!h || !gamma || !beta || !proj || !out || R <= 0 || W <= 0 || E <= 0 || row_mul <= 0) return CC_ERR_INVALID;
+    return cc_launch_head_project(h, row_mul, row_idx, gamma, beta, proj, out, R, W, E, static_cast<hipStream_t>(stream));
 }
 
 size_t cc_clip_workspace_bytes(const cc_vit_model* vm, int32_t B, int32_t T, const cc_text_model* tm, int32_t Bt,
@@ -372,15 +417,16 @@ size_t cc_clip_workspace_bytes(const cc_vit_model* vm, int32_t B, int32_t T, con
 }
 
 int cc_clip_encode_frames(const cc_vit_model* vm, const cc_frames* frames, int32_t B, int32_t T,
-                          float* visual_features, int64_t* medoids_out, const cc_text_model* tm, const int64_t* ids,
-                          int32_t Bt, int32_t Lt, float* text_features, void* ws, size_t ws_bytes, void* stream) {
+                          float* visual_features, int64_t* medoids_out, const int64_t* forced_medoids,
+                          const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt, float* text_features,
+                          void* ws, size_t ws_bytes, void* stream) {
     if (!vm || !tm || !frames || !frames->data || !ids || !visual_features || !text_features || !vm->blocks ||
         !tm->blocks)
         return CC_ERR_INVALID;
     if (B <= 0 || T <= 0 || Bt <= 0 || Lt <= 0 || Lt > tm->context_length) return CC_ERR_INVALID;
     if (!vit_ok(vm) || !text_ok(tm, Lt)) return CC_ERR_UNSUPPORTED;
-    return encode_towers(vm, frames, B, T, visual_features, nullptr, medoids_out, nullptr, tm, ids, Bt, Lt,
-                         text_features, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    return encode_towers(vm, frames, B, T, visual_features, nullptr, medoids_out, forced_medoids, tm, ids, Bt, Lt,
+                         text_features, nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_t T, float* visual_features,
@@ -389,8 +435,8 @@ int cc_clip_encode(const cc_vit_model* vm, const float* video, int32_t B, int32_
     cc_frames fr{};
     fr.data = video;
     fr.format = CC_FRAMES_F32_CHW;
-    return cc_clip_encode_frames(vm, &fr, B, T, visual_features, medoids_out, tm, ids, Bt, Lt, text_features, ws,
-                                 ws_bytes, stream);
+    return cc_clip_encode_frames(vm, &fr, B, T, visual_features, medoids_out, nullptr, tm, ids, Bt, Lt, text_features,
+                                 ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -947,28 +947,46 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
                                                             const float* __restrict__ cluster_embed,
                                                             const float* __restrict__ cls_mult,
                                                             float* __restrict__ out, int64_t out_tok, int64_t out_frame,
-                                                            _Float16* __restrict__ h16, float* __restrict__ stats) {
+                                                            _Float16* __restrict__ h16, float* __restrict__ stats,
+                                                            float* __restrict__ shift) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int Lout = (mode == 2) ? 1 + n : 1 + K;
     if (row >= B * T_new * Lout) return;
     // optional by-products for the fused forward (the next block's folded ln_1): fp16 copy of the output row at
-    // h16[row][W] and its (sum, sum of squares) - formed exactly as row_stats_kernel forms them
-    float st_s = 0.f, st_q = 0.f;
+    // h16[row][W], centred on the row mean (see layernorm_row in transformer.hip), its (sum, sum of squares) and the mean.
+    // The row is parked in registers (W <= 1024 on this path) until the mean is known.
+    float4 keep[4];
+    float st_t = 0.f;
     auto emit = [&](int w, const float4& v) {
         if (!h16) return;
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
-        const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-        st_s += (q0 + q1) + (q2 + q3);
-        st_q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+        const int t = (w >> 8) & 3;                           // wave-uniform (keeps `keep` in registers)
+        if (t == 0) keep[0] = v; else if (t == 1) keep[1] = v; else if (t == 2) keep[2] = v; else keep[3] = v;
+        st_t += (v.x + v.y) + (v.z + v.w);
     };
     auto finish = [&]() {
         if (!h16) return;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const float om = cc_wave_sum(st_t) / (float)W;
+        float st_s = 0.f, st_q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            if (w < W) {
+                const float4 v = keep[t];
+                h4 o = {(_Float16)(v.x - om), (_Float16)(v.y - om), (_Float16)(v.z - om), (_Float16)(v.w - om)};
+                *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
+                const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+                st_s += (q0 + q1) + (q2 + q3);
+                st_q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+            }
+        }
         st_s = cc_wave_sum(st_s);
         st_q = cc_wave_sum(st_q);
-        if (lane == 0) reinterpret_cast<float2*>(stats)[row] = make_float2(st_s, st_q);
+        if (lane == 0) {
+            reinterpret_cast<float2*>(stats)[row] = make_float2(st_s, st_q);
+            if (shift) shift[row] = om;
+        }
     };
     const int seg = row / Lout, l = row - seg * Lout;
     const int b = seg / T_new, sgm = seg - b * T_new;
@@ -1258,7 +1276,10 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
                           float norm_p, float threshold, int32_t iter_limit, int32_t id_sort, int32_t split_size,
                           int32_t pre_norm, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
                           size_t ws_bytes, void* stream) {
-    (void)threshold;
+    // Stop test: every problem iterates to its fixed point (medoids unchanged), which gives the final state of the
+    // reference's chunk-mean test (fast_kmeans.py:85-88) whenever the threshold is below the distance between any two
+    // distinct tokens.  A loose threshold would stop the reference earlier: refused instead of silently ignored.
+    if (!(threshold <= CC_KMEDOIDS_MAX_THRESHOLD)) return CC_ERR_UNSUPPORTED;
     if (!x || !medoids || !layout_ok(lay, W)) return CC_ERR_INVALID;
     const int P = lay->B * lay->S, N = lay->fd * lay->n;
     if (K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
@@ -1278,13 +1299,13 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
 // *_rows: the public entry plus the by-products the fused forward wants from the same launch - row_h16 [rows][W] fp16
 // copy of the output rows and row_stats [rows][2] their (sum, sum of squares); output must be dense ([seg][1+K][W]).
 static bool rows_layout_ok(const _Float16* row_h16, const float* row_stats, int W, int Lout, int64_t out_tok, int64_t out_frame) {
-    return !row_h16 || (row_stats && out_tok == W && out_frame == (int64_t)Lout * W);
+    return !row_h16 || (row_stats && W <= 1024 && out_tok == W && out_frame == (int64_t)Lout * W);
 }
 
 int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                          int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
                          int64_t out_tok_stride, int64_t out_frame_stride, _Float16* row_h16, float* row_stats,
-                         void* stream) {
+                         float* row_shift, void* stream) {
     if (!x || !out || !medoids || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
     if (!rows_layout_ok(row_h16, row_stats, W, 1 + K, out_tok_stride, out_frame_stride)) return CC_ERR_INVALID;
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
@@ -1293,7 +1314,7 @@ int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame
     hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(medoids), K,
                        (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
-                       out_frame_stride, row_h16, row_stats);
+                       out_frame_stride, row_h16, row_stats, row_shift);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -1302,7 +1323,7 @@ int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_
                         int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
                         int64_t out_tok_stride, int64_t out_frame_stride, void* stream) {
     return cc_token_gather_rows(x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, medoids, out, out_tok_stride,
-                                out_frame_stride, nullptr, nullptr, stream);
+                                out_frame_stride, nullptr, nullptr, nullptr, stream);
 }
 
 int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
@@ -1312,13 +1333,15 @@ int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_fra
     if (!x || !out || !assign || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
     _Float16* const row_h16 = nullptr;
     float* const row_stats = nullptr;
+    float* const row_shift = nullptr;
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
     const int rows = B * T_new * (1 + K);
     hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 1, (const long long*)nullptr, 0,
                        reinterpret_cast<const long long*>(assign), var ? var->cluster_embed : nullptr,
-                       var ? var->cls_multiplier : nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats);
+                       var ? var->cls_multiplier : nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats,
+                       row_shift);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -1328,7 +1351,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
                                   float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
                                   const cc_cluster_variant* var, float* out, int64_t out_tok_stride,
                                   int64_t out_frame_stride, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
-                                  size_t ws_bytes, _Float16* row_h16, float* row_stats, void* stream) {
+                                  size_t ws_bytes, _Float16* row_h16, float* row_stats, float* row_shift, void* stream) {
     if (!x || !out || !var || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0) return CC_ERR_INVALID;
     if (!rows_layout_ok(row_h16, row_stats, W, 1 + (var->algorithm == CC_CLUSTER_POOLING ? n : K), out_tok_stride,
                         out_frame_stride))
@@ -1341,7 +1364,8 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
         const int rows = B * T_new * (1 + n);
         hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, n, 2, (const long long*)nullptr, 0, (const long long*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats);
+                           (const float*)nullptr, (const float*)nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats,
+                           row_shift);
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
@@ -1351,7 +1375,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
         hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(var->fixed_ids), 0,
                            (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
-                           out_frame_stride, row_h16, row_stats);
+                           out_frame_stride, row_h16, row_stats, row_shift);
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
@@ -1377,7 +1401,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
                        T, T_new, n, W, K, mean ? 1 : 0, reinterpret_cast<const long long*>(med), K,
                        reinterpret_cast<const long long*>(asg), var->cluster_embed, var->cls_multiplier, out,
-                       out_tok_stride, out_frame_stride, row_h16, row_stats);
+                       out_tok_stride, out_frame_stride, row_h16, row_stats, row_shift);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -1390,7 +1414,7 @@ int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t 
                                  size_t ws_bytes, void* stream) {
     return cc_token_cluster_variant_rows(x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, metric, norm_p, threshold,
                                          iter_limit, split_size, pre_norm, var, out, out_tok_stride, out_frame_stride,
-                                         medoids, assign, iters, ws, ws_bytes, nullptr, nullptr, stream);
+                                         medoids, assign, iters, ws, ws_bytes, nullptr, nullptr, nullptr, stream);
 }
 
 int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,

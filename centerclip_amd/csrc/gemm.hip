@@ -137,6 +137,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         const float var = fmaxf(sq / (float)g.K - row_mu * row_mu, 0.f);
         row_rs = 1.0f / sqrtf(var + g.ln_eps);
     }
+    // residual epilogue with row centring: c_row = the row's mean one sublayer ago (the shift the previous producer used
+    // + the mean of the centred copy it wrote), reduced here the same way; parked in row_mu until the epilogue
+    if (EPI == EPI_F32_RESID_STATS && g.shift_stats && tid < BM) {
+        const int m = min(row0 + tid, g.M - 1);
+        const float2* ps = reinterpret_cast<const float2*>(g.shift_stats) + (int64_t)m * g.shift_slots;
+        float sum = 0.f;
+        for (int q0 = 0; q0 < g.shift_slots; q0 += 8) {
+            float2 t2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t2[u] = (q0 + u < g.shift_slots) ? ps[q0 + u] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += t2[u].x;
+        }
+        row_mu = (g.shift_in ? g.shift_in[m] : 0.f) + sum / (float)g.N;
+    }
     __syncthreads();
     GEMM_STAMP(1);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -410,6 +425,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     static_assert(OUT_F16 || LPRF == 16 || LPRF == 8, "fp32 epilogue geometry");
     static_assert(NWAVES * 16 * LDF * 4 <= 2 * (A_BYTES + B_BYTES), "fp32 epilogue strip fits the staging buffers");
     float* fstg = reinterpret_cast<float*>(smem) + wave * (16 * LDF);
+    float* rowsh = reinterpret_cast<float*>(smem) + NWAVES * (16 * LDF);       // [BM] per-row shift (STATS with centring)
+    static_assert(OUT_F16 || (NWAVES * 16 * LDF + BM) * 4 <= 2 * (A_BYTES + B_BYTES), "row shifts fit behind the strips");
+    const bool centred = STATS && g.shift_stats != nullptr;
+    if (centred) {
+        if (tid < BM) rowsh[tid] = row_mu;
+        __syncthreads();
+    }
     const int er = lane / LPRF, ec = (lane % LPRF) * 4;           // this lane's row (within a pass) and column
     const int ncol = col0 + wc * WTN + ec;
     auto out_row = [&](int i, int ps) { return row0 + wr * WTM + i * 16 + ps * RPP + er; };
@@ -444,8 +466,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
                 if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
                 if (STATS) {
-                    const h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    // the consumer multiplies fp16(h - c_row): without the centring the rounding error of the copy scales
+                    // with |mean| / sigma of the row (LayerNorm itself is shift invariant, so the consumer is unchanged)
+                    const float cr = centred ? rowsh[wr * WTM + i * 16 + ps * RPP + er] : 0.f;
+                    const h4 o = {(_Float16)(v.x - cr), (_Float16)(v.y - cr), (_Float16)(v.z - cr), (_Float16)(v.w - cr)};
                     if (m < g.M) *reinterpret_cast<h4*>(g.c16 + (int64_t)m * g.ldc + ncol) = o;
+                    if (centred && g.shift_out && tn == 0 && wc == 0 && (lane % LPRF) == 0 && m < g.M) g.shift_out[m] = cr;
                     // statistics of what the consumer will actually multiply: the fp16-rounded row
                     const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
                     float psum = (q0 + q1) + (q2 + q3);
@@ -523,8 +549,12 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1].tiles_n = g1->N / BN;
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
         // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
-        // (2.172 vs 2.182 ms per step over 5 A/B rounds; CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+        // (2.172 vs 2.182 ms per step over 5 A/B rounds; dev builds: CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+#ifdef CC_DEV_KNOBS
         static const int rp = [] { const char* e = getenv("CC_RIDER_PRIO"); return e ? atoi(e) : 1; }();
+#else
+        constexpr int rp = 1;
+#endif
         pr.rider_prio = (rp == 2) || (rp == 1 && g0.M < 5000);
     } else {
         pr.p[1] = g0;
@@ -557,8 +587,12 @@ int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1].tiles_n = g1->N / BN;
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
         // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
-        // (2.172 vs 2.182 ms per step over 5 A/B rounds; CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+        // (2.172 vs 2.182 ms per step over 5 A/B rounds; dev builds: CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
+#ifdef CC_DEV_KNOBS
         static const int rp = [] { const char* e = getenv("CC_RIDER_PRIO"); return e ? atoi(e) : 1; }();
+#else
+        constexpr int rp = 1;
+#endif
         pr.rider_prio = (rp == 2) || (rp == 1 && g0.M < 5000);
     } else {
         pr.p[1] = g0;
@@ -617,8 +651,9 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
         tile = pick_tile(g0, epi);
-        // tuning aid: CC_TILE_E<epi>_<S|B>[_K<k>]=<tile> overrides the choice for small (M < 5000) / big problems; the
-        // environment is scanned once, the per-launch look-ups only happen when such a variable exists
+#ifdef CC_DEV_KNOBS
+        // tuning aid (development builds only, -DCC_DEV_KNOBS): CC_TILE_E<epi>_<S|B>[_K<k>]=<tile> overrides the choice for
+        // small (M < 5000) / big problems; the environment is scanned once
         static const bool any_override = [] {
             for (char** e = environ; e && *e; ++e)
                 if (!strncmp(*e, "CC_TILE_", 8)) return true;
@@ -633,6 +668,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             ov = getenv(name);
             if (ov && ov[0] >= '1' && ov[0] <= '8') tile = ov[0] - '0';
         }
+#endif
         if (g1) {                                  // the rider must be divisible by the carrier's BN
             if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7)) ? 1 : 4;
             if (g1->K % tile_bk(tile)) tile = 4;
@@ -694,12 +730,39 @@ int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, c
     return cc_gemm_dispatch(g, gelu ? EPI_F16_GELU_LN : EPI_F16_LN, tile, static_cast<hipStream_t>(stream));
 }
 
+/* Host-side query: the tile the dispatcher picks for a stand-alone launch of this shape and epilogue (CC_EPI_* or the
+ * internal ids 5 = LN-folded f16, 6 = LN-folded f16 + QuickGELU, 7 = residual + statistics): 1 = 128x128, 2 = 128x64,
+ * 3 = 64x128, 4 = 64x64 (4 waves), 5 = 256x256, 7 = 256x192 (8 waves), 8 = 64x64 with 128-deep k-steps; <= 0: unsupported.
+ * (bench.py names the kernel instantiation a shape runs on with it.) */
+int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K;
+    if (!gemm_shape_ok(g) || epilogue < 0 || epilogue > EPI_F32_RESID_STATS) return CC_ERR_INVALID;
+    return pick_tile(g, epilogue);
+}
+
+/* Host-side query: the number of partial-sum slots per row cc_linear_resid_stats_f16 writes for this shape and tile
+ * (0 = auto), i.e. (N / tile columns) x (wave columns of the tile); <= 0: the shape / tile is not supported. */
+int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K;
+    if (!gemm_shape_ok(g)) return CC_ERR_INVALID;
+    if (tile == 0) tile = pick_tile(g, EPI_F32_RESID_STATS);
+    if (tile < 1 || tile > 8 || tile == 7 || (K % tile_bk(tile)) || (N % tile_bn(tile))) return CC_ERR_INVALID;
+    const int slots = N / tile_bn(tile) * ((tile == 5) ? 4 : 2);
+    return slots > CC_LN_MAX_SLOTS ? CC_ERR_UNSUPPORTED : slots;
+}
+
 /* Residual Linear that also emits what the next folded LayerNorm needs: h (fp32, in place) += a W^T + b;
- * h16 = fp16(h); stats_out [M][*slots_out][2] = per-tile partial (sum, sum of squares) of the fp16 rows. */
+ * h16 = fp16(h - c_row); stats_out [M][*slots_out][2] = per-tile partial (sum, sum of squares) of the fp16 rows;
+ * c_row = shift_in[m] + mean of the previous centred copy (stats_in [M][slots_in][2]), written to shift_out [M]
+ * (stats_in NULL: c_row = 0). */
 int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
-                              float* stats_out, int32_t* slots_out, int32_t M, int32_t N, int32_t K, int32_t tile,
+                              float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
+                              int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
                               void* stream) {
     if (!a_f16 || !w_f16 || !h || !h16_out || !stats_out || !slots_out) return CC_ERR_INVALID;
+    if (stats_in && (slots_in <= 0 || slots_in > CC_LN_MAX_SLOTS || !shift_out)) return CC_ERR_INVALID;
     GemmArgs g{};
     g.A = static_cast<const _Float16*>(a_f16);
     g.W = static_cast<const _Float16*>(w_f16);
@@ -708,6 +771,7 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
     g.M = M; g.N = N; g.K = K; g.ldc = N;
     g.c16 = static_cast<_Float16*>(h16_out);
     g.stats_out = stats_out;
+    g.shift_in = shift_in; g.shift_stats = stats_in; g.shift_slots = slots_in; g.shift_out = shift_out;
     int slots[2] = {0, 0};
     const int rc = cc_gemm_dispatch2(g, nullptr, EPI_F32_RESID_STATS, tile, static_cast<hipStream_t>(stream), slots);
     *slots_out = slots[0];

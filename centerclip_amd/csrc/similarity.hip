@@ -21,19 +21,28 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 }
 
 // visual [Bv, Tn, E], mask [Bv, Tn] int64 -> pooled [Bv, E]   (one wave per video)
+// Videos may come in groups of `vg` (the packed all-gather buffer: one record per rank): video v = (group, local) lives at
+// visual + group*vgs + local*Tn*E, its mask row at mask + group*mgs + local*mrs (+ t*mcs).
+struct VidAddr {
+    int vg;
+    int64_t vgs, mgs, mrs, mcs;
+};
 __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
-                                                         const long long* __restrict__ mask, int64_t mrs, int64_t mcs,
+                                                         const long long* __restrict__ mask, VidAddr ad,
                                                          float* __restrict__ pooled, int Bv, int Tn, int E) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= Bv) return;
+    const int grp = v / ad.vg, loc = v - grp * ad.vg;
+    visual += (int64_t)grp * ad.vgs + (int64_t)loc * Tn * E;
+    mask += (int64_t)grp * ad.mgs + (int64_t)loc * ad.mrs;
     constexpr int MAXE = 16;                      // E <= 1024
     float acc[MAXE];
 #pragma unroll
     for (int q = 0; q < MAXE; ++q) acc[q] = 0.f;
     float cnt = 0.f;
     for (int t = 0; t < Tn; ++t) {
-        const float* src = visual + ((int64_t)v * Tn + t) * E;
+        const float* src = visual + (int64_t)t * E;
         float x[MAXE];
         float s = 0.f;
 #pragma unroll
@@ -43,7 +52,7 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
             s = fmaf(x[q], x[q], s);
         }
         const float nrm = sqrtf(cc_wave_sum(s));
-        const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];   // element strides: a strided view is fine
+        const float mk = (float)mask[(int64_t)t * ad.mcs];   // element strides: a strided view is fine
         cnt += mk;
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
@@ -68,21 +77,26 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
 // video_pool_kernel does, parks it in LDS, then the four waves normalise one text each and take the dot product.
 __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float* __restrict__ text,
                                                                      const float* __restrict__ visual,
-                                                                     const long long* __restrict__ mask, int64_t mrs,
-                                                                     int64_t mcs, float* __restrict__ logits, int ldl,
+                                                                     const long long* __restrict__ mask, VidAddr ad,
+                                                                     float* __restrict__ logits, int ldl,
                                                                      float* __restrict__ pooled_out, int Bt, int Bv,
                                                                      int Tn, int E, float mult) {
     __shared__ float vp[1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v = blockIdx.x;
     constexpr int MAXE = 16;                      // E <= 1024
+    {
+        const int grp = v / ad.vg, loc = v - grp * ad.vg;
+        visual += (int64_t)grp * ad.vgs + (int64_t)loc * Tn * E;
+        mask += (int64_t)grp * ad.mgs + (int64_t)loc * ad.mrs;
+    }
     if (wave == 0) {
         float acc[MAXE];
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) acc[q] = 0.f;
         float cnt = 0.f;
         for (int t = 0; t < Tn; ++t) {
-            const float* src = visual + ((int64_t)v * Tn + t) * E;
+            const float* src = visual + (int64_t)t * E;
             float x[MAXE];
             float s = 0.f;
 #pragma unroll
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
                 s = fmaf(x[q], x[q], s);
             }
             const float nrm = sqrtf(cc_wave_sum(s));
-            const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];   // element strides: a strided view is fine
+            const float mk = (float)mask[(int64_t)t * ad.mcs];   // element strides: a strided view is fine
             cnt += mk;
 #pragma unroll
             for (int q = 0; q < MAXE; ++q) acc[q] += (x[q] / nrm) * mk;
@@ -234,19 +248,28 @@ size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E) {
     return cc_align_up((size_t)Bt * E * 4, 256) + cc_align_up((size_t)Bv * E * 4, 256);
 }
 
-static int video_pool_launch(const float* visual, const int64_t* video_mask, int64_t mrs, int64_t mcs, int32_t Bv,
+static int video_pool_launch(const float* visual, const int64_t* video_mask, const VidAddr& ad, int32_t Bv,
                              int32_t Tn, int32_t E, float* pooled, void* stream) {
-    if (!visual || !video_mask || !pooled || Bv <= 0 || Tn <= 0 || E <= 0) return CC_ERR_INVALID;
+    if (!visual || !video_mask || !pooled || Bv <= 0 || Tn <= 0 || E <= 0 || ad.vg <= 0) return CC_ERR_INVALID;
     if (E > 1024) return CC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(video_pool_kernel, dim3((Bv + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), visual,
-                       reinterpret_cast<const long long*>(video_mask), mrs, mcs, pooled, Bv, Tn, E);
+                       reinterpret_cast<const long long*>(video_mask), ad, pooled, Bv, Tn, E);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
 int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
                                 float* pooled, void* stream) {
-    return video_pool_launch(visual, video_mask, Tn, 1, Bv, Tn, E, pooled, stream);
+    const VidAddr ad{Bv > 0 ? Bv : 1, 0, 0, Tn, 1};
+    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, stream);
+}
+
+/* rows [R, E] -> rows / |row| (the text half of _loose_similarity, modules/clip4clip.py:361-362) */
+int cc_normalize_rows_f32(const float* in, float* out, int32_t R, int32_t E, void* stream) {
+    if (!in || !out || R <= 0 || E <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, R, E);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
 }
 
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult, float* logits,
@@ -259,17 +282,19 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
     return CC_OK;
 }
 
-int cc_loose_similarity_strided_f32(const float* text, const float* visual, const int64_t* video_mask,
-                                    int64_t mask_row_stride, int64_t mask_col_stride, int32_t Bt, int32_t Bv, int32_t Tn,
-                                    int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out, void* ws,
+int cc_loose_similarity_grouped_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t group,
+                                    int64_t vis_group_stride, int64_t mask_group_stride, int64_t mask_row_stride,
+                                    int64_t mask_col_stride, int32_t Bt, int32_t Bv, int32_t Tn, int32_t E,
+                                    float logit_scale, float* logits, int32_t ldl, float* pooled_out, void* ws,
                                     size_t ws_bytes, void* stream) {
-    if (!text || !visual || !video_mask || !logits) return CC_ERR_INVALID;
+    if (!text || !visual || !video_mask || !logits || group <= 0) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_similarity_workspace_bytes(Bt, Bv, E)) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const VidAddr ad{group, vis_group_stride, mask_group_stride, mask_row_stride, mask_col_stride};
     if ((long)Bt * Bv <= 4096 && E <= 1024 && Bt > 0 && Bv > 0) {      // one launch for a step's own logits
         hipLaunchKernelGGL(loose_similarity_small_kernel, dim3(Bv), dim3(256), 0, st, text, visual,
-                           reinterpret_cast<const long long*>(video_mask), mask_row_stride, mask_col_stride, logits, ldl,
-                           pooled_out, Bt, Bv, Tn, E, expf(logit_scale));
+                           reinterpret_cast<const long long*>(video_mask), ad, logits, ldl, pooled_out, Bt, Bv, Tn, E,
+                           expf(logit_scale));
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
@@ -278,9 +303,18 @@ int cc_loose_similarity_strided_f32(const float* text, const float* visual, cons
                            : reinterpret_cast<float*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, tn, Bt, E);
     CC_LAUNCH_CHECK();
-    int rc = video_pool_launch(visual, video_mask, mask_row_stride, mask_col_stride, Bv, Tn, E, vp, stream);
+    int rc = video_pool_launch(visual, video_mask, ad, Bv, Tn, E, vp, stream);
     if (rc) return rc;
     return cc_scaled_dot_nt_f32(tn, vp, Bt, Bv, E, expf(logit_scale), logits, ldl, stream);
+}
+
+int cc_loose_similarity_strided_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                    int64_t mask_row_stride, int64_t mask_col_stride, int32_t Bt, int32_t Bv, int32_t Tn,
+                                    int32_t E, float logit_scale, float* logits, int32_t ldl, float* pooled_out, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    return cc_loose_similarity_grouped_f32(text, visual, video_mask, Bv > 0 ? Bv : 1, 0, 0, mask_row_stride,
+                                           mask_col_stride, Bt, Bv, Tn, E, logit_scale, logits, ldl, pooled_out, ws,
+                                           ws_bytes, stream);
 }
 
 int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t Bt, int32_t Bv,
@@ -350,6 +384,59 @@ extern "C" int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, 
     if (!sim || !counts || rows <= 0 || cols <= 0 || diag_offset < 0 || diag_offset + rows > cols) return CC_ERR_INVALID;
     hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
                        cols, row_stride, col_stride, diag_offset, (const int*)nullptr, counts);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+// ============================================================================ N4 (forward part): contrastive loss
+// CrossEn.forward (modules/losses.py:8-18): logpt = log_softmax(sim, -1); loss = mean(-diag(logpt)), and the symmetric
+// form CLIP4Clip.forward builds from it (modules/clip4clip.py:250-253): (CrossEn(sim) + CrossEn(sim^T)) / 2.
+// One wave per row (row i of sim, or column i through the strides): nce_i = log(sum_j exp(x_j - max)) + max - x_i.
+__global__ __launch_bounds__(256) void cross_entropy_rows_kernel(const float* __restrict__ sim, int n, int64_t rs,
+                                                                 int64_t cs, float* __restrict__ nce) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* row = sim + (int64_t)i * rs;
+    float mx = -3.0e38f;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, row[(int64_t)j * cs]);
+    mx = cc_wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += expf(row[(int64_t)j * cs] - mx);
+    s = cc_wave_sum(s);
+    if (lane == 0) nce[i] = (logf(s) + mx) - row[(int64_t)i * cs];
+}
+
+// out[0] = mean(nce_rows), out[1] = mean(nce_cols), out[2] = (out[0] + out[1]) / 2; one workgroup, fixed order
+__global__ __launch_bounds__(256) void contrastive_mean_kernel(const float* __restrict__ nce, int n, float* __restrict__ out) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { a += nce[i]; b += nce[n + i]; }
+    a = cc_wave_sum(a);
+    b = cc_wave_sum(b);
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)n;
+        const float l2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)n;
+        out[0] = l1;
+        out[1] = l2;
+        out[2] = (l1 + l2) / 2.0f;
+    }
+}
+
+extern "C" int cc_contrastive_loss_f32(const float* sim, int32_t n, int64_t row_stride, int64_t col_stride, float* loss3,
+                                       void* ws, size_t ws_bytes, void* stream) {
+    if (!sim || !loss3 || n <= 0) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < (size_t)n * 2 * sizeof(float)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* nce = static_cast<float*>(ws);
+    hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, sim, n, row_stride, col_stride, nce);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, sim, n, col_stride, row_stride, nce + n);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(contrastive_mean_kernel, dim3(1), dim3(256), 0, st, nce, n, loss3);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

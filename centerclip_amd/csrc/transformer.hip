@@ -51,35 +51,51 @@ __device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane
         }
     }
     const float rstd = 1.0f / sqrtf(cc_wave_sum(q) / (float)W + eps);
-    float osum = 0.f, osq = 0.f;
+    float4 ov[4];
+    float ot = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int w = lane * 4 + t * 256;
+        ov[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (w < W) {
             const float4 gm = *reinterpret_cast<const float4*>(a.gamma + w);
             const float4 bt = *reinterpret_cast<const float4*>(a.beta + w);
             const float o0 = (v[t].x - mean) * rstd * gm.x + bt.x, o1 = (v[t].y - mean) * rstd * gm.y + bt.y;
             const float o2 = (v[t].z - mean) * rstd * gm.z + bt.z, o3 = (v[t].w - mean) * rstd * gm.w + bt.w;
+            ov[t] = make_float4(o0, o1, o2, o3);
+            ot += (o0 + o1) + (o2 + o3);
             if (OUT_F16) {
                 h4 o = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
                 *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(a.out) + (int64_t)row * a.out_stride + w) = o;
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (int64_t)row * a.out_stride + w) =
                     make_float4(o0, o1, o2, o3);
-                if (a.out16) {      // fp16 copy of the new residual row + its (sum, sumsq) for the folded LayerNorm
-                    h4 o = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
-                    *reinterpret_cast<h4*>(a.out16 + (int64_t)row * W + w) = o;
-                    const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-                    osum += (q0 + q1) + (q2 + q3);
-                    osq += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
-                }
             }
         }
     }
-    if (!OUT_F16 && a.stats) {
-        osum = cc_wave_sum(osum);
-        osq = cc_wave_sum(osq);
-        if (lane == 0) reinterpret_cast<float2*>(a.stats)[row] = make_float2(osum, osq);
+    if (!OUT_F16 && a.out16) {
+        // fp16 copy of the new residual row for the folded LayerNorm of the next block: centred on the row mean (the
+        // consumer's LayerNorm is shift invariant; an un-centred copy loses |mean| / sigma in precision), + its
+        // (sum, sumsq) and the mean that was subtracted
+        const float om = cc_wave_sum(ot) / (float)W;
+        float osum = 0.f, osq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            if (w < W) {
+                h4 o = {(_Float16)(ov[t].x - om), (_Float16)(ov[t].y - om), (_Float16)(ov[t].z - om), (_Float16)(ov[t].w - om)};
+                *reinterpret_cast<h4*>(a.out16 + (int64_t)row * W + w) = o;
+                const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+                osum += (q0 + q1) + (q2 + q3);
+                osq += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+            }
+        }
+        if (a.stats) {
+            osum = cc_wave_sum(osum);
+            osq = cc_wave_sum(osq);
+            if (lane == 0) reinterpret_cast<float2*>(a.stats)[row] = make_float2(osum, osq);
+        }
+        if (a.shift && lane == 0) a.shift[row] = om;
     }
 }
 
@@ -92,24 +108,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnPair pr, float eps) {
     layernorm_row<OUT_F16>(a, row, threadIdx.x & 63, eps);
 }
 
-// fp16 copy + (sum, sum of squares of the fp16-rounded values) of contiguous fp32 rows; one wave per row
+// fp16 copy + (sum, sum of squares of the fp16-rounded values) of contiguous fp32 rows; one wave per row (W <= 1024).
+// shift != nullptr: the copy is centred on the row mean (written to shift[row]) - see layernorm_row.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ h, _Float16* __restrict__ h16,
-                                                        float* __restrict__ stats, int rows, int W) {
+                                                        float* __restrict__ stats, float* __restrict__ shift, int rows,
+                                                        int W) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    float4 v[4];
+    float tot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        v[t] = (w < W) ? *reinterpret_cast<const float4*>(h + (int64_t)row * W + w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tot += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    }
+    const float om = shift ? cc_wave_sum(tot) / (float)W : 0.f;
     float s = 0.f, q = 0.f;
-    for (int w = lane * 4; w < W; w += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * W + w);
-        h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
-        const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-        s += (q0 + q1) + (q2 + q3);
-        q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        if (w < W) {
+            h4 o = {(_Float16)(v[t].x - om), (_Float16)(v[t].y - om), (_Float16)(v[t].z - om), (_Float16)(v[t].w - om)};
+            *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
+            const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+            s += (q0 + q1) + (q2 + q3);
+            q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+        }
     }
     s = cc_wave_sum(s);
     q = cc_wave_sum(q);
-    if (lane == 0) reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
+    if (lane == 0) {
+        reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
+        if (shift) shift[row] = om;
+    }
 }
 
 // LayerNorm folding of a Linear layer: w_out[n,k] = fp16(W[n,k] * gamma[k]); c1[n] = sum_k float(w_out[n,k]);
@@ -176,8 +209,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
     _Float16* Vt = Ks + KT * ATT_D;                                          // 64 * VS
     _Float16* Ps = Vt + ATT_D * VS;                                          // 4 waves * 16 * VS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t ld = 3 * (int64_t)W;
-    const _Float16* base = qkv + (int64_t)seq * L * ld + head * ATT_D;
+    const int64_t ld = 3 * (int64_t)W * at.tok_rows;          // qkv stride between consecutive tokens of a sequence
+    const _Float16* base = qkv + (int64_t)seq * at.seq_rows * 3 * W + head * ATT_D;
 
     // ---- stage K (swizzled) and V^T; rows >= L are zero
     for (int idx = tid; idx < KT * 8; idx += 256) {
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
             }
         }
         if (q < L) {
-            _Float16* dst = out + ((int64_t)seq * L + q) * W + head * ATT_D;
+            _Float16* dst = out + ((int64_t)seq * at.seq_rows + (int64_t)q * at.tok_rows) * W + head * ATT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
@@ -300,8 +333,8 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
     const int L = at.L, heads = at.heads, W = at.W;
     const bool CAUSAL = at.causal != 0;
     const int seq = u / heads, head = u - seq * heads;
-    const int64_t ld = 3 * (int64_t)W;
-    const _Float16* base = at.qkv + (int64_t)seq * L * ld + head * ATT_D;
+    const int64_t ld = 3 * (int64_t)W * at.tok_rows;
+    const _Float16* base = at.qkv + (int64_t)seq * at.seq_rows * 3 * W + head * ATT_D;
     _Float16* Vt = lds[wave];
     _Float16* Pw = Vt + ATT_D * ATTW_KT;
     constexpr int PS = ATTW_KT + 8;
@@ -405,7 +438,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
             }
         }
         if (q < L) {
-            _Float16* dst = at.out + ((int64_t)seq * L + q) * W + head * ATT_D;
+            _Float16* dst = at.out + ((int64_t)seq * at.seq_rows + (int64_t)q * at.tok_rows) * W + head * ATT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
@@ -520,24 +553,40 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
     const int b = row / Lt, t = row - b * Lt;
     const long long id = ids[row];
     const float* src = e.tok_emb + (int64_t)id * W;
-    float s = 0.f, q = 0.f;
-    for (int w = lane * 4; w < W; w += 256) {
-        const float4 a = *reinterpret_cast<const float4*>(src + w);
-        const float4 pe = *reinterpret_cast<const float4*>(e.pos + (int64_t)t * W + w);
-        const float4 v = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
-        *reinterpret_cast<float4*>(e.h + (int64_t)row * W + w) = v;
-        if (e.h16) {
-            h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            *reinterpret_cast<h4*>(e.h16 + (int64_t)row * W + w) = o;
-            const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-            s += (q0 + q1) + (q2 + q3);
-            q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+    float4 v[4];
+    float tot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int w = lane * 4 + u * 256;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w < W) {
+            const float4 a = *reinterpret_cast<const float4*>(src + w);
+            const float4 pe = *reinterpret_cast<const float4*>(e.pos + (int64_t)t * W + w);
+            v[u] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+            *reinterpret_cast<float4*>(e.h + (int64_t)row * W + w) = v[u];
+            tot += (v[u].x + v[u].y) + (v[u].z + v[u].w);
         }
     }
-    if (e.h16) {
+    if (e.h16) {                                   // centred fp16 copy + its statistics + the mean (see layernorm_row)
+        const float om = cc_wave_sum(tot) / (float)W;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = lane * 4 + u * 256;
+            if (w < W) {
+                h4 o = {(_Float16)(v[u].x - om), (_Float16)(v[u].y - om), (_Float16)(v[u].z - om), (_Float16)(v[u].w - om)};
+                *reinterpret_cast<h4*>(e.h16 + (int64_t)row * W + w) = o;
+                const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+                s += (q0 + q1) + (q2 + q3);
+                q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+            }
+        }
         s = cc_wave_sum(s);
         q = cc_wave_sum(q);
-        if (lane == 0) reinterpret_cast<float2*>(e.stats)[row] = make_float2(s, q);
+        if (lane == 0) {
+            reinterpret_cast<float2*>(e.stats)[row] = make_float2(s, q);
+            if (e.shift) e.shift[row] = om;
+        }
     }
     if (t == 0) {      // one wave scans the row for the first maximum id (modules/clip.py:484)
         unsigned long long key = 0ull;
@@ -656,15 +705,19 @@ int cc_fold_layernorm_linear_f32(const float* weight, const float* bias, const f
     return CC_OK;
 }
 
-int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, int32_t rows, int32_t W, void* stream) {
+int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, float* shift_out, int32_t rows, int32_t W,
+                     void* stream) {
     if (!h || !h16_out || !stats_out || rows <= 0 || W <= 0) return CC_ERR_INVALID;
-    return cc_launch_row_stats(h, static_cast<_Float16*>(h16_out), stats_out, rows, W, static_cast<hipStream_t>(stream));
+    return cc_launch_row_stats(h, static_cast<_Float16*>(h16_out), stats_out, shift_out, rows, W,
+                               static_cast<hipStream_t>(stream));
 }
 
 int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, const float* beta, void* out,
                      int64_t out_stride, int32_t rows, int32_t W, float eps, int32_t out_f16, void* stream) {
     if (!in || !gamma || !beta || !out || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
-    LnArgs a{in, in_stride, gamma, beta, out, out_stride, rows, W, nullptr, nullptr};
+    LnArgs a{};
+    a.in = in; a.in_stride = in_stride; a.gamma = gamma; a.beta = beta; a.out = out; a.out_stride = out_stride;
+    a.rows = rows; a.W = W;
     return cc_launch_layernorm2(a, nullptr, eps, out_f16, static_cast<hipStream_t>(stream));
 }
 
@@ -672,7 +725,17 @@ int cc_attention_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L
                      int32_t causal, void* stream) {
     if (!qkv_f16 || !out_f16 || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * ATT_D) return CC_ERR_INVALID;
     if (L > ATT_MAX_KT) return CC_ERR_UNSUPPORTED;
-    AttArgs a{static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), nseq, L, heads, W, causal};
+    AttArgs a{static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), nseq, L, heads, W, causal, 0, 0};
+    return cc_launch_attention2(a, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int cc_attention_strided_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads, int32_t W,
+                             int32_t causal, int64_t seq_rows, int64_t tok_rows, void* stream) {
+    if (!qkv_f16 || !out_f16 || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * ATT_D) return CC_ERR_INVALID;
+    if (seq_rows <= 0 || tok_rows <= 0) return CC_ERR_INVALID;
+    if (L > ATT_MAX_KT) return CC_ERR_UNSUPPORTED;
+    AttArgs a{static_cast<const _Float16*>(qkv_f16), static_cast<_Float16*>(out_f16), nseq, L, heads, W, causal, seq_rows,
+              tok_rows};
     return cc_launch_attention2(a, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -694,9 +757,9 @@ int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_
     return CC_OK;
 }
 
-int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, int rows, int W, hipStream_t st) {
-    if (W & 3) return CC_ERR_INVALID;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, rows, W);
+int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, float* shift, int rows, int W, hipStream_t st) {
+    if ((W & 3) || W > 1024) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, shift, rows, W);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -711,9 +774,15 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
     AttPair pr{};
     pr.a[0] = a0;
     pr.a[1] = a1 ? *a1 : a0;
+    for (int q = 0; q < 2; ++q)
+        if (pr.a[q].seq_rows == 0 && pr.a[q].tok_rows == 0) { pr.a[q].seq_rows = pr.a[q].L; pr.a[q].tok_rows = 1; }
     pr.wgs0 = a0.nseq * a0.heads;
     const int total = pr.wgs0 + (a1 ? a1->nseq * a1->heads : 0);
+#ifdef CC_DEV_KNOBS
     static const bool wave_path = !(getenv("CC_ATT_BLOCK") && getenv("CC_ATT_BLOCK")[0] == '1');   // A/B switch
+#else
+    constexpr bool wave_path = true;
+#endif
     if (wave_path && a0.L <= 56 && (!a1 || a1->L <= 56)) {          // one wave per (sequence, head)
         hipLaunchKernelGGL(attention_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, st, pr, 0.125f);
         CC_LAUNCH_CHECK();
@@ -759,14 +828,14 @@ int cc_launch_im2col(const cc_frames& fr, _Float16* A, int F, int res, int p, hi
 }
 
 int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st) {
-    if ((e.W & 3) || (e.h16 && !e.stats)) return CC_ERR_INVALID;
+    if ((e.W & 3) || e.W > 1024 || (e.h16 && !e.stats)) return CC_ERR_INVALID;
     hipLaunchKernelGGL(text_embed_kernel, dim3((e.Bt * e.Lt + 3) / 4), dim3(256), 0, st, e);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
 int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hipStream_t st) {
-    if (ln.W > 1024 || (ln.W & 3) || (te.W & 3) || (te.h16 && !te.stats) || (ln.cls && (!ln.pos0 || ln.cls_period <= 0)))
+    if (ln.W > 1024 || (ln.W & 3) || (te.W & 3) || te.W > 1024 || (te.h16 && !te.stats) || (ln.cls && (!ln.pos0 || ln.cls_period <= 0)))
         return CC_ERR_INVALID;
     const int blocks_ln = (ln.rows + 3) / 4;
     hipLaunchKernelGGL(pre_stage_kernel, dim3(blocks_ln + (te.Bt * te.Lt + 3) / 4), dim3(256), 0, st, ln, te, blocks_ln, eps);
@@ -776,6 +845,7 @@ int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hi
 
 int cc_launch_head_project2(const HeadArgs& a0, const HeadArgs* a1, hipStream_t st) {
     if (a0.W > 1024 || (a0.E & 3) || (a1 && (a1->W > 1024 || (a1->E & 3)))) return CC_ERR_UNSUPPORTED;
+    if (a0.R + (a1 ? a1->R : 0) > 65535) return CC_ERR_UNSUPPORTED;       // grid y
     HeadPair hp{};
     hp.p[0] = a0;
     hp.p[1] = a1 ? *a1 : a0;

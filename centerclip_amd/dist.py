@@ -1,12 +1,16 @@
-"""Collectives of the retrieval path over torch.distributed (backend "nccl" is RCCL on ROCm; the same
-code runs on "gloo" for the CPU tests): one process per GPU, clips sharded across ranks.
+"""Collectives of the retrieval path over torch.distributed (backend "nccl" is RCCL on ROCm; the same code runs on
+"gloo" for the CPU tests): one process per GPU, clips sharded across ranks.
 
-* all_gather(*tensors): the three per-step feature all-gathers + barrier of the reference
-  (modules/utils.py:47-64 called at modules/clip4clip.py:351-355) packed into ONE all-gather of a
-  byte buffer - the messages are <= 2 MB (latency-bound over xGMI), so fewer, larger collectives.
-* shard_rows / sharded_similarity: the eval similarity matrix (main.py:502-534, rank-0 only in the
-  reference) row-sharded over ranks: every rank keeps its text rows, receives all pooled video
-  embeddings with one all-gather and computes its [Nt/G, Nv] row block.
+* all_gather(*tensors) / AllGather: the per-step feature all-gathers + barrier of the reference
+  (modules/utils.py:25-64 called at modules/clip4clip.py:351-355) packed into ONE all-gather of a byte buffer - the
+  messages are <= 2 MB (latency-bound over xGMI), so fewer, larger collectives.  Own-shard re-insert semantics as in
+  the reference (utils.py:56: ``gathered_tensor[rank] = tensor``).
+* PackedFeatures: the same exchange with NO packing step at all - the encoders write their features straight into a
+  preallocated record (visual | text | mask), one all_gather_into_tensor moves the records, and the similarity kernel
+  reads the gathered records in place (cc_loose_similarity_grouped_f32).
+* shard_rows / gather_rows / sharded_similarity: the eval similarity matrix (main.py:502-534, rank-0 only in the
+  reference) row-sharded over ranks: every rank keeps its text rows, receives all pooled video embeddings with one
+  all-gather and computes its [Nt/G, Nv] row block with the HIP NT GEMM.
 """
 import torch
 import torch.distributed as dist
@@ -16,10 +20,19 @@ def is_dist():
     return dist.is_available() and dist.is_initialized()
 
 
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
 def all_gather(*tensors):
     """Concatenate each tensor over ranks along dim 0 (rank order).  Tensors may differ in dtype and
     trailing shape but must have identical shapes on every rank.  Without an initialised process
-    group this is the identity (world size 1)."""
+    group this is the identity (world size 1).  The own shard of every result is the input tensor's
+    data (utils.py:56)."""
     if not is_dist() or dist.get_world_size() == 1:
         return tensors if len(tensors) > 1 else tensors[0]
     world = dist.get_world_size()
@@ -35,6 +48,64 @@ def all_gather(*tensors):
         outs.append(part)
         off += sz
     return tuple(outs) if len(outs) > 1 else outs[0]
+
+
+class AllGather(torch.autograd.Function):
+    """modules/utils.py:25-44: all-gather along dim 0 whose backward hands every rank the gradient slice of its own
+    shard.  Forward = all_gather above (one collective)."""
+
+    @staticmethod
+    def forward(ctx, tensor, args=None):
+        ctx.rank = rank()
+        ctx.batch_size = tensor.shape[0]
+        return all_gather(tensor)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None
+
+
+class PackedFeatures:
+    """One rank's record of a step's features, laid out for a single all_gather_into_tensor:
+
+        [ visual  B*Tn*E fp32 | text  B*E fp32 | mask  B*Tn int64 | pad to 16 B ]
+
+    ``vis`` / ``seq`` / ``mask`` are views into the send record - hand ``(vis, seq)`` to CLIP.encode_pair(out=...) so the
+    projection heads write there directly, copy the segment mask into ``mask`` - then ``gather()`` returns the
+    [G, rec_bytes] uint8 buffer of all ranks' records (preallocated; world size 1: a view of the send record) and
+    ``logits(text)`` runs the similarity tail on it in place."""
+
+    def __init__(self, B, Tn, E, device, world=None):
+        self.B, self.Tn, self.E = B, Tn, E
+        self.world = world_size() if world is None else world
+        self.vis_off = 0
+        self.seq_off = B * Tn * E * 4
+        self.mask_off = self.seq_off + B * E * 4
+        assert self.mask_off % 8 == 0
+        self.rec = -(-(self.mask_off + B * Tn * 8) // 16) * 16
+        self.send = torch.zeros(self.rec, dtype=torch.uint8, device=device)
+        self.vis = self.send[self.vis_off:self.seq_off].view(torch.float32).view(B * Tn, E)
+        self.seq = self.send[self.seq_off:self.mask_off].view(torch.float32).view(B, E)
+        self.mask = self.send[self.mask_off:self.mask_off + B * Tn * 8].view(torch.long).view(B, Tn)
+        self.recv = (torch.zeros(self.world * self.rec, dtype=torch.uint8, device=device) if self.world > 1
+                     else self.send)
+        self.bytes_per_gather = self.world * self.rec
+
+    def gather(self):
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        return self.recv.view(self.world, self.rec)
+
+    def logits(self, text, logit_scale):
+        """text [Bt, E] x all gathered videos -> [Bt, G*B] (this rank's row block when text is the local text)."""
+        from . import ops
+        return ops.loose_similarity_packed(text, self.recv.view(self.world, self.rec), self.B, self.Tn, self.E,
+                                           self.vis_off, self.mask_off, logit_scale)
+
+    def gathered_text(self):
+        """[G*B, E] text features of all ranks (a strided view of the gathered records)."""
+        r = self.recv.view(self.world, self.rec)[:, self.seq_off:self.mask_off]
+        return r.contiguous().view(torch.float32).view(self.world * self.B, self.E)
 
 
 def shard_rows(n, rank=None, world=None):
@@ -66,8 +137,12 @@ def gather_rows(local_rows, n_total):
     return torch.cat(parts, 0)
 
 
-def sharded_similarity(text_local, pooled_video_local, n_video_total, logit_mult, dot_fn):
+def sharded_similarity(text_local, pooled_video_local, n_video_total, logit_mult, dot_fn=None):
     """Row block [Nt_local, Nv] of the similarity matrix: all-gather the (pooled, normalised) video
-    embeddings, then one local NT GEMM.  ``dot_fn(a, b, mult)`` is the device kernel."""
+    embeddings, then one local NT GEMM.  ``dot_fn(a, b, mult)`` defaults to the HIP exact-fp32 MFMA kernel
+    (ops.scaled_dot_nt); the CPU (gloo) tests pass their own."""
     video_all = gather_rows(pooled_video_local, n_video_total)
+    if dot_fn is None:
+        from . import ops
+        dot_fn = ops.scaled_dot_nt
     return dot_fn(text_local, video_all, logit_mult)

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import torch_ops  # noqa: F401  (registers torch.ops.centerclip)
 
 
 def rank_counts(sim, transpose=False, diag_offset=0):
@@ -13,12 +14,7 @@ def rank_counts(sim, transpose=False, diag_offset=0):
     (or per row of sim.T when transpose=True, without materialising the transpose)."""
     L.require_device(sim)
     assert sim.dtype == torch.float32 and sim.dim() == 2
-    rows, cols = (sim.shape[1], sim.shape[0]) if transpose else sim.shape
-    rs, cs = (sim.stride(1), sim.stride(0)) if transpose else (sim.stride(0), sim.stride(1))
-    counts = torch.empty(rows, 2, dtype=torch.int32, device=sim.device)
-    L.check(L.lib().cc_rank_counts_f32(L.ptr(sim), rows, cols, rs, cs, int(diag_offset), L.ptr(counts),
-                                       L.stream_ptr(sim.device)), "cc_rank_counts_f32")
-    return counts
+    return torch.ops.centerclip.rank_counts(sim, bool(transpose), int(diag_offset))
 
 
 def metrics_from_counts(counts):
@@ -58,9 +54,7 @@ def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10)):
     x = sim_tensor.float().contiguous()
     G, Lmax, C = x.shape
     gt = torch.arange(G, dtype=torch.int32, device=x.device).repeat_interleave(Lmax).contiguous()
-    counts = torch.empty(G * Lmax, 3, dtype=torch.int32, device=x.device)
-    L.check(L.lib().cc_rank_counts_cols_f32(L.ptr(x), G * Lmax, C, C, 1, L.ptr(gt), L.ptr(counts),
-                                            L.stream_ptr(x.device)), "cc_rank_counts_cols_f32")
+    counts = torch.ops.centerclip.rank_counts_cols(x.view(G * Lmax, C), gt)
     truth = x.reshape(G * Lmax, C).gather(1, gt.long().unsqueeze(1)).squeeze(1)
     valid = torch.isfinite(truth).cpu().numpy()
     c = counts.cpu().numpy().astype(np.int64)

@@ -37,6 +37,12 @@ typedef enum cc_status {
     CC_ERR_HIP = -4           /* a HIP runtime call failed (hipGetLastError after a launch ...)  */
 } cc_status;
 
+/* Largest `threshold` the k-medoids entry points accept (reference default 1e-5, fast_kmeans.py:14; the shipped scripts
+ * pass 1e-6): every problem iterates to its fixed point, which is the final state of the reference's chunk-mean stop
+ * test (fast_kmeans.py:85-88) for any threshold below the distance between two distinct tokens.  A looser threshold
+ * would end the reference's loop earlier, so it is refused (CC_ERR_UNSUPPORTED) rather than ignored. */
+#define CC_KMEDOIDS_MAX_THRESHOLD 1e-5f
+
 /* metric: reference strings 'euclidean' / 'cosine' (modules/cluster/cluster_utils.py:21-33) */
 #define CC_METRIC_EUCLIDEAN 0
 #define CC_METRIC_COSINE 1
@@ -104,8 +110,8 @@ int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, 
 /*
  * C2..C5 - replaces batch_fast_kmedoids_with_split(X, K, distance, threshold, iter_limit,
  *      id_sort, norm_p, split_size, pre_norm)  modules/cluster/fast_kmeans.py:14-40 and
- *      batch_fast_kmedoids (:45-97; pass split_size >= P).  `threshold` is accepted for
- *      signature parity; the stop test is the equivalent fixed-point test (see above).
+ *      batch_fast_kmedoids (:45-97; pass split_size >= P).  The stop test is the fixed-point test (see above);
+ *      threshold > CC_KMEDOIDS_MAX_THRESHOLD returns CC_ERR_UNSUPPORTED.
  */
 int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K,
                           int32_t metric, float norm_p, float threshold, int32_t iter_limit,
@@ -215,16 +221,29 @@ int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, con
 
 /* The three pieces of the folded-LayerNorm pipeline the encoders use instead of stand-alone LayerNorm passes
  * (replaces ln_1 -> in_proj and ln_2 -> c_fc of modules/clip.py:240,251):
- *   cc_row_stats_f16          h [rows,W] fp32 -> h16 = fp16(h), stats [rows][1][2] = (sum, sum of squares) of h16
+ *   cc_row_stats_f16          h [rows,W] fp32 -> h16 = fp16(h - c), stats [rows][1][2] = (sum, sum of squares) of h16,
+ *                             c = the row mean, written to shift_out [rows] (shift_out NULL: c = 0).  W <= 1024.
  *   cc_linear_ln_f16          out(fp16) = [QuickGELU](LN(h) W^T + b), from h16, the folded weight and the stats
- *   cc_linear_resid_stats_f16 h += a W^T + b (residual), h16 = fp16(h), stats [M][*slots_out][2] (one slot per
- *                             tile column x wave column; stats buffers must hold 32 slots per row)            */
-int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, int32_t rows, int32_t W, void* stream);
+ *                             (LayerNorm is invariant to the per-row shift c, so the consumer never sees it)
+ *   cc_linear_resid_stats_f16 h += a W^T + b (residual), h16 = fp16(h - c), stats [M][*slots_out][2] (one slot per
+ *                             tile column x wave column; stats buffers must hold 32 slots per row).  c = the row mean
+ *                             before this update = shift_in[m] + mean of the centred copy the previous stage wrote
+ *                             (stats_in [M][slots_in][2]); written to shift_out [M].  stats_in NULL: c = 0.
+ * Centring keeps the rounding error of the fp16 copy relative to the row's spread, not to its mean (rows of real
+ * checkpoints can have |mean| >> sigma). */
+int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, float* shift_out, int32_t rows, int32_t W,
+                     void* stream);
 int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
                      const float* stats, int32_t slots, float eps, void* out_f16,
                      int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* stream);
+/* host-side query: the tile (1-8, see cc_linear_f16) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
+ * LN-folded f16 without / with QuickGELU, 7 = residual + statistics); <= 0: unsupported */
+int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue);
+/* host-side query: slots per row cc_linear_resid_stats_f16 will write for this shape (tile 0 = auto); <= 0: unsupported */
+int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile);
 int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h,
-                              void* h16_out, float* stats_out, int32_t* slots_out,
+                              void* h16_out, float* stats_out, int32_t* slots_out, const float* shift_in,
+                              const float* stats_in, int32_t slots_in, float* shift_out,
                               int32_t M, int32_t N, int32_t K, int32_t tile, void* stream);
 
 /* Multi-head self-attention core of nn.MultiheadAttention (modules/clip.py:220-226):
@@ -233,6 +252,11 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
  * triangular -inf mask of clip.py:448-454.  head_dim is 64 (W == 64*heads), L <= 256. */
 int cc_attention_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads,
                      int32_t W, int32_t causal, void* stream);
+/* The same for other row orders: token t of sequence s is row s*seq_rows + t*tok_rows of qkv / out.  The LND
+ * activations ResidualAttentionBlock.forward receives (modules/clip.py:228-253: x [L, N, W]) are seq_rows = 1,
+ * tok_rows = N; cc_attention_f16 is seq_rows = L, tok_rows = 1. */
+int cc_attention_strided_f16(const void* qkv_f16, void* out_f16, int32_t nseq, int32_t L, int32_t heads,
+                             int32_t W, int32_t causal, int64_t seq_rows, int64_t tok_rows, void* stream);
 
 /* One ResidualAttentionBlock (state-dict keys resblocks.{i}.*) */
 typedef struct cc_block_weights {
@@ -305,10 +329,11 @@ size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T);
  * fp32 -> features [B*T_final, embed_dim] fp32 (CLS row of ln_post(hidden) @ proj; only the
  * CLS row is projected - identical values).  hidden_out (optional):
  * the final hidden state [B*T_final, L_final, W] fp32 before ln_post (VisualTransformer.forward
- * output, clip.py:304-349).  medoids_out (optional): int64 [T_new*B, K] of the LAST cluster block.
+ * output, clip.py:304-349).  medoids_out (optional): int64 [T_new*B, K] of the LAST k-medoids block of the
+ * plan (T_new, K of THAT block; earlier cluster blocks do not write it).
  * forced_medoids (optional, test hook for "embeddings given identical medoid sets"):
- * int64 [T_new*B, K]; when non-NULL every cluster block skips the k-medoids selection and gathers
- * these ids instead (meaningful for plans with one cluster block, which is all shipped configs). */
+ * int64 [T_new*B, K]; when non-NULL the cluster block skips the k-medoids selection and gathers these ids
+ * instead.  Plans with more than one cluster block return CC_ERR_UNSUPPORTED with forced_medoids. */
 int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t T,
                   float* features, float* hidden_out, int64_t* medoids_out,
                   const int64_t* forced_medoids, void* ws, size_t ws_bytes, void* stream);
@@ -329,6 +354,17 @@ size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt);
  * (EOT has the largest id, clip.py:484) of ln_final(x) @ text_projection. */
 int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt,
                    float* features, void* ws, size_t ws_bytes, void* stream);
+/* ... also returning the final hidden state [Bt, Lt, W] fp32 before ln_final (hidden_out may be NULL) */
+int cc_text_encode_hidden(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt,
+                          float* features, float* hidden_out, void* ws, size_t ws_bytes, void* stream);
+
+/* out[r] = LayerNorm(h[r*row_mul + (row_idx ? row_idx[r] : 0)]) @ proj   (fp32 throughout; h rows of W floats,
+ * proj [W, E], out [R, E]).  The ln_post @ proj / ln_final @ text_projection tail of CLIP.encode_image / encode_text
+ * (modules/clip.py:463,480) for any set of rows: row_mul = 1, row_idx = NULL projects every token
+ * (return_hidden=True, clip.py:466-467,491-492).  W <= 1024, E % 4 == 0, R <= 65535. */
+int cc_head_project_f32(const float* h, int32_t row_mul, const int32_t* row_idx, const float* gamma,
+                        const float* beta, const float* proj, float* out, int32_t R, int32_t W, int32_t E,
+                        void* stream);
 
 /* Both encoders of one CLIP4Clip.forward call (modules/clip4clip.py:199-243: get_sequence_output
  * + get_visual_output) in one enqueue.  Block i of the text tower shares every launch with block i
@@ -348,9 +384,9 @@ int cc_vit_encode_frames(const cc_vit_model* m, const cc_frames* frames, int32_t
                          float* features, float* hidden_out, int64_t* medoids_out,
                          const int64_t* forced_medoids, void* ws, size_t ws_bytes, void* stream);
 int cc_clip_encode_frames(const cc_vit_model* vm, const cc_frames* frames, int32_t B, int32_t T,
-                          float* visual_features, int64_t* medoids_out, const cc_text_model* tm,
-                          const int64_t* ids, int32_t Bt, int32_t Lt, float* text_features,
-                          void* ws, size_t ws_bytes, void* stream);
+                          float* visual_features, int64_t* medoids_out, const int64_t* forced_medoids,
+                          const cc_text_model* tm, const int64_t* ids, int32_t Bt, int32_t Lt,
+                          float* text_features, void* ws, size_t ws_bytes, void* stream);
 
 /* S2 - the meanP similarity tail, CLIP4Clip._loose_similarity (modules/clip4clip.py:357-366) with
  * _mean_pooling_for_similarity_visual (:305-316):
@@ -372,10 +408,29 @@ int cc_loose_similarity_strided_f32(const float* text, const float* visual, cons
                                     int64_t mask_row_stride, int64_t mask_col_stride, int32_t Bt, int32_t Bv,
                                     int32_t Tn, int32_t E, float logit_scale, float* logits, int32_t ldl,
                                     float* pooled_out, void* ws, size_t ws_bytes, void* stream);
+/* The same on the packed all-gather buffer of the multi-GPU step (modules/utils.py:47-64 + clip4clip.py:351-355 as
+ * ONE collective): videos come in groups of `group` (one record per rank); video v = (g, l) has its frames at
+ * visual + g*vis_group_stride + l*Tn*E (floats) and its mask row at video_mask + g*mask_group_stride +
+ * l*mask_row_stride (int64 elements).  group >= Bv is the plain layout. */
+int cc_loose_similarity_grouped_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t group,
+                                    int64_t vis_group_stride, int64_t mask_group_stride, int64_t mask_row_stride,
+                                    int64_t mask_col_stride, int32_t Bt, int32_t Bv, int32_t Tn, int32_t E,
+                                    float logit_scale, float* logits, int32_t ldl, float* pooled_out,
+                                    void* ws, size_t ws_bytes, void* stream);
+/* rows [R, E] -> rows / |row|: the text half of _loose_similarity (clip4clip.py:361-362) for the pre-pooled
+ * (2-D visual_output) branch */
+int cc_normalize_rows_f32(const float* in, float* out, int32_t R, int32_t E, void* stream);
 /* logits[Bt,Bv] = mult * a[Bt,E] b[Bv,E]^T for already-normalised rows (the sharded eval
  * similarity matrix, main.py:502-534, computed in one launch per row block). */
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult,
                          float* logits, int32_t ldl, void* stream);
+
+/* N4, forward values only - CrossEn (modules/losses.py:8-18) in both directions and their mean as CLIP4Clip.forward's
+ * training branch forms it (modules/clip4clip.py:245-253): loss3[0] = mean_i -log_softmax(sim[i,:])[i],
+ * loss3[1] = the same on sim^T, loss3[2] = (loss3[0] + loss3[1]) / 2.  sim [n,n] fp32 addressed through element strides.
+ * ws: 2*n floats.  (No backward: training is out of scope; this is the loss a validation pass reports.) */
+int cc_contrastive_loss_f32(const float* sim, int32_t n, int64_t row_stride, int64_t col_stride, float* loss3,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* N1 - the rank extraction of compute_metrics (utils/metrics.py:11-26) on the device: for row i with
  * ground-truth column g = diag_offset + i, counts[2i] = #{j: sim[i,j] > sim[i,g]} and counts[2i+1] =

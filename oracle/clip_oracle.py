@@ -175,3 +175,35 @@ def similarity_matrix_blocked(seq_batches, vis_batches, mask_batches, logit_scal
     for t in seq_batches:
         rows.append(torch.cat([loose_similarity(t, v, m, logit_scale) for v, m in zip(vis_batches, mask_batches)], dim=-1))
     return torch.cat(rows, dim=0)
+
+
+def cross_en(sim_matrix):
+    """modules/losses.py:8-18: mean over rows of -log_softmax(sim, -1)[i, i]."""
+    return -torch.diag(F.log_softmax(sim_matrix.float(), dim=-1)).mean()
+
+
+def clip4clip_forward(sd, ids, video, video_mask, max_frames, final_frames, cluster_plan, logit_scale,
+                      pre_visual_pooling=False, forced_medoids=None):
+    """CLIP4Clip.forward (eval branch) followed by get_similarity_logits (modules/clip4clip.py:199-243,412-434) for the
+    meanP head: ids [B, 1, L] (or [B, L]), video [B, 1, T, 3, H, W], video_mask [B, 1, T] ->
+    (sequence_output [B, 1, E], visual_output [B, T_new, E] or pooled [B, E], logits [B, B])."""
+    ids = ids.view(-1, ids.shape[-1])
+    T = video.shape[2]
+    v = video.reshape((-1,) + tuple(video.shape[3:])).float()
+    vmask = video_mask.view(-1, video_mask.shape[-1])
+    if cluster_plan:
+        vmask = video_mask_after_cluster(vmask, max_frames, final_frames)
+    seq = text_forward(sd, ids).view(ids.shape[0], 1, -1)
+    vis = visual_forward(sd, v, T, cluster_plan=cluster_plan, forced_medoids=forced_medoids).view(vmask.shape[0], -1, seq.shape[-1])
+    if pre_visual_pooling:
+        pooled = mean_pool_visual(vis, vmask)
+        t = seq.squeeze(1)
+        t = t / t.norm(dim=-1, keepdim=True)
+        return seq, pooled, math.exp(float(logit_scale)) * torch.matmul(t, pooled.t())
+    return seq, vis, loose_similarity(seq, vis, vmask, logit_scale)
+
+
+def clip4clip_train_loss(sd, ids, video, video_mask, max_frames, final_frames, cluster_plan, logit_scale):
+    """The loss of the training branch at world size 1 (clip4clip.py:245-262): (CrossEn(sim) + CrossEn(sim^T)) / 2."""
+    _, _, sim = clip4clip_forward(sd, ids, video, video_mask, max_frames, final_frames, cluster_plan, logit_scale)
+    return (cross_en(sim) + cross_en(sim.t())) / 2

@@ -123,3 +123,46 @@ def variant_input(cfg):
     embed = fullmant(cfg["seed"] + 2000, (cfg["K"], W), 24) if cfg.get("embed") else None
     mult = (fullmant(cfg["seed"] + 3000, (cfg["T"],), 24) + np.float32(1.0)) if cfg.get("adaptive") else None
     return x, embed, mult
+
+
+def _four_squares(r):
+    """Non-negative integers (a, b, c, d) with a^2 + b^2 + c^2 + d^2 = r (Lagrange), first in lexicographic order."""
+    a = 0
+    while a * a <= r:
+        b = 0
+        while a * a + b * b <= r:
+            c = 0
+            while a * a + b * b + c * c <= r:
+                d2 = r - a * a - b * b - c * c
+                d = int(round(d2 ** 0.5))
+                if d * d == d2:
+                    return a, b, c, d
+                c += 1
+            b += 1
+        a += 1
+    raise ValueError(r)
+
+
+def norm32_tokens(seed, shape):
+    """Integer-valued fp32 tokens whose L2 norm is EXACTLY 32 (sum of squares 1024): W - 4 entries in [-3, 3], the last
+    four complete the sum of squares.  32 + 1e-6 rounds to 32 in fp32, so the reference's pre-normalisation
+    X / (|X| + 1e-6) (fast_kmeans.py:21-22) is an exact division by 2^5: a bit-exact target for pre_norm=True."""
+    rng = np.random.default_rng(seed)
+    *lead, W = shape
+    x = rng.integers(-3, 4, size=tuple(lead) + (W,)).astype(np.int64)
+    flat = x.reshape(-1, W)
+    for row in flat:
+        row[W - 4:] = 0
+        rem = 1024 - int((row * row).sum())
+        assert rem >= 0, "W too large for a norm-32 token"
+        sq = _four_squares(rem)
+        signs = rng.integers(0, 2, size=4) * 2 - 1
+        row[W - 4:] = np.array(sq) * signs
+    return flat.reshape(shape).astype(np.float32)
+
+
+# name: (seed, P, N, W, K, split)   -- pre_norm=True fixtures (r2_golden.npz)
+PRENORM_CASES = {
+    "pn_small": (111, 5, 60, 96, 9, 2),
+    "pn_cfg2": (112, 16, 196, 128, 49, 16),
+}

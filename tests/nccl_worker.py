@@ -1,0 +1,73 @@
+"""Worker of tests/test_r2_gpu.py::test_nccl_packed_all_gather_and_sharded_similarity - run by torch.distributed.run,
+one process per GPU, backend nccl (= RCCL).  Checks, against data every rank can regenerate from seeds:
+  * dist.PackedFeatures: ONE all_gather_into_tensor of the preallocated records, logits read in place
+  * dist.all_gather / AllGather (reference semantics, modules/utils.py:25-64) incl. the own-shard backward slice
+  * dist.sharded_similarity with the HIP NT GEMM == the single-rank matrix
+Prints NCCL_WORKER_OK world=<n> on rank 0."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def feats(rank, B, Tn, E):
+    g = torch.Generator().manual_seed(100 + rank)
+    vis = torch.randn(B * Tn, E, generator=g)
+    seq = torch.randn(B, E, generator=g)
+    mask = (torch.rand(B, Tn, generator=g) > 0.3).long()
+    mask[:, 0] = 1
+    return vis, seq, mask
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    from centerclip_amd import ops
+    from centerclip_amd.dist import AllGather, PackedFeatures, all_gather, gather_rows, shard_rows, sharded_similarity
+    B, Tn, E = 16, 3, 512
+    vis, seq, mask = feats(rank, B, Tn, E)
+    pf = PackedFeatures(B, Tn, E, dev)
+    assert pf.world == world
+    pf.vis.copy_(vis)
+    pf.seq.copy_(seq)
+    pf.mask.copy_(mask)
+    pf.gather()
+    got = pf.logits(pf.seq, 1.5)
+    allv = torch.cat([feats(r, B, Tn, E)[0].view(B, Tn, E) for r in range(world)]).to(dev)
+    allm = torch.cat([feats(r, B, Tn, E)[2] for r in range(world)]).to(dev)
+    alls = torch.cat([feats(r, B, Tn, E)[1] for r in range(world)]).to(dev)
+    want = ops.loose_similarity(seq.to(dev), allv, allm, 1.5)
+    assert got.shape == (B, world * B) and torch.equal(got, want), "packed records"
+    assert torch.equal(pf.gathered_text(), alls)
+    # generic packed all_gather, reference semantics
+    gv, gm, gs = all_gather(vis.view(B, Tn, E).to(dev), mask.to(dev), seq.view(B, 1, E).to(dev))
+    assert torch.equal(gv, allv) and torch.equal(gm, allm) and torch.equal(gs.squeeze(1), alls)
+    x = seq.to(dev).clone().requires_grad_(True)
+    y = AllGather.apply(x)
+    y.backward(torch.arange(world * B, device=dev, dtype=torch.float32)[:, None].expand(-1, E).contiguous())
+    assert torch.equal(x.grad[:, 0], torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32))
+    # row-sharded eval similarity with the HIP kernel
+    Nt, Nv = 1003, 257
+    g = torch.Generator().manual_seed(7)
+    t = torch.nn.functional.normalize(torch.randn(Nt, E, generator=g), dim=-1).to(dev)
+    v = torch.nn.functional.normalize(torch.randn(Nv, E, generator=g), dim=-1).to(dev)
+    t0, t1 = shard_rows(Nt)
+    v0, v1 = shard_rows(Nv)
+    block = sharded_similarity(t[t0:t1], v[v0:v1], Nv, 2.0)
+    full = gather_rows(block, Nt)
+    assert torch.equal(full, ops.scaled_dot_nt(t, v, 2.0)), "sharded similarity"
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        print("NCCL_WORKER_OK world=%d backend=%s" % (world, dist.get_backend()), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,12 +16,19 @@ def _bench():
 
 def test_pmc_traffic_resolves_for_the_profiled_gemms():
     b = _bench()
-    for kernel, algorithmic in (("gemm_f16_kernel:c_fc", 78.4e6), ("gemm_f16_kernel:c_proj", 137e6)):
+    for kernel, algorithmic in (("gemm_f16_kernel<256, 256, 2, 4, 6, 64>", 78.4e6), ("gemm_f16_kernel<128, 128, 2, 2, 7, 64>", 137e6)):
         tr = b.pmc_traffic(kernel)
         assert tr is not None, kernel
         assert tr["hbm_bytes_per_launch"] == tr["fetch_bytes"] + tr["write_bytes"]
         assert 0.9 * algorithmic < tr["hbm_bytes_per_launch"] < 4 * algorithmic      # measured >= algorithmic, no wild re-reads
-    assert b.pmc_traffic("gemm_f16_kernel:unknown") is None
+    assert b.pmc_traffic("gemm_f16_kernel<1, 2, 3, 4, 5, 6>") is None
+
+
+def test_kernel_symbol_names_the_instantiation_the_dispatcher_picks():
+    b = _bench()
+    assert b.kernel_symbol(9600, 3072, 768, 6) == "gemm_f16_kernel<256, 256, 2, 4, 6, 64>"      # c_fc
+    assert b.kernel_symbol(9600, 2304, 768, 5) == "gemm_f16_kernel<256, 192, 2, 4, 5, 64>"      # in_proj
+    assert b.kernel_symbol(2400, 768, 3072, 7) == "gemm_f16_kernel<64, 64, 2, 2, 7, 128>"       # c_proj, clustered blocks
 
 
 def test_cluster_pmc_traffic_resolves():

@@ -98,3 +98,50 @@ def test_all_gather_is_identity_without_process_group():
     a, b = torch.arange(6).view(2, 3), torch.ones(2, 1)
     x, y = all_gather(a, b)
     assert x is a and y is b and all_gather(a) is a
+
+
+def case_packed_features(rank, world):
+    """dist.PackedFeatures over gloo: ONE all_gather_into_tensor of the preallocated records; the gathered buffer holds
+    every rank's (visual | text | mask) at the documented offsets."""
+    from centerclip_amd.dist import PackedFeatures
+    B, Tn, E = 3, 2, 8
+    pf = PackedFeatures(B, Tn, E, torch.device("cpu"))
+    vis, mask, seq = _features(rank, B, Tn, E)
+    pf.vis.copy_(vis.view(B * Tn, E))
+    pf.seq.copy_(seq.view(B, E))
+    pf.mask.copy_(mask)
+    rec = pf.gather()
+    ok = rec.shape == (world, pf.rec) and pf.rec % 16 == 0 and pf.world == world
+    for r in range(world):
+        v, m, s = _features(r, B, Tn, E)
+        ok = ok and torch.equal(rec[r, pf.vis_off:pf.seq_off].view(torch.float32).view(B, Tn, E), v)
+        ok = ok and torch.equal(rec[r, pf.seq_off:pf.mask_off].view(torch.float32).view(B, 1, E), s)
+        ok = ok and torch.equal(rec[r, pf.mask_off:pf.mask_off + B * Tn * 8].view(torch.long).view(B, Tn), m)
+    ok = ok and torch.equal(pf.gathered_text(), torch.cat([_features(r, B, Tn, E)[2].view(B, E) for r in range(world)]))
+    return bool(ok)
+
+
+def case_allgather_autograd(rank, world):
+    """AllGather (modules/utils.py:25-44): forward = concatenation in rank order, backward = this rank's slice."""
+    from centerclip_amd.dist import AllGather
+    x = torch.full((2, 3), float(rank + 1), requires_grad=True)
+    y = AllGather.apply(x)
+    y.backward(torch.arange(2 * world, dtype=torch.float32)[:, None].expand(-1, 3).contiguous())
+    want = torch.cat([torch.full((2, 3), float(r + 1)) for r in range(world)])
+    return bool(torch.equal(y.detach(), want) and torch.equal(x.grad[:, 0], torch.arange(2 * rank, 2 * rank + 2, dtype=torch.float32)))
+
+
+def test_packed_features_world2():
+    assert all(_run("case_packed_features").values())
+
+
+def test_allgather_autograd_world2():
+    assert all(_run("case_allgather_autograd").values())
+
+
+def test_packed_features_single_process_is_a_view():
+    from centerclip_amd.dist import PackedFeatures
+    pf = PackedFeatures(4, 3, 8, torch.device("cpu"), world=1)
+    pf.vis.fill_(2.0)
+    assert pf.gather().data_ptr() == pf.send.data_ptr() and pf.recv is pf.send
+    assert pf.vis.shape == (12, 8) and pf.seq.shape == (4, 8) and pf.mask.shape == (4, 3) and pf.mask.dtype == torch.long

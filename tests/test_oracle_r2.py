@@ -1,0 +1,67 @@
+"""Pin the oracle against the round-2 fixtures captured from the imported reference (tests/golden/r2_golden.npz,
+written by oracle/gen_golden_r2.py): the whole CLIP4Clip.forward -> get_similarity_logits path of the reference's own
+module (with / without pre_visual_pooling, masks with zeros, a fully masked clip), the training branch's loss values,
+CrossEn, and batch_fast_kmedoids_with_split(pre_norm=True) on tokens of norm exactly 32.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as clo
+from oracle import cluster_oracle as co
+from oracle.recipes import PRENORM_CASES, norm32_tokens
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r2_golden.npz")
+PLAN = {1: (2, 6)}           # block 2 (index 1): 4 frames -> 2 segments of 6 tokens
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN)
+
+
+def s1_state_dict(g):
+    return {k[6:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+            for k in g.files if k.startswith("s1_sd/")}
+
+
+@pytest.mark.parametrize("pvp", [0, 1])
+def test_s1_full_module_forward_and_logits(g, pvp):
+    sd = s1_state_dict(g)
+    T, T_new = int(g["s1_cfg"][11]), int(g["s1_cfg"][12])
+    seq, vis, logits = clo.clip4clip_forward(sd, torch.from_numpy(g["s1_ids"]), torch.from_numpy(g["s1_video"]),
+                                             torch.from_numpy(g["s1_vmask"]), T, T_new, PLAN, float(sd["logit_scale"]),
+                                             pre_visual_pooling=bool(pvp))
+    tag = "s1_pvp%d_" % pvp
+    np.testing.assert_allclose(seq.numpy(), g[tag + "seq"], rtol=0, atol=2e-5)
+    # (the fully masked clip pools to 0 / 0 = NaN in the reference too, clip4clip.py:313-316,360)
+    np.testing.assert_allclose(vis.numpy(), g[tag + "vis"], rtol=0, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(logits.numpy(), g[tag + "logits"], rtol=0, atol=5e-5, equal_nan=True)
+    assert np.isnan(g[tag + "logits"][:, 2]).all() and np.isfinite(g[tag + "logits"][:, :2]).all()
+    # pooling first or last gives the same logits (what pre_visual_pooling relies on)
+    np.testing.assert_allclose(g["s1_pvp0_logits"], g["s1_pvp1_logits"], rtol=0, atol=2e-5, equal_nan=True)
+
+
+def test_s1_training_branch_loss_and_crossen(g):
+    sd = s1_state_dict(g)
+    T, T_new = int(g["s1_cfg"][11]), int(g["s1_cfg"][12])
+    loss = clo.clip4clip_train_loss(sd, torch.from_numpy(g["s1_ids"]), torch.from_numpy(g["s1_video"]),
+                                    torch.from_numpy(g["s1_train_vmask"]), T, T_new, PLAN, float(sd["logit_scale"]))
+    assert abs(float(loss) - float(g["s1_train_loss"])) < 2e-5
+    assert float(g["s1_train_loss"]) == float(g["s1_train_sim_loss"])           # cluster_loss is 0 on this path
+    sim = torch.from_numpy(g["n4_sim"])
+    got = np.array([float(clo.cross_en(sim)), float(clo.cross_en(sim.t()))], dtype=np.float32)
+    np.testing.assert_allclose(got, g["n4_crossen"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", sorted(PRENORM_CASES))
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_pre_norm_fixture(g, tag, metric):
+    seed, P, N, W, K, split = PRENORM_CASES[tag]
+    X = torch.from_numpy(norm32_tokens(seed, (P, N, W)))
+    assert bool((torch.norm(X, dim=-1) == 32.0).all())
+    a, m = co.literal_batch_kmedoids_with_split(X, K, metric, 1e-6, 100, True, 2.0, split, True)
+    key = tag + ("_cos" if metric == "cosine" else "")
+    assert np.array_equal(m.numpy(), g[key + "_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g[key + "_assign"].astype(np.int64))

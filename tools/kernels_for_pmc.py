@@ -11,7 +11,7 @@ M = 9600
 for name, N, K in [("c_fc", 3072, 768), ("in_proj", 2304, 768)]:
     w = torch.randn(N, K, device="cuda") * K ** -0.5
     b = torch.randn(N, device="cuda")
-    h16, _ = ops.row_stats(torch.randn(M, K, device="cuda"))
+    h16, _, _ = ops.row_stats(torch.randn(M, K, device="cuda"))
     stats = torch.randn(M, 12, 2, device="cuda").abs()
     wf, c1, c2 = ops.fold_layernorm_linear(w, b, torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"))
     out = torch.empty(M, N, device="cuda", dtype=torch.float16)
@@ -21,8 +21,15 @@ for name, N, K in [("c_fc", 3072, 768), ("in_proj", 2304, 768)]:
 a = torch.randn(M, 3072, device="cuda").half(); w = (torch.randn(768, 3072, device="cuda") * 3072 ** -0.5).half()
 b = torch.randn(768, device="cuda"); hres = torch.zeros(M, 768, device="cuda")
 h16b = torch.empty(M, 768, device="cuda", dtype=torch.float16); stb = torch.empty(M * 64, device="cuda")
+_, st_in, sh_in = ops.row_stats(torch.randn(M, 768, device="cuda"))
+sh_out = torch.empty(M, device="cuda")
 for _ in range(5):
-    ops.linear_resid_stats_f16(a, w, b, hres, h16=h16b, stats=stb)
+    ops.linear_resid_stats_f16(a, w, b, hres, h16=h16b, stats=stb, shift_in=sh_in, stats_in=st_in.view(M, 1, 2), shift_out=sh_out)
+torch.cuda.synchronize()
+# out_proj shape on the same residual epilogue
+a2 = torch.randn(M, 768, device="cuda").half(); w2 = (torch.randn(768, 768, device="cuda") * 768 ** -0.5).half()
+for _ in range(5):
+    ops.linear_resid_stats_f16(a2, w2, b, hres, h16=h16b, stats=stb, shift_in=sh_in, stats_in=st_in.view(M, 1, 2), shift_out=sh_out)
 torch.cuda.synchronize()
 x = torch.randn(16 * 12, 50, W, device="cuda")
 mod = TokenClusterInter(before_cluster_num=49, cluster_num=49, before_block_frames=12, after_block_frames=3,
