@@ -228,7 +228,7 @@ def cluster_bench(c, device, iters=30):
     x = torch.randn(B * T, 1 + n, W, device=device)
     mod = TokenClusterInter(before_cluster_num=n, cluster_num=K, before_block_frames=T, after_block_frames=Tn,
                             original_frame=T, threshold=1e-6, iter_limit=100, split_size=c["split"], norm_p=2.0)
-    ms = event_time_ms(lambda: mod.cluster_frame_major(x), iters)
+    ms = graph_time_ms(lambda: mod.cluster_frame_major(x, keep_ids=False), launches=10, replays=max(2, iters // 10))
     P, N = B * Tn, (T // Tn) * n
     tokens = P * N
     alg_bytes = P * N * W * 4 + P * K * W * 4 + P * K * 8

@@ -757,9 +757,45 @@ int cc_launch_layernorm2(const LnArgs& a0, const LnArgs* a1, float eps, int out_
     return CC_OK;
 }
 
+// the same for rows wider than the register-resident kernel holds (W > 1024): the row is streamed twice
+__global__ __launch_bounds__(256) void row_stats_wide_kernel(const float* __restrict__ h, _Float16* __restrict__ h16,
+                                                             float* __restrict__ stats, float* __restrict__ shift,
+                                                             int rows, int W) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float om = 0.f;
+    if (shift) {
+        float tot = 0.f;
+        for (int w = lane * 4; w < W; w += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * W + w);
+            tot += (v.x + v.y) + (v.z + v.w);
+        }
+        om = cc_wave_sum(tot) / (float)W;
+    }
+    float s = 0.f, q = 0.f;
+    for (int w = lane * 4; w < W; w += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * W + w);
+        h4 o = {(_Float16)(v.x - om), (_Float16)(v.y - om), (_Float16)(v.z - om), (_Float16)(v.w - om)};
+        *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
+        const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+        s += (q0 + q1) + (q2 + q3);
+        q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+    }
+    s = cc_wave_sum(s);
+    q = cc_wave_sum(q);
+    if (lane == 0) {
+        reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
+        if (shift) shift[row] = om;
+    }
+}
+
 int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, float* shift, int rows, int W, hipStream_t st) {
-    if ((W & 3) || W > 1024) return CC_ERR_INVALID;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, shift, rows, W);
+    if (W & 3) return CC_ERR_INVALID;
+    if (W > 1024)
+        hipLaunchKernelGGL(row_stats_wide_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, shift, rows, W);
+    else
+        hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, h, h16, stats, shift, rows, W);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -222,7 +222,7 @@ int cc_layernorm_f32(const float* in, int64_t in_stride, const float* gamma, con
 /* The three pieces of the folded-LayerNorm pipeline the encoders use instead of stand-alone LayerNorm passes
  * (replaces ln_1 -> in_proj and ln_2 -> c_fc of modules/clip.py:240,251):
  *   cc_row_stats_f16          h [rows,W] fp32 -> h16 = fp16(h - c), stats [rows][1][2] = (sum, sum of squares) of h16,
- *                             c = the row mean, written to shift_out [rows] (shift_out NULL: c = 0).  W <= 1024.
+ *                             c = the row mean, written to shift_out [rows] (shift_out NULL: c = 0).
  *   cc_linear_ln_f16          out(fp16) = [QuickGELU](LN(h) W^T + b), from h16, the folded weight and the stats
  *                             (LayerNorm is invariant to the per-row shift c, so the consumer never sees it)
  *   cc_linear_resid_stats_f16 h += a W^T + b (residual), h16 = fp16(h - c), stats [M][*slots_out][2] (one slot per
