@@ -245,10 +245,18 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     if (vm) { v = carve_vit(vm, B, T, ws); off = v.total; }
     if (tm) { t = carve_text(tm, Bt, Lt, static_cast<char*>(ws) + off); off += t.total; }
     if (!ws || ws_bytes < off) return CC_ERR_WORKSPACE;
-    int rc;
+    int rc = CC_OK;
     float* h = nullptr;
     float* hother = nullptr;
     int frames = T, tokens = 0, W = 0;
+    const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
+    BlockCtx cv{}, ct{};
+    cv.slots0 = ct.slots0 = 1;
+    if (tm) {
+        ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.sh0 = t.sh0; ct.sh1 = t.sh1;
+        ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
+        ct.nseq = Bt; ct.L = Lt; ct.W = tm->width; ct.heads = tm->heads; ct.causal = 1;
+    }
     if (vm) {
         const int g = vm->resolution / vm->patch, n = g * g, F = B * T;
         W = vm->width;
@@ -284,7 +292,6 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                         : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;
     }
-    const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
     // medoids_out receives the ids of the LAST k-medoids block only (it is sized for that block); forced_medoids is a
     // single id tensor, so it is only meaningful for plans with one cluster block
     int last_kmed = -1, cluster_blocks = 0;
@@ -295,10 +302,9 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS) last_kmed = i;
         }
     if (forced_medoids && cluster_blocks > 1) return CC_ERR_UNSUPPORTED;
-    BlockCtx cv{}, ct{};
-    cv.slots0 = ct.slots0 = 1;
-    for (int i = 0; i < (vl > tl ? vl : tl); ++i) {
-        const bool hv = i < vl, ht = i < tl;
+    int ti = 0;                 // next text block
+    for (int i = 0; i < vl || ti < tl; ++i) {
+        const bool hv = i < vl;
         if (hv) {
             if (vm->cluster_tokens[i] > 0) {        // token cluster before the attention of this block (clip.py:236-242)
                 const int Tn = vm->cluster_frames[i], K = vm->cluster_tokens[i];
@@ -334,14 +340,11 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             cv.qkv = v.qkv; cv.att = v.att; cv.u = v.u;
             cv.nseq = B * frames; cv.L = tokens + 1; cv.W = W; cv.heads = vm->heads; cv.causal = 0;
         }
-        if (ht) {
-            ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.sh0 = t.sh0; ct.sh1 = t.sh1;
-            ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
-            ct.nseq = Bt; ct.L = Lt; ct.W = tm->width; ct.heads = tm->heads; ct.causal = 1;
-        }
-        rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[i] : nullptr,
+        const bool ht = ti < tl;
+        rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[ti] : nullptr,
                             ht ? &ct : nullptr, st);
         if (rc) return rc;
+        if (ht) ++ti;
     }
     // ln_post + proj on the CLS rows only (clip.py:463-464); ln_final + text_projection on the EOT rows only
     // (clip.py:480-484) - one launch for both heads
