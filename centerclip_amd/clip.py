@@ -48,6 +48,18 @@ def frames_descriptor(x, mean=PIXEL_MEAN, std=PIXEL_STD):
     return fr, x
 
 
+_ZERO = {}
+
+
+def zero_scalar(device):
+    """The `cluster_loss` the retrieval path returns (torch.zeros([]) in the reference, clip.py:265): one cached tensor
+    per device instead of a fill kernel per forward."""
+    key = str(device)
+    if key not in _ZERO:
+        _ZERO[key] = torch.zeros([], device=device)
+    return _ZERO[key]
+
+
 class LayerNorm(nn.Module):
     """LayerNorm computed in fp32 whatever the input dtype (modules/clip.py:183-189)."""
 
@@ -139,7 +151,7 @@ class Transformer(nn.Module):
 
     def forward(self, x, video_frame=-1, visual=False):
         """x [L, N, W] (LND) through the blocks one by one (clip.py:264-269); visual=True returns the whole tuple."""
-        cluster_loss = torch.zeros([], device=x.device)
+        cluster_loss = zero_scalar(x.device)
         out = self.resblocks((x, video_frame, cluster_loss))
         return out if visual else out[0]
 
@@ -318,7 +330,7 @@ class VisualTransformer(nn.Module):
         reference's self.transformer(x, video_frame, visual=True) call is inside it); the block-by-block form is
         Transformer.forward."""
         _, hidden = self.encode(x, video_frame, want_hidden=True)
-        return hidden, torch.zeros([], device=x.device)
+        return hidden, zero_scalar(x.device)
 
 
 class CLIP(nn.Module):
@@ -376,7 +388,7 @@ class CLIP(nn.Module):
             hidden = hidden.view(h.shape[0], h.shape[1], -1)
             return hidden[:, 0, :], hidden
         feats, _ = self.visual.encode(image, video_frame)
-        return feats, torch.zeros([], device=image.device)
+        return feats, zero_scalar(image.device)
 
     def _text_model(self):
         tower = nn.ModuleList([self.transformer, self.token_embedding, self.ln_final])

@@ -13,7 +13,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from . import torch_ops as T
-from .clip import build_clip_model, load_clip_state_dict
+from .clip import build_clip_model, load_clip_state_dict, zero_scalar
 from .dist import all_gather
 from .losses import symmetric_contrastive_loss
 
@@ -88,7 +88,7 @@ class CLIP4Clip(nn.Module):
             vfeat, tfeat = self.clip.encode_pair(video, input_ids, video_frame=video_frame)
             sequence_output = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
             visual_output = vfeat.view(video_mask.size(0), -1, vfeat.size(-1))
-            cluster_loss = torch.zeros([], device=vfeat.device)
+            cluster_loss = zero_scalar(vfeat.device)
         elif input_ids is not None:
             sequence_output = self.get_sequence_output(input_ids, token_type_ids, attention_mask)
         elif video is not None:

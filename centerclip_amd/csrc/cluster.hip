@@ -66,19 +66,28 @@ __device__ __forceinline__ float cc_dpp_f32(float x) {       // lane exchange in
 }
 
 // ============================================================================ K1
-// 64x64 tile of the Gram matrix of one problem per 256-thread workgroup (4 waves, 32x32 per
-// wave, 2x2 v_mfma_f32_16x16x4_f32 accumulators).  Only tiles with tj >= ti are launched;
-// the transposed tile is written by the same workgroup (g_ij == g_ji bit for bit: same
-// k order, commutative products).  The MFMA is an exact fp32 fma chain, so on exactly
-// representable inputs D equals any correct fp32 evaluation (parity level P1).
+// 64x64 tile of the Gram matrix of one problem per 256-thread workgroup (4 waves, 32x32 per wave, 2x2 accumulator
+// fragments).  Only tiles with tj >= ti are launched; the transposed tile is written by the same workgroup
+// (g_ij == g_ji bit for bit: same k order, commutative products).
 //
-// LDS tile [64 rows][40 floats] (32 k + 8 pad): the 16 lanes of a ds_read_b128 group land on
-// 16 distinct 4-bank slots.  k is consumed in a permuted order (lane group g owns k = g*4+t
-// of each 16-k slice for the t-th MFMA) - A and B use the same permutation, so it is only a
-// fixed re-ordering of the summation.
+// Arithmetic: every fp32 token element x is split, while it is staged, into two fp16 values hi = fp16(x) and
+// lo = fp16(x - hi) (x = hi + lo to 22 bits), and x.y is accumulated in fp32 as hi.hi + hi.lo + lo.hi on the fp16
+// matrix cores (v_mfma_f32_16x16x32_f16: 16x the rate of the exact-fp32 MFMA this kernel used before, which bounded
+// it: 2,048 of ~2,400 cycles per k-step).  The dropped lo.lo term is 2^-22 relative, the size of fp32 rounding itself.
+// On inputs that fp16 represents exactly (the integer / dyadic lattices of parity levels P1 / P2, the norm-32 tokens
+// of the pre_norm fixtures) lo = 0, every product and every partial sum is exact, and D equals any correct fp32
+// evaluation bit for bit - the property the index-parity fixtures rest on.  Range: fp16 holds |x| <= 65504 (token
+// values of a LayerNorm-ed residual stream are O(1..1e3)); beyond it hi and lo saturate - finite, monotone, but
+// outside the accuracy contract.  Below 2^-14 * 2^11 the lo part runs into fp16 subnormals and carries
+// fewer bits: the absolute error per element stays <= 2^-25, negligible next to the O(1) elements of the same token.
+//
+// LDS image per tile: hi and lo planes of [64 rows][64 k] fp16, 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7)
+// exactly as the fp16 GEMM stages its operands (conflict-free ds_read_b128 fragment reads).
 #define GT 64
 #define GK 64
-#define GLD 72     /* 64 k + 8 pad floats: 72 == 8 (mod 64) words -> rows r, r+8 alias; groups read 16 rows x 16 B = conflict-free in 2 passes */
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+#define GPLANE (GT * GK)            /* halfs per plane */
 
 template <int METRIC>
 __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
@@ -87,8 +96,10 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
                                                         int ntiles, int nprob) {
     // own_norms: the row norms come out of this kernel (sum of squares of the rows it stages anyway; the diagonal
     // tiles publish sqn / nrm / inv for the selection kernel) instead of a separate pass over the tokens (K0).
-    extern __shared__ __attribute__((aligned(16))) float gram_lds[];       // [2 buffers][A,B][GT * GLD] + 2 x GT norms
-    auto tile = [&](int buf, int which) { return gram_lds + (buf * 2 + which) * (GT * GLD); };
+    extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds_raw[];   // [2 buffers][A,B][hi,lo][GPLANE] halfs + 2 x GT floats
+    auto plane = [&](int buf, int which, int hl) {
+        return reinterpret_cast<_Float16*>(gram_lds_raw) + ((buf * 2 + which) * 2 + hl) * GPLANE;
+    };
     // Workgroup b runs on XCD b % 8, each with its own L2: all tiles of a problem are given to ONE XCD (problem
     // p -> XCD p % 8), so a problem's tokens are fetched into one L2 once instead of into up to 8 of them (PMC: the Gram
     // kernel fetched 116 MB for 28.9 MB of tokens with the tile-major order).
@@ -140,12 +151,24 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         }
     };
     float na[4] = {0.f, 0.f, 0.f, 0.f}, nb[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the rows' sums of squares
+    auto split_store = [&](_Float16* hi_plane, _Float16* lo_plane, int row, const float4& v) {
+        // x = hi + lo, hi = fp16(x) (saturated to the fp16 range), lo = fp16(x - hi)
+        const float c0 = fminf(fmaxf(v.x, -65504.f), 65504.f), c1 = fminf(fmaxf(v.y, -65504.f), 65504.f);
+        const float c2 = fminf(fmaxf(v.z, -65504.f), 65504.f), c3 = fminf(fmaxf(v.w, -65504.f), 65504.f);
+        const gh4 hi = {(_Float16)c0, (_Float16)c1, (_Float16)c2, (_Float16)c3};
+        const float r0 = fminf(fmaxf(v.x - (float)hi[0], -65504.f), 65504.f), r1 = fminf(fmaxf(v.y - (float)hi[1], -65504.f), 65504.f);
+        const float r2 = fminf(fmaxf(v.z - (float)hi[2], -65504.f), 65504.f), r3 = fminf(fmaxf(v.w - (float)hi[3], -65504.f), 65504.f);
+        const gh4 lo = {(_Float16)r0, (_Float16)r1, (_Float16)r2, (_Float16)r3};
+        const int off = row * GK + ((((lchunk >> 1) ^ (row & 7)) << 3) | ((lchunk & 1) << 2));     // halfs
+        *reinterpret_cast<gh4*>(hi_plane + off) = hi;
+        *reinterpret_cast<gh4*>(lo_plane + off) = lo;
+    };
     auto lstore = [&](int buf, int st) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 va = ra_[st][q], vb = rb_[st][q];
-            *reinterpret_cast<float4*>(tile(buf, 0) + (lrow + 16 * q) * GLD + lchunk * 4) = va;
-            if (!diag) *reinterpret_cast<float4*>(tile(buf, 1) + (lrow + 16 * q) * GLD + lchunk * 4) = vb;
+            split_store(plane(buf, 0, 0), plane(buf, 0, 1), lrow + 16 * q, va);
+            if (!diag) split_store(plane(buf, 1, 0), plane(buf, 1, 1), lrow + 16 * q, vb);
             if (own_norms) {
                 na[q] = fmaf(va.x, va.x, na[q]); na[q] = fmaf(va.y, va.y, na[q]);
                 na[q] = fmaf(va.z, va.z, na[q]); na[q] = fmaf(va.w, va.w, na[q]);
@@ -163,6 +186,9 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
     lstore(0, 0);
     __syncthreads();
     const int g = lane >> 4, l15 = lane & 15;
+    auto frag = [&](const _Float16* pl, int row, int ks) {     // 8 consecutive k of `row` at k = ks*32 + g*8
+        return *reinterpret_cast<const gh8*>(pl + row * GK + ((((ks << 2) | g) ^ (row & 7)) << 3));
+    };
     for (int kt0 = 0; kt0 < nk; kt0 += GD) {
 #pragma unroll
       for (int u = 0; u < GD; ++u) {
@@ -171,20 +197,36 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         const int buf = kt & 1;
         if (kt + GD < nk) gload(kt + GD, u);
         if (active) {
-            const float* A = tile(buf, 0) + (wr * 32 + l15) * GLD + g * 4;
-            const float* Bm = tile(buf, diag ? 0 : 1) + (wc * 32 + l15) * GLD + g * 4;
+            const _Float16* Ah = plane(buf, 0, 0);
+            const _Float16* Al = plane(buf, 0, 1);
+            const _Float16* Bh = plane(buf, diag ? 0 : 1, 0);
+            const _Float16* Bl = plane(buf, diag ? 0 : 1, 1);
+            const int ar = wr * 32 + l15, br = wc * 32 + l15;
 #pragma unroll
-            for (int ks = 0; ks < GK / 16; ++ks) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(A + ks * 16);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(A + 16 * GLD + ks * 16);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bm + ks * 16);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bm + 16 * GLD + ks * 16);
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b0[tt], acc[0][0], 0, 0, 0);
-                    if (f01) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], b1[tt], acc[0][1], 0, 0, 0);
-                    if (f10) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b0[tt], acc[1][0], 0, 0, 0);
-                    if (f11) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], b1[tt], acc[1][1], 0, 0, 0);
+            for (int ks = 0; ks < GK / 32; ++ks) {
+                const gh8 a0h = frag(Ah, ar, ks), a0l = frag(Al, ar, ks);
+                const gh8 b0h = frag(Bh, br, ks), b0l = frag(Bl, br, ks);
+                gh8 a1h = a0h, a1l = a0l, b1h = b0h, b1l = b0l;
+                if (f10 || f11) { a1h = frag(Ah, ar + 16, ks); a1l = frag(Al, ar + 16, ks); }
+                if (f01 || f11) { b1h = frag(Bh, br + 16, ks); b1l = frag(Bl, br + 16, ks); }
+                // acc[fm][fn][r] <-> row i = .. + fm*16 + g*4 + r (A operand rows), column j = .. + fn*16 + l15
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, b0h, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, b0l, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, b0h, acc[0][0], 0, 0, 0);
+                if (f01) {
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, b1h, acc[0][1], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, b1l, acc[0][1], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, b1h, acc[0][1], 0, 0, 0);
+                }
+                if (f10) {
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, b0h, acc[1][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, b0l, acc[1][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, b0h, acc[1][0], 0, 0, 0);
+                }
+                if (f11) {
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, b1l, acc[1][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, b1h, acc[1][1], 0, 0, 0);
                 }
             }
         }
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
       }
     }
 
-    float* lsq = gram_lds + 2 * 2 * GT * GLD;                 // [2][GT]: sum of squares of the A rows, of the B rows
+    float* lsq = reinterpret_cast<float*>(gram_lds_raw + (size_t)2 * 2 * 2 * GPLANE * sizeof(_Float16));   // [2][GT]
     if (own_norms) {
         // the 16 threads of a row (lchunk) sit in one DPP row: quad swaps, half mirror, mirror
 #pragma unroll
@@ -471,6 +513,7 @@ struct SelSmem {
     unsigned short* mem;        // tokens grouped by cluster, each group in summation-rank order
     unsigned short* cnt;        // members per cluster
     unsigned short* off;        // K + 1 group offsets into mem
+    unsigned long long* kkz;    // [2][4] per-wave (key, index) pairs of the KKZ arg-max
 };
 
 static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
@@ -483,6 +526,7 @@ static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
     b += 3 * cc_align_up((size_t)N * 2, 8);     // asg, order, mem
     b += cc_align_up((size_t)K * 2, 8);         // cnt
     b += cc_align_up((size_t)(K + 1) * 2, 8);   // off
+    b += 64;                                    // kkz
     return cc_align_up(b, 16);
 }
 
@@ -529,7 +573,8 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         s.order = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
         s.mem = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
         s.cnt = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)K * 2, 8);
-        s.off = reinterpret_cast<unsigned short*>(q);
+        s.off = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)(K + 1) * 2, 8);
+        s.kkz = reinterpret_cast<unsigned long long*>(q);
     }
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -620,45 +665,53 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
 
     for (int j = tid; j < N; j += 256) s.order[sum_rank(j, N)] = (unsigned short)j;
 
-    // ---- KKZ init on wave 0 (cluster_utils.py:93,106-118).  The running minimum lives in registers as
-    // order-preserving uint keys; arg-max = DPP max + ballots (lowest index wins ties).
-    if (wave == 0) {
-        unsigned nearest[NE];
+    // ---- KKZ init (cluster_utils.py:93,106-118) on all four waves: thread t owns tokens t, t + 256, ...; the running
+    // minimum lives in registers as order-preserving uint keys.  Per step: wave arg-max = DPP max + ballots (lowest
+    // index wins ties), the four (key, index) pairs meet in LDS (one barrier; the slots are double-buffered so that a
+    // step's writes never race the previous step's reads), every thread takes the best pair and folds the new medoid's
+    // row into its minimum.  (One wave doing all of it took ~990 cycles per step: 4 LDS rows + 4 ballots in a chain.)
+    {
+        constexpr int NT = (NE + 3) / 4;
+        unsigned nearest[NT];
         const float* nr = norms + (int64_t)p * N;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int n = lane + 64 * e;
+        for (int e = 0; e < NT; ++e) {
+            const int n = tid + 256 * e;
             nearest[e] = (n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
         }
-        long long kq0 = 0, kq1 = 0;
+        unsigned long long* red = s.kkz;
         for (int i = 0; i < K; ++i) {
-            long long ks0 = 0, ks1 = 0;
-            if (prof) ks0 = (long long)__builtin_readcyclecounter();
-            // arg-max with lowest-index tie break: DPP max of the keys, then one ballot per 64-token chunk - the first
-            // chunk with a lane at the maximum holds the smallest index (all scalar work: s_ff1 on the ballot)
             unsigned loc = nearest[0];
 #pragma unroll
-            for (int e = 1; e < NE; ++e) loc = max(loc, nearest[e]);
+            for (int e = 1; e < NT; ++e) loc = max(loc, nearest[e]);
             const unsigned mx = cc_wave_umax(loc);
             int m = -1;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NT; ++e) {
                 const unsigned long long b = __ballot(nearest[e] == mx);
-                if (m < 0 && b) m = 64 * e + __ffsll((long long)b) - 1;
+                if (m < 0 && b) m = 256 * e + 64 * wave + __ffsll((long long)b) - 1;
             }
-            if (lane == 0) s.med[i] = m;
-            if (prof) ks1 = (long long)__builtin_readcyclecounter();
+            // (a wave that owns only padding reports key 0 and loses against every real key)
+            if (lane == 0)
+                red[(i & 1) * 4 + wave] = ((unsigned long long)mx << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)m);
+            __syncthreads();
+            unsigned long long best = red[(i & 1) * 4];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int n = lane + 64 * e;
+            for (int w = 1; w < 4; ++w) {
+                const unsigned long long o = red[(i & 1) * 4 + w];
+                best = o > best ? o : best;
+            }
+            m = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+            if (tid == 0) s.med[i] = m;
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                const int n = tid + 256 * e;
                 if (n < N) {
                     const unsigned kd = cc_float_to_ordered_uint(DREAD(m, n));
                     nearest[e] = (i == 0) ? kd : min(nearest[e], kd);
                 }
             }
-            if (prof) { kq0 += ks1 - ks0; kq1 += (long long)__builtin_readcyclecounter() - ks1; }
         }
-        if (prof && lane == 0) { prof[(int64_t)blockIdx.x * 16 + 9] = kq0; prof[(int64_t)blockIdx.x * 16 + 10] = kq1; }
     }
     __syncthreads();
     SEL_STAMP(2);
@@ -955,31 +1008,25 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
     if (row >= B * T_new * Lout) return;
     // optional by-products for the fused forward (the next block's folded ln_1): fp16 copy of the output row at
     // h16[row][W], centred on the row mean (see layernorm_row in transformer.hip), its (sum, sum of squares) and the mean.
-    // The row is parked in registers (W <= 1024 on this path) until the mean is known.
-    float4 keep[4];
+    // The mean needs the whole row: every lane re-reads the elements it has just written (same lane, program order).
     float st_t = 0.f;
+    float* own_row = nullptr;
     auto emit = [&](int w, const float4& v) {
-        if (!h16) return;
-        const int t = (w >> 8) & 3;                           // wave-uniform (keeps `keep` in registers)
-        if (t == 0) keep[0] = v; else if (t == 1) keep[1] = v; else if (t == 2) keep[2] = v; else keep[3] = v;
-        st_t += (v.x + v.y) + (v.z + v.w);
+        (void)w;
+        if (h16) st_t += (v.x + v.y) + (v.z + v.w);
     };
     auto finish = [&]() {
         if (!h16) return;
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const float om = cc_wave_sum(st_t) / (float)W;
         float st_s = 0.f, st_q = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int w = lane * 4 + t * 256;
-            if (w < W) {
-                const float4 v = keep[t];
-                h4 o = {(_Float16)(v.x - om), (_Float16)(v.y - om), (_Float16)(v.z - om), (_Float16)(v.w - om)};
-                *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
-                const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
-                st_s += (q0 + q1) + (q2 + q3);
-                st_q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
-            }
+        for (int w = lane * 4; w < W; w += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(own_row + w);
+            h4 o = {(_Float16)(v.x - om), (_Float16)(v.y - om), (_Float16)(v.z - om), (_Float16)(v.w - om)};
+            *reinterpret_cast<h4*>(h16 + (int64_t)row * W + w) = o;
+            const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+            st_s += (q0 + q1) + (q2 + q3);
+            st_q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
         }
         st_s = cc_wave_sum(st_s);
         st_q = cc_wave_sum(st_q);
@@ -992,6 +1039,7 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
     const int b = seg / T_new, sgm = seg - b * T_new;
     const int fd = T / T_new, N = fd * n;
     float* dst = out + (int64_t)l * out_tok + (int64_t)seg * out_frame;
+    own_row = dst;
     const float* seg0 = x + (int64_t)(b * T + sgm * fd) * in_frame;       // CLS token of the segment's first frame
     if (l == 0 || mode == 2) {
         const float* src = seg0 + (int64_t)l * in_tok;
@@ -1142,7 +1190,7 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     }
     const int nt = (N + GT - 1) / GT;
     dim3 grid((unsigned)(((P + 7) / 8) * 8 * (nt * (nt + 1) / 2)));       // 1-D: problem p on XCD p % 8
-    const size_t gram_smem = (size_t)(2 * 2 * GT * GLD + 2 * GT) * sizeof(float);      // 74,240 B
+    const size_t gram_smem = (size_t)2 * 2 * 2 * GT * GK * sizeof(_Float16) + 2 * GT * sizeof(float);   // 66,048 B
     if (metric == CC_METRIC_COSINE || p == 2.0f) {
         static bool configured = false;
         if (!configured) {
@@ -1299,7 +1347,7 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
 // *_rows: the public entry plus the by-products the fused forward wants from the same launch - row_h16 [rows][W] fp16
 // copy of the output rows and row_stats [rows][2] their (sum, sum of squares); output must be dense ([seg][1+K][W]).
 static bool rows_layout_ok(const _Float16* row_h16, const float* row_stats, int W, int Lout, int64_t out_tok, int64_t out_frame) {
-    return !row_h16 || (row_stats && W <= 1024 && out_tok == W && out_frame == (int64_t)Lout * W);
+    return !row_h16 || (row_stats && out_tok == W && out_frame == (int64_t)Lout * W);
 }
 
 int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
