@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libcenterclip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-pass-failed"]
+         "-Wno-pass-failed"] + os.environ.get("CC_EXTRA_FLAGS", "").split()      # e.g. -DCC_DEV_KNOBS for A/B builds
 # the cluster / similarity paths promise IEEE single operations in source order (no fma contraction)
 STRICT = {"cluster.hip": ["-ffp-contract=off"], "similarity.hip": ["-ffp-contract=off"]}
 
