@@ -55,6 +55,10 @@ def _declare(lib):
                                                  c.POINTER(ClusterVariant), vp, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.cc_token_aggregate_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, c.POINTER(ClusterVariant), vp,
                                            i64, i64, vp]
+    lib.cc_spectral_laplacian_f32.argtypes = [vp, lay, i32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_svd_sign_flip_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.cc_spectral_laplacian_f32.restype = c.c_int
+    lib.cc_svd_sign_flip_f32.restype = c.c_int
     for name in ("cc_token_norms_f32", "cc_pairwise_distance_f32", "cc_kmedoids_from_dist_f32",
                  "cc_batch_kmedoids_f32", "cc_token_cluster_f32", "cc_token_cluster_variant_f32",
                  "cc_token_aggregate_f32"):

@@ -85,6 +85,7 @@ __device__ __forceinline__ float cc_dpp_f32(float x) {       // lane exchange in
 // exactly as the fp16 GEMM stages its operands (conflict-free ds_read_b128 fragment reads).
 #define GT 64
 #define GK 64
+#define CC_METRIC_SQL2 2      /* internal: squared L2 for the spectral affinity (not a clustering metric of the C ABI) */
 typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
 #define GPLANE (GT * GK)            /* halfs per plane */
@@ -283,6 +284,8 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
                         if (METRIC == CC_METRIC_EUCLIDEAN) {
                             const float d2 = (sqi + sqj) - 2.0f * gij;
                             d = (i == j) ? 0.0f : sqrtf(fmaxf(d2, 0.0f));
+                        } else if (METRIC == CC_METRIC_SQL2) {            // batched_cdist_l2 (cluster_utils.py:121-133):
+                            d = (sqj - 2.0f * gij) + sqi;                 // baddbmm(|y|^2, x, y^T, alpha=-2) + |x|^2, unclamped
                         } else {
                             const float ivi = own_norms ? 1.0f / (sqrtf(sqi) + 1e-6f) : iv[i];
                             const float ivj = own_norms ? 1.0f / (sqrtf(sqj) + 1e-6f) : iv[j];
@@ -1219,6 +1222,25 @@ int run_distance(const float* x, cc_token_layout lay, int W, int metric, float p
     return CC_OK;
 }
 
+// raw squared-L2 distances (spectral affinity): the Gram kernel with its own row norms, no shift
+int run_distance_sq(const float* x, cc_token_layout lay, int W, const ClusterWs& c, hipStream_t st) {
+    const int P = lay.B * lay.S, N = lay.fd * lay.n;
+    const int nt = (N + GT - 1) / GT;
+    dim3 grid((unsigned)(((P + 7) / 8) * 8 * (nt * (nt + 1) / 2)));
+    const size_t gram_smem = (size_t)2 * 2 * 2 * GT * GK * sizeof(_Float16) + 2 * GT * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gram_dist_kernel<CC_METRIC_SQL2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_smem) != hipSuccess)
+            return CC_ERR_HIP;
+        configured = true;
+    }
+    hipLaunchKernelGGL(gram_dist_kernel<CC_METRIC_SQL2>, grid, dim3(256), gram_smem, st, x, lay, N, W, c.sqn, c.nrm, c.inv,
+                       1, c.draw, c.tilemax, P, nt, P);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int slots_pp, int chunk,
                int apply_shift, int P, int N, int K, int iter_limit, int id_sort, long long* med, long long* assign,
                int* iters, hipStream_t st) {
@@ -1476,6 +1498,106 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
     return cc_token_cluster_variant_f32(x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, metric, norm_p, threshold,
                                         iter_limit, split_size, pre_norm, &var, out, out_tok_stride, out_frame_stride,
                                         medoids, assign, iters, ws, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+// ============================================================================ N4 (forward pieces of spectral clustering)
+// modules/cluster/spectral.py:17-137 minus the eigensolve (which has no parity definition):
+//   constructW ('HeatKernel', optional spatial-temporal mask)   W = exp(-|x_i - x_j|^2 / (2 sigma^2)) [* graph]   (:79-107)
+//   normalised Laplacian                                         L_sym = D^-1/2 (D - W) D^-1/2, D = diag(W 1)   (:44-52)
+//   batch_sign_flip_rasmus_bro                                   U[:, k] *= sign(sum_j sign(s_k v_kj) (s_k v_kj)^2) (:110-137)
+// The squared distances come from the Gram kernel above (raw, unshifted D of METRIC 2 = squared L2, no clamp, no sqrt:
+// batched_cdist_l2, cluster_utils.py:121-133).
+
+// W[p][i][j] = exp(-d2 / (2 sigma^2)) (* graph[i][j]); deg[p][i] = sum_j W[p][i][j].  One wave per row, in place on d2.
+__global__ __launch_bounds__(256) void heat_kernel_rows_kernel(float* __restrict__ d2w, const unsigned char* __restrict__ graph,
+                                                               float* __restrict__ deg, int P, int N, float inv_two_sigma2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P * N) return;
+    const int i = row % N;
+    float* r = d2w + (int64_t)row * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        float w = expf(-1.0f * r[j] * inv_two_sigma2);
+        if (graph) w = graph[(int64_t)i * N + j] ? w : 0.f;
+        r[j] = w;
+        s += w;
+    }
+    s = cc_wave_sum(s);
+    if (lane == 0) deg[row] = s;
+}
+
+// L[p][i][j] = ((i == j ? deg_i : 0) - W_ij) * deg_i^-1/2 * deg_j^-1/2   (the two bmm's with diagonal matrices, :51)
+__global__ __launch_bounds__(256) void sym_laplacian_kernel(const float* __restrict__ w, const float* __restrict__ deg,
+                                                            float* __restrict__ L, int P, int N) {
+    const int64_t total = (int64_t)P * N * N;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int p = (int)(idx / ((int64_t)N * N));
+        const int rem = (int)(idx - (int64_t)p * N * N);
+        const int i = rem / N, j = rem - i * N;
+        const float di = deg[(int64_t)p * N + i], dj = deg[(int64_t)p * N + j];
+        const float l = (i == j ? di : 0.f) - w[idx];
+        L[idx] = (powf(di, -0.5f) * l) * powf(dj, -0.5f);
+    }
+}
+
+// sign_left[p][k] = sum_j sign(S_k VT_kj) (S_k VT_kj)^2; U[p][:, k] *= sign(sign_left[p][k]).  One workgroup per (p, k).
+__global__ __launch_bounds__(256) void svd_sign_flip_kernel(float* __restrict__ U, const float* __restrict__ S,
+                                                            const float* __restrict__ VT, int M, int Kc, int Ncols) {
+    __shared__ float red[4];
+    const int p = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    const float sk = S[(int64_t)p * Kc + k];
+    const float* v = VT + ((int64_t)p * Kc + k) * Ncols;
+    float acc = 0.f;
+    for (int j = tid; j < Ncols; j += 256) {
+        const float t = sk * v[j];
+        const float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+        acc += sg * (t * t);
+    }
+    acc = cc_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float sg = (tot > 0.f) ? 1.f : ((tot < 0.f) ? -1.f : 0.f);
+    float* u = U + (int64_t)p * M * Kc + k;
+    for (int i = tid; i < M; i += 256) u[(int64_t)i * Kc] *= sg;
+}
+
+extern "C" {
+
+int cc_spectral_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma,
+                              const uint8_t* graph, float* laplacian, float* affinity_out, float* degree_out, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (!x || !laplacian || !layout_ok(lay, W) || !(sigma > 0.f)) return CC_ERR_INVALID;
+    const int P = lay->B * lay->S, N = lay->fd * lay->n;
+    ClusterWs c = carve(ws, P, N, W, 0, N);
+    if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* wbuf = affinity_out ? affinity_out : c.draw;
+    float* deg = degree_out ? degree_out : c.sqn;               // (sqn is free once the Gram kernel has run)
+    ClusterWs g = c;
+    g.draw = wbuf;
+    g.sqn = c.nrm;                                              // keep the norm scratch apart from `deg`
+    int rc = run_distance_sq(x, *lay, W, g, st);
+    if (rc != CC_OK) return rc;
+    hipLaunchKernelGGL(heat_kernel_rows_kernel, dim3((P * N + 3) / 4), dim3(256), 0, st, wbuf, graph, deg, P, N,
+                       1.0f / (2.0f * sigma * sigma));
+    CC_LAUNCH_CHECK();
+    const int64_t total = (int64_t)P * N * N;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(sym_laplacian_kernel, dim3(blocks), dim3(256), 0, st, wbuf, deg, laplacian, P, N);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_svd_sign_flip_f32(float* U, const float* S, const float* VT, int32_t P, int32_t M, int32_t K, int32_t N,
+                         void* stream) {
+    if (!U || !S || !VT || P <= 0 || M <= 0 || K <= 0 || N <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(svd_sign_flip_kernel, dim3(K, P), dim3(256), 0, static_cast<hipStream_t>(stream), U, S, VT, M, K, N);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
 }
 
 }  // extern "C"

@@ -350,6 +350,42 @@ def _(x):
     return x.new_empty(x.shape[:2])
 
 
+@custom_op(NS + "::spectral_laplacian", mutates_args=(), device_types="cuda")
+def spectral_laplacian(x: torch.Tensor, sigma: float, graph: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Normalised graph Laplacian of the heat-kernel affinity (modules/cluster/spectral.py:42-52,79-107): x [P,N,W] fp32,
+    graph [N,N] uint8 or None -> (L_sym [P,N,N], W [P,N,N])."""
+    P, N, Wd = x.shape
+    lay = L.TokenLayout(P, 1, 1, N, N * Wd, 0, 0, Wd)
+    lap = _e(P, N, N, like=x, dtype=torch.float32)
+    aff = _e(P, N, N, like=x, dtype=torch.float32)
+    lib = L.lib()
+    ws = L.workspace(lib.cc_cluster_workspace_bytes(P, N, Wd, 0), x.device)
+    L.check(lib.cc_spectral_laplacian_f32(L.ptr(x), ctypes.byref(lay), Wd, float(sigma), L.ptr(graph), L.ptr(lap), L.ptr(aff),
+                                          None, L.ptr(ws), ws.numel(), _st(x)), "cc_spectral_laplacian_f32")
+    return lap, aff
+
+
+@spectral_laplacian.register_fake
+def _(x, sigma, graph):
+    P, N, _W = x.shape
+    return x.new_empty((P, N, N)), x.new_empty((P, N, N))
+
+
+@custom_op(NS + "::svd_sign_flip", mutates_args=(), device_types="cuda")
+def svd_sign_flip(U: torch.Tensor, S: torch.Tensor, VT: torch.Tensor) -> torch.Tensor:
+    """batch_sign_flip_rasmus_bro (spectral.py:110-137): U [P,M,K], S [P,K], VT [P,K,N] -> sign-corrected copy of U."""
+    P, M, K = U.shape
+    out = U.clone()
+    L.check(L.lib().cc_svd_sign_flip_f32(L.ptr(out), L.ptr(S), L.ptr(VT), P, M, K, VT.shape[2], _st(U)),
+            "cc_svd_sign_flip_f32")
+    return out
+
+
+@svd_sign_flip.register_fake
+def _(U, S, VT):
+    return torch.empty_like(U)
+
+
 # ------------------------------------------------------------------------------------------ encoders
 @custom_op(NS + "::vit_encode", mutates_args=(), device_types="cuda")
 def vit_encode(frames: torch.Tensor, handle: int, B: int, T: int, want_hidden: bool, want_medoids: bool,
@@ -582,7 +618,7 @@ def _(sim):
     return sim.new_empty((3,))
 
 
-OPS = ("contrastive_loss", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
+OPS = ("contrastive_loss", "spectral_laplacian", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
        "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",

@@ -181,6 +181,22 @@ int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t 
 
 
 /*
+ * N4 (forward pieces of cluster_algo 'spectral', modules/cluster/spectral.py:17-137; the eigen-decomposition between
+ * them is NOT built - torch.linalg.svd's subspace for near-degenerate singular values is solver-rounding dependent, so
+ * it has no parity definition):
+ *   cc_spectral_laplacian_f32  W = exp(-|x_i - x_j|^2 / (2 sigma^2)) (constructW 'HeatKernel', spectral.py:79-88, squared
+ *                              distances as batched_cdist_l2, cluster_utils.py:121-133), optionally * graph [N,N] uint8
+ *                              (spatial_temporal_graph, :139-165); D = diag(W 1); laplacian [P,N,N] = D^-1/2 (D - W) D^-1/2
+ *                              (:44-52).  affinity_out [P,N,N] / degree_out [P,N] optional.  ws: cc_cluster_workspace_bytes.
+ *   cc_svd_sign_flip_f32       batch_sign_flip_rasmus_bro (:110-137), in place on U [P,M,K] given S [P,K], VT [P,K,N].
+ */
+int cc_spectral_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma,
+                              const uint8_t* graph, float* laplacian, float* affinity_out, float* degree_out,
+                              void* ws, size_t ws_bytes, void* stream);
+int cc_svd_sign_flip_f32(float* U, const float* S, const float* VT, int32_t P, int32_t M, int32_t K, int32_t N,
+                         void* stream);
+
+/*
  * C6 alone - the gather half of TokenClusterInter.forward for given medoid ids:
  *      x_tmp = res_tmp[batch_index, mediods_ids] (modules/cluster/cluster.py:289), the per-segment
  *      CLS mean (:307-308) and the restack (:303,310).  medoids [T_new*B, K] int64, p = s*B + b.

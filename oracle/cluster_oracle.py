@@ -433,3 +433,26 @@ def exact_zero_diag_distance(X, metric="euclidean", p=2.0, chunk_max=None):
     idx = np.arange(d.shape[-1])
     d[:, idx, idx] -= np.float32(1.0)
     return d.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: forward pieces of spectral clustering (modules/cluster/spectral.py) - pinned by tests/golden/r2_golden.npz (sp_*)
+def spectral_laplacian(X, sigma=2.5, graph=None):
+    """constructW('HeatKernel') + normalised Laplacian (spectral.py:42-52,79-107; squared distances as
+    batched_cdist_l2, cluster_utils.py:121-133).  X [B,N,L] -> (L_sym [B,N,N], W [B,N,N])."""
+    x = X.float()
+    n1 = x.pow(2).sum(dim=-1, keepdim=True)
+    d2 = torch.baddbmm(n1.transpose(-2, -1), x, x.transpose(-2, -1), alpha=-2).add(n1)
+    W = torch.exp(-1.0 * d2 / (2 * sigma ** 2))
+    if graph is not None:
+        W = W * graph
+    deg = W.sum(dim=-1)
+    inv = torch.diag_embed(torch.pow(deg, -0.5))
+    return torch.bmm(torch.bmm(inv, torch.diag_embed(deg) - W), inv), W
+
+
+def svd_sign_flip(U, S, VT):
+    """batch_sign_flip_rasmus_bro (spectral.py:110-137)."""
+    SVT = S.unsqueeze(-1) * VT
+    sign_left = torch.sum(torch.sign(SVT) * torch.square(SVT), dim=2)
+    return torch.sign(sign_left).unsqueeze(1) * U

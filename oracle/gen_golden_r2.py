@@ -132,10 +132,36 @@ def gen_prenorm(out):
         print(tag, "done", flush=True)
 
 
+def gen_spectral(out):
+    """N4: the forward pieces of spectral clustering captured from the reference (spectral.py): the normalised Laplacian
+    of a heat-kernel graph (plain and with the spatial-temporal mask), the SVD sign flip on stored factors, and the
+    k-medoids tail on a stored lattice embedding."""
+    import cluster.spectral as sp
+    g = torch.Generator().manual_seed(99)
+    B, N, W, sigma = 3, 48, 32, 2.5
+    X = torch.randn(B, N, W, generator=g) * 0.6
+    Wm = sp.constructW(X, X, sigma=sigma, mode='HeatKernel')
+    diag_D = Wm.sum(dim=-1)
+    inv_D = torch.diag_embed(torch.pow(diag_D, -0.5))
+    L_sym = torch.bmm(torch.bmm(inv_D, torch.diag_embed(diag_D) - Wm), inv_D)
+    out["sp_x"], out["sp_sigma"], out["sp_w"], out["sp_lsym"] = X.numpy(), np.float32(sigma), Wm.numpy(), L_sym.numpy()
+    graph = sp.spatial_temporal_graph(N, 16, s_kernel=3, t_kernel=3)
+    Wg = sp.constructW(X, X, sigma=sigma, mode='HeatKernel', spatial_temporal_graph=graph)
+    dg = Wg.sum(dim=-1)
+    ig = torch.diag_embed(torch.pow(dg, -0.5))
+    out["sp_graph"] = graph.numpy().astype(np.uint8)
+    out["sp_lsym_graph"] = torch.bmm(torch.bmm(ig, torch.diag_embed(dg) - Wg), ig).numpy()
+    U, S, Vh = torch.linalg.svd(L_sym, full_matrices=False)
+    out["sp_u"], out["sp_s"], out["sp_vh"] = U.numpy(), S.numpy(), Vh.numpy()
+    out["sp_u_flipped"] = sp.batch_sign_flip_rasmus_bro(U, S, Vh, backend="pytorch").numpy()
+    print("spectral done", flush=True)
+
+
 if __name__ == "__main__":
     out = {}
     gen_s1(out)
     gen_prenorm(out)
+    gen_spectral(out)
     path = os.path.join(GOLD, "r2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -65,3 +65,15 @@ def test_pre_norm_fixture(g, tag, metric):
     key = tag + ("_cos" if metric == "cosine" else "")
     assert np.array_equal(m.numpy(), g[key + "_medoids"].astype(np.int64))
     assert np.array_equal(a.numpy(), g[key + "_assign"].astype(np.int64))
+
+
+def test_spectral_forward_pieces(g):
+    """N4: Laplacian of the heat-kernel graph (plain and masked) and the SVD sign flip vs the reference's own outputs."""
+    X = torch.from_numpy(g["sp_x"])
+    L, W = co.spectral_laplacian(X, float(g["sp_sigma"]))
+    np.testing.assert_allclose(W.numpy(), g["sp_w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(L.numpy(), g["sp_lsym"], rtol=0, atol=1e-6)
+    Lg, _ = co.spectral_laplacian(X, float(g["sp_sigma"]), torch.from_numpy(g["sp_graph"]).bool())
+    np.testing.assert_allclose(Lg.numpy(), g["sp_lsym_graph"], rtol=0, atol=1e-6)
+    U = co.svd_sign_flip(torch.from_numpy(g["sp_u"]), torch.from_numpy(g["sp_s"]), torch.from_numpy(g["sp_vh"]))
+    assert np.array_equal(U.numpy(), g["sp_u_flipped"])

@@ -606,6 +606,37 @@ def test_two_cluster_blocks_medoids_buffer(gc):
         model.visual.encode(video, T, forced_medoids=med)
 
 
+def test_spectral_forward_pieces_match_reference(g):
+    """N4 (forward pieces of cluster_algo 'spectral'): the normalised Laplacian of the heat-kernel graph - plain and with
+    the spatial-temporal mask - within 2e-5 of the reference's, the SVD sign flip exact, the k-medoids tail on an
+    embedding, and batch_spectral_clustering end to end with a caller-supplied decomposition (the eigensolve itself has
+    no parity definition and is not built: without one the call raises)."""
+    from centerclip_amd.cluster.spectral import (batch_sign_flip_rasmus_bro, batch_spectral_clustering, spectral_laplacian,
+                                                  spectral_embedding_kmedoids)
+    X = torch.from_numpy(g["sp_x"]).to(DEV)
+    sigma = float(g["sp_sigma"])
+    lap, aff = spectral_laplacian(X, sigma=sigma, return_affinity=True)
+    np.testing.assert_allclose(aff.cpu().numpy(), g["sp_w"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lap.cpu().numpy(), g["sp_lsym"], rtol=0, atol=2e-5)
+    lap_g = spectral_laplacian(X, sigma=sigma, spatial_temporal_graph=torch.from_numpy(g["sp_graph"]))
+    np.testing.assert_allclose(lap_g.cpu().numpy(), g["sp_lsym_graph"], rtol=0, atol=2e-5)
+    U, S, Vh = (torch.from_numpy(g[k]).to(DEV) for k in ("sp_u", "sp_s", "sp_vh"))
+    flipped = batch_sign_flip_rasmus_bro(U, S, Vh)
+    assert np.array_equal(flipped.cpu().numpy(), g["sp_u_flipped"])
+    # tail: row-normalised embedding -> k-medoids == the k-medoids op with pre_norm on the same embedding
+    K = 6
+    Q = torch.from_numpy(g["sp_u_flipped"][:, :, -K:].copy()).to(DEV)
+    a, m = spectral_embedding_kmedoids(Q, K, norm_p=2.0, threshold=1e-6, iter_limit=100)
+    ao, mo = co.literal_batch_kmedoids_with_split(Q.cpu(), K, "euclidean", 1e-6, 100, True, 2.0, Q.shape[0], True)
+    Qn = (Q.cpu() / (Q.cpu().norm(dim=-1, keepdim=True) + 1e-6))
+    assert abs(kmedoids_objective(Qn, m.cpu()) - kmedoids_objective(Qn, mo)) <= 0.01 * kmedoids_objective(Qn, mo)
+    with pytest.raises(NotImplementedError):
+        batch_spectral_clustering(X, K, sigma=sigma)
+    a2, m2 = batch_spectral_clustering(X, K, sigma=sigma, correct_sign=True, norm_p=2.0, threshold=1e-6, iter_limit=100,
+                                       eigensolver=lambda L_: torch.linalg.svd(L_, full_matrices=False))
+    assert a2.shape == (X.shape[0], X.shape[1]) and m2.shape == (X.shape[0], K) and bool((m2[:, 1:] > m2[:, :-1]).all())
+
+
 def test_custom_ops_are_registered_with_fake_kernels():
     """torch.ops.centerclip.*: every op has a schema and a fake (meta) kernel; opcheck on two of them with real inputs."""
     from centerclip_amd import torch_ops
