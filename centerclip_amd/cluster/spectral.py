@@ -24,7 +24,7 @@ def spectral_laplacian(X, sigma=2.5, mode='HeatKernel', spatial_temporal_graph=N
     """X [B,N,L] -> L_sym [B,N,N] = D^-1/2 (D - W) D^-1/2 with W = constructW(X, X, sigma, mode) (spectral.py:42-52)."""
     if mode != 'HeatKernel':
         raise NotImplementedError("only the 'HeatKernel' graph is built (spectral.py:86-88); got %r" % (mode,))
-    L.require_device(X, spatial_temporal_graph)
+    L.require_device(X)                                   # (the constant graph mask may live on the host, as in the reference)
     g = None
     if spatial_temporal_graph is not None:
         g = spatial_temporal_graph.to(device=X.device).ne(0).to(torch.uint8).contiguous()
@@ -45,6 +45,8 @@ def spectral_embedding_kmedoids(Q, K, metric='euclidean', threshold=1e-5, iter_l
     """The tail of batch_spectral_clustering (spectral.py:58-73): Q [B,N,K] (the K trailing singular vectors) ->
     Q / (|Q| + 1e-6) row-wise -> k-medoids.  The row normalisation is the k-medoids op's own pre_norm pass."""
     B = Q.shape[0]
+    if Q.shape[-1] % 4:          # the token kernels read 16-byte pieces: zero columns change no norm and no distance
+        Q = torch.nn.functional.pad(Q, (0, 4 - Q.shape[-1] % 4))
     if split_size > 1 and B > split_size:
         return batch_fast_kmedoids_with_split(Q, K, distance=metric, threshold=threshold, iter_limit=iter_limit,
                                               id_sort=id_sort, norm_p=norm_p, split_size=split_size, pre_norm=True)
