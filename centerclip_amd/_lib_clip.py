@@ -98,7 +98,7 @@ def declare(lib):
     lib.cc_loose_similarity_strided_f32.argtypes = [vp, vp, vp, c.c_int64, c.c_int64, i32, i32, i32, i32, f32, vp, i32, vp,
                                                     vp, sz, vp]
     lib.cc_loose_similarity_strided_f32.restype = c.c_int
-    lib.cc_scaled_dot_nt_f32.argtypes = [vp, vp, i32, i32, i32, f32, vp, i32, vp]
+    lib.cc_scaled_dot_nt_f32.argtypes = [vp, vp, i32, i32, i32, f32, vp, i32, vp, sz, vp]
     for name in ("cc_linear_f16", "cc_layernorm_f32", "cc_attention_f16", "cc_vit_encode", "cc_text_encode",
                  "cc_video_pool_normalize_f32", "cc_loose_similarity_f32", "cc_scaled_dot_nt_f32"):
         getattr(lib, name).restype = c.c_int

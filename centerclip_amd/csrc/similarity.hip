@@ -8,8 +8,20 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // rows [R, E] -> rows / |row|   (one wave per row)
+// Split form of a normalised value for the fp16 matrix cores (see dot_nt_kernel): hi = fp16(2^10 x), lo = fp16(2^10 x - hi)
+struct SplitOut {
+    _Float16* hi;       // [R, E] or nullptr
+    _Float16* lo;
+};
+__device__ __forceinline__ void split_put(const SplitOut& so, int64_t idx, float x) {
+    const float sx = x * 1024.0f;
+    const _Float16 h = (_Float16)sx;
+    so.hi[idx] = h;
+    so.lo[idx] = (_Float16)(sx - (float)h);
+}
+
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                             int R, int E) {
+                                                             SplitOut so, int R, int E) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -17,7 +29,16 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     float s = 0.f;
     for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
     const float nrm = sqrtf(cc_wave_sum(s));
-    for (int e = lane; e < E; e += 64) out[(int64_t)r * E + e] = src[e] / nrm;
+    for (int e = lane; e < E; e += 64) {
+        const float v = src[e] / nrm;
+        if (out) out[(int64_t)r * E + e] = v;
+        if (so.hi) split_put(so, (int64_t)r * E + e, v);
+    }
+}
+
+// rows that are normalised already -> split planes (the pre-pooled branch, where the video side arrives normalised)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, SplitOut so, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) split_put(so, i, in[i]);
 }
 
 // visual [Bv, Tn, E], mask [Bv, Tn] int64 -> pooled [Bv, E]   (one wave per video)
@@ -29,7 +50,7 @@ struct VidAddr {
 };
 __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
                                                          const long long* __restrict__ mask, VidAddr ad,
-                                                         float* __restrict__ pooled, int Bv, int Tn, int E) {
+                                                         float* __restrict__ pooled, SplitOut so, int Bv, int Tn, int E) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= Bv) return;
@@ -68,7 +89,11 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < MAXE; ++q) {
         const int e = lane + 64 * q;
-        if (e < E) pooled[(int64_t)v * E + e] = acc[q] / nrm;
+        if (e < E) {
+            const float pv = acc[q] / nrm;
+            if (pooled) pooled[(int64_t)v * E + e] = pv;
+            if (so.hi) split_put(so, (int64_t)v * E + e, pv);
+        }
     }
 }
 
@@ -152,75 +177,82 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
     }
 }
 
-// C[i][j] = mult * sum_k A[i][k] B[j][k]; 64x64 tile per workgroup, exact-fp32 MFMA (16x16x4),
-// same LDS layout as the Gram kernel of cluster.hip.
+// C[i][j] = mult * sum_k A[i][k] B[j][k]; 64x64 tile per workgroup.
+// Arithmetic as in the Gram kernel of cluster.hip: each normalised fp32 value x (|x| <= 1) was split by its producer
+// (normalize_rows_kernel / video_pool_kernel / split_rows_kernel) into hi = fp16(2^10 x) and lo = fp16(2^10 x - hi) -
+// both in fp16's normal range, 2^10 x = hi + lo to 22 bits - and the dot product is accumulated in fp32 as
+// hi.hi + hi.lo + lo.hi on the fp16 matrix cores (16x the rate of the exact-fp32 MFMA the first version used and was
+// bound by), then scaled back by the exact factor 2^-20.  The dropped lo.lo term is 2^-22 relative: fp32 rounding level.
+// Splitting once per row instead of in every tile keeps the tile's staging a pure copy: the four operand planes go
+// HBM -> LDS by LDS-DMA (16 B per lane, chunks XOR-swizzled through the source address as in gemm.hip).
 #define ST 64
-#define SK 32
-#define SLD 40
-__global__ __launch_bounds__(256) void dot_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                     float* __restrict__ C, int M, int N, int K, int ldc,
-                                                     float mult) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][ST * SLD];
+#define SKK 64
+typedef _Float16 sh8 __attribute__((ext_vector_type(8)));
+#define SPLANE (ST * SKK)
+__device__ __forceinline__ void sim_glds16(const _Float16* g, _Float16* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__global__ __launch_bounds__(256) void dot_nt_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                     const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
+                                                     float* __restrict__ C, int M, int N, int K, int ldc, float mult) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][SPLANE];      // [buffer][Ah, Al, Bh, Bl]
     const int ti = blockIdx.y, tj = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 3, lchunk = tid & 7;
-    const float* pa[2];
-    const float* pb[2];
+    // staging: LDS chunk idx (16 B) = q*256 + tid -> row idx / 8, position idx % 8; source chunk = position ^ (row & 7)
+    const _Float16* src[4][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        pa[q] = A + (int64_t)min(ti * ST + lrow + 32 * q, M - 1) * K + lchunk * 4;
-        pb[q] = B + (int64_t)min(tj * ST + lrow + 32 * q, N - 1) * K + lchunk * 4;
+        const int idx = q * 256 + tid, r = idx >> 3, c = (idx & 7) ^ (r & 7);
+        const int64_t ra = (int64_t)min(ti * ST + r, M - 1) * K + c * 8, rb = (int64_t)min(tj * ST + r, N - 1) * K + c * 8;
+        src[0][q] = Ah + ra; src[1][q] = Al + ra; src[2][q] = Bh + rb; src[3][q] = Bl + rb;
     }
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) sim_glds16(src[pl][q] + kt * SKK, &lds[buf][pl][(q * 4 + wave) * 512]);
+    };
     const int wr = wave >> 1, wc = wave & 1;
     f32x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 ra[2], rb[2];
-    const int nk = (K + SK - 1) / SK;
-    auto gload = [&](int kt) {
-        const bool ok = kt * SK + lchunk * 4 < K;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            ra[q] = ok ? *reinterpret_cast<const float4*>(pa[q] + kt * SK) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[q] = ok ? *reinterpret_cast<const float4*>(pb[q] + kt * SK) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * q) * SLD + lchunk * 4]) = ra[q];
-            *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * q) * SLD + lchunk * 4]) = rb[q];
-        }
-    };
-    gload(0);
-    lstore(0);
+    const int nk = K / SKK;                                    // K % 64 == 0 (checked by the launcher)
+    stage(0, 0);
     __syncthreads();
     const int g = lane >> 4, l15 = lane & 15;
+    auto frag = [&](const _Float16* pl, int row, int ks) {     // 8 consecutive k of `row` at k = ks*32 + g*8
+        return *reinterpret_cast<const sh8*>(pl + row * SKK + ((((ks << 2) | g) ^ (row & 7)) << 3));
+    };
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const float* As = &lds[buf][0][(wr * 32 + l15) * SLD + g * 4];
-        const float* Bs = &lds[buf][1][(wc * 32 + l15) * SLD + g * 4];
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const int ar = wr * 32 + l15, br = wc * 32 + l15;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ks * 16);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 16 * SLD + ks * 16);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + ks * 16);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + 16 * SLD + ks * 16);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                // B fragment as the A operand: a lane then owns 4 consecutive j of one i (16-byte stores)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[tt], a0[tt], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[tt], a0[tt], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[tt], a1[tt], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[tt], a1[tt], acc[1][1], 0, 0, 0);
-            }
+            const sh8 a0h = frag(lds[buf][0], ar, ks), a0l = frag(lds[buf][1], ar, ks);
+            const sh8 a1h = frag(lds[buf][0], ar + 16, ks), a1l = frag(lds[buf][1], ar + 16, ks);
+            const sh8 b0h = frag(lds[buf][2], br, ks), b0l = frag(lds[buf][3], br, ks);
+            const sh8 b1h = frag(lds[buf][2], br + 16, ks), b1l = frag(lds[buf][3], br + 16, ks);
+            // B fragment as the first operand: a lane then owns 4 consecutive j of one i (16-byte stores)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a0h, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a0l, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0l, a0h, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a0h, acc[0][1], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a0l, acc[0][1], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1l, a0h, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a1h, acc[1][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a1l, acc[1][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0l, a1h, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a1h, acc[1][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a1l, acc[1][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1l, a1h, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
+    const float sc = mult * 9.5367431640625e-07f;              // 2^-20: undo the two 2^10 operand scalings (exact)
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm) {
         const int i = ti * ST + wr * 32 + fm * 16 + l15;
@@ -231,11 +263,11 @@ __global__ __launch_bounds__(256) void dot_nt_kernel(const float* __restrict__ A
             float* dst = C + (int64_t)i * ldc + j;
             const f32x4 v = acc[fm][fn];
             if (j + 3 < N && ((ldc & 3) == 0)) {
-                *reinterpret_cast<float4*>(dst) = make_float4(mult * v[0], mult * v[1], mult * v[2], mult * v[3]);
+                *reinterpret_cast<float4*>(dst) = make_float4(sc * v[0], sc * v[1], sc * v[2], sc * v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (j + e < N) dst[e] = mult * v[e];
+                    if (j + e < N) dst[e] = sc * v[e];
             }
         }
     }
@@ -249,11 +281,11 @@ size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E) {
 }
 
 static int video_pool_launch(const float* visual, const int64_t* video_mask, const VidAddr& ad, int32_t Bv,
-                             int32_t Tn, int32_t E, float* pooled, void* stream) {
-    if (!visual || !video_mask || !pooled || Bv <= 0 || Tn <= 0 || E <= 0 || ad.vg <= 0) return CC_ERR_INVALID;
+                             int32_t Tn, int32_t E, float* pooled, SplitOut so, void* stream) {
+    if (!visual || !video_mask || (!pooled && !so.hi) || Bv <= 0 || Tn <= 0 || E <= 0 || ad.vg <= 0) return CC_ERR_INVALID;
     if (E > 1024) return CC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(video_pool_kernel, dim3((Bv + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), visual,
-                       reinterpret_cast<const long long*>(video_mask), ad, pooled, Bv, Tn, E);
+                       reinterpret_cast<const long long*>(video_mask), ad, pooled, so, Bv, Tn, E);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -261,25 +293,48 @@ static int video_pool_launch(const float* visual, const int64_t* video_mask, con
 int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
                                 float* pooled, void* stream) {
     const VidAddr ad{Bv > 0 ? Bv : 1, 0, 0, Tn, 1};
-    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, stream);
+    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, SplitOut{nullptr, nullptr}, stream);
 }
 
 /* rows [R, E] -> rows / |row| (the text half of _loose_similarity, modules/clip4clip.py:361-362) */
 int cc_normalize_rows_f32(const float* in, float* out, int32_t R, int32_t E, void* stream) {
     if (!in || !out || R <= 0 || E <= 0) return CC_ERR_INVALID;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, R, E);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       SplitOut{nullptr, nullptr}, R, E);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+// split planes of the text rows ([Bt,E] hi | lo) and the video rows ([Bv,E] hi | lo) inside the similarity workspace
+// (cc_similarity_workspace_bytes = (Bt + Bv) * E floats, each region exactly the size of its two fp16 planes)
+static void sim_planes(void* ws, int Bt, int Bv, int E, SplitOut& ta, SplitOut& vb) {
+    _Float16* t = static_cast<_Float16*>(ws);
+    ta = SplitOut{t, t + (size_t)Bt * E};
+    _Float16* v = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
+    vb = SplitOut{v, v + (size_t)Bv * E};
+}
+
+static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int Bv, int E, float mult, float* logits,
+                             int ldl, hipStream_t st) {
+    dim3 grid((Bv + ST - 1) / ST, (Bt + ST - 1) / ST);
+    hipLaunchKernelGGL(dot_nt_kernel, grid, dim3(256), 0, st, ta.hi, ta.lo, vb.hi, vb.lo, logits, Bt, Bv, E, ldl, mult);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult, float* logits,
-                         int32_t ldl, void* stream) {
-    if (!a || !b || !logits || Bt <= 0 || Bv <= 0 || E <= 0 || (E & 3) || ldl < Bv) return CC_ERR_INVALID;
-    dim3 grid((Bv + ST - 1) / ST, (Bt + ST - 1) / ST);
-    hipLaunchKernelGGL(dot_nt_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, b, logits, Bt, Bv, E, ldl,
-                       mult);
+                         int32_t ldl, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !b || !logits || Bt <= 0 || Bv <= 0 || E <= 0 || (E & 63) || ldl < Bv) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < cc_similarity_workspace_bytes(Bt, Bv, E)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SplitOut ta, vb;
+    sim_planes(ws, Bt, Bv, E, ta, vb);
+    const int64_t na = (int64_t)Bt * E, nb = (int64_t)Bv * E;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((na + 255) / 256 < 4096 ? (na + 255) / 256 : 4096)), dim3(256), 0, st, a, ta, na);
     CC_LAUNCH_CHECK();
-    return CC_OK;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((nb + 255) / 256 < 4096 ? (nb + 255) / 256 : 4096)), dim3(256), 0, st, b, vb, nb);
+    CC_LAUNCH_CHECK();
+    return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, st);
 }
 
 int cc_loose_similarity_grouped_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t group,
@@ -298,14 +353,15 @@ int cc_loose_similarity_grouped_f32(const float* text, const float* visual, cons
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
-    float* tn = static_cast<float*>(ws);
-    float* vp = pooled_out ? pooled_out
-                           : reinterpret_cast<float*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, tn, Bt, E);
+    if (E & 63) return CC_ERR_UNSUPPORTED;                    // the NT GEMM walks K in steps of 64
+    // text rows: normalise -> split planes; videos: pool + normalise -> split planes (+ fp32 pooled_out); then the GEMM
+    SplitOut ta, vb;
+    sim_planes(ws, Bt, Bv, E, ta, vb);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, (float*)nullptr, ta, Bt, E);
     CC_LAUNCH_CHECK();
-    int rc = video_pool_launch(visual, video_mask, ad, Bv, Tn, E, vp, stream);
+    int rc = video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled_out, vb, stream);
     if (rc) return rc;
-    return cc_scaled_dot_nt_f32(tn, vp, Bt, Bv, E, expf(logit_scale), logits, ldl, stream);
+    return dot_planes_launch(ta, vb, Bt, Bv, E, expf(logit_scale), logits, ldl, st);
 }
 
 int cc_loose_similarity_strided_f32(const float* text, const float* visual, const int64_t* video_mask,

@@ -549,8 +549,10 @@ def scaled_dot_nt(a: torch.Tensor, b: torch.Tensor, mult: float) -> torch.Tensor
     Bt, E = a.shape
     Bv = b.shape[0]
     out = _e(Bt, Bv, like=a, dtype=torch.float32)
-    L.check(L.lib().cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, Bv, E, float(mult), L.ptr(out), Bv, _st(a)),
-            "cc_scaled_dot_nt_f32")
+    lib = L.lib()
+    ws = L.workspace(lib.cc_similarity_workspace_bytes(Bt, Bv, E), a.device)
+    L.check(lib.cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, Bv, E, float(mult), L.ptr(out), Bv, L.ptr(ws), ws.numel(),
+                                     _st(a)), "cc_scaled_dot_nt_f32")
     return out
 
 
@@ -562,8 +564,10 @@ def _(a, b, mult):
 @custom_op(NS + "::scaled_dot_nt_out", mutates_args=("out",), device_types="cuda")
 def scaled_dot_nt_out(a: torch.Tensor, b: torch.Tensor, mult: float, out: torch.Tensor) -> None:
     Bt, E = a.shape
-    L.check(L.lib().cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, b.shape[0], E, float(mult), L.ptr(out), out.stride(0),
-                                         _st(a)), "cc_scaled_dot_nt_f32")
+    lib = L.lib()
+    ws = L.workspace(lib.cc_similarity_workspace_bytes(Bt, b.shape[0], E), a.device)
+    L.check(lib.cc_scaled_dot_nt_f32(L.ptr(a), L.ptr(b), Bt, b.shape[0], E, float(mult), L.ptr(out), out.stride(0),
+                                     L.ptr(ws), ws.numel(), _st(a)), "cc_scaled_dot_nt_f32")
 
 
 @scaled_dot_nt_out.register_fake

@@ -436,10 +436,13 @@ int cc_loose_similarity_grouped_f32(const float* text, const float* visual, cons
 /* rows [R, E] -> rows / |row|: the text half of _loose_similarity (clip4clip.py:361-362) for the pre-pooled
  * (2-D visual_output) branch */
 int cc_normalize_rows_f32(const float* in, float* out, int32_t R, int32_t E, void* stream);
-/* logits[Bt,Bv] = mult * a[Bt,E] b[Bv,E]^T for already-normalised rows (the sharded eval
+/* logits[Bt,Bv] = mult * a[Bt,E] b[Bv,E]^T for already-normalised rows (|element| <= 1; the kernel splits each fp32
+ * operand into two fp16 parts scaled by 2^10 and accumulates hi.hi + hi.lo + lo.hi in fp32 on the fp16 matrix cores -
+ * 22-bit operands, fp32-level results; elements beyond +-63 overflow to inf).  E % 64 == 0.
+ * ws: cc_similarity_workspace_bytes(Bt, Bv, E) (the split planes). (the sharded eval
  * similarity matrix, main.py:502-534, computed in one launch per row block). */
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult,
-                         float* logits, int32_t ldl, void* stream);
+                         float* logits, int32_t ldl, void* ws, size_t ws_bytes, void* stream);
 
 /* N4, forward values only - CrossEn (modules/losses.py:8-18) in both directions and their mean as CLIP4Clip.forward's
  * training branch forms it (modules/clip4clip.py:245-253): loss3[0] = mean_i -log_softmax(sim[i,:])[i],
