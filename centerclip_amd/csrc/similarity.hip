@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
                                                                      int Tn, int E, float mult) {
     __shared__ float vp[1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v = blockIdx.x;
-    constexpr int MAXE = 16;                      // E <= 1024
+    const int v = blockIdx.x;                     // grid.y = groups of 4 texts: every wave owns ONE text (a workgroup per
+    constexpr int MAXE = 16;                      // video made each wave walk Bt / 4 texts in a dependent chain); E <= 1024
     {
         const int grp = v / ad.vg, loc = v - grp * ad.vg;
         visual += (int64_t)grp * ad.vgs + (int64_t)loc * Tn * E;
@@ -150,12 +150,12 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
             if (e < E) {
                 const float p = acc[q] / nrm;
                 vp[e] = p;
-                if (pooled_out) pooled_out[(int64_t)v * E + e] = p;
+                if (pooled_out && blockIdx.y == 0) pooled_out[(int64_t)v * E + e] = p;
             }
         }
     }
     __syncthreads();
-    for (int t = wave; t < Bt; t += 4) {
+    for (int t = (int)blockIdx.y * 4 + wave; t < Bt; t += 4 * (int)gridDim.y) {
         const float* src = text + (int64_t)t * E;
         float x[MAXE];
         float s = 0.f;
@@ -347,7 +347,7 @@ int cc_loose_similarity_grouped_f32(const float* text, const float* visual, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const VidAddr ad{group, vis_group_stride, mask_group_stride, mask_row_stride, mask_col_stride};
     if ((long)Bt * Bv <= 4096 && E <= 1024 && Bt > 0 && Bv > 0) {      // one launch for a step's own logits
-        hipLaunchKernelGGL(loose_similarity_small_kernel, dim3(Bv), dim3(256), 0, st, text, visual,
+        hipLaunchKernelGGL(loose_similarity_small_kernel, dim3(Bv, (Bt + 3) / 4), dim3(256), 0, st, text, visual,
                            reinterpret_cast<const long long*>(video_mask), ad, logits, ldl, pooled_out, Bt, Bv, Tn, E,
                            expf(logit_scale));
         CC_LAUNCH_CHECK();
