@@ -109,7 +109,9 @@ def graph_time_ms(fn, launches=20, replays=4):
             fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread of an initialised process group may query events meanwhile
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             for _ in range(launches):
                 fn()
         g.replay()
