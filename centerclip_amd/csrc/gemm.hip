@@ -637,6 +637,13 @@ static int pick_tile(const GemmArgs& g, int epi) {
             return 7;
     }
     if (ok256) return 5;
+    // residual epilogue at N = 768: the 256x128 tile (8 waves, one workgroup per CU) when its grid is one nearly full
+    // round of the 256 CUs - half the A-panel re-reads of the 128x128 tile (stand-alone c_proj 55.5 vs 58.7 us = 816
+    // TFLOP/s, out_proj 24.9 vs 26.2; on the step 2.124 vs 2.128 ms over 3 same-session A/B rounds)
+    if (epi == EPI_F32_RESID_STATS && n128) {
+        const long t6 = (long)((g.M + 255) / 256) * (g.N / 128);
+        if (t6 >= 200 && t6 <= 256) return 6;
+    }
     if (n128 && mt128 * (g.N / 128) >= 300) return 1;
     if (n128 && mt64 * (g.N / 128) >= 400) return 3;
     if (mt128 * (g.N / 64) >= 400) return 2;
@@ -670,7 +677,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         }
 #endif
         if (g1) {                                  // the rider must be divisible by the carrier's BN
-            if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7)) ? 1 : 4;
+            if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7 || tile == 6)) ? 1 : 4;
             if (g1->K % tile_bk(tile)) tile = 4;
         }
     }
