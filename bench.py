@@ -516,6 +516,18 @@ def main():
                 res["gemm_breakdown"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
                 res["gemm_time_share_of_step"] = round(gemm_us / (ms_per_step * 1e3), 3)
                 res["forward_algorithmic_tflops"] = round(gemm_flops * 1.0 / (ms_per_step * 1e-3) / 1e12, 1)
+                # the same step with the text tower on all 16 x 32 rows (caption compaction off), for transparency
+                from centerclip_amd import _lib as L_
+                L_.lib().cc_debug_set_text_compaction(0)
+                try:
+                    ms_dense = graph_time_ms(step1, launches=1, replays=20)
+                finally:
+                    L_.lib().cc_debug_set_text_compaction(1)
+                lens = (ids.argmax(dim=-1) + 1).float()
+                res["text_rows"] = {"policy": "captions compacted to their EOT on the device: tokens behind the EOT cannot reach the "
+                                              "caption's feature (causal mask, EOT row projected) - features bit-identical to all rows",
+                                    "rows_computed": int(lens.sum()), "rows_all": int(ids.numel()),
+                                    "ms_per_step_all_rows": round(ms_dense, 3)}
                 # N3: the same step fed with decoder-layout uint8 frames (normalisation fused into the patch gather)
                 u8 = torch.randint(0, 256, (c["B"], 1, c["T"], 224, 224, 3), dtype=torch.uint8, device=device)
                 ms_u8 = event_time_ms(lambda: model(ids, torch.zeros_like(ids), amask, u8, vmask), 10)

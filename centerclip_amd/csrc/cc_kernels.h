@@ -34,6 +34,9 @@ struct GemmArgs {
     const float* shift_stats;
     int shift_slots;
     float* shift_out;
+    // Device-side row count (text tower with compacted captions): when non-null the kernel reads the number of valid
+    // rows from *m_dev (<= M, which sizes the grid); tiles beyond it exit at once, rows beyond it are never stored.
+    const int* m_dev;
 };
 
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
@@ -63,6 +66,13 @@ struct TextEmbedArgs {
     _Float16* h16;       // optional: centred fp16 copy of the rows + its (sum, sum of squares) [rows][2] + the row means
     float* stats;
     float* shift;
+    // Caption compaction: tokens behind a caption's EOT cannot reach its feature (causal attention, and only the EOT row is
+    // projected, modules/clip.py:480-484), so only rows t <= eot[b] are kept, packed back to back: row seq_off[b] + t.
+    // seq_off / seq_len [Bt], m_total [1] = number of kept rows, eot[b] = ABSOLUTE row of caption b's EOT token.
+    // All null: every row of the [Bt, Lt] grid is kept at b*Lt + t and eot[b] is the position inside the caption.
+    int* seq_off;
+    int* seq_len;
+    int* m_total;
 };
 // fp16 copy + (sum, sumsq) of fp32 rows (one wave per row); rows contiguous with stride W
 int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, float* shift, int rows, int W, hipStream_t st);
@@ -72,6 +82,10 @@ struct AttArgs {
     const _Float16* qkv; _Float16* out; int nseq, L, heads, W, causal;
     // row of (sequence s, token t) in qkv / out = s*seq_rows + t*tok_rows; 0, 0 = frame-major (seq_rows = L, tok_rows = 1)
     int64_t seq_rows, tok_rows;
+    // variable-length sequences packed back to back (compacted captions): sequence s has seq_len[s] tokens starting at
+    // row seq_off[s] of qkv / out (L is then the upper bound that sizes the kernel); null = nseq sequences of L tokens
+    const int* seq_off;
+    const int* seq_len;
 };
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 

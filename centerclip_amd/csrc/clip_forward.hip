@@ -11,6 +11,10 @@
 
 namespace {
 
+// debug hook (cc_debug_set_text_compaction, not part of the public ABI): 0 = run the text tower on all Bt * Lt rows, as the
+// reference does - bench.py reports the step both ways, tests compare the two forms bit for bit
+int g_text_compaction = 1;
+
 struct Carver {
     char* base;
     size_t off = 0;
@@ -88,6 +92,10 @@ struct BlockCtx {          // one tower's activations for the current block
     _Float16* u;
     int nseq, L, W, heads, causal;
     int slots0, slots1;    // partial-sum slots per row currently held in st0 / st1
+    // compacted captions (text tower): device-side row count and per-caption (offset, length); null = dense [nseq, L]
+    const int* m_dev;
+    const int* seq_off;
+    const int* seq_len;
 };
 
 // One ResidualAttentionBlock for up to two towers at once (modules/clip.py:240,251).  Every phase is
@@ -125,7 +133,7 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         g.A = A; g.W = static_cast<const _Float16*>(Wt); g.bias = bias; g.C = C;
         g.M = M; g.N = N; g.K = K; g.ldc = N;
         g.ln_eps = 1e-5f;
-        (void)c;
+        g.m_dev = c->m_dev;
         return g;
     };
     // ---- q,k,v = in_proj(ln_1(x))   [LayerNorm folded]
@@ -141,9 +149,9 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         if (rc) return rc;
     }
     {
-        AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal};
+        AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal, 0, 0, c0->seq_off, c0->seq_len};
         AttArgs a1{};
-        if (c1) a1 = AttArgs{c1->qkv, c1->att, c1->nseq, c1->L, c1->heads, c1->W, c1->causal};
+        if (c1) a1 = AttArgs{c1->qkv, c1->att, c1->nseq, c1->L, c1->heads, c1->W, c1->causal, 0, 0, c1->seq_off, c1->seq_len};
         rc = cc_launch_attention2(a0, c1 ? &a1 : nullptr, st);
         if (rc) return rc;
     }
@@ -205,6 +213,9 @@ struct TextWs {
     _Float16* att;
     _Float16* u;
     int* eot;
+    int* seq_off;    // compacted captions: first row of caption b
+    int* seq_len;    //                      its length (EOT position + 1)
+    int* mcount;     //                      total number of kept rows
     size_t total;
 };
 
@@ -222,6 +233,9 @@ TextWs carve_text(const cc_text_model* m, int Bt, int Lt, void* ws) {
     t.att = c.take<_Float16>(M * W);
     t.u = c.take<_Float16>(M * 4 * W);
     t.eot = c.take<int>(Bt);
+    t.seq_off = c.take<int>(Bt);
+    t.seq_len = c.take<int>(Bt);
+    t.mcount = c.take<int>(1);
     t.total = c.off;
     return t;
 }
@@ -250,12 +264,17 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     float* hother = nullptr;
     int frames = T, tokens = 0, W = 0;
     const int vl = vm ? vm->layers : 0, tl = tm ? tm->layers : 0;
+    // Caption compaction (see TextEmbedArgs): the text tower runs on the rows up to each caption's EOT only - the launches
+    // are sized for Bt * Lt rows, the kernels read the real count from the device, so nothing synchronises and a
+    // captured graph stays valid for any batch.  Off when the caller wants the full hidden state.
+    const bool compact = tm && !text_hidden_out && Bt <= 256 && g_text_compaction;
     BlockCtx cv{}, ct{};
     cv.slots0 = ct.slots0 = 1;
     if (tm) {
         ct.h = t.h; ct.h16 = t.h16; ct.st0 = t.st0; ct.st1 = t.st1; ct.sh0 = t.sh0; ct.sh1 = t.sh1;
         ct.qkv = t.qkv; ct.att = t.att; ct.u = t.u;
         ct.nseq = Bt; ct.L = Lt; ct.W = tm->width; ct.heads = tm->heads; ct.causal = 1;
+        if (compact) { ct.m_dev = t.mcount; ct.seq_off = t.seq_off; ct.seq_len = t.seq_len; }
     }
     if (vm) {
         const int g = vm->resolution / vm->patch, n = g * g, F = B * T;
@@ -287,7 +306,8 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         }
         if (tm)
             te = TextEmbedArgs{reinterpret_cast<const long long*>(ids), tm->token_embedding, tm->positional_embedding,
-                               t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0, t.sh0};
+                               t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0, t.sh0,
+                               compact ? t.seq_off : nullptr, compact ? t.seq_len : nullptr, compact ? t.mcount : nullptr};
         rc = (vm && tm) ? cc_launch_pre_stage(a, te, 1e-5f, st)
                         : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;
@@ -350,7 +370,8 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     // (clip.py:480-484) - one launch for both heads
     HeadArgs hv{}, ht{};
     if (vm) hv = HeadArgs{h, tokens + 1, nullptr, vm->ln_post_weight, vm->ln_post_bias, vm->proj, vfeat, B * frames, W, vm->embed_dim};
-    if (tm) ht = HeadArgs{t.h, Lt, t.eot, tm->ln_final_weight, tm->ln_final_bias, tm->text_projection, tfeat, Bt, tm->width, tm->embed_dim};
+    // (compacted captions: eot[b] is already the absolute row of the EOT token)
+    if (tm) ht = HeadArgs{t.h, compact ? 0 : Lt, t.eot, tm->ln_final_weight, tm->ln_final_bias, tm->text_projection, tfeat, Bt, tm->width, tm->embed_dim};
     rc = cc_launch_head_project2(vm ? hv : ht, (vm && tm) ? &ht : nullptr, st);
     if (rc) return rc;
     if (vm && hidden_out && hipMemcpyAsync(hidden_out, h, (size_t)B * frames * (tokens + 1) * W * sizeof(float),
@@ -365,6 +386,11 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
 }  // namespace
 
 extern "C" {
+
+int cc_debug_set_text_compaction(int on) {
+    g_text_compaction = on ? 1 : 0;
+    return CC_OK;
+}
 
 size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T) {
     if (!m || B <= 0 || T <= 0 || m->patch <= 0 || m->resolution % m->patch) return 0;

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     long long* prof = g_gemm_prof;
     GEMM_STAMP(0);
     const bool second = (int)blockIdx.x >= pr.tiles0;
-    const GemmArgs g = second ? pr.p[1] : pr.p[0];
+    GemmArgs g = second ? pr.p[1] : pr.p[0];
+    if (g.m_dev) g.M = *g.m_dev;                             // device-side row count (compacted captions): wave-uniform
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int in_group = bid - group * per_group;
     const int tm = first_m + in_group % gsz, tn = in_group / gsz;
     const int row0 = tm * BM, col0 = tn * BN;
+    if (row0 >= g.M) return;                                 // (only with m_dev: the grid was sized for the upper bound)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;

@@ -199,10 +199,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
     const AttArgs at = second ? pr.a[1] : pr.a[0];
     const _Float16* __restrict__ qkv = at.qkv;
     _Float16* __restrict__ out = at.out;
-    const int L = at.L, heads = at.heads, W = at.W;
+    const int heads = at.heads, W = at.W;
     const bool CAUSAL = at.causal != 0;
     const int wg = (int)blockIdx.x - (second ? pr.wgs0 : 0);
     const int seq = wg / heads, head = wg - seq * heads;
+    const int L = at.seq_len ? at.seq_len[seq] : at.L;         // (LDS is sized for at.L, the upper bound)
+    const int64_t seq_row0 = at.seq_off ? at.seq_off[seq] : (int64_t)seq * at.seq_rows;
     const int KT = (L + 31) & ~31;
     const int VS = att_vs_halfs(KT);
     _Float16* Ks = reinterpret_cast<_Float16*>(smem);                       // KT * 64
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
     _Float16* Ps = Vt + ATT_D * VS;                                          // 4 waves * 16 * VS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t ld = 3 * (int64_t)W * at.tok_rows;          // qkv stride between consecutive tokens of a sequence
-    const _Float16* base = qkv + (int64_t)seq * at.seq_rows * 3 * W + head * ATT_D;
+    const _Float16* base = qkv + seq_row0 * 3 * W + head * ATT_D;
 
     // ---- stage K (swizzled) and V^T; rows >= L are zero
     for (int idx = tid; idx < KT * 8; idx += 256) {
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
             }
         }
         if (q < L) {
-            _Float16* dst = out + ((int64_t)seq * at.seq_rows + (int64_t)q * at.tok_rows) * W + head * ATT_D;
+            _Float16* dst = out + (seq_row0 + (int64_t)q * at.tok_rows) * W + head * ATT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
@@ -330,11 +332,13 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
     const AttArgs at = second ? pr.a[1] : pr.a[0];
     const int u = unit - (second ? units0 : 0);
     if (u >= at.nseq * at.heads) return;                       // wave-uniform; no barriers below
-    const int L = at.L, heads = at.heads, W = at.W;
+    const int heads = at.heads, W = at.W;
     const bool CAUSAL = at.causal != 0;
     const int seq = u / heads, head = u - seq * heads;
+    const int L = at.seq_len ? at.seq_len[seq] : at.L;         // wave-uniform; a compacted caption may be shorter than at.L
+    const int64_t seq_row0 = at.seq_off ? at.seq_off[seq] : (int64_t)seq * at.seq_rows;
     const int64_t ld = 3 * (int64_t)W * at.tok_rows;
-    const _Float16* base = at.qkv + (int64_t)seq * at.seq_rows * 3 * W + head * ATT_D;
+    const _Float16* base = at.qkv + seq_row0 * 3 * W + head * ATT_D;
     _Float16* Vt = lds[wave];
     _Float16* Pw = Vt + ATT_D * ATTW_KT;
     constexpr int PS = ATTW_KT + 8;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
             }
         }
         if (q < L) {
-            _Float16* dst = at.out + ((int64_t)seq * at.seq_rows + (int64_t)q * at.tok_rows) * W + head * ATT_D;
+            _Float16* dst = at.out + (seq_row0 + (int64_t)q * at.tok_rows) * W + head * ATT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
@@ -546,12 +550,40 @@ __global__ __launch_bounds__(256) void im2col_u8_f16_kernel(const unsigned char*
 
 // text: h[b*Lt + t] = token_embedding[ids[b,t]] + positional_embedding[t]; eot[b] = first argmax ids[b,:]
 // (optionally also the fp16 copy of the row and its (sum, sum of squares), exactly as row_stats_kernel forms them)
+// first position of the largest id of caption b (the EOT token, modules/clip.py:484), one wave
+__device__ __forceinline__ int text_eot_position(const long long* ids, int b, int Lt, int lane) {
+    unsigned long long key = 0ull;
+    for (int u = lane; u < Lt; u += 64) {
+        const unsigned long long k2 = ((unsigned long long)(ids[(int64_t)b * Lt + u] + 0x40000000LL) << 32) |
+                                      (unsigned)(0xFFFFFFFFu - (unsigned)u);
+        key = k2 > key ? k2 : key;
+    }
+    key = cc_wave_max_u64(key);
+    return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
+
 __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, int lane) {
     const long long* ids = e.ids;
     const int Lt = e.Lt, W = e.W;
     int* eot = e.eot;
     const int b = row / Lt, t = row - b * Lt;
-    const long long id = ids[row];
+    const int src_row = row;                                     // (b, t) in the id grid
+    if (e.seq_off) {
+        // compaction: this wave works out where caption b starts (the EOT positions of the captions before it: Bt is a
+        // batch of captions, a few wave reductions over L2-resident ids) and drops the row if it lies behind the EOT
+        int off = 0;
+        for (int bb = 0; bb < b; ++bb) off += text_eot_position(ids, bb, Lt, lane) + 1;
+        const int my_eot = text_eot_position(ids, b, Lt, lane);
+        if (t == 0 && lane == 0) {
+            e.seq_off[b] = off;
+            e.seq_len[b] = my_eot + 1;
+            eot[b] = off + my_eot;                                // absolute row of the EOT token
+            if (b == e.Bt - 1) *e.m_total = off + my_eot + 1;
+        }
+        if (t > my_eot) return;
+        row = off + t;
+    }
+    const long long id = ids[src_row];
     const float* src = e.tok_emb + (int64_t)id * W;
     float4 v[4];
     float tot = 0.f;
@@ -588,15 +620,9 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
             if (e.shift) e.shift[row] = om;
         }
     }
-    if (t == 0) {      // one wave scans the row for the first maximum id (modules/clip.py:484)
-        unsigned long long key = 0ull;
-        for (int u = lane; u < Lt; u += 64) {
-            const unsigned long long k2 = ((unsigned long long)(ids[(int64_t)b * Lt + u] + 0x40000000LL) << 32) |
-                                          (unsigned)(0xFFFFFFFFu - (unsigned)u);
-            key = k2 > key ? k2 : key;
-        }
-        key = cc_wave_max_u64(key);
-        if (lane == 0) eot[b] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    if (t == 0 && !e.seq_off) {      // one wave scans the caption for the first maximum id (modules/clip.py:484)
+        const int p = text_eot_position(ids, b, Lt, lane);
+        if (lane == 0) eot[b] = p;
     }
 }
 

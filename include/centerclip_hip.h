@@ -367,7 +367,11 @@ typedef struct cc_text_model {
 size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt);
 
 /* ids [Bt, Lt] int64 -> features [Bt, embed_dim] fp32: row at the first argmax of the ids
- * (EOT has the largest id, clip.py:484) of ln_final(x) @ text_projection. */
+ * (EOT has the largest id, clip.py:484) of ln_final(x) @ text_projection.
+ * Caption compaction: the attention mask is causal (clip.py:448-454) and only the EOT row is projected, so tokens behind
+ * a caption's EOT cannot reach its feature.  The tower therefore runs on the rows up to each caption's EOT only, packed
+ * back to back (positions found on the device, launches sized for Bt*Lt rows, no host synchronisation) - the features
+ * are bit-identical to running all Bt*Lt rows.  cc_text_encode_hidden with hidden_out != NULL runs every row. */
 int cc_text_encode(const cc_text_model* m, const int64_t* ids, int32_t Bt, int32_t Lt,
                    float* features, void* ws, size_t ws_bytes, void* stream);
 /* ... also returning the final hidden state [Bt, Lt, W] fp32 before ln_final (hidden_out may be NULL) */

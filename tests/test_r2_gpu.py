@@ -226,6 +226,42 @@ def test_return_hidden_and_clip_forward(gc):
     assert float((li.cpu() - want).abs().max()) <= 1e-3 * mult and float((lt.cpu() - want.t()).abs().max()) <= 1e-3 * mult
 
 
+def test_caption_compaction_is_bit_identical_to_all_rows(gc):
+    """The text tower runs on the rows up to each caption's EOT (found on the device); the features equal the all-rows
+    run bit for bit - also for a caption without padding, one of length 1, both towers paired, and through the debug
+    switch that turns the compaction off."""
+    from centerclip_amd import _lib as L
+    model, sd, T = small_clip(gc, cluster=True)
+    CTX, VOCAB = int(gc["cfg"][5]), int(gc["cfg"][6])
+    gen = torch.Generator().manual_seed(4)
+    lens = [CTX, 1, 2, 5, 9, CTX - 1, 3, 7]
+    ids = torch.zeros(len(lens), CTX, dtype=torch.long)
+    for b, ln in enumerate(lens):
+        if ln > 1:
+            ids[b, 0] = VOCAB - 2
+            ids[b, 1:ln - 1] = torch.randint(1, VOCAB - 2, (max(ln - 2, 0),), generator=gen)
+        ids[b, ln - 1] = VOCAB - 1                                   # EOT = largest id, at position ln - 1
+    ids = ids.to(DEV)
+    lib = L.lib()
+    feat = model.encode_text(ids)
+    dense_feat, hidden = model.encode_text(ids, return_hidden=True)   # the all-rows path (hidden state requested)
+    assert torch.equal(feat, dense_feat)
+    assert lib.cc_debug_set_text_compaction(0) == 0
+    try:
+        off = model.encode_text(ids)
+        video = torch.from_numpy(gc["video"]).to(DEV)
+        v_off, t_off = model.encode_pair(video, ids[:3], video_frame=T)
+    finally:
+        lib.cc_debug_set_text_compaction(1)
+    assert torch.equal(feat, off)
+    v_on, t_on = model.encode_pair(video, ids[:3], video_frame=T)
+    assert torch.equal(t_on, t_off) and torch.equal(v_on, v_off)
+    ref = clo.text_forward(sd, ids.cpu())
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    # hidden rows behind the EOT exist in the all-rows run (the reference computes them too)
+    assert hidden.shape == (len(lens), CTX, model.embed_dim) and bool(torch.isfinite(hidden).all())
+
+
 # ------------------------------------------------------------------------------------------------ eval loop (S3)
 def test_run_on_single_gpu_follows_the_reference_call_sequence(g):
     """main.py:430-449 (cache the features batch by batch) and :511-524 (get_similarity_logits per text-batch x video-batch
