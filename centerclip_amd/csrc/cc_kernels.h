@@ -37,6 +37,13 @@ struct GemmArgs {
     // Device-side row count (text tower with compacted captions): when non-null the kernel reads the number of valid
     // rows from *m_dev (<= M, which sizes the grid); tiles beyond it exit at once, rows beyond it are never stored.
     const int* m_dev;
+    // Row selection (cc_gemm_rows_dispatch2 only): logical row m of the problem lives at physical row
+    // prow(m) = row_map ? row_map[m] : m * row_step (row_step 0 = 1) of A / C / c16 and of every per-row side array
+    // (statistics, shifts).  The last block of a tower only needs the rows the projection head reads (the CLS token of
+    // every frame: row_step = tokens per frame; the EOT token of every caption: row_map), so its out_proj / c_fc /
+    // c_proj run on those rows in place.
+    int row_step;
+    const int* row_map;
 };
 
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
@@ -50,6 +57,11 @@ struct GemmPair {
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st);
 // slots_out (optional, [2]): for RESID_STATS the number of partial-sum slots per row each problem wrote
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out = nullptr);
+// The same product for a FEW selected rows (GemmArgs::row_step / row_map; epilogues EPI_F16_GELU_LN, EPI_F32_RESID and
+// EPI_F32_RESID_STATS; N % 32 == 0, K % 32 == 0; with statistics N <= 32 * CC_LN_MAX_SLOTS): latency-bound, so the K
+// range is split over the 8 waves of a workgroup and the grid has one workgroup per 32 output columns.
+bool cc_gemm_rows_ok(int N, int K, int epi);
+int cc_gemm_rows_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st, int* slots_out = nullptr);
 
 struct LnArgs {
     const float* in; int64_t in_stride; const float* gamma; const float* beta; void* out; int64_t out_stride;

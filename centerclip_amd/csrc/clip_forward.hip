@@ -14,6 +14,9 @@ namespace {
 // debug hook (cc_debug_set_text_compaction, not part of the public ABI): 0 = run the text tower on all Bt * Lt rows, as the
 // reference does - bench.py reports the step both ways, tests compare the two forms bit for bit
 int g_text_compaction = 1;
+// debug hook (cc_debug_set_last_block_rows): 0 = the last block of each tower computes every row behind its attention,
+// as the reference does, instead of the rows the projection heads read
+int g_last_block_rows = 1;
 
 struct Carver {
     char* base;
@@ -96,6 +99,10 @@ struct BlockCtx {          // one tower's activations for the current block
     const int* m_dev;
     const int* seq_off;
     const int* seq_len;
+    // Last block of a tower when nobody asked for the hidden state: only sel_rows rows feed the projection head (row
+    // m -> sel_map ? sel_map[m] : m * sel_step), so everything after the attention runs on those rows in place
+    int sel_rows, sel_step;
+    const int* sel_map;
 };
 
 // One ResidualAttentionBlock for up to two towers at once (modules/clip.py:240,251).  Every phase is
@@ -136,6 +143,24 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         g.m_dev = c->m_dev;
         return g;
     };
+    // the phases behind the attention: every row, or the rows the head will read (GemmArgs::row_step / row_map) with the
+    // few-rows kernel; a tower whose partner is not in the same mode gets a launch of its own
+    auto tail = [&](const BlockCtx* c, int M, const _Float16* A, const void* Wt, const float* bias, void* C, int N, int K) {
+        GemmArgs g = base(c, M, A, Wt, bias, C, N, K);
+        if (c->sel_rows > 0) { g.M = c->sel_rows; g.m_dev = nullptr; g.row_step = c->sel_step; g.row_map = c->sel_map; }
+        return g;
+    };
+    auto tail_dispatch = [&](GemmArgs& g0, GemmArgs& g1, int epi, int bit, int* sl) {
+        const bool s0 = c0->sel_rows > 0, s1 = c1 && c1->sel_rows > 0;
+        if (!s0 && !s1) return dispatch(g0, g1, epi, bit, sl);
+        if (s0 && (s1 || !c1)) return cc_gemm_rows_dispatch2(g0, c1 ? &g1 : nullptr, epi, st, sl);
+        int a[2] = {0, 0}, b[2] = {0, 0};
+        int r = s0 ? cc_gemm_rows_dispatch2(g0, nullptr, epi, st, a) : cc_gemm_dispatch2(g0, nullptr, epi, 0, st, a);
+        if (r) return r;
+        r = s1 ? cc_gemm_rows_dispatch2(g1, nullptr, epi, st, b) : cc_gemm_dispatch2(g1, nullptr, epi, 0, st, b);
+        if (sl) { sl[0] = a[0]; sl[1] = b[0]; }
+        return r;
+    };
     // ---- q,k,v = in_proj(ln_1(x))   [LayerNorm folded]
     {
         GemmArgs g0 = base(c0, M0, c0->h16, w0->in_proj_ln_weight_f16, w0->in_proj_ln_c2, c0->qkv, 3 * Wa, Wa);
@@ -157,44 +182,44 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
     }
     // ---- x = x + out_proj(attn)   [+ fp16 copy and row statistics for ln_2]
     {
-        GemmArgs g0 = base(c0, M0, c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa);
+        GemmArgs g0 = tail(c0, M0, c0->att, w0->out_proj_weight_f16, w0->out_proj_bias, c0->h, Wa, Wa);
         g0.c16 = c0->h16; g0.stats_out = c0->st1;
         g0.shift_in = c0->sh0; g0.shift_stats = c0->st0; g0.shift_slots = c0->slots0; g0.shift_out = c0->sh1;
         GemmArgs g1{};
         if (c1) {
-            g1 = base(c1, M1, c1->att, w1->out_proj_weight_f16, w1->out_proj_bias, c1->h, Wb, Wb);
+            g1 = tail(c1, M1, c1->att, w1->out_proj_weight_f16, w1->out_proj_bias, c1->h, Wb, Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st1;
             g1.shift_in = c1->sh0; g1.shift_stats = c1->st0; g1.shift_slots = c1->slots0; g1.shift_out = c1->sh1;
         }
-        rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 2, slots);
+        rc = tail_dispatch(g0, g1, EPI_F32_RESID_STATS, 2, slots);
         if (rc) return rc;
         c0->slots1 = slots[0];
         if (c1) c1->slots1 = slots[1];
     }
     // ---- u = QuickGELU(c_fc(ln_2(x)))   [LayerNorm folded]
     {
-        GemmArgs g0 = base(c0, M0, c0->h16, w0->c_fc_ln_weight_f16, w0->c_fc_ln_c2, c0->u, 4 * Wa, Wa);
+        GemmArgs g0 = tail(c0, M0, c0->h16, w0->c_fc_ln_weight_f16, w0->c_fc_ln_c2, c0->u, 4 * Wa, Wa);
         g0.ln_stats = c0->st1; g0.ln_slots = c0->slots1; g0.ln_c1 = w0->c_fc_ln_c1;
         GemmArgs g1{};
         if (c1) {
-            g1 = base(c1, M1, c1->h16, w1->c_fc_ln_weight_f16, w1->c_fc_ln_c2, c1->u, 4 * Wb, Wb);
+            g1 = tail(c1, M1, c1->h16, w1->c_fc_ln_weight_f16, w1->c_fc_ln_c2, c1->u, 4 * Wb, Wb);
             g1.ln_stats = c1->st1; g1.ln_slots = c1->slots1; g1.ln_c1 = w1->c_fc_ln_c1;
         }
-        rc = dispatch(g0, g1, EPI_F16_GELU_LN, 4, nullptr);
+        rc = tail_dispatch(g0, g1, EPI_F16_GELU_LN, 4, nullptr);
         if (rc) return rc;
     }
     // ---- x = x + c_proj(u)   [+ fp16 copy and row statistics for the next block's ln_1]
     {
-        GemmArgs g0 = base(c0, M0, c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa);
+        GemmArgs g0 = tail(c0, M0, c0->u, w0->c_proj_weight_f16, w0->c_proj_bias, c0->h, Wa, 4 * Wa);
         g0.c16 = c0->h16; g0.stats_out = c0->st0;
         g0.shift_in = c0->sh1; g0.shift_stats = c0->st1; g0.shift_slots = c0->slots1; g0.shift_out = c0->sh0;
         GemmArgs g1{};
         if (c1) {
-            g1 = base(c1, M1, c1->u, w1->c_proj_weight_f16, w1->c_proj_bias, c1->h, Wb, 4 * Wb);
+            g1 = tail(c1, M1, c1->u, w1->c_proj_weight_f16, w1->c_proj_bias, c1->h, Wb, 4 * Wb);
             g1.c16 = c1->h16; g1.stats_out = c1->st0;
             g1.shift_in = c1->sh1; g1.shift_stats = c1->st1; g1.shift_slots = c1->slots1; g1.shift_out = c1->sh0;
         }
-        rc = dispatch(g0, g1, EPI_F32_RESID_STATS, 8, slots);
+        rc = tail_dispatch(g0, g1, EPI_F32_RESID_STATS, 8, slots);
         if (rc) return rc;
         c0->slots0 = slots[0];
         if (c1) c1->slots0 = slots[1];
@@ -361,6 +386,19 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             cv.nseq = B * frames; cv.L = tokens + 1; cv.W = W; cv.heads = vm->heads; cv.causal = 0;
         }
         const bool ht = ti < tl;
+        // last block, nobody wants the hidden state: everything behind the attention on the CLS / EOT rows only
+        auto few_rows_ok = [](int Wd) {
+            return cc_gemm_rows_ok(Wd, Wd, EPI_F32_RESID_STATS) && cc_gemm_rows_ok(4 * Wd, Wd, EPI_F16_GELU_LN) &&
+                   cc_gemm_rows_ok(Wd, 4 * Wd, EPI_F32_RESID_STATS);
+        };
+        if (hv && i == vl - 1 && !hidden_out && g_last_block_rows && cv.L > 1 && few_rows_ok(W)) {
+            cv.sel_rows = cv.nseq;
+            cv.sel_step = cv.L;
+        }
+        if (ht && ti == tl - 1 && compact && g_last_block_rows && few_rows_ok(tm->width)) {
+            ct.sel_rows = Bt;
+            ct.sel_map = t.eot;
+        }
         rc = run_block_pair(hv ? &vm->blocks[i] : nullptr, hv ? &cv : nullptr, ht ? &tm->blocks[ti] : nullptr,
                             ht ? &ct : nullptr, st);
         if (rc) return rc;
@@ -389,6 +427,11 @@ extern "C" {
 
 int cc_debug_set_text_compaction(int on) {
     g_text_compaction = on ? 1 : 0;
+    return CC_OK;
+}
+
+int cc_debug_set_last_block_rows(int on) {
+    g_last_block_rows = on ? 1 : 0;
     return CC_OK;
 }
 

@@ -706,6 +706,228 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ selected rows
+// The last block of a tower feeds only the rows its projection head reads (48 CLS rows of 2,400 at the bench shape):
+// out_proj / c_fc / c_proj for those rows are weight-streaming problems (M <= 64 per chunk, 1.2 - 4.7 MB of weights),
+// bound by the latency of the k chain, not by MFMA or HBM rate.  So: one workgroup per 32 output columns, its 8 waves
+// split K (each wave keeps 4 k-steps = 24 16-byte loads per lane in flight, fragments loaded straight from global memory
+// in MFMA layout - both operands are K-contiguous), partial tiles summed through LDS, and the epilogues of the main
+// kernel (folded LayerNorm + QuickGELU; residual add with the centred fp16 copy + partial row statistics) applied on
+// the physical rows.
+struct RowsPair {
+    GemmArgs p[2];
+    int blocks0;
+};
+
+constexpr int ROWS_BM = 64, ROWS_BN = 32, ROWS_WAVES = 8, ROWS_LDR = ROWS_BN + 4;
+
+template <int EPI>
+__global__ __launch_bounds__(64 * ROWS_WAVES) void gemm_rows_kernel(RowsPair pr) {
+    const bool second = (int)blockIdx.x >= pr.blocks0;
+    const GemmArgs g = second ? pr.p[1] : pr.p[0];
+    const int bid = second ? blockIdx.x - pr.blocks0 : blockIdx.x;
+    const int ncb = g.N / ROWS_BN;
+    const int cb = bid % ncb, row0 = (bid / ncb) * ROWS_BM, col0 = cb * ROWS_BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    __shared__ float red[ROWS_WAVES / 2][ROWS_BM][ROWS_LDR];     // 36 KB
+    __shared__ float2 rowst[ROWS_BM];
+    constexpr bool LNFOLD = (EPI == EPI_F16_GELU_LN);
+    constexpr bool STATS = (EPI == EPI_F32_RESID_STATS);
+    // The kernel is a chain of memory round trips, so every load is issued as early as its address is known: (1) the
+    // physical rows, (2) statistics + the first operand fragments + the epilogue operands, (3..) the rest of K.
+    const int r = tid >> 3, sub = tid & 7, c = sub * 4;           // epilogue geometry: 8 threads per row, 4 columns each
+    const int n = col0 + c;
+    int mrow[5];                                                  // this lane's 4 fragment rows + its epilogue row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mrow[i] = min(row0 + i * 16 + l15, g.M - 1);
+    mrow[4] = min(row0 + r, g.M - 1);
+    int64_t prw[5];
+    if (g.row_map) {
+        int t[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) t[i] = g.row_map[mrow[i]];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) prw[i] = t[i];
+    } else {
+        const int step = g.row_step ? g.row_step : 1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) prw[i] = (int64_t)mrow[i] * step;
+    }
+    const int64_t pm = prw[4];
+    const bool on = row0 + r < g.M;
+    // ---- this wave's K range
+    const int tsteps = g.K / 32, spw = (tsteps + ROWS_WAVES - 1) / ROWS_WAVES;      // 32-wide k-steps, per wave
+    const int kbeg = min(wave * spw, tsteps), ksteps = min(spw, tsteps - kbeg);        // (0 steps: a wave without work)
+    const int klast = max(ksteps - 1, 0) * 32 + min(kbeg, tsteps - 1) * 32;            // a valid k offset for clamped loads
+    const _Float16* wp[2];
+    const _Float16* ap[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wp[j] = g.W + (int64_t)(col0 + j * 16 + l15) * g.K + lg * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = g.A + prw[i] * g.K + lg * 8;
+    // 3 k-steps = 18 16-byte loads per lane per batch, the next batch in flight under the MFMAs of the current one (6 steps
+    // in one batch without the overlap measured slower: c_fc 12.5 vs 9.2 us)
+    constexpr int U = 3;
+    h8 bf[U][2], af[U][4];
+    auto load_batch = [&](int s0) {                               // always U full steps: the ones behind the range re-read
+#pragma unroll                                                    // the last valid step and multiply zeros
+        for (int u = 0; u < U; ++u) {
+            const int k = (s0 + u < ksteps) ? (kbeg + s0 + u) * 32 : klast;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[u][j] = *reinterpret_cast<const h8*>(wp[j] + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[u][i] = *reinterpret_cast<const h8*>(ap[i] + k);
+        }
+    };
+    load_batch(0);
+    // per-row scalars (LayerNorm statistics / the centring shift): 8 threads per row take every 8th slot (<= 4 loads each)
+    // and combine inside their 8-lane group
+    float2 t2[CC_LN_MAX_SLOTS / 8];
+    float shin = 0.f;
+    const bool rowscal = LNFOLD || (STATS && g.shift_stats);
+    if (rowscal) {
+        const int nslots = LNFOLD ? g.ln_slots : g.shift_slots;
+        const float2* ps = reinterpret_cast<const float2*>(LNFOLD ? g.ln_stats : g.shift_stats) + pm * nslots;
+#pragma unroll
+        for (int u = 0; u < CC_LN_MAX_SLOTS / 8; ++u) t2[u] = ps[min(sub + u * 8, nslots - 1)];
+        if (!LNFOLD && g.shift_in) shin = g.shift_in[pm];
+    }
+    // epilogue operands
+    const float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), res = c1;
+    if (LNFOLD) c1 = *reinterpret_cast<const float4*>(g.ln_c1 + n);
+    else res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + pm * g.ldc + n);
+    if (rowscal) {
+        const int nslots = LNFOLD ? g.ln_slots : g.shift_slots;
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < CC_LN_MAX_SLOTS / 8; ++u) {
+            const bool ok = sub + u * 8 < nslots;
+            sum += ok ? t2[u].x : 0.f;
+            sq += ok ? t2[u].y : 0.f;
+        }
+        sum += dpp_f32<0xB1>(sum);
+        sq += dpp_f32<0xB1>(sq);
+        sum += dpp_f32<0x4E>(sum);
+        sq += dpp_f32<0x4E>(sq);
+        sum += dpp_f32<0x141>(sum);
+        sq += dpp_f32<0x141>(sq);
+        if (sub == 0) {
+            if (LNFOLD) {
+                const float mu = sum / (float)g.K;
+                const float var = fmaxf(sq / (float)g.K - mu * mu, 0.f);
+                rowst[r] = make_float2(mu, 1.0f / sqrtf(var + g.ln_eps));
+            } else {
+                rowst[r] = make_float2(shin + sum / (float)g.N, 1.f);
+            }
+        }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ksteps; s0 += U) {
+        h8 bq[U][2], aq[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = s0 + u < ksteps;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[u][j] = ok ? bf[u][j] : h8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aq[u][i] = af[u][i];
+        }
+        if (s0 + U < ksteps) load_batch(s0 + U);                 // next batch in flight under this one's MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[u][j], aq[u][i], acc[i][j], 0, 0, 0);
+    }
+    // ---- sum the 8 partial tiles (the lane holds C[m = i*16 + l15][n = j*16 + lg*4 + 0..3]): the upper four waves park
+    // theirs, the lower four add their own on top, every thread then sums four
+    auto slot = [&](int i, int j) { return reinterpret_cast<float4*>(&red[wave & 3][i * 16 + l15][j * 16 + lg * 4]); };
+    if (wave >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *slot(i, j) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 t4 = *slot(i, j);
+                *slot(i, j) = make_float4(acc[i][j][0] + t4.x, acc[i][j][1] + t4.y, acc[i][j][2] + t4.z, acc[i][j][3] + t4.w);
+            }
+    }
+    __syncthreads();
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < ROWS_WAVES / 2; ++w) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&red[w][r][c]);
+        v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+    }
+    if (LNFOLD) {
+        const float2 st = rowst[r];
+        v.x = quick_gelu(st.y * (v.x - st.x * c1.x) + bb.x);
+        v.y = quick_gelu(st.y * (v.y - st.x * c1.y) + bb.y);
+        v.z = quick_gelu(st.y * (v.z - st.x * c1.z) + bb.z);
+        v.w = quick_gelu(st.y * (v.w - st.x * c1.w) + bb.w);
+        const h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        if (on) *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(g.C) + pm * g.ldc + n) = o;
+        return;
+    }
+    v.x += bb.x + res.x; v.y += bb.y + res.y; v.z += bb.z + res.z; v.w += bb.w + res.w;
+    if (on) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + pm * g.ldc + n) = v;
+    if (STATS && g.c16) {
+        const float cr = g.shift_stats ? rowst[r].x : 0.f;
+        const h4 o = {(_Float16)(v.x - cr), (_Float16)(v.y - cr), (_Float16)(v.z - cr), (_Float16)(v.w - cr)};
+        if (on) *reinterpret_cast<h4*>(g.c16 + pm * g.ldc + n) = o;
+        if (on && g.shift_out && cb == 0 && c == 0) g.shift_out[pm] = cr;
+        const float q0 = (float)o[0], q1 = (float)o[1], q2 = (float)o[2], q3 = (float)o[3];
+        float psum = (q0 + q1) + (q2 + q3);
+        float psq = (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+        psum += dpp_f32<0xB1>(psum);                              // the 8 lanes of a row: quad swaps + half mirror
+        psq += dpp_f32<0xB1>(psq);
+        psum += dpp_f32<0x4E>(psum);
+        psq += dpp_f32<0x4E>(psq);
+        psum += dpp_f32<0x141>(psum);
+        psq += dpp_f32<0x141>(psq);
+        if (on && c == 0 && g.stats_out) reinterpret_cast<float2*>(g.stats_out)[pm * ncb + cb] = make_float2(psum, psq);
+    }
+}
+
+bool cc_gemm_rows_ok(int N, int K, int epi) {
+    if (N <= 0 || K <= 0 || (N % ROWS_BN) || (K % 32)) return false;
+    if (epi == EPI_F32_RESID_STATS) return N / ROWS_BN <= CC_LN_MAX_SLOTS;
+    return epi == EPI_F16_GELU_LN || epi == EPI_F32_RESID;
+}
+
+int cc_gemm_rows_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st, int* slots_out) {
+    if (!cc_gemm_rows_ok(g0.N, g0.K, epi) || (g1 && !cc_gemm_rows_ok(g1->N, g1->K, epi))) return CC_ERR_UNSUPPORTED;
+    if (g0.M <= 0 || (g1 && g1->M <= 0)) return CC_ERR_INVALID;
+    RowsPair pr{};
+    pr.p[0] = g0;
+    auto blocks = [](const GemmArgs& g) { return (g.N / ROWS_BN) * ((g.M + ROWS_BM - 1) / ROWS_BM); };
+    pr.blocks0 = blocks(g0);
+    int total = pr.blocks0;
+    if (g1) { pr.p[1] = *g1; total += blocks(*g1); }
+    if (slots_out) { slots_out[0] = g0.N / ROWS_BN; slots_out[1] = g1 ? g1->N / ROWS_BN : 0; }
+    const dim3 grid(total), block(64 * ROWS_WAVES);
+    switch (epi) {
+        case EPI_F16_GELU_LN: hipLaunchKernelGGL(gemm_rows_kernel<EPI_F16_GELU_LN>, grid, block, 0, st, pr); break;
+        case EPI_F32_RESID: hipLaunchKernelGGL(gemm_rows_kernel<EPI_F32_RESID>, grid, block, 0, st, pr); break;
+        case EPI_F32_RESID_STATS: hipLaunchKernelGGL(gemm_rows_kernel<EPI_F32_RESID_STATS>, grid, block, 0, st, pr); break;
+        default: return CC_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_HIP;
+}
+
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_gemm_dispatch2(g, nullptr, epi, tile, st, nullptr); }
 
 extern "C" {

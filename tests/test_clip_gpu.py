@@ -635,7 +635,11 @@ def test_n2_variants_inside_the_fused_forward(g, algo, agg):
     video = torch.from_numpy(g["video"])
     feat, hidden = model.visual.encode(video.to(DEV), T, want_hidden=True)
     feat2, _ = model.visual.encode(video.to(DEV), T)
-    assert torch.equal(feat, feat2) and bool(torch.isfinite(feat).all())
+    feat3, _ = model.visual.encode(video.to(DEV), T)
+    # deterministic; with the hidden state requested the last block computes every row instead of the CLS rows only (other
+    # GEMM tiles: agreement to rounding, tests/test_r2_gpu.py::test_last_block_runs_on_the_rows_the_heads_read)
+    assert torch.equal(feat2, feat3) and bool(torch.isfinite(feat).all())
+    assert float((feat - feat2).abs().max() / feat.abs().max()) < 1e-5
     assert hidden.shape == (video.shape[0] // T * 2, 1 + K, int(g["cfg"][3]))
     if agg is None:
         ref = clo.visual_forward(golden_state_dict(g), video, T, cluster_plan={1: (2, K)},

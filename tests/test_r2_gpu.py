@@ -243,23 +243,52 @@ def test_caption_compaction_is_bit_identical_to_all_rows(gc):
         ids[b, ln - 1] = VOCAB - 1                                   # EOT = largest id, at position ln - 1
     ids = ids.to(DEV)
     lib = L.lib()
-    feat = model.encode_text(ids)
-    dense_feat, hidden = model.encode_text(ids, return_hidden=True)   # the all-rows path (hidden state requested)
-    assert torch.equal(feat, dense_feat)
-    assert lib.cc_debug_set_text_compaction(0) == 0
+    # (the last block's row selection is a separate saving with its own test; off here so that both forms run the same GEMMs)
+    assert lib.cc_debug_set_last_block_rows(0) == 0
     try:
-        off = model.encode_text(ids)
-        video = torch.from_numpy(gc["video"]).to(DEV)
-        v_off, t_off = model.encode_pair(video, ids[:3], video_frame=T)
+        feat = model.encode_text(ids)
+        dense_feat, hidden = model.encode_text(ids, return_hidden=True)   # the all-rows path (hidden state requested)
+        assert torch.equal(feat, dense_feat)
+        assert lib.cc_debug_set_text_compaction(0) == 0
+        try:
+            off = model.encode_text(ids)
+            video = torch.from_numpy(gc["video"]).to(DEV)
+            v_off, t_off = model.encode_pair(video, ids[:3], video_frame=T)
+        finally:
+            lib.cc_debug_set_text_compaction(1)
+        assert torch.equal(feat, off)
+        v_on, t_on = model.encode_pair(video, ids[:3], video_frame=T)
+        assert torch.equal(t_on, t_off) and torch.equal(v_on, v_off)
     finally:
-        lib.cc_debug_set_text_compaction(1)
-    assert torch.equal(feat, off)
-    v_on, t_on = model.encode_pair(video, ids[:3], video_frame=T)
-    assert torch.equal(t_on, t_off) and torch.equal(v_on, v_off)
+        lib.cc_debug_set_last_block_rows(1)
     ref = clo.text_forward(sd, ids.cpu())
     assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
     # hidden rows behind the EOT exist in the all-rows run (the reference computes them too)
     assert hidden.shape == (len(lens), CTX, model.embed_dim) and bool(torch.isfinite(hidden).all())
+
+
+def test_last_block_runs_on_the_rows_the_heads_read(gc):
+    """Without a request for the hidden state the last block of each tower computes out_proj / c_fc / c_proj for the CLS
+    (visual) and EOT (text) rows only.  The same rows of the all-rows run differ only through the tile the GEMMs pick
+    (different partition of the LayerNorm partial sums): compared at 1e-5 relative, far inside the parity tolerance."""
+    from centerclip_amd import _lib as L
+    lib = L.lib()
+    for cluster in (True, False):
+        model, sd, T = small_clip(gc, cluster=cluster)
+        video = torch.from_numpy(gc["video"]).to(DEV)
+        ids = torch.from_numpy(gc["t_ids"]).to(DEV)
+        v_sel, t_sel = model.encode_pair(video, ids, video_frame=T)
+        only_v = model.encode_image(video, video_frame=T)[0]
+        only_t = model.encode_text(ids)
+        assert lib.cc_debug_set_last_block_rows(0) == 0
+        try:
+            v_all, t_all = model.encode_pair(video, ids, video_frame=T)
+        finally:
+            lib.cc_debug_set_last_block_rows(1)
+        full_v, hid_v = model.encode_image(video, video_frame=T, return_hidden=True)
+        for a, b in ((v_sel, v_all), (t_sel, t_all), (only_v, v_all), (only_t, t_all), (full_v, v_all)):
+            assert a.shape == b.shape and relerr(a.cpu(), b.cpu()) < 1e-5
+        assert bool(torch.isfinite(hid_v).all())
 
 
 # ------------------------------------------------------------------------------------------------ eval loop (S3)
