@@ -155,9 +155,11 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         if (!s0 && !s1) return dispatch(g0, g1, epi, bit, sl);
         if (s0 && (s1 || !c1)) return cc_gemm_rows_dispatch2(g0, c1 ? &g1 : nullptr, epi, st, sl);
         int a[2] = {0, 0}, b[2] = {0, 0};
-        int r = s0 ? cc_gemm_rows_dispatch2(g0, nullptr, epi, st, a) : cc_gemm_dispatch2(g0, nullptr, epi, 0, st, a);
+        int* pa = sl ? a : nullptr;
+        int* pb = sl ? b : nullptr;
+        int r = s0 ? cc_gemm_rows_dispatch2(g0, nullptr, epi, st, pa) : cc_gemm_dispatch2(g0, nullptr, epi, 0, st, pa);
         if (r) return r;
-        r = s1 ? cc_gemm_rows_dispatch2(g1, nullptr, epi, st, b) : cc_gemm_dispatch2(g1, nullptr, epi, 0, st, b);
+        r = s1 ? cc_gemm_rows_dispatch2(g1, nullptr, epi, st, pb) : cc_gemm_dispatch2(g1, nullptr, epi, 0, st, pb);
         if (sl) { sl[0] = a[0]; sl[1] = b[0]; }
         return r;
     };

@@ -286,7 +286,14 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
         finally:
             lib.cc_debug_set_last_block_rows(1)
         full_v, hid_v = model.encode_image(video, video_frame=T, return_hidden=True)
-        for a, b in ((v_sel, v_all), (t_sel, t_all), (only_v, v_all), (only_t, t_all), (full_v, v_all)):
+        # the towers in different modes (captions not compacted -> all text rows, CLS rows only on the visual side)
+        assert lib.cc_debug_set_text_compaction(0) == 0
+        try:
+            v_mix, t_mix = model.encode_pair(video, ids, video_frame=T)
+        finally:
+            lib.cc_debug_set_text_compaction(1)
+        for a, b in ((v_sel, v_all), (t_sel, t_all), (only_v, v_all), (only_t, t_all), (full_v, v_all), (v_mix, v_all),
+                     (t_mix, t_all)):
             assert a.shape == b.shape and relerr(a.cpu(), b.cpu()) < 1e-5
         assert bool(torch.isfinite(hid_v).all())
 
