@@ -55,6 +55,9 @@ def _declare(lib):
                                                  c.POINTER(ClusterVariant), vp, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.cc_token_aggregate_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, c.POINTER(ClusterVariant), vp,
                                            i64, i64, vp]
+    lib.cc_token_cluster_backward_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, c.POINTER(ClusterVariant), vp, vp,
+                                                  vp, i64, i64, vp, i64, i64, vp, vp, vp]
+    lib.cc_token_cluster_backward_f32.restype = c.c_int
     lib.cc_spectral_laplacian_f32.argtypes = [vp, lay, i32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_svd_sign_flip_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.cc_spectral_laplacian_f32.restype = c.c_int

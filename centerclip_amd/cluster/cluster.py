@@ -1,6 +1,7 @@
 """Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and TokenClusterInter (:66-352) for the
 algorithms 'kmediods++' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
-'sparse_sampling' in eval mode."""
+'sparse_sampling' in eval mode.  Differentiable with respect to x, cluster_embed and cls_multiplier
+(torch.ops.centerclip.token_cluster_train / token_cluster_backward, cc_token_cluster_backward_f32)."""
 import numpy as np
 import torch
 
@@ -149,6 +150,19 @@ class TokenClusterInter(torch.nn.Module):
         n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
         N = self.frame_duration * n
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: the differentiable op (gradient of the gather / cluster means / CLS mean for the selection made in
+            # the forward pass, which is a constant of the backward pass as in the reference: fast_kmeans.py:13,44)
+            embed = self.cluster_embed.to(x.device).float().contiguous() if self.cluster_embedding else None
+            mult = self.cls_multiplier.to(x.device).float().reshape(-1) if self.adaptive_cls else None
+            ids = self._sparse_ids(N, x.device) if self.algorithm == 'sparse_sampling' else None
+            out, medoids, _ = torch.ops.centerclip.token_cluster_train(
+                x, bool(frame_major), self.before_block_frames, self.after_block_frames, K, L.METRIC_IDS[self.distance],
+                float(self.norm_p), float(self.threshold), int(self.iter_limit), int(self.split_size), bool(self.pre_norm),
+                {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2}[self.algorithm],
+                0 if self.aggregation in [None, 'None'] else 1, embed, mult, ids)
+            self.last_medoids = medoids if medoids.numel() else None
+            return out
         var, keep = self.variant(N, x.device)
         out, medoids = torch.ops.centerclip.token_cluster(
             x, bool(frame_major), self.before_block_frames, self.after_block_frames, K, L.METRIC_IDS[self.distance],

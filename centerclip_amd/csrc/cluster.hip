@@ -1500,6 +1500,161 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
 
 }  // extern "C"
 
+// ============================================================================ N4 (training support): backward of K3
+// Gradient of TokenClusterInter.forward with respect to its input and its parameters, for a fixed selection (the medoid
+// ids / assignment are piecewise constant in x: the reference runs them under no_grad, fast_kmeans.py:13,44).
+//   medoid gather (cluster.py:289)      gx[token medoid_k] = g[1 + k]          (ids are distinct: every row written once)
+//   cluster means (:291-301)            gx[j] = g[1 + assign_j] / |cluster(assign_j)|
+//   cluster_embed add (:304-305)        g_embed[k] = sum over segments of g[1 + k]
+//   CLS = mean over the segment's frames of (cls * cls_multiplier) (:244-245,307-308)
+//                                       gx[cls of frame t] = g[0] / fd (* m_t);  g_m[t] = sum_{b,w} g[0] / fd * cls
+//   pooling (:319-324)                  gx[every token] = g[same token] / fd
+// One wave per INPUT row: each row of gx is written exactly once (zeros included) - no memset, no atomics, deterministic.
+__global__ __launch_bounds__(256) void token_grad_kernel(const float* __restrict__ g, int64_t g_tok, int64_t g_frame, int B,
+                                                         int T, int T_new, int n, int W, int K, int mode,
+                                                         const long long* __restrict__ ids, int id_stride,
+                                                         const long long* __restrict__ assign,
+                                                         const float* __restrict__ cls_mult, float* __restrict__ gx,
+                                                         int64_t gx_tok, int64_t gx_frame) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T * (1 + n)) return;
+    const int frame = row / (1 + n), l = row - frame * (1 + n);
+    const int b = frame / T, t = frame - b * T;
+    const int fd = T / T_new, N = fd * n;
+    const int sgm = t / fd, f = t - sgm * fd;
+    const int seg = b * T_new + sgm, p = sgm * B + b;
+    const float* gseg = g + (int64_t)seg * g_frame;
+    float* dst = gx + (int64_t)l * gx_tok + (int64_t)frame * gx_frame;
+    const float den = (float)fd;
+    if (l == 0 || mode == 2) {
+        const float* src = gseg + (int64_t)l * g_tok;
+        const float m = (cls_mult && l == 0 && mode != 2) ? cls_mult[t] : 1.f;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + w);
+            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            if (cls_mult && l == 0 && mode != 2) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+            *reinterpret_cast<float4*>(dst + w) = v;
+        }
+        return;
+    }
+    const int j = f * n + (l - 1);
+    if (mode == 1) {
+        const long long* a = assign + (int64_t)p * N;
+        const long long k = a[j];
+        int cnt = 0;
+        for (int jj = lane; jj < N; jj += 64) cnt += (a[jj] == k) ? 1 : 0;
+        const float c = cc_wave_sum((float)cnt);                  // exact: counts < 2^24
+        const float* src = gseg + (int64_t)(1 + k) * g_tok;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + w);
+            v.x = v.x / c; v.y = v.y / c; v.z = v.z / c; v.w = v.w / c;
+            *reinterpret_cast<float4*>(dst + w) = v;
+        }
+        return;
+    }
+    // gather: every k with ids[k] == j contributes (k-medoids ids are distinct; fixed ids of 'sparse_sampling' may repeat)
+    const long long* idp = ids + (int64_t)p * id_stride;
+    for (int w0 = 0; w0 < W; w0 += 256) {
+        const int w = w0 + lane * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            unsigned long long hit = __ballot(k < K && idp[k] == (long long)j);
+            while (hit) {
+                const int kk = k0 + __builtin_ctzll(hit);
+                hit &= hit - 1;
+                if (w < W) {
+                    const float4 v = *reinterpret_cast<const float4*>(gseg + (int64_t)(1 + kk) * g_tok + w);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+        }
+        if (w < W) *reinterpret_cast<float4*>(dst + w) = acc;
+    }
+}
+
+// Parameter gradients: rows [0, K) -> g_embed[k] (sum over the segments, ascending), rows [K, K + T) -> g_mult[t].
+__global__ __launch_bounds__(256) void token_param_grad_kernel(const float* __restrict__ g, int64_t g_tok, int64_t g_frame,
+                                                               const float* __restrict__ x, int64_t x_frame, int B, int T,
+                                                               int T_new, int W, int K, float* __restrict__ g_embed,
+                                                               float* __restrict__ g_mult) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= K + T) return;
+    const int segs = B * T_new, fd = T / T_new;
+    if (row < K) {
+        if (!g_embed) return;
+        for (int w = lane * 4; w < W; w += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sg = 0; sg < segs; ++sg) {
+                const float4 v = *reinterpret_cast<const float4*>(g + (int64_t)(1 + row) * g_tok + (int64_t)sg * g_frame + w);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(g_embed + (int64_t)row * W + w) = acc;
+        }
+        return;
+    }
+    if (!g_mult) return;
+    const int t = row - K, sgm = t / fd;
+    const float den = (float)fd;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* gs = g + (int64_t)(b * T_new + sgm) * g_frame;
+        const float* xs = x + (int64_t)(b * T + t) * x_frame;
+        for (int w = lane; w < W; w += 64) acc += (gs[w] / den) * xs[w];
+    }
+    acc = cc_wave_sum(acc);
+    if (lane == 0) g_mult[t] = acc;
+}
+
+extern "C" int cc_token_cluster_backward_f32(const float* grad_out, int64_t go_tok_stride, int64_t go_frame_stride,
+                                             int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                                             const cc_cluster_variant* var, const int64_t* medoids,
+                                             const int64_t* assign, const float* x, int64_t x_tok_stride,
+                                             int64_t x_frame_stride, float* grad_x, int64_t gx_tok_stride,
+                                             int64_t gx_frame_stride, float* grad_cluster_embed, float* grad_cls_mult,
+                                             void* stream) {
+    (void)x_tok_stride;
+    if (!grad_out || !grad_x || !var || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+    if ((T % T_new) || (W & 3)) return CC_ERR_INVALID;
+    const int fd = T / T_new, N = fd * n;
+    int mode = 0, id_stride = K;
+    const long long* ids = reinterpret_cast<const long long*>(medoids);
+    if (var->algorithm == CC_CLUSTER_POOLING) {
+        if (K != n) return CC_ERR_INVALID;
+        mode = 2;
+    } else if (var->algorithm == CC_CLUSTER_SPARSE_SAMPLING) {
+        if (!var->fixed_ids) return CC_ERR_INVALID;
+        ids = reinterpret_cast<const long long*>(var->fixed_ids);
+        id_stride = 0;
+    } else if (var->algorithm == CC_CLUSTER_KMEDOIDS) {
+        if (K > N) return CC_ERR_INVALID;
+        if (var->aggregation == CC_AGGREGATE_MEAN) {
+            if (!assign) return CC_ERR_INVALID;
+            mode = 1;
+        } else if (!medoids) {
+            return CC_ERR_INVALID;
+        }
+    } else {
+        return CC_ERR_UNSUPPORTED;
+    }
+    if (grad_cls_mult && !x) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = B * T * (1 + n);
+    hipLaunchKernelGGL(token_grad_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, grad_out, go_tok_stride, go_frame_stride, B,
+                       T, T_new, n, W, K, mode, ids, id_stride, reinterpret_cast<const long long*>(assign),
+                       mode == 2 ? nullptr : var->cls_multiplier, grad_x, gx_tok_stride, gx_frame_stride);
+    if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
+    if (grad_cluster_embed || grad_cls_mult) {
+        if (mode == 2) return CC_ERR_INVALID;
+        hipLaunchKernelGGL(token_param_grad_kernel, dim3((K + T + 3) / 4), dim3(256), 0, st, grad_out, go_tok_stride,
+                           go_frame_stride, x, x_frame_stride, B, T, T_new, W, K, grad_cluster_embed, grad_cls_mult);
+        if (hipGetLastError() != hipSuccess) return CC_ERR_HIP;
+    }
+    return CC_OK;
+}
+
 // ============================================================================ N4 (forward pieces of spectral clustering)
 // modules/cluster/spectral.py:17-137 minus the eigensolve (which has no parity definition):
 //   constructW ('HeatKernel', optional spatial-temporal mask)   W = exp(-|x_i - x_j|^2 / (2 sigma^2)) [* graph]   (:79-107)

@@ -268,6 +268,110 @@ def _(x, frame_major, T, T_new, K, metric, norm_p, threshold, iter_limit, split_
     return out, x.new_empty((rows, K), dtype=torch.long)
 
 
+def _cluster_strides(shape, frame_major):
+    if frame_major:
+        BT, Lt, W = shape
+        return BT, Lt, W, W, Lt * W
+    Lt, BT, W = shape
+    return BT, Lt, W, BT * W, W
+
+
+@custom_op(NS + "::token_cluster_train", mutates_args=(), device_types="cuda")
+def token_cluster_train(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int, metric: int, norm_p: float,
+                        threshold: float, iter_limit: int, split_size: int, pre_norm: bool, algorithm: int, aggregation: int,
+                        cluster_embed: Optional[torch.Tensor], cls_mult: Optional[torch.Tensor],
+                        fixed_ids: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """token_cluster that also returns what its backward needs: medoids [T_new*B, K] and assign [T_new*B, fd*n] (both
+    empty for 'pooling' / 'sparse_sampling').  Differentiable with respect to x, cluster_embed and cls_mult
+    (torch.ops.centerclip.token_cluster_backward); the selection is a constant of the backward pass, as in the reference,
+    whose k-medoids runs under no_grad (fast_kmeans.py:13,44)."""
+    BT, Lt, W, tok, frame = _cluster_strides(x.shape, frame_major)
+    B, n = BT // T, Lt - 1
+    oshape = (B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W)
+    out = _e(*oshape, like=x, dtype=torch.float32)
+    _, _, _, o_tok, o_frame = _cluster_strides(oshape, frame_major)
+    kmed = algorithm == 0
+    N = (T // T_new) * n
+    med = _e(B * T_new if kmed else 0, K, like=x, dtype=torch.long)
+    assign = _e(B * T_new if kmed else 0, N, like=x, dtype=torch.long)
+    var = _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids)
+    lib = L.lib()
+    ws = L.workspace(lib.cc_cluster_workspace_bytes(B * T_new, N, W, int(pre_norm)), x.device)
+    L.check(lib.cc_token_cluster_variant_f32(L.ptr(x), tok, frame, B, T, T_new, n, W, K, metric, float(norm_p),
+                                             float(threshold), int(iter_limit), int(split_size), int(pre_norm),
+                                             ctypes.byref(var), L.ptr(out), o_tok, o_frame,
+                                             L.ptr(med) if kmed else None, L.ptr(assign) if kmed else None, None,
+                                             L.ptr(ws), ws.numel(), _st(x)), "cc_token_cluster_variant_f32")
+    return out, med, assign
+
+
+@token_cluster_train.register_fake
+def _(x, frame_major, T, T_new, K, metric, norm_p, threshold, iter_limit, split_size, pre_norm, algorithm, aggregation,
+      cluster_embed, cls_mult, fixed_ids):
+    BT, Lt, W, _, _ = _cluster_strides(x.shape, frame_major)
+    B, n = BT // T, Lt - 1
+    out = x.new_empty((B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W))
+    rows = B * T_new if algorithm == 0 else 0
+    return out, x.new_empty((rows, K), dtype=torch.long), x.new_empty((rows, (T // T_new) * n), dtype=torch.long)
+
+
+@custom_op(NS + "::token_cluster_backward", mutates_args=(), device_types="cuda")
+def token_cluster_backward(grad_out: torch.Tensor, x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int,
+                           algorithm: int, aggregation: int, medoids: torch.Tensor, assign: torch.Tensor,
+                           cls_mult: Optional[torch.Tensor], fixed_ids: Optional[torch.Tensor], want_embed: bool,
+                           want_mult: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Gradient of token_cluster_train for a fixed selection (cc_token_cluster_backward_f32): -> (grad_x like x,
+    grad_cluster_embed [K, W] or empty, grad_cls_mult [T] or empty)."""
+    BT, Lt, W, tok, frame = _cluster_strides(x.shape, frame_major)
+    B, n = BT // T, Lt - 1
+    _, _, _, g_tok, g_frame = _cluster_strides(grad_out.shape, frame_major)
+    gx = torch.empty_like(x)
+    g_embed = _e(K if want_embed else 0, W, like=x, dtype=torch.float32)
+    g_mult = _e(T if want_mult else 0, like=x, dtype=torch.float32)
+    var = _variant(algorithm, aggregation, None, cls_mult, fixed_ids)
+    L.check(L.lib().cc_token_cluster_backward_f32(L.ptr(grad_out), g_tok, g_frame, B, T, T_new, n, W, K, ctypes.byref(var),
+                                                  L.ptr(medoids) if medoids.numel() else None,
+                                                  L.ptr(assign) if assign.numel() else None, L.ptr(x), tok, frame,
+                                                  L.ptr(gx), tok, frame, L.ptr(g_embed) if want_embed else None,
+                                                  L.ptr(g_mult) if want_mult else None, _st(x)),
+            "cc_token_cluster_backward_f32")
+    return gx, g_embed, g_mult
+
+
+@token_cluster_backward.register_fake
+def _(grad_out, x, frame_major, T, T_new, K, algorithm, aggregation, medoids, assign, cls_mult, fixed_ids, want_embed,
+      want_mult):
+    W = x.shape[-1]
+    return torch.empty_like(x), x.new_empty((K if want_embed else 0, W)), x.new_empty((T if want_mult else 0,))
+
+
+def _token_cluster_setup(ctx, inputs, output):
+    (x, frame_major, T, T_new, K, _m, _p, _t, _i, _s, _pn, algorithm, aggregation, cluster_embed, cls_mult, fixed_ids) = inputs
+    _, med, assign = output
+    ctx.cfg = (frame_major, T, T_new, K, algorithm, aggregation)
+    ctx.has = (cluster_embed is not None, cls_mult is not None, fixed_ids is not None)
+    ctx.save_for_backward(x, med, assign, *(t for t in (cls_mult, fixed_ids) if t is not None))
+
+
+def _token_cluster_bwd(ctx, grad_out, _gmed, _gassign):
+    frame_major, T, T_new, K, algorithm, aggregation = ctx.cfg
+    has_embed, has_mult, has_ids = ctx.has
+    saved = list(ctx.saved_tensors)
+    x, med, assign = saved[:3]
+    rest = saved[3:]
+    cls_mult = rest.pop(0) if has_mult else None
+    fixed_ids = rest.pop(0) if has_ids else None
+    want_embed = has_embed and ctx.needs_input_grad[13]
+    want_mult = has_mult and ctx.needs_input_grad[14]
+    gx, ge, gm = torch.ops.centerclip.token_cluster_backward(grad_out.contiguous().float(), x, frame_major, T, T_new, K,
+                                                             algorithm, aggregation, med, assign, cls_mult, fixed_ids,
+                                                             want_embed, want_mult)
+    return (gx,) + (None,) * 12 + (ge if want_embed else None, gm if want_mult else None, None)
+
+
+token_cluster_train.register_autograd(_token_cluster_bwd, setup_context=_token_cluster_setup)
+
+
 @custom_op(NS + "::batch_kmedoids", mutates_args=(), device_types="cuda")
 def batch_kmedoids(x: torch.Tensor, K: int, metric: int, norm_p: float, threshold: float, iter_limit: int, id_sort: bool,
                    split_size: int, pre_norm: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -623,7 +727,8 @@ def _(sim):
 
 
 OPS = ("contrastive_loss", "spectral_laplacian", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
-       "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "batch_kmedoids", "kmedoids_from_dist",
+       "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward",
+       "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",
        "rank_counts_cols")

@@ -179,6 +179,27 @@ int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t 
                                  int64_t* medoids, int64_t* assign, int32_t* iters,
                                  void* ws, size_t ws_bytes, void* stream);
 
+/*
+ * N4 (training support): gradient of TokenClusterInter.forward (modules/cluster/cluster.py:239-310,319-343) with respect to
+ * its input and parameters for a FIXED selection - the reference selects under no_grad (fast_kmeans.py:13,44), so the
+ * medoid ids / assignment are constants of the backward pass, exactly what torch.autograd does with the reference module:
+ *   medoid gather (:289)            grad_x[token medoid_k] = grad_out[1 + k]
+ *   cluster means (:291-301)        grad_x[j] = grad_out[1 + assign_j] / |cluster(assign_j)|     (assign [T_new*B, fd*n])
+ *   cluster_embed (:304-305)        grad_cluster_embed[k] = sum over segments of grad_out[1 + k]            ([K, W] or NULL)
+ *   CLS mean (* cls_multiplier, :244-245,307-308)   grad_x[cls, frame t] = grad_out[0] / fd (* m_t);
+ *                                   grad_cls_mult[t] = sum_{b,w} grad_out[0] / fd * x[cls, frame t]         ([T] or NULL; needs x)
+ *   pooling (:319-324)              grad_x[token] = grad_out[token] / fd
+ *   sparse_sampling (:326-343)      gather with variant->fixed_ids
+ * Every row of grad_x ([1+n, B*T, W] through the strides) is written exactly once, zeros included: no memset, no atomics.
+ * medoids [T_new*B, K] as returned by cc_token_cluster_variant_f32 (ignored for mean / pooling / sparse_sampling).
+ */
+int cc_token_cluster_backward_f32(const float* grad_out, int64_t go_tok_stride, int64_t go_frame_stride,
+                                  int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                                  const cc_cluster_variant* variant, const int64_t* medoids, const int64_t* assign,
+                                  const float* x, int64_t x_tok_stride, int64_t x_frame_stride,
+                                  float* grad_x, int64_t gx_tok_stride, int64_t gx_frame_stride,
+                                  float* grad_cluster_embed, float* grad_cls_mult, void* stream);
+
 
 /*
  * N4 (forward pieces of cluster_algo 'spectral', modules/cluster/spectral.py:17-137; the eigen-decomposition between

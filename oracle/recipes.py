@@ -110,6 +110,20 @@ VARIANT_CASES = {
 }
 
 
+# N4 gradient fixtures (TokenClusterInter under autograd): the variant cases whose selection is an exact target + the
+# shipped default branch.  The upstream gradient G [1+K', B*T_new, W] is fullmant(seed + 5000).
+GRAD_CASES = dict(VARIANT_CASES)
+for _k in ("mean_generic", "pooling_12_3"):
+    GRAD_CASES.pop(_k)
+GRAD_CASES["default_12_3"] = dict(seed=89, inp="lattice", B=2, T=12, T_new=3, n=49, W=64, K=20, algorithm="kmediods++",
+                                  aggregation=None)
+
+
+def grad_output(cfg):
+    Kp = cfg["n"] if cfg["algorithm"] == "pooling" else cfg["K"]
+    return fullmant(cfg["seed"] + 5000, (1 + Kp, cfg["B"] * cfg["T_new"], cfg["W"]))
+
+
 def variant_input(cfg):
     """x [1+n, B*T, W] fp32 for a VARIANT_CASES entry (+ cluster_embed [K,W], cls_multiplier [T] when asked)."""
     L, BT, W = 1 + cfg["n"], cfg["B"] * cfg["T"], cfg["W"]

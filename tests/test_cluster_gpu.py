@@ -12,12 +12,14 @@ Parity contract, asserted exactly as stated there:
   C3  distances: <= 2e-4 absolute vs the reference's fp32 values (tolerance for ATen's
       Gram-trick rounding, diag noise up to 0.031 excluded on the diagonal)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import (DUPLICATE_CASES, VARIANT_CASES, duplicate_token_problem, dyadic, fullmant, lattice,
+from oracle.recipes import (DUPLICATE_CASES, GRAD_CASES, VARIANT_CASES, grad_output, duplicate_token_problem, dyadic, fullmant, lattice,
                             variant_input)
 
 pytestmark = pytest.mark.gpu
@@ -483,10 +485,11 @@ def test_n2_variants_match_reference(cl, cluster_variants_golden, tag):
     if cfg["algorithm"] != "kmediods++" or cfg["inp"].startswith("lattice"):
         y, res = mod(dev(x))
         assert res is None
-        assert np.array_equal(y.cpu().numpy(), want, equal_nan=True), tag
+        # (a module with parameters records its output for autograd, like the reference's)
+        assert np.array_equal(y.detach().cpu().numpy(), want, equal_nan=True), tag
         # frame-major layout used inside the fused forward: same values
         yf = mod.cluster_frame_major(dev(x).permute(1, 0, 2).contiguous())
-        assert np.array_equal(yf.permute(1, 0, 2).cpu().numpy(), want, equal_nan=True)
+        assert np.array_equal(yf.detach().permute(1, 0, 2).cpu().numpy(), want, equal_nan=True)
     if cfg["aggregation"] is not None:
         B, T, Tn, n, W, K = (cfg[k] for k in ("B", "T", "T_new", "n", "W", "K"))
         xd = dev(x)
@@ -496,6 +499,67 @@ def test_n2_variants_match_reference(cl, cluster_variants_golden, tag):
         L.check(L.lib().cc_token_aggregate_f32(L.ptr(xd), B * T * W, W, B, T, Tn, n, W, K, L.ptr(asg), ctypes.byref(var),
                                                L.ptr(out), B * Tn * W, W, L.stream_ptr(xd.device)), "aggregate")
         assert np.array_equal(out.cpu().numpy(), want, equal_nan=True), tag
+
+
+@pytest.mark.parametrize("tag", list(GRAD_CASES))
+def test_n4_token_cluster_gradients_match_reference_autograd(cl, tag):
+    """Training support: TokenClusterInter under torch.autograd.  The gradients of the reference module
+    (tests/golden/cluster_grad_golden.npz) are reproduced by cc_token_cluster_backward_f32 - d/dx bit for bit (a gather,
+    divisions by fd and by cluster sizes), the parameter gradients to rounding (summation order).  Exact-selection inputs
+    run through the module's own forward (both layouts); the others hand the reference's selection to the backward op."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cluster_grad_golden.npz"))
+    cfg = GRAD_CASES[tag]
+    x, embed, mult = variant_input(cfg)
+    mod = _variant_module(cl, cfg, embed, mult)
+    G = dev(grad_output(cfg))
+    algo = {"kmediods++": 0, "pooling": 1, "sparse_sampling": 2}[cfg["algorithm"]]
+    agg = 0 if cfg["aggregation"] is None else 1
+    B, T, Tn, n, W, K = (cfg[k] for k in ("B", "T", "T_new", "n", "W", "K"))
+    Kp = n if algo == 1 else K
+    if cfg["algorithm"] != "kmediods++" or cfg["inp"].startswith("lattice"):
+        for frame_major in (False, True):
+            mod.zero_grad()
+            xd = dev(x).requires_grad_(True)
+            if frame_major:
+                y = mod.cluster_frame_major(xd.permute(1, 0, 2).contiguous())
+                y.backward(G.permute(1, 0, 2).contiguous())
+            else:
+                y, _ = mod(xd)
+                y.backward(G)
+            assert y.requires_grad and np.array_equal(xd.grad.cpu().numpy(), g[f"{tag}_gx"]), (tag, frame_major)
+            if embed is not None:
+                np.testing.assert_allclose(mod.cluster_embed.grad.cpu().numpy(), g[f"{tag}_gembed"], rtol=1e-6, atol=1e-6)
+            if mult is not None:
+                np.testing.assert_allclose(mod.cls_multiplier.grad.reshape(-1).cpu().numpy(), g[f"{tag}_gmult"],
+                                           rtol=1e-5, atol=1e-4)
+        # without a gradient request the plain op runs and nothing is recorded
+        with torch.no_grad():
+            assert not mod(dev(x))[0].requires_grad
+    # the backward op alone, on the selection the reference made
+    med = dev(g[f"{tag}_medoids"].astype(np.int64)) if f"{tag}_medoids" in g.files else torch.empty(0, K, dtype=torch.long, device=DEV)
+    asg = dev(g[f"{tag}_assign"].astype(np.int64)) if f"{tag}_assign" in g.files else torch.empty(0, (T // Tn) * n, dtype=torch.long, device=DEV)
+    ids = mod._sparse_ids((T // Tn) * n, torch.device(DEV)) if algo == 2 else None
+    gx, ge, gm = torch.ops.centerclip.token_cluster_backward(G, dev(x), False, T, Tn, Kp, algo, agg, med, asg,
+                                                             None if mult is None else dev(mult), ids, embed is not None,
+                                                             mult is not None)
+    assert np.array_equal(gx.cpu().numpy(), g[f"{tag}_gx"]), tag
+    if embed is not None:
+        np.testing.assert_allclose(ge.cpu().numpy(), g[f"{tag}_gembed"], rtol=1e-6, atol=1e-6)
+    if mult is not None:
+        np.testing.assert_allclose(gm.cpu().numpy(), g[f"{tag}_gmult"], rtol=1e-5, atol=1e-4)
+
+
+def test_n4_token_cluster_autograd_registration():
+    """torch.library.opcheck on the differentiable op: schema, fake kernel, autograd registration."""
+    x = dev(lattice(77, (17, 12, 32))).requires_grad_(True)
+    args = (x, False, 6, 2, 5, 0, 2.0, 1e-6, 100, 4, False, 0, 0, None, None, None)
+    torch.library.opcheck(torch.ops.centerclip.token_cluster_train.default, args,
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    out, med, asg = torch.ops.centerclip.token_cluster_train(*args)
+    assert out.requires_grad and med.shape == (4, 5) and asg.shape == (4, 48)
+    torch.library.opcheck(torch.ops.centerclip.token_cluster_backward.default,
+                          (torch.ones_like(out), x.detach(), False, 6, 2, 5, 0, 0, med, asg, None, None, False, False),
+                          test_utils=("test_schema", "test_faketensor"))
 
 
 def test_cluster_frame_embedding_is_a_parameter_the_forward_ignores(cl):

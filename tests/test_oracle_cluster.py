@@ -8,12 +8,13 @@ CPU only.  Parity levels follow SURVEY.md §8(c):
   P1 / P2      from-X on lattice / dyadic inputs: indices bit-exact
   C1           module output (gather + CLS mean + restack): exact
 """
+import os
 import numpy as np
 import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import (DUPLICATE_CASES, VARIANT_CASES, duplicate_token_problem, dyadic, fullmant, lattice,
+from oracle.recipes import (DUPLICATE_CASES, GRAD_CASES, VARIANT_CASES, grad_output, duplicate_token_problem, dyadic, fullmant, lattice,
                             variant_input)
 
 t = torch.from_numpy
@@ -188,6 +189,29 @@ def test_n2_variant_oracle_reproduces_reference(cluster_variants_golden, tag):
         y2 = co.literal_token_cluster_variant(t(x), cfg["T"], cfg["T_new"], cfg["K"], cfg["algorithm"], cfg["aggregation"],
                                               None if embed is None else t(embed), None if mult is None else t(mult))
         assert np.array_equal(y2.numpy(), g[f"{tag}_out"], equal_nan=True)
+
+
+@pytest.mark.parametrize("tag", list(GRAD_CASES))
+def test_n4_variant_oracle_gradients_reproduce_reference(tag):
+    """torch.autograd through the oracle's restatement of TokenClusterInter.forward == the gradients the reference module
+    produced (tests/golden/cluster_grad_golden.npz, oracle/gen_golden_grad.py): d/dx exactly (gathers, divisions by
+    counts), the parameter gradients to rounding (sums over segments / batch in an unspecified order)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cluster_grad_golden.npz"))
+    cfg = GRAD_CASES[tag]
+    x, embed, mult = variant_input(cfg)
+    xt = t(x).clone().requires_grad_(True)
+    et = None if embed is None else t(embed).clone().requires_grad_(True)
+    mt = None if mult is None else t(mult).clone().requires_grad_(True)
+    kw = {}
+    if f"{tag}_assign" in g.files:
+        kw = dict(assign=t(g[f"{tag}_assign"].astype(np.int64)), medoids=t(g[f"{tag}_medoids"].astype(np.int64)))
+    y = co.literal_token_cluster_variant(xt, cfg["T"], cfg["T_new"], cfg["K"], cfg["algorithm"], cfg["aggregation"], et, mt, **kw)
+    y.backward(t(grad_output(cfg)))
+    assert np.array_equal(xt.grad.numpy(), g[f"{tag}_gx"])
+    if et is not None:
+        np.testing.assert_allclose(et.grad.numpy(), g[f"{tag}_gembed"], rtol=1e-6, atol=1e-6)
+    if mt is not None:
+        np.testing.assert_allclose(mt.grad.numpy(), g[f"{tag}_gmult"], rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("n,C", [(1, 64), (3, 32), (5, 40), (16, 64), (17, 96), (33, 64), (196, 768), (257, 64), (588, 32),
