@@ -536,7 +536,7 @@ def main():
                     L_.lib().cc_debug_set_last_block_rows(1)
                 res["last_block_rows"] = {"policy": "the last block of each tower computes out_proj / c_fc / c_proj for the rows its "
                                                     "projection head reads (CLS of every frame, EOT of every caption); features "
-                                                    "agree with the all-rows form to rounding (1e-5 relative, tested)",
+                                                    "agree with the all-rows form to the rounding of the fp16 intermediates (<= 2e-4 relative, tested)",
                                           "rows_computed": c["B"] * c["T_new"] + c["B"],
                                           "rows_all": c["B"] * c["T_new"] * (c["K"] + 1) + int(lens.sum()),
                                           "ms_per_step_all_rows": round(ms_all12, 3)}

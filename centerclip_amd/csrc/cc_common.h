@@ -33,6 +33,24 @@ __device__ __forceinline__ float cc_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CC_WAVE);
     return v;
 }
+// The same sum over the 64 lanes on the DPP path: four in-row steps (quad swaps, half mirror, mirror - all 16 lanes of a
+// DPP row then hold the row's sum) + four v_readlane, instead of six dependent ds_bpermute round trips through the LDS
+// crossbar.  Another association than cc_wave_sum ((l ^ 1, l ^ 2, ... inside a row, then (r0 + r1) + (r2 + r3)): for the
+// tolerance-bound reductions (LayerNorm statistics, norms of feature rows), not where a summation order is pinned.
+template <int CTRL>
+__device__ __forceinline__ float cc_dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float cc_wave_sum_fast(float v) {
+    v += cc_dpp_f32<0xB1>(v);
+    v += cc_dpp_f32<0x4E>(v);
+    v += cc_dpp_f32<0x141>(v);
+    v += cc_dpp_f32<0x140>(v);
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float cc_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, CC_WAVE));

@@ -60,10 +60,7 @@ __global__ __launch_bounds__(256) void token_norm_kernel(const float* __restrict
     }
 }
 
-template <int CTRL>
-__device__ __forceinline__ float cc_dpp_f32(float x) {       // lane exchange inside a 16-lane DPP row (bit pattern)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
+// (cc_dpp_f32<CTRL>: lane exchange inside a 16-lane DPP row - cc_common.h)
 
 // ============================================================================ K1
 // 64x64 tile of the Gram matrix of one problem per 256-thread workgroup (4 waves, 32x32 per wave, 2x2 accumulator

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     const float* src = in + (int64_t)r * E;
     float s = 0.f;
     for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
-    const float nrm = sqrtf(cc_wave_sum(s));
+    const float nrm = sqrtf(cc_wave_sum_fast(s));
     for (int e = lane; e < E; e += 64) {
         const float v = src[e] / nrm;
         if (out) out[(int64_t)r * E + e] = v;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
             x[q] = e < E ? src[e] : 0.f;
             s = fmaf(x[q], x[q], s);
         }
-        const float nrm = sqrtf(cc_wave_sum(s));
+        const float nrm = sqrtf(cc_wave_sum_fast(s));
         const float mk = (float)mask[(int64_t)t * ad.mcs];   // element strides: a strided view is fine
         cnt += mk;
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
         acc[q] = acc[q] / cnt;
         s = fmaf(acc[q], acc[q], s);
     }
-    const float nrm = sqrtf(cc_wave_sum(s));
+    const float nrm = sqrtf(cc_wave_sum_fast(s));
 #pragma unroll
     for (int q = 0; q < MAXE; ++q) {
         const int e = lane + 64 * q;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
                 x[q] = e < E ? src[e] : 0.f;
                 s = fmaf(x[q], x[q], s);
             }
-            const float nrm = sqrtf(cc_wave_sum(s));
+            const float nrm = sqrtf(cc_wave_sum_fast(s));
             const float mk = (float)mask[(int64_t)t * ad.mcs];   // element strides: a strided view is fine
             cnt += mk;
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
             acc[q] = acc[q] / cnt;
             s = fmaf(acc[q], acc[q], s);
         }
-        const float nrm = sqrtf(cc_wave_sum(s));
+        const float nrm = sqrtf(cc_wave_sum_fast(s));
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) {
             const int e = lane + 64 * q;
@@ -165,14 +165,14 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
             x[q] = e < E ? src[e] : 0.f;
             s = fmaf(x[q], x[q], s);
         }
-        const float nrm = sqrtf(cc_wave_sum(s));
+        const float nrm = sqrtf(cc_wave_sum_fast(s));
         float d = 0.f;
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) {
             const int e = lane + 64 * q;
             if (e < E) d = fmaf(x[q] / nrm, vp[e], d);
         }
-        d = cc_wave_sum(d);
+        d = cc_wave_sum_fast(d);
         if (lane == 0) logits[(int64_t)t * ldl + v] = mult * d;
     }
 }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void cross_entropy_rows_kernel(const float* __
     mx = cc_wave_max(mx);
     float s = 0.f;
     for (int j = lane; j < n; j += 64) s += expf(row[(int64_t)j * cs] - mx);
-    s = cc_wave_sum(s);
+    s = cc_wave_sum_fast(s);
     if (lane == 0) nce[i] = (logf(s) + mx) - row[(int64_t)i * cs];
 }
 
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void contrastive_mean_kernel(const float* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { a += nce[i]; b += nce[n + i]; }
-    a = cc_wave_sum(a);
-    b = cc_wave_sum(b);
+    a = cc_wave_sum_fast(a);
+    b = cc_wave_sum_fast(b);
     if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -40,7 +40,7 @@ __device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane
         } else v[t] = *reinterpret_cast<const float4*>(src + w);
         s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
     }
-    const float mean = cc_wave_sum(s) / (float)W;
+    const float mean = cc_wave_sum_fast(s) / (float)W;
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane
             q += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
         }
     }
-    const float rstd = 1.0f / sqrtf(cc_wave_sum(q) / (float)W + eps);
+    const float rstd = 1.0f / sqrtf(cc_wave_sum_fast(q) / (float)W + eps);
     float4 ov[4];
     float ot = 0.f;
 #pragma unroll
@@ -77,7 +77,7 @@ __device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane
         // fp16 copy of the new residual row for the folded LayerNorm of the next block: centred on the row mean (the
         // consumer's LayerNorm is shift invariant; an un-centred copy loses |mean| / sigma in precision), + its
         // (sum, sumsq) and the mean that was subtracted
-        const float om = cc_wave_sum(ot) / (float)W;
+        const float om = cc_wave_sum_fast(ot) / (float)W;
         float osum = 0.f, osq = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -91,8 +91,8 @@ __device__ __forceinline__ void layernorm_row(const LnArgs& a, int row, int lane
             }
         }
         if (a.stats) {
-            osum = cc_wave_sum(osum);
-            osq = cc_wave_sum(osq);
+            osum = cc_wave_sum_fast(osum);
+            osq = cc_wave_sum_fast(osq);
             if (lane == 0) reinterpret_cast<float2*>(a.stats)[row] = make_float2(osum, osq);
         }
         if (a.shift && lane == 0) a.shift[row] = om;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
         v[t] = (w < W) ? *reinterpret_cast<const float4*>(h + (int64_t)row * W + w) : make_float4(0.f, 0.f, 0.f, 0.f);
         tot += (v[t].x + v[t].y) + (v[t].z + v[t].w);
     }
-    const float om = shift ? cc_wave_sum(tot) / (float)W : 0.f;
+    const float om = shift ? cc_wave_sum_fast(tot) / (float)W : 0.f;
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
             q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
         }
     }
-    s = cc_wave_sum(s);
-    q = cc_wave_sum(q);
+    s = cc_wave_sum_fast(s);
+    q = cc_wave_sum_fast(q);
     if (lane == 0) {
         reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
         if (shift) shift[row] = om;
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __rest
         s1 += (float)wf;
         s2 = fmaf(beta[k], w, s2);
     }
-    s1 = cc_wave_sum(s1);
-    s2 = cc_wave_sum(s2);
+    s1 = cc_wave_sum_fast(s1);
+    s2 = cc_wave_sum_fast(s2);
     if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
     __syncthreads();
     if (tid == 0) {
@@ -600,7 +600,7 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
         }
     }
     if (e.h16) {                                   // centred fp16 copy + its statistics + the mean (see layernorm_row)
-        const float om = cc_wave_sum(tot) / (float)W;
+        const float om = cc_wave_sum_fast(tot) / (float)W;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -613,8 +613,8 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
                 q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
             }
         }
-        s = cc_wave_sum(s);
-        q = cc_wave_sum(q);
+        s = cc_wave_sum_fast(s);
+        q = cc_wave_sum_fast(q);
         if (lane == 0) {
             reinterpret_cast<float2*>(e.stats)[row] = make_float2(s, q);
             if (e.shift) e.shift[row] = om;
@@ -632,14 +632,16 @@ __global__ __launch_bounds__(256) void text_embed_kernel(TextEmbedArgs e) {
 }
 
 // The stage in front of the first blocks of both towers in ONE launch: ln_pre of the visual rows (in place, CLS rows
-// formed on the fly, + fp16 copy + row statistics) in workgroups [0, blocks_ln), the text embedding rows behind them.
+// formed on the fly, + fp16 copy + row statistics) in the last blocks_ln workgroups, the text embedding rows in front of them.
 __global__ __launch_bounds__(256) void pre_stage_kernel(LnArgs ln, TextEmbedArgs te, int blocks_ln, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x < blocks_ln) {
-        const int row = blockIdx.x * 4 + wave;
+    // the text rows (a longer dependent chain each: EOT search over the earlier captions, table gather) are dispatched first
+    const int blocks_te = (int)gridDim.x - blocks_ln;
+    if ((int)blockIdx.x >= blocks_te) {
+        const int row = ((int)blockIdx.x - blocks_te) * 4 + wave;
         if (row < ln.rows) layernorm_row<false>(ln, row, lane, eps);
     } else {
-        const int row = ((int)blockIdx.x - blocks_ln) * 4 + wave;
+        const int row = (int)blockIdx.x * 4 + wave;
         if (row < te.Bt * te.Lt) text_embed_row(te, row, lane);
     }
 }
@@ -671,13 +673,13 @@ __global__ __launch_bounds__(256) void head_project_kernel(HeadPair hp, float ep
     const float* src = h + ((int64_t)r * row_mul + (row_idx ? row_idx[r] : 0)) * W;
     float s = 0.f;
     for (int w = tid; w < W; w += 256) { const float v = src[w]; xn[w] = v; s += v; }
-    s = cc_wave_sum(s);
+    s = cc_wave_sum_fast(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
     float q = 0.f;
     for (int w = tid; w < W; w += 256) { const float d = xn[w] - mean; q += d * d; }
-    q = cc_wave_sum(q);
+    q = cc_wave_sum_fast(q);
     if (lane == 0) red[4 + wave] = q;
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + eps);
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(256) void row_stats_wide_kernel(const float* __rest
             const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * W + w);
             tot += (v.x + v.y) + (v.z + v.w);
         }
-        om = cc_wave_sum(tot) / (float)W;
+        om = cc_wave_sum_fast(tot) / (float)W;
     }
     float s = 0.f, q = 0.f;
     for (int w = lane * 4; w < W; w += 256) {
@@ -808,8 +810,8 @@ __global__ __launch_bounds__(256) void row_stats_wide_kernel(const float* __rest
         s += (q0 + q1) + (q2 + q3);
         q += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
     }
-    s = cc_wave_sum(s);
-    q = cc_wave_sum(q);
+    s = cc_wave_sum_fast(s);
+    q = cc_wave_sum_fast(q);
     if (lane == 0) {
         reinterpret_cast<float2*>(stats)[row] = make_float2(s, q);
         if (shift) shift[row] = om;

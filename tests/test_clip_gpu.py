@@ -639,7 +639,7 @@ def test_n2_variants_inside_the_fused_forward(g, algo, agg):
     # deterministic; with the hidden state requested the last block computes every row instead of the CLS rows only (other
     # GEMM tiles: agreement to rounding, tests/test_r2_gpu.py::test_last_block_runs_on_the_rows_the_heads_read)
     assert torch.equal(feat2, feat3) and bool(torch.isfinite(feat).all())
-    assert float((feat - feat2).abs().max() / feat.abs().max()) < 1e-5
+    assert float((feat - feat2).abs().max() / feat.abs().max()) < 2e-4
     assert hidden.shape == (video.shape[0] // T * 2, 1 + K, int(g["cfg"][3]))
     if agg is None:
         ref = clo.visual_forward(golden_state_dict(g), video, T, cluster_plan={1: (2, K)},

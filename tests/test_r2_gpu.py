@@ -269,8 +269,10 @@ def test_caption_compaction_is_bit_identical_to_all_rows(gc):
 
 def test_last_block_runs_on_the_rows_the_heads_read(gc):
     """Without a request for the hidden state the last block of each tower computes out_proj / c_fc / c_proj for the CLS
-    (visual) and EOT (text) rows only.  The same rows of the all-rows run differ only through the tile the GEMMs pick
-    (different partition of the LayerNorm partial sums): compared at 1e-5 relative, far inside the parity tolerance."""
+    (visual) and EOT (text) rows only.  The same rows of the all-rows run differ only through the summation order of the
+    GEMMs (another K split, another partition of the LayerNorm partial sums), which can flip the rounding of an fp16
+    intermediate (the QuickGELU output, the fp16 copy of the residual row): observed <= 8e-5 relative on a few rows, 5e-6
+    typically; asserted at 2e-4, and both forms are equally far from the fp32 oracle (checked below for the text tower)."""
     from centerclip_amd import _lib as L
     lib = L.lib()
     for cluster in (True, False):
@@ -294,8 +296,29 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
             lib.cc_debug_set_text_compaction(1)
         for a, b in ((v_sel, v_all), (t_sel, t_all), (only_v, v_all), (only_t, t_all), (full_v, v_all), (v_mix, v_all),
                      (t_mix, t_all)):
-            assert a.shape == b.shape and relerr(a.cpu(), b.cpu()) < 1e-5
+            assert a.shape == b.shape and relerr(a.cpu(), b.cpu()) < 2e-4
         assert bool(torch.isfinite(hid_v).all())
+    # more selected rows than one 64-row chunk of the few-rows kernel (cfg 3 has 256 per rank): 35 clips -> 70 CLS rows, 70 EOT rows
+    model, sd, T = small_clip(gc, cluster=True)
+    RES, CTX, VOCAB = int(gc["cfg"][1]), int(gc["cfg"][5]), int(gc["cfg"][6])
+    gen = torch.Generator().manual_seed(21)
+    video = torch.randn(35 * T, 3, RES, RES, generator=gen).to(DEV)
+    ids = torch.randint(1, VOCAB - 2, (70, CTX), generator=gen)
+    eot = torch.randint(2, CTX, (70,), generator=gen)
+    for b in range(70):
+        ids[b, eot[b]] = VOCAB - 1
+        ids[b, eot[b] + 1:] = 0
+    ids = ids.to(DEV)
+    v_sel, t_sel = model.encode_pair(video, ids, video_frame=T)
+    assert lib.cc_debug_set_last_block_rows(0) == 0
+    try:
+        v_all, t_all = model.encode_pair(video, ids, video_frame=T)
+    finally:
+        lib.cc_debug_set_last_block_rows(1)
+    assert v_sel.shape[0] == 70 and relerr(v_sel.cpu(), v_all.cpu()) < 2e-4 and relerr(t_sel.cpu(), t_all.cpu()) < 2e-4
+    ref = nrm(clo.text_forward(sd, ids.cpu()))
+    e_sel, e_all = (nrm(t_sel.cpu()) - ref).abs().max(), (nrm(t_all.cpu()) - ref).abs().max()
+    assert float(e_sel) <= 1e-3 and float(e_all) <= 1e-3 and abs(float(e_sel) - float(e_all)) <= 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ eval loop (S3)
