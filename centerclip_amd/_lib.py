@@ -30,10 +30,13 @@ _lib = None
 
 
 class ClusterVariant(ctypes.Structure):
-    """cc_cluster_variant (include/centerclip_hip.h): algorithm 0 kmedoids / 1 pooling / 2 sparse_sampling,
+    """cc_cluster_variant (include/centerclip_hip.h): algorithm 0 kmedoids / 1 pooling / 2 sparse_sampling / 3 spectral,
     aggregation 0 medoid / 1 mean."""
     _fields_ = [("algorithm", ctypes.c_int32), ("aggregation", ctypes.c_int32), ("cluster_embed", ctypes.c_void_p),
-                ("cls_multiplier", ctypes.c_void_p), ("fixed_ids", ctypes.c_void_p)]
+                ("cls_multiplier", ctypes.c_void_p), ("fixed_ids", ctypes.c_void_p),
+                ("spectral_sigma", ctypes.c_float), ("spectral_graph_mode", ctypes.c_int32),
+                ("spectral_knn_k", ctypes.c_int32), ("spectral_correct_sign", ctypes.c_int32),
+                ("spectral_graph", ctypes.c_void_p)]
 
 
 def _declare(lib):
@@ -55,11 +58,22 @@ def _declare(lib):
                                                  c.POINTER(ClusterVariant), vp, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.cc_token_aggregate_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, vp, c.POINTER(ClusterVariant), vp,
                                            i64, i64, vp]
+    lib.cc_token_apply_selection_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, c.POINTER(ClusterVariant), vp, vp,
+                                                 vp, i64, i64, vp]
+    lib.cc_token_apply_selection_f32.restype = c.c_int
     lib.cc_token_cluster_backward_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, c.POINTER(ClusterVariant), vp, vp,
                                                   vp, i64, i64, vp, i64, i64, vp, vp, vp]
     lib.cc_token_cluster_backward_f32.restype = c.c_int
     lib.cc_spectral_laplacian_f32.argtypes = [vp, lay, i32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_svd_sign_flip_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.cc_spectral_graph_laplacian_f32.argtypes = [vp, lay, i32, f32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_spectral_graph_laplacian_f32.restype = c.c_int
+    lib.cc_spectral_embedding_workspace_bytes.argtypes = [i32, i32]
+    lib.cc_spectral_embedding_workspace_bytes.restype = sz
+    lib.cc_spectral_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.cc_spectral_workspace_bytes.restype = sz
+    lib.cc_spectral_embedding_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]
+    lib.cc_spectral_embedding_f32.restype = c.c_int
     lib.cc_spectral_laplacian_f32.restype = c.c_int
     lib.cc_svd_sign_flip_f32.restype = c.c_int
     for name in ("cc_token_norms_f32", "cc_pairwise_distance_f32", "cc_kmedoids_from_dist_f32",

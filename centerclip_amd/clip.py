@@ -292,7 +292,7 @@ class VisualTransformer(nn.Module):
         med = None
         for blk in self.transformer.resblocks:
             tc = blk.tokencluster_inter
-            if tc is not None and tc.algorithm == 'kmediods++':
+            if tc is not None and tc.algorithm in ('kmediods++', 'spectral'):
                 med = (tc.after_block_frames, tc.cluster_num)
         return frames, ltok, med
 

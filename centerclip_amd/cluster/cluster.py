@@ -1,5 +1,5 @@
 """Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and TokenClusterInter (:66-352) for the
-algorithms 'kmediods++' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
+algorithms 'kmediods++' and 'spectral' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
 'sparse_sampling' in eval mode.  Differentiable with respect to x, cluster_embed and cls_multiplier
 (torch.ops.centerclip.token_cluster_train / token_cluster_backward, cc_token_cluster_backward_f32)."""
 import numpy as np
@@ -33,6 +33,11 @@ def get_cluster_inter(width, block_id, args=None):
                              cluster_embedding=getattr(args, 'cluster_embedding', False),
                              cluster_frame_embedding=getattr(args, 'cluster_frame_embedding', False),
                              adaptive_cls=False,          # hard-coded in the reference too (cluster.py:59)
+                             spectral_sigma=getattr(args, 'spectral_sigma', 2.0),
+                             spectral_graph=getattr(args, 'spectral_graph', 'HeatKernel'),
+                             spectral_knn_k=getattr(args, 'spectral_knn_k', 1),
+                             spectral_spatial_temporal_graph=getattr(args, 'spectral_spg', 0),
+                             svd_correct_sign=getattr(args, 'svd_correct_sign', 1),
                              transformer_width=width, pre_norm=getattr(args, 'pre_norm', False))
 
 
@@ -44,8 +49,10 @@ class TokenClusterInter(torch.nn.Module):
     means, cluster.py:291-301), cluster_embedding, adaptive_cls; 'pooling'; 'sparse_sampling' in eval mode.
     cluster_frame_embedding is accepted the way the reference treats it: the parameter exists (checkpoints that carry
     `cluster_frame_embed` load) and the forward does not use it (its use is commented out, :283-285).
-    'spectral', the shift algorithms and mean_residual (not reachable from the reference's arguments) raise
-    NotImplementedError at construction.
+    'spectral' (cluster.py:262-272): the selection comes from spectral clustering of the segment's tokens (graph Laplacian,
+    batched Jacobi eigensolver, k-medoids on the embedding - all on the device, cluster/spectral.py), the rest is shared.
+    The shift algorithms and mean_residual (not reachable from the reference's arguments) raise NotImplementedError at
+    construction.
     """
 
     def __init__(self, algorithm='kmediods++', block_id=1, before_cluster_num=49, cluster_num=49,
@@ -57,12 +64,12 @@ class TokenClusterInter(torch.nn.Module):
                  svd_correct_sign=1, pre_norm=False):
         super().__init__()
         assert algorithm in ['kmediods++', 'pooling', 'sparse_sampling', 'spectral', 'temporal_shift', 'token_shift']
-        if algorithm not in ('kmediods++', 'pooling', 'sparse_sampling'):
-            raise NotImplementedError("centerclip_amd builds cluster_algo 'kmediods++', 'pooling' and "
+        if algorithm not in ('kmediods++', 'pooling', 'sparse_sampling', 'spectral'):
+            raise NotImplementedError("centerclip_amd builds cluster_algo 'kmediods++', 'spectral', 'pooling' and "
                                       "'sparse_sampling' (got %r)" % algorithm)
         if mean_residual:
             raise NotImplementedError("mean_residual is not built")
-        kmed = algorithm == 'kmediods++'
+        kmed = algorithm in ('kmediods++', 'spectral')                            # cluster.py:240 (shared branch)
         self.cluster_embedding = bool(cluster_embedding) if kmed else False      # cluster.py:154-156
         self.adaptive_cls = bool(adaptive_cls) if kmed else False
         scale = transformer_width ** -0.5
@@ -92,6 +99,23 @@ class TokenClusterInter(torch.nn.Module):
         self.norm_p = norm_p
         self.pre_norm = pre_norm
         self.last_medoids = None
+        # cluster_algo 'spectral' (cluster.py:142-152,174-182)
+        self.spectral_graph = spectral_graph
+        self.spectral_sigma = spectral_sigma
+        fd = before_block_frames // after_block_frames
+        if spectral_knn_k < 5:                     # "when K of spectral_knn_k is small, use an adaptive number"
+            self.spectral_knn_k = int(5 * fd) if before_cluster_num < 100 else int(5 * fd + 5)
+        else:
+            self.spectral_knn_k = spectral_knn_k
+        self.svd_correct_sign = svd_correct_sign
+        self.spectral_spatial_temporal_graph = spectral_spatial_temporal_graph
+        if algorithm == 'spectral' and spectral_spatial_temporal_graph:
+            from .spectral import spatial_temporal_graph
+            spg = spatial_temporal_graph(before_cluster_num * fd, before_cluster_num,
+                                         s_kernel=9 if before_cluster_num < 100 else 19, t_kernel=7)
+            self.register_buffer("spg", spg.unsqueeze(0).float())
+        else:
+            self.spg = None
 
     def cluster_frame_major(self, x_nld, keep_ids=False):
         """Fast path used by the HIP transformer: x [B*T, 1+n, W] (frame-major) ->
@@ -124,7 +148,7 @@ class TokenClusterInter(torch.nn.Module):
     def variant(self, N, device):
         """-> (cc_cluster_variant for this module, tensors it points to)."""
         var = L.ClusterVariant()
-        var.algorithm = {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2}[self.algorithm]
+        var.algorithm = {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2, 'spectral': 3}[self.algorithm]
         var.aggregation = 0 if self.aggregation in [None, 'None'] else 1
         keep = []
         if self.cluster_embedding:
@@ -136,6 +160,13 @@ class TokenClusterInter(torch.nn.Module):
         if self.algorithm == 'sparse_sampling':
             keep.append(self._sparse_ids(N, device))
             var.fixed_ids = keep[-1].data_ptr()
+        if self.algorithm == 'spectral':
+            from .spectral import GRAPH_MODES
+            var.spectral_sigma, var.spectral_graph_mode = float(self.spectral_sigma), GRAPH_MODES[self.spectral_graph]
+            var.spectral_knn_k, var.spectral_correct_sign = int(self.spectral_knn_k), int(bool(self.svd_correct_sign))
+            if self.spg is not None:
+                keep.append(self.spg[0].to(device).ne(0).to(torch.uint8).contiguous())
+                var.spectral_graph = keep[-1].data_ptr()
         return var, keep
 
     @property
@@ -150,6 +181,9 @@ class TokenClusterInter(torch.nn.Module):
         n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
         N = self.frame_duration * n
+        if self.algorithm == 'spectral' and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("autograd through cluster_algo 'spectral' is not built")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: the differentiable op (gradient of the gather / cluster means / CLS mean for the selection made in
             # the forward pass, which is a constant of the backward pass as in the reference: fast_kmeans.py:13,44)
@@ -171,6 +205,8 @@ class TokenClusterInter(torch.nn.Module):
             keep[0] if self.cluster_embedding else None,
             keep[1 if self.cluster_embedding else 0] if self.adaptive_cls else None,
             keep[-1] if self.algorithm == 'sparse_sampling' else None,
-            bool(keep_ids and self.algorithm == 'kmediods++'))
+            bool(keep_ids and self.algorithm in ('kmediods++', 'spectral')),
+            float(var.spectral_sigma), int(var.spectral_graph_mode), int(var.spectral_knn_k), bool(var.spectral_correct_sign),
+            keep[-1] if (self.algorithm == 'spectral' and self.spg is not None) else None)
         self.last_medoids = medoids if medoids.numel() else None
         return out

@@ -1,16 +1,17 @@
-"""Mirror of the well-posed pieces of modules/cluster/spectral.py (cluster_algo 'spectral'):
+"""Mirror of modules/cluster/spectral.py (cluster_algo 'spectral'), every step a HIP kernel:
 
-    constructW ('HeatKernel' [+ spatial_temporal_graph])  ->  normalised Laplacian  ->  [ eigen-decomposition ]  ->
-    batch_sign_flip_rasmus_bro  ->  row-normalise the K trailing vectors  ->  k-medoids on them
+    constructW ('HeatKernel' or 'KNN' [+ spatial_temporal_graph])  ->  normalised Laplacian  ->  the K eigenvectors with the
+    smallest eigenvalues  ->  batch_sign_flip_rasmus_bro  ->  row-normalise  ->  k-medoids on them
 
-Everything except the bracketed step runs as HIP kernels.  The eigen-decomposition is deliberately NOT built: the reference
-takes the K singular vectors of L_sym with the smallest singular values from a fp32 LAPACK SVD, and on token-like inputs the
-gap between the K-th and (K+1)-th value is ~1e-5 relative, so the subspace depends on the solver's rounding (its own fp64
-run reproduces 0 of 20 medoid sets at N = 196; measured by the probe script named in DESIGN.md §6) - there is no parity
-target to build to.
-`batch_spectral_clustering` therefore takes the decomposition as a callable (``eigensolver(L_sym) -> (U, S, Vh)``, e.g.
-``torch.linalg.svd`` on the device) and raises without one; parity is asserted on L_sym, on the sign flip and on the
-tail given the reference's own embedding.
+The decomposition (the reference: the trailing K left singular vectors of a fp32 LAPACK SVD of L_sym) is a batched
+one-sided Jacobi solver (cc_spectral_embedding_f32).  What "the same result" can mean for it: eigenpairs to working
+precision and the reference's singular values to 1e-5 - yes; the same *vectors* only up to sign and, where eigenvalues
+coincide to rounding, up to a rotation of that eigenspace, which no two solvers share.  The k-medoids tail only sees row
+distances of the K selected vectors, which are invariant to both when the K-th and (K+1)-th eigenvalue are separated
+(planted-partition inputs: tested against the reference module); on token-like inputs that gap is ~1e-5 relative and the
+reference does not reproduce its own medoids under a float64 solve (0 of 20 problems at N = 196, K = 49; the probe script
+named in DESIGN.md §6) - there the tests report the objective instead of asserting indices.
+`batch_spectral_clustering(..., eigensolver=callable)` still accepts an external decomposition (L_sym -> (U, S, Vh)).
 """
 import torch
 
@@ -19,17 +20,46 @@ from .. import torch_ops  # noqa: F401  (registers torch.ops.centerclip)
 from .fast_kmeans import batch_fast_kmedoids, batch_fast_kmedoids_with_split
 
 
+GRAPH_MODES = {'HeatKernel': 0, 'KNN': 1}
+
+
+def spatial_temporal_graph(N, tokens_per_frame, s_kernel=5, t_kernel=5):
+    """[N, N] bool: token i is connected to token j when their frames are at most t_kernel // 2 apart and their grid
+    positions at most s_kernel // 2 apart in both directions (spectral.py:139-165).  A constant of the module, built once."""
+    side = int(tokens_per_frame ** 0.5)
+    idx = torch.arange(N)
+    t, hh, ww = idx // tokens_per_frame, idx % tokens_per_frame // side, idx % tokens_per_frame % side
+    frames = N // tokens_per_frame
+    near = lambda v, half: (v[:, None] - v[None, :]).abs() <= half
+    ok = near(t, t_kernel // 2) & near(hh, s_kernel // 2) & near(ww, s_kernel // 2)
+    # neighbours are enumerated from valid frames / rows / columns of the grid only; tokens of a partial last frame
+    # (t == frames) or beyond the square grid are never the TARGET of an edge
+    target_ok = (t < frames) & (hh < side)
+    return ok & target_ok[None, :]
+
+
 @torch.no_grad()
-def spectral_laplacian(X, sigma=2.5, mode='HeatKernel', spatial_temporal_graph=None, return_affinity=False):
-    """X [B,N,L] -> L_sym [B,N,N] = D^-1/2 (D - W) D^-1/2 with W = constructW(X, X, sigma, mode) (spectral.py:42-52)."""
-    if mode != 'HeatKernel':
-        raise NotImplementedError("only the 'HeatKernel' graph is built (spectral.py:86-88); got %r" % (mode,))
+def spectral_laplacian(X, sigma=2.5, mode='HeatKernel', spatial_temporal_graph=None, return_affinity=False, knn_k=10,
+                       mutual=False):
+    """X [B,N,L] -> L_sym [B,N,N] = D^-1/2 (D - W) D^-1/2 with W = constructW(X, X, sigma, mode, knn_k, mutual)
+    (spectral.py:42-52,79-107)."""
+    if mode not in GRAPH_MODES:
+        raise NotImplementedError(mode)
     L.require_device(X)                                   # (the constant graph mask may live on the host, as in the reference)
     g = None
     if spatial_temporal_graph is not None:
-        g = spatial_temporal_graph.to(device=X.device).ne(0).to(torch.uint8).contiguous()
-    lap, aff = torch.ops.centerclip.spectral_laplacian(X.float().contiguous(), float(sigma), g)
+        g = spatial_temporal_graph.to(device=X.device).ne(0).to(torch.uint8).reshape(X.shape[1], X.shape[1]).contiguous()
+    lap, aff = torch.ops.centerclip.spectral_graph_laplacian(X.float().contiguous(), False, 0, 0, float(sigma),
+                                                             GRAPH_MODES[mode], int(knn_k), bool(mutual), g)
     return (lap, aff) if return_affinity else lap
+
+
+@torch.no_grad()
+def spectral_embedding(L_sym, K, correct_sign=False):
+    """-> (Q [B,N,K] = the reference's U[:, :, -K:] up to sign / rotations inside degenerate eigenspaces, eigenvalues [B,K])."""
+    L.require_device(L_sym)
+    Q, ev, _ = torch.ops.centerclip.spectral_embedding(L_sym.float().contiguous(), int(K), bool(correct_sign))
+    return Q[:, :, :K], ev
 
 
 @torch.no_grad()
@@ -58,15 +88,33 @@ def spectral_embedding_kmedoids(Q, K, metric='euclidean', threshold=1e-5, iter_l
 def batch_spectral_clustering(X, K, mode='HeatKernel', knn_k=10, metric='euclidean', threshold=1e-5, iter_limit=60,
                               id_sort=True, norm_p=1.0, correct_sign=False, split_size=8, sigma=2.5,
                               spatial_temporal_graph=None, eigensolver=None):
-    """modules/cluster/spectral.py:17-75 with the decomposition supplied by the caller (see the module docstring).
-    -> (cluster_assignment [B,N], medoids [B,K])."""
+    """modules/cluster/spectral.py:17-75 -> (cluster_assignment [B,N], medoids [B,K]).  eigensolver: optional callable
+    L_sym -> (U, S, Vh) replacing the built-in decomposition."""
     assert metric in ['euclidean', 'cosine'] and X.ndim == 3
+    L_sym = spectral_laplacian(X, sigma=sigma, mode=mode, spatial_temporal_graph=spatial_temporal_graph, knn_k=knn_k)
+    return _cluster_from_laplacian(L_sym, K, metric, threshold, iter_limit, id_sort, norm_p, correct_sign, split_size,
+                                   eigensolver)
+
+
+def _cluster_from_laplacian(L_sym, K, metric, threshold, iter_limit, id_sort, norm_p, correct_sign, split_size, eigensolver):
     if eigensolver is None:
-        raise NotImplementedError("the eigen-decomposition of spectral clustering is not built (no parity definition): "
-                                  "pass eigensolver=callable(L_sym) -> (U, S, Vh)")
-    L_sym = spectral_laplacian(X, sigma=sigma, mode=mode, spatial_temporal_graph=spatial_temporal_graph)
+        Q4, _, _ = torch.ops.centerclip.spectral_embedding(L_sym, int(K), bool(correct_sign))   # zero-padded to K % 4 == 0
+        return spectral_embedding_kmedoids(Q4, K, metric, threshold, iter_limit, id_sort, norm_p, split_size)
     U, S, Vh = eigensolver(L_sym)
     if correct_sign:
         U = batch_sign_flip_rasmus_bro(U, S, Vh)
     Q = U[:, :, -K:].contiguous()
     return spectral_embedding_kmedoids(Q, K, metric, threshold, iter_limit, id_sort, norm_p, split_size)
+
+
+@torch.no_grad()
+def spectral_clustering_of_tokens(x, frame_major, T, T_new, K, mode='HeatKernel', knn_k=10, metric='euclidean',
+                                  threshold=1e-5, iter_limit=60, id_sort=True, norm_p=1.0, correct_sign=False, split_size=8,
+                                  sigma=2.5, graph=None, eigensolver=None):
+    """batch_spectral_clustering on the patch tokens of TokenClusterInter's activations ([1+n, B*T, W] or frame-major),
+    regrouped into T_new segments per clip through strides (no copy): -> (assign [T_new*B, fd*n], medoids [T_new*B, K])."""
+    L.require_device(x)
+    L_sym, _ = torch.ops.centerclip.spectral_graph_laplacian(x, bool(frame_major), int(T), int(T_new), float(sigma),
+                                                             GRAPH_MODES[mode], int(knn_k), False, graph)
+    return _cluster_from_laplacian(L_sym, K, metric, threshold, iter_limit, id_sort, norm_p, correct_sign, split_size,
+                                   eigensolver)

@@ -70,7 +70,9 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
         if (m->cluster_tokens[i] > 0) {
             const int Tn = m->cluster_frames[i];
             if (Tn > 0 && frames % Tn == 0) {
-                const size_t need = cc_cluster_workspace_bytes(B * Tn, (frames / Tn) * tokens, W, m->cluster_pre_norm);
+                size_t need = cc_cluster_workspace_bytes(B * Tn, (frames / Tn) * tokens, W, m->cluster_pre_norm);
+                if (m->cluster_variants && m->cluster_variants[i].algorithm == CC_CLUSTER_SPECTRAL)
+                    need += cc_spectral_workspace_bytes(B * Tn, (frames / Tn) * tokens, m->cluster_tokens[i]);
                 cb = need > cb ? need : cb;
                 frames = Tn;
                 tokens = m->cluster_tokens[i];
@@ -346,7 +348,7 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         if (vm->cluster_tokens[i] > 0) {
             ++cluster_blocks;
             const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
-            if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS) last_kmed = i;
+            if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS || var->algorithm == CC_CLUSTER_SPECTRAL) last_kmed = i;
         }
     if (forced_medoids && cluster_blocks > 1) return CC_ERR_UNSUPPORTED;
     int ti = 0;                 // next text block

@@ -1129,6 +1129,39 @@ struct ClusterWs {
     size_t total;
 };
 
+// extra scratch of the spectral selection: L_sym [P,N,N], the eigensolver's global copy (N > 201), Q [P,N,K4], and the
+// k-medoids scratch for P problems of N K4-wide rows (pre-normalised)
+struct SpectralWs {
+    float* lap;
+    float* q;
+    int k4;
+    void* eig;
+    size_t eig_bytes;
+    void* km;
+    size_t km_bytes;
+    size_t total;
+};
+ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med);
+extern "C" size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N);
+SpectralWs carve_spectral(void* ws, int P, int N, int K) {
+    SpectralWs s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* ptr = ws ? static_cast<char*>(ws) + off : nullptr;
+        off += cc_align_up(bytes, 256);
+        return ptr;
+    };
+    s.k4 = (K + 3) / 4 * 4;
+    s.lap = static_cast<float*>(take((size_t)P * N * N * sizeof(float)));
+    s.q = static_cast<float*>(take((size_t)P * N * s.k4 * sizeof(float)));
+    s.eig_bytes = cc_spectral_embedding_workspace_bytes(P, N);
+    s.eig = take(s.eig_bytes);
+    s.km_bytes = carve(nullptr, P, N, s.k4, 1, N).total;
+    s.km = take(s.km_bytes);
+    s.total = off;
+    return s;
+}
+
 ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med) {
     ClusterWs c{};
     size_t off = 0;
@@ -1279,6 +1312,11 @@ int cc_debug_set_select_profile(long long* buf) {   // debug only; buf [P,16] in
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), &buf, sizeof(buf)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
 
+size_t cc_spectral_workspace_bytes(int32_t P, int32_t N, int32_t K) {
+    if (P <= 0 || N <= 0 || K <= 0) return 0;
+    return carve_spectral(nullptr, P, N, K).total;
+}
+
 size_t cc_cluster_workspace_bytes(int32_t P, int32_t N, int32_t W, int32_t pre_norm) {
     if (P <= 0 || N <= 0 || W <= 0) return 0;
     return carve(nullptr, P, N, W, pre_norm, N).total;
@@ -1411,6 +1449,29 @@ int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_fra
     return CC_OK;
 }
 
+int cc_token_apply_selection_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+                                 int32_t T_new, int32_t n, int32_t W, int32_t K, const cc_cluster_variant* var,
+                                 const int64_t* medoids, const int64_t* assign, float* out, int64_t out_tok_stride,
+                                 int64_t out_frame_stride, void* stream) {
+    if (!x || !out || B <= 0 || T <= 0 || T_new <= 0 || n <= 0 || W <= 0 || K <= 0) return CC_ERR_INVALID;
+    if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
+        return CC_ERR_INVALID;
+    const bool mean = var && var->aggregation == CC_AGGREGATE_MEAN;
+    if (mean ? !assign : !medoids) return CC_ERR_INVALID;
+    _Float16* const row_h16 = nullptr;
+    float* const row_stats = nullptr;
+    float* const row_shift = nullptr;
+    const int rows = B * T_new * (1 + K);
+    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, mean ? 1 : 0,
+                       mean ? (const long long*)nullptr : reinterpret_cast<const long long*>(medoids), mean ? 0 : K,
+                       mean ? reinterpret_cast<const long long*>(assign) : (const long long*)nullptr,
+                       var ? var->cluster_embed : nullptr, var ? var->cls_multiplier : nullptr, out, out_tok_stride,
+                       out_frame_stride, row_h16, row_stats, row_shift);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                                   int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
                                   float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
@@ -1444,7 +1505,8 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
         CC_LAUNCH_CHECK();
         return CC_OK;
     }
-    if (var->algorithm != CC_CLUSTER_KMEDOIDS || K <= 0) return CC_ERR_INVALID;
+    const bool spectral = var->algorithm == CC_CLUSTER_SPECTRAL;
+    if ((var->algorithm != CC_CLUSTER_KMEDOIDS && !spectral) || K <= 0) return CC_ERR_INVALID;
     if (var->aggregation != CC_AGGREGATE_MEDOID && var->aggregation != CC_AGGREGATE_MEAN) return CC_ERR_INVALID;
     cc_token_layout lay;
     lay.B = B; lay.S = T_new; lay.fd = fd; lay.n = n;
@@ -1459,8 +1521,31 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     int64_t* med = medoids ? medoids : reinterpret_cast<int64_t*>(c.med);
     const bool mean = var->aggregation == CC_AGGREGATE_MEAN;
     int64_t* asg = assign ? assign : (mean ? reinterpret_cast<int64_t*>(c.asg) : nullptr);
-    int rc = cc_batch_kmedoids_f32(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
+    int rc;
+    if (spectral) {
+        // graph Laplacian of the segment's tokens -> K trailing eigenvectors -> k-medoids on their normalised rows
+        // (spectral.py:42-73; a single chunk unless split_size > 1 and P > split_size, :64-72)
+        SpectralWs sw = carve_spectral(static_cast<char*>(ws) + c.total, P, N, K);
+        if (ws_bytes < c.total + sw.total) return CC_ERR_WORKSPACE;
+        if (metric != CC_METRIC_EUCLIDEAN && metric != CC_METRIC_COSINE) return CC_ERR_INVALID;
+        rc = cc_spectral_graph_laplacian_f32(x + in_tok_stride, &lay, W, var->spectral_sigma, var->spectral_graph_mode,
+                                             var->spectral_knn_k, 0, var->spectral_graph, sw.lap, nullptr, nullptr, ws,
+                                             c.total, stream);
+        if (rc != CC_OK) return rc;
+        rc = cc_spectral_embedding_f32(sw.lap, P, N, K, var->spectral_correct_sign, sw.q, sw.k4, nullptr, nullptr, sw.eig,
+                                       sw.eig_bytes, stream);
+        if (rc != CC_OK) return rc;
+        cc_token_layout ql;
+        ql.B = P; ql.S = 1; ql.fd = 1; ql.n = N;
+        ql.stride_b = (int64_t)N * sw.k4; ql.stride_s = 0; ql.stride_f = 0; ql.stride_i = sw.k4;
+        int64_t* asg_q = asg ? asg : reinterpret_cast<int64_t*>(c.asg);
+        rc = cc_batch_kmedoids_f32(sw.q, &ql, sw.k4, K, metric, norm_p, threshold, iter_limit, 1,
+                                   (split_size > 1 && P > split_size) ? split_size : P, 1, med, asg_q, iters, sw.km, sw.km_bytes,
+                                   stream);
+    } else {
+        rc = cc_batch_kmedoids_f32(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
                                    pre_norm, med, asg, iters, ws, ws_bytes, stream);
+    }
     if (rc != CC_OK) return rc;
     const int rows = B * T_new * (1 + K);
     hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
@@ -1652,8 +1737,8 @@ extern "C" int cc_token_cluster_backward_f32(const float* grad_out, int64_t go_t
     return CC_OK;
 }
 
-// ============================================================================ N4 (forward pieces of spectral clustering)
-// modules/cluster/spectral.py:17-137 minus the eigensolve (which has no parity definition):
+// ============================================================================ N4 (spectral clustering)
+// modules/cluster/spectral.py:17-165:
 //   constructW ('HeatKernel', optional spatial-temporal mask)   W = exp(-|x_i - x_j|^2 / (2 sigma^2)) [* graph]   (:79-107)
 //   normalised Laplacian                                         L_sym = D^-1/2 (D - W) D^-1/2, D = diag(W 1)   (:44-52)
 //   batch_sign_flip_rasmus_bro                                   U[:, k] *= sign(sum_j sign(s_k v_kj) (s_k v_kj)^2) (:110-137)
@@ -1693,6 +1778,188 @@ __global__ __launch_bounds__(256) void sym_laplacian_kernel(const float* __restr
     }
 }
 
+// constructW 'KNN' (spectral.py:89-100): kth[p][i] = the knn_k-th largest entry of row i of the heat-kernel affinity
+// (torch.topk(W, knn_k)[..., -1]: duplicates count).  One wave per row: repeatedly the largest value below the previous
+// one, with its multiplicity, until knn_k entries are covered.
+__global__ __launch_bounds__(256) void knn_threshold_rows_kernel(const float* __restrict__ w, float* __restrict__ kth, int P,
+                                                                 int N, int knn_k) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P * N) return;
+    const float* r = w + (int64_t)row * N;
+    float bound = __builtin_inff();
+    int covered = 0;
+    float cur = 0.f;
+    while (covered < knn_k) {
+        float m = -__builtin_inff();
+        for (int j = lane; j < N; j += 64) {
+            const float v = r[j];
+            if (v < bound) m = fmaxf(m, v);
+        }
+        m = cc_wave_max(m);
+        if (!(m > -__builtin_inff())) break;                     // fewer than knn_k entries in the row
+        int c = 0;
+        for (int j = lane; j < N; j += 64) c += (r[j] == m) ? 1 : 0;
+        covered += (int)cc_wave_sum((float)c);
+        cur = m;
+        bound = m;
+    }
+    if (lane == 0) kth[row] = cur;
+}
+
+// W_ij *= (W_ij >= kth_i) or/and (W_ji >= kth_j) (spectral.py:93-99), then the optional spatial-temporal mask (:104-105)
+// and the degrees.  One wave per row; W is symmetric, so W_ji is read as W_ij.
+__global__ __launch_bounds__(256) void knn_mask_rows_kernel(float* __restrict__ w, const float* __restrict__ kth,
+                                                            const unsigned char* __restrict__ graph, float* __restrict__ deg,
+                                                            int P, int N, int mutual) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P * N) return;
+    const int p = row / N, i = row - p * N;
+    float* r = w + (int64_t)row * N;
+    const float ki = kth[row];
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float v = r[j];
+        const bool a = v >= ki, b = v >= kth[(int64_t)p * N + j];
+        float o = (mutual ? (a && b) : (a || b)) ? v : 0.f;
+        if (graph) o = graph[(int64_t)i * N + j] ? o : 0.f;
+        r[j] = o;
+        s += o;
+    }
+    s = cc_wave_sum(s);
+    if (lane == 0) deg[row] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The decomposition step of batch_spectral_clustering (spectral.py:54-61): the K eigenvectors of L_sym with the smallest
+// eigenvalues (the reference takes the trailing K left singular vectors of torch.linalg.svd; L_sym is symmetric positive
+// semi-definite, so they are those eigenvectors up to sign / a rotation inside degenerate eigenspaces).
+// One-sided (Hestenes) Jacobi on G = 2I - L_sym (eigenvalues mu = 2 - lambda in [0, 2]: the wanted vectors belong to the
+// LARGEST mu, where the one-sided method is accurate to working precision).  One workgroup per problem, G held row-major in
+// LDS (N <= 201) or in a global scratch (larger N); a "vector" is a contiguous row.  Every round rotates N/2 disjoint row
+// pairs (round-robin tournament order): alpha = |x|^2, beta = |y|^2, gamma = x.y by one pass + DPP sums, rotation by the
+// smaller angle, rows rewritten in place.  At convergence row_j = mu_j u_j^T.
+// Output Q[p][i][c], c = K - 1 - rank(mu_j descending) - the reference's column order (singular values descending, last K
+// columns) - with the sign of batch_sign_flip_rasmus_bro applied when correct_sign (for a symmetric matrix the flip only
+// depends on the vector itself); eigenvalues lambda = 2 - mu in the same order.
+constexpr int EIG_WAVES = 16;
+
+// MAXE = ceil(N / 16): a row pair is owned by one 16-lane DPP row (lane g holds elements g, g + 16, ...), four pairs per
+// wave, so the three dot products reduce inside the DPP row (no cross-row step) and the rotation arithmetic is issued once
+// for four pairs.
+template <int MAXE, bool IN_LDS>
+__global__ __launch_bounds__(64 * EIG_WAVES) void sym_eig_jacobi_kernel(const float* __restrict__ Lsym, float* __restrict__ work,
+                                                                        float* __restrict__ Q, float* __restrict__ evals,
+                                                                        int* __restrict__ sweeps_out, int N, int K, int ldq,
+                                                                        int correct_sign, int max_sweeps, float tol) {
+    extern __shared__ __align__(16) unsigned char eig_smem[];
+    const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* A = IN_LDS ? reinterpret_cast<float*>(eig_smem) : work + (int64_t)p * N * N;
+    float* mu = reinterpret_cast<float*>(eig_smem) + (IN_LDS ? (size_t)N * N : 0);
+    int* rank = reinterpret_cast<int*>(mu + N);
+    unsigned* flag = reinterpret_cast<unsigned*>(rank + N);
+    const float* Lp = Lsym + (int64_t)p * N * N;
+    for (int idx = tid; idx < N * N; idx += 64 * EIG_WAVES) {
+        const int i = idx / N, j = idx - i * N;
+        A[idx] = (i == j ? 2.f : 0.f) - Lp[idx];
+    }
+    const int m = N + (N & 1);                                   // even number of players (the odd one sits out)
+    const int grp = lane >> 4, gl = lane & 15;
+    int sweeps = 0;
+    for (; sweeps < max_sweeps; ++sweeps) {
+        if (tid == 0) *flag = 0u;
+        __syncthreads();
+        float off = 0.f;
+        for (int r = 0; r < m - 1; ++r) {
+            for (int k = wave * 4 + grp; k < m / 2 + 3; k += 4 * EIG_WAVES) {      // (+3: the groups of a wave stay together)
+                int i = r + k;                                   // (r + k) mod (m - 1), both < m - 1 when k is in range
+                if (i >= m - 1) i -= m - 1;
+                int j = r - k;
+                if (j < 0) j += m - 1;
+                if (k == 0) j = m - 1;
+                const bool on = k < m / 2 && i < N && j < N;
+                if (!on) { i = 0; j = 0; }
+                if (i > j) { const int t = i; i = j; j = t; }
+                float* xi = A + (int64_t)i * N + gl;
+                float* xj = A + (int64_t)j * N + gl;
+                float x[MAXE], y[MAXE];
+                float al = 0.f, be = 0.f, ga = 0.f;
+#pragma unroll
+                for (int t = 0; t < MAXE; ++t) {
+                    const bool in = gl + 16 * t < N;
+                    x[t] = in ? xi[16 * t] : 0.f;
+                    y[t] = in ? xj[16 * t] : 0.f;
+                    al += x[t] * x[t];
+                    be += y[t] * y[t];
+                    ga += x[t] * y[t];
+                }
+                al += cc_dpp_f32<0xB1>(al); be += cc_dpp_f32<0xB1>(be); ga += cc_dpp_f32<0xB1>(ga);
+                al += cc_dpp_f32<0x4E>(al); be += cc_dpp_f32<0x4E>(be); ga += cc_dpp_f32<0x4E>(ga);
+                al += cc_dpp_f32<0x141>(al); be += cc_dpp_f32<0x141>(be); ga += cc_dpp_f32<0x141>(ga);
+                al += cc_dpp_f32<0x140>(al); be += cc_dpp_f32<0x140>(be); ga += cc_dpp_f32<0x140>(ga);
+                const float ab = al * be;
+                const float rel = fabsf(ga) * __builtin_amdgcn_rsqf(fmaxf(ab, 1e-37f));     // |gamma| / sqrt(alpha beta)
+                if (on && rel > tol) {
+                    off = fmaxf(off, rel);
+                    const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.f * ga);
+                    const float t = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
+                    const float d = 1.f + t * t;
+                    float c = __builtin_amdgcn_rsqf(d);
+                    c = c * (1.5f - 0.5f * d * c * c);           // one Newton step: c^2 (1 + t^2) = 1 to rounding
+                    const float sn = c * t;
+#pragma unroll
+                    for (int q = 0; q < MAXE; ++q) {
+                        if (gl + 16 * q < N) {
+                            xi[16 * q] = c * x[q] - sn * y[q];
+                            xj[16 * q] = sn * x[q] + c * y[q];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        off = cc_wave_max(off);
+        if (lane == 0 && off > 0.f) atomicMax(flag, __float_as_uint(off));       // (non-negative floats order as unsigned)
+        __syncthreads();
+        const float worst = __uint_as_float(*flag);
+        __syncthreads();
+        if (!(worst > tol)) { ++sweeps; break; }
+    }
+    if (tid == 0 && sweeps_out) sweeps_out[p] = sweeps;
+    // mu_j = |row_j|
+    for (int j = wave; j < N; j += EIG_WAVES) {
+        float a = 0.f;
+        for (int c = lane; c < N; c += 64) { const float v = A[(int64_t)j * N + c]; a += v * v; }
+        a = cc_wave_sum_fast(a);
+        if (lane == 0) mu[j] = sqrtf(a);
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 64 * EIG_WAVES) {
+        const float mj = mu[j];
+        int rk = 0;
+        for (int q = 0; q < N; ++q) rk += (mu[q] > mj || (mu[q] == mj && q < j)) ? 1 : 0;
+        rank[j] = rk;
+    }
+    __syncthreads();
+    float* Qp = Q + (int64_t)p * N * ldq;
+    for (int j = wave; j < N; j += EIG_WAVES) {
+        const int rk = rank[j];
+        if (rk >= K) continue;
+        const int col = K - 1 - rk;
+        const float inv = 1.f / mu[j];
+        float sg = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float u = A[(int64_t)j * N + c] * inv;
+            sg += (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (u * u);
+        }
+        sg = cc_wave_sum_fast(sg);
+        const float flip = correct_sign ? (sg > 0.f ? 1.f : (sg < 0.f ? -1.f : 0.f)) : 1.f;
+        for (int c = lane; c < N; c += 64) Qp[(int64_t)c * ldq + col] = A[(int64_t)j * N + c] * inv * flip;
+        if (lane == 0 && evals) evals[(int64_t)p * K + col] = 2.f - mu[j];
+    }
+}
+
 // sign_left[p][k] = sum_j sign(S_k VT_kj) (S_k VT_kj)^2; U[p][:, k] *= sign(sign_left[p][k]).  One workgroup per (p, k).
 __global__ __launch_bounds__(256) void svd_sign_flip_kernel(float* __restrict__ U, const float* __restrict__ S,
                                                             const float* __restrict__ VT, int M, int Kc, int Ncols) {
@@ -1720,7 +1987,16 @@ extern "C" {
 int cc_spectral_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma,
                               const uint8_t* graph, float* laplacian, float* affinity_out, float* degree_out, void* ws,
                               size_t ws_bytes, void* stream) {
+    return cc_spectral_graph_laplacian_f32(x, lay, W, sigma, CC_GRAPH_HEAT_KERNEL, 0, 0, graph, laplacian, affinity_out,
+                                           degree_out, ws, ws_bytes, stream);
+}
+
+int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma, int32_t mode,
+                                    int32_t knn_k, int32_t mutual, const uint8_t* graph, float* laplacian,
+                                    float* affinity_out, float* degree_out, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !laplacian || !layout_ok(lay, W) || !(sigma > 0.f)) return CC_ERR_INVALID;
+    if (mode != CC_GRAPH_HEAT_KERNEL && mode != CC_GRAPH_KNN) return CC_ERR_UNSUPPORTED;
+    if (mode == CC_GRAPH_KNN && (knn_k <= 0 || knn_k > lay->fd * lay->n)) return CC_ERR_INVALID;
     const int P = lay->B * lay->S, N = lay->fd * lay->n;
     ClusterWs c = carve(ws, P, N, W, 0, N);
     if (!ws || ws_bytes < c.total) return CC_ERR_WORKSPACE;
@@ -1732,12 +2008,62 @@ int cc_spectral_laplacian_f32(const float* x, const cc_token_layout* lay, int32_
     g.sqn = c.nrm;                                              // keep the norm scratch apart from `deg`
     int rc = run_distance_sq(x, *lay, W, g, st);
     if (rc != CC_OK) return rc;
-    hipLaunchKernelGGL(heat_kernel_rows_kernel, dim3((P * N + 3) / 4), dim3(256), 0, st, wbuf, graph, deg, P, N,
+    const bool knn = mode == CC_GRAPH_KNN;
+    hipLaunchKernelGGL(heat_kernel_rows_kernel, dim3((P * N + 3) / 4), dim3(256), 0, st, wbuf, knn ? nullptr : graph, deg, P, N,
                        1.0f / (2.0f * sigma * sigma));
     CC_LAUNCH_CHECK();
+    if (knn) {                                                  // threshold per row, then mask (+ graph) and the degrees
+        float* kth = c.nrm;
+        hipLaunchKernelGGL(knn_threshold_rows_kernel, dim3((P * N + 3) / 4), dim3(256), 0, st, wbuf, kth, P, N, knn_k);
+        CC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(knn_mask_rows_kernel, dim3((P * N + 3) / 4), dim3(256), 0, st, wbuf, kth, graph, deg, P, N, mutual);
+        CC_LAUNCH_CHECK();
+    }
     const int64_t total = (int64_t)P * N * N;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(sym_laplacian_kernel, dim3(blocks), dim3(256), 0, st, wbuf, deg, laplacian, P, N);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N) {
+    if (P <= 0 || N <= 0) return 0;
+    return N <= 201 ? 256 : cc_align_up((size_t)P * N * N * sizeof(float), 256);
+}
+
+int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
+                              float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
+                              void* stream) {
+    if (!laplacian || !Q || P <= 0 || N <= 1 || K <= 0 || K > N || ldq < K) return CC_ERR_INVALID;
+    if (N > 640) return CC_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ldq > K && hipMemsetAsync(Q, 0, (size_t)P * N * ldq * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
+    const bool in_lds = N <= 201;
+    if (!in_lds && (!ws || ws_bytes < cc_spectral_embedding_workspace_bytes(P, N))) return CC_ERR_WORKSPACE;
+    const size_t smem = (in_lds ? (size_t)N * N * 4 : 0) + (size_t)N * 8 + 64;
+    const int max_sweeps = 30;
+    const float tol = 1e-6f;
+#define EIG_LAUNCH(MAXR, INLDS)                                                                                        \
+    do {                                                                                                               \
+        auto kern = sym_eig_jacobi_kernel<MAXR, INLDS>;                                                                \
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
+            return CC_ERR_HIP;                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(64 * EIG_WAVES), smem, st, laplacian, static_cast<float*>(ws), Q, eigenvalues, \
+                           sweeps_out, N, K, ldq, correct_sign, max_sweeps, tol);                                     \
+    } while (0)
+    if (in_lds) {
+        if (N <= 64) EIG_LAUNCH(4, true);
+        else if (N <= 128) EIG_LAUNCH(8, true);
+        else EIG_LAUNCH(13, true);
+    } else if (N <= 256) {
+        EIG_LAUNCH(16, false);
+    } else if (N <= 400) {
+        EIG_LAUNCH(25, false);
+    } else {
+        EIG_LAUNCH(40, false);
+    }
+#undef EIG_LAUNCH
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -211,23 +211,37 @@ def _(h, row_mul, row_idx, gamma, beta, proj, R):
 
 
 # ------------------------------------------------------------------------------------------ token cluster
-def _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids):
+def _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids, spectral=None):
     var = L.ClusterVariant()
     var.algorithm, var.aggregation = int(algorithm), int(aggregation)
     var.cluster_embed = cluster_embed.data_ptr() if cluster_embed is not None else None
     var.cls_multiplier = cls_mult.data_ptr() if cls_mult is not None else None
     var.fixed_ids = fixed_ids.data_ptr() if fixed_ids is not None else None
+    if spectral is not None:                       # (sigma, graph mode, knn_k, correct_sign, graph [N,N] uint8 | None)
+        sigma, mode, knn_k, sign, graph = spectral
+        var.spectral_sigma, var.spectral_graph_mode, var.spectral_knn_k = float(sigma), int(mode), int(knn_k)
+        var.spectral_correct_sign = int(bool(sign))
+        var.spectral_graph = graph.data_ptr() if graph is not None else None
     return var
+
+
+def _cluster_ws(lib, P, N, W, pre_norm, K, algorithm, device):
+    need = lib.cc_cluster_workspace_bytes(P, N, W, int(pre_norm))
+    if algorithm == 3:
+        need += lib.cc_spectral_workspace_bytes(P, N, K)
+    return L.workspace(need, device)
 
 
 @custom_op(NS + "::token_cluster", mutates_args=(), device_types="cuda")
 def token_cluster(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int, metric: int, norm_p: float,
                   threshold: float, iter_limit: int, split_size: int, pre_norm: bool, algorithm: int, aggregation: int,
                   cluster_embed: Optional[torch.Tensor], cls_mult: Optional[torch.Tensor], fixed_ids: Optional[torch.Tensor],
-                  want_medoids: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+                  want_medoids: bool, spectral_sigma: float = 0.0, spectral_mode: int = 0, spectral_knn_k: int = 0,
+                  spectral_sign: bool = False, spectral_graph: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """TokenClusterInter.forward (modules/cluster/cluster.py:206-352).  x contiguous fp32: [1+n, B*T, W] (LND, the
     reference's layout) or [B*T, 1+n, W] (frame_major) -> same layout with T_new segments of 1+K tokens; medoids
-    [T_new*B, K] int64 (empty unless want_medoids and algorithm 0)."""
+    [T_new*B, K] int64 (empty unless want_medoids and algorithm 0 / 3).  algorithm 3 = 'spectral' (the spectral_* arguments:
+    sigma, graph mode 0 HeatKernel / 1 KNN, knn_k, sign correction, optional [N,N] uint8 spatial-temporal mask)."""
     if frame_major:
         BT, Lt, W = x.shape
         tok, frame = W, Lt * W
@@ -241,12 +255,13 @@ def token_cluster(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int
     else:
         out = _e(1 + K, B * T_new, W, like=x, dtype=torch.float32)
         o_tok, o_frame = B * T_new * W, W
-    kmed = algorithm == 0
+    kmed = algorithm in (0, 3)
     med = _e(B * T_new if (want_medoids and kmed) else 0, K, like=x, dtype=torch.long)
-    var = _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids)
+    var = _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids,
+                   (spectral_sigma, spectral_mode, spectral_knn_k, spectral_sign, spectral_graph) if algorithm == 3 else None)
     lib = L.lib()
     N = (T // T_new) * n
-    ws = L.workspace(lib.cc_cluster_workspace_bytes(B * T_new, N, W, int(pre_norm)), x.device)
+    ws = _cluster_ws(lib, B * T_new, N, W, pre_norm, K, algorithm, x.device)
     L.check(lib.cc_token_cluster_variant_f32(L.ptr(x), tok, frame, B, T, T_new, n, W, K, metric, float(norm_p),
                                              float(threshold), int(iter_limit), int(split_size), int(pre_norm),
                                              ctypes.byref(var), L.ptr(out), o_tok, o_frame,
@@ -257,14 +272,15 @@ def token_cluster(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int
 
 @token_cluster.register_fake
 def _(x, frame_major, T, T_new, K, metric, norm_p, threshold, iter_limit, split_size, pre_norm, algorithm, aggregation,
-      cluster_embed, cls_mult, fixed_ids, want_medoids):
+      cluster_embed, cls_mult, fixed_ids, want_medoids, spectral_sigma=0.0, spectral_mode=0, spectral_knn_k=0,
+      spectral_sign=False, spectral_graph=None):
     if frame_major:
         BT, Lt, W = x.shape
         out = x.new_empty((BT // T * T_new, 1 + K, W))
     else:
         Lt, BT, W = x.shape
         out = x.new_empty((1 + K, BT // T * T_new, W))
-    rows = BT // T * T_new if (want_medoids and algorithm == 0) else 0
+    rows = BT // T * T_new if (want_medoids and algorithm in (0, 3)) else 0
     return out, x.new_empty((rows, K), dtype=torch.long)
 
 
@@ -313,6 +329,32 @@ def _(x, frame_major, T, T_new, K, metric, norm_p, threshold, iter_limit, split_
     out = x.new_empty((B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W))
     rows = B * T_new if algorithm == 0 else 0
     return out, x.new_empty((rows, K), dtype=torch.long), x.new_empty((rows, (T // T_new) * n), dtype=torch.long)
+
+
+@custom_op(NS + "::token_apply_selection", mutates_args=(), device_types="cuda")
+def token_apply_selection(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int, aggregation: int,
+                          medoids: torch.Tensor, assign: torch.Tensor, cluster_embed: Optional[torch.Tensor],
+                          cls_mult: Optional[torch.Tensor]) -> torch.Tensor:
+    """The gather / aggregation half of TokenClusterInter.forward (cluster.py:287-310) for a selection made elsewhere
+    (cluster_algo 'spectral'): medoids [T_new*B, K] or, for cluster means, assign [T_new*B, fd*n]."""
+    BT, Lt, W, tok, frame = _cluster_strides(x.shape, frame_major)
+    B, n = BT // T, Lt - 1
+    oshape = (B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W)
+    out = _e(*oshape, like=x, dtype=torch.float32)
+    _, _, _, o_tok, o_frame = _cluster_strides(oshape, frame_major)
+    var = _variant(0, aggregation, cluster_embed, cls_mult, None)
+    L.check(L.lib().cc_token_apply_selection_f32(L.ptr(x), tok, frame, B, T, T_new, n, W, K, ctypes.byref(var),
+                                                 L.ptr(medoids) if medoids.numel() else None,
+                                                 L.ptr(assign) if assign.numel() else None, L.ptr(out), o_tok, o_frame,
+                                                 _st(x)), "cc_token_apply_selection_f32")
+    return out
+
+
+@token_apply_selection.register_fake
+def _(x, frame_major, T, T_new, K, aggregation, medoids, assign, cluster_embed, cls_mult):
+    BT, Lt, W, _, _ = _cluster_strides(x.shape, frame_major)
+    B = BT // T
+    return x.new_empty((B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W))
 
 
 @custom_op(NS + "::token_cluster_backward", mutates_args=(), device_types="cuda")
@@ -473,6 +515,67 @@ def spectral_laplacian(x: torch.Tensor, sigma: float, graph: Optional[torch.Tens
 def _(x, sigma, graph):
     P, N, _W = x.shape
     return x.new_empty((P, N, N)), x.new_empty((P, N, N))
+
+
+@custom_op(NS + "::spectral_graph_laplacian", mutates_args=(), device_types="cuda")
+def spectral_graph_laplacian(x: torch.Tensor, frame_major: bool, T: int, T_new: int, sigma: float, mode: int, knn_k: int,
+                             mutual: bool, graph: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """constructW + normalised Laplacian (spectral.py:42-52,79-107) for the heat-kernel (mode 0) and the KNN graph (mode 1).
+    x: [P,N,W] (T = T_new = 0), or the activations of TokenClusterInter ([1+n, B*T, W] LND / [B*T, 1+n, W] frame-major) whose
+    patch tokens are regrouped into T_new segments per clip through strides (problem p = s*B + b, cluster.py:247-250).
+    -> (L_sym [P,N,N], W [P,N,N])."""
+    if T == 0:
+        P, N, Wd = x.shape
+        lay = L.TokenLayout(P, 1, 1, N, N * Wd, 0, 0, Wd)
+        base = x
+    else:
+        BT, Lt, Wd, tok, frame = _cluster_strides(x.shape, frame_major)
+        B, n, fd = BT // T, Lt - 1, T // T_new
+        P, N = B * T_new, fd * n
+        lay = L.TokenLayout(B, T_new, fd, n, T * frame, fd * frame, frame, tok)
+        base = x.reshape(-1)[tok:]                       # first patch token of frame 0 (the CLS token is skipped)
+    lap = _e(P, N, N, like=x, dtype=torch.float32)
+    aff = _e(P, N, N, like=x, dtype=torch.float32)
+    lib = L.lib()
+    ws = L.workspace(lib.cc_cluster_workspace_bytes(P, N, Wd, 0), x.device)
+    L.check(lib.cc_spectral_graph_laplacian_f32(L.ptr(base), ctypes.byref(lay), Wd, float(sigma), int(mode), int(knn_k),
+                                                int(mutual), L.ptr(graph), L.ptr(lap), L.ptr(aff), None, L.ptr(ws), ws.numel(),
+                                                _st(x)), "cc_spectral_graph_laplacian_f32")
+    return lap, aff
+
+
+@spectral_graph_laplacian.register_fake
+def _(x, frame_major, T, T_new, sigma, mode, knn_k, mutual, graph):
+    if T == 0:
+        P, N, _W = x.shape
+    else:
+        BT, Lt, _W, _, _ = _cluster_strides(x.shape, frame_major)
+        P, N = BT // T * T_new, (T // T_new) * (Lt - 1)
+    return x.new_empty((P, N, N)), x.new_empty((P, N, N))
+
+
+@custom_op(NS + "::spectral_embedding", mutates_args=(), device_types="cuda")
+def spectral_embedding(laplacian: torch.Tensor, K: int, correct_sign: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The decomposition of batch_spectral_clustering (spectral.py:54-61, cc_spectral_embedding_f32): laplacian [P,N,N] ->
+    (Q [P,N,K4] with K4 = K rounded up to 4 and zero padding columns - the k-medoids kernels read 16-byte pieces -,
+    eigenvalues [P,K] in the reference's order, sweeps [P])."""
+    P, N, _ = laplacian.shape
+    K4 = (K + 3) // 4 * 4
+    Q = _e(P, N, K4, like=laplacian, dtype=torch.float32)
+    ev = _e(P, K, like=laplacian, dtype=torch.float32)
+    sw = _e(P, like=laplacian, dtype=torch.int32)
+    lib = L.lib()
+    ws = L.workspace(lib.cc_spectral_embedding_workspace_bytes(P, N), laplacian.device)
+    L.check(lib.cc_spectral_embedding_f32(L.ptr(laplacian), P, N, int(K), int(correct_sign), L.ptr(Q), K4, L.ptr(ev), L.ptr(sw),
+                                          L.ptr(ws), ws.numel(), _st(laplacian)), "cc_spectral_embedding_f32")
+    return Q, ev, sw
+
+
+@spectral_embedding.register_fake
+def _(laplacian, K, correct_sign):
+    P, N, _ = laplacian.shape
+    return (laplacian.new_empty((P, N, (K + 3) // 4 * 4)), laplacian.new_empty((P, K)),
+            laplacian.new_empty((P,), dtype=torch.int32))
 
 
 @custom_op(NS + "::svd_sign_flip", mutates_args=(), device_types="cuda")
@@ -726,8 +829,8 @@ def _(sim):
     return sim.new_empty((3,))
 
 
-OPS = ("contrastive_loss", "spectral_laplacian", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
-       "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward",
+OPS = ("contrastive_loss", "spectral_laplacian", "spectral_graph_laplacian", "spectral_embedding", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
+       "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward", "token_apply_selection",
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",

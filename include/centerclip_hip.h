@@ -153,6 +153,7 @@ int cc_token_cluster_f32(const float* x, int64_t in_tok_stride, int64_t in_frame
  *                                the same for every segment; gather + CLS mean as for medoids */
 #define CC_CLUSTER_KMEDOIDS 0
 #define CC_CLUSTER_POOLING  1
+#define CC_CLUSTER_SPECTRAL 3          /* spectral clustering picks the medoids / the assignment (cluster_algo 'spectral') */
 #define CC_CLUSTER_SPARSE_SAMPLING 2   /* fixed_ids [K]: token_sparse_sampling(K, fd*n, random_shift=False) */
 #define CC_AGGREGATE_MEDOID 0
 #define CC_AGGREGATE_MEAN   1
@@ -162,6 +163,16 @@ typedef struct cc_cluster_variant {
     const float* cluster_embed;
     const float* cls_multiplier;
     const int64_t* fixed_ids;
+    /* CC_CLUSTER_SPECTRAL (cluster.py:262-272 -> spectral.py:17-75): the selection is made by spectral clustering of the
+     * segment's tokens (graph mode CC_GRAPH_*, sigma, knn_k, optional [N,N] uint8 spatial-temporal mask, sign correction),
+     * the k-medoids tail runs on the row-normalised eigenvectors with the call's metric / norm_p / threshold / iter_limit /
+     * split_size; gather / cluster means / CLS mean as for CC_CLUSTER_KMEDOIDS.  Needs cc_spectral_workspace_bytes more
+     * scratch behind cc_cluster_workspace_bytes. */
+    float spectral_sigma;
+    int32_t spectral_graph_mode;
+    int32_t spectral_knn_k;
+    int32_t spectral_correct_sign;
+    const uint8_t* spectral_graph;
 } cc_cluster_variant;
 /* The aggregation step of CC_AGGREGATE_MEAN alone, from a given assignment [T_new*B, fd*n] int64 (values 0..K-1;
  * problem p = s*B + b as everywhere) - the counterpart of cc_token_gather_f32 for cluster means
@@ -170,6 +181,13 @@ int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_fra
                            int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
                            const int64_t* assign, const cc_cluster_variant* variant,
                            float* out, int64_t out_tok_stride, int64_t out_frame_stride, void* stream);
+
+/* The same step for a selection made elsewhere (cluster_algo 'spectral', cluster.py:262-272 + :287-310): medoids
+ * [T_new*B, K] (aggregation None) or assign [T_new*B, fd*n] (cluster means), + the variant's cluster_embed / cls_multiplier. */
+int cc_token_apply_selection_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride,
+                                 int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
+                                 const cc_cluster_variant* variant, const int64_t* medoids, const int64_t* assign,
+                                 float* out, int64_t out_tok_stride, int64_t out_frame_stride, void* stream);
 
 int cc_token_cluster_variant_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_stride,
                                  int32_t B, int32_t T, int32_t T_new, int32_t n, int32_t W, int32_t K,
@@ -202,9 +220,8 @@ int cc_token_cluster_backward_f32(const float* grad_out, int64_t go_tok_stride, 
 
 
 /*
- * N4 (forward pieces of cluster_algo 'spectral', modules/cluster/spectral.py:17-137; the eigen-decomposition between
- * them is NOT built - torch.linalg.svd's subspace for near-degenerate singular values is solver-rounding dependent, so
- * it has no parity definition):
+ * N4: cluster_algo 'spectral' (modules/cluster/spectral.py:17-165), step by step; the whole selection also runs inside
+ * cc_token_cluster_variant_f32 / the fused encoders through cc_cluster_variant.algorithm = CC_CLUSTER_SPECTRAL:
  *   cc_spectral_laplacian_f32  W = exp(-|x_i - x_j|^2 / (2 sigma^2)) (constructW 'HeatKernel', spectral.py:79-88, squared
  *                              distances as batched_cdist_l2, cluster_utils.py:121-133), optionally * graph [N,N] uint8
  *                              (spatial_temporal_graph, :139-165); D = diag(W 1); laplacian [P,N,N] = D^-1/2 (D - W) D^-1/2
@@ -214,6 +231,30 @@ int cc_token_cluster_backward_f32(const float* grad_out, int64_t go_tok_stride, 
 int cc_spectral_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma,
                               const uint8_t* graph, float* laplacian, float* affinity_out, float* degree_out,
                               void* ws, size_t ws_bytes, void* stream);
+/* constructW graph modes (spectral.py:86-100): heat kernel, or the heat kernel kept where j is among the knn_k largest entries
+ * of row i or i among those of row j (mutual: and).  The spatial-temporal mask is applied after either (:104-105). */
+#define CC_GRAPH_HEAT_KERNEL 0
+#define CC_GRAPH_KNN         1
+int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, int32_t W, float sigma, int32_t mode,
+                                    int32_t knn_k, int32_t mutual, const uint8_t* graph, float* laplacian,
+                                    float* affinity_out, float* degree_out, void* ws, size_t ws_bytes, void* stream);
+/*
+ * The decomposition of batch_spectral_clustering (spectral.py:54-61): Q [P, N, ldq] (columns 0..K-1, the rest zeroed) = the
+ * K eigenvectors of the symmetric positive semi-definite laplacian [P,N,N] with the smallest eigenvalues, in the reference's
+ * column order (U[:, :, -K:] of torch.linalg.svd: eigenvalue descending), eigenvalues [P,K] optional, sweeps_out [P]
+ * optional.  Batched one-sided Jacobi on 2I - L (one workgroup per problem, the matrix in LDS for N <= 201; N <= 640).
+ * correct_sign: batch_sign_flip_rasmus_bro (:110-137) applied (for a symmetric matrix it depends on the vector alone).
+ * Parity: eigenpairs to fp32 working precision, the eigenvalues equal the reference's singular values to 1e-5; the vectors
+ * equal the reference's up to sign and, where eigenvalues coincide to rounding, up to a rotation inside that eigenspace -
+ * which no solver pins.  Row distances of Q, which is all the k-medoids tail uses, are invariant to both
+ * as long as the K-th and (K+1)-th eigenvalue are separated.  ws: cc_spectral_embedding_workspace_bytes.
+ */
+size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N);
+/* Extra scratch of a CC_CLUSTER_SPECTRAL token-cluster call, appended to cc_cluster_workspace_bytes(P, N, W, pre_norm). */
+size_t cc_spectral_workspace_bytes(int32_t P, int32_t N, int32_t K);
+int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
+                              float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
+                              void* stream);
 int cc_svd_sign_flip_f32(float* U, const float* S, const float* VT, int32_t P, int32_t M, int32_t K, int32_t N,
                          void* stream);
 

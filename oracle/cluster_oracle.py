@@ -437,13 +437,20 @@ def exact_zero_diag_distance(X, metric="euclidean", p=2.0, chunk_max=None):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # N4: forward pieces of spectral clustering (modules/cluster/spectral.py) - pinned by tests/golden/r2_golden.npz (sp_*)
-def spectral_laplacian(X, sigma=2.5, graph=None):
-    """constructW('HeatKernel') + normalised Laplacian (spectral.py:42-52,79-107; squared distances as
+def spectral_laplacian(X, sigma=2.5, graph=None, mode="HeatKernel", knn_k=10, mutual=False):
+    """constructW('HeatKernel' | 'KNN') + normalised Laplacian (spectral.py:42-52,79-107; squared distances as
     batched_cdist_l2, cluster_utils.py:121-133).  X [B,N,L] -> (L_sym [B,N,N], W [B,N,N])."""
     x = X.float()
     n1 = x.pow(2).sum(dim=-1, keepdim=True)
     d2 = torch.baddbmm(n1.transpose(-2, -1), x, x.transpose(-2, -1), alpha=-2).add(n1)
     W = torch.exp(-1.0 * d2 / (2 * sigma ** 2))
+    if mode == "KNN":                                      # spectral.py:89-100
+        k_value = torch.topk(W, knn_k, dim=-1, largest=True)[0][:, :, -1:]
+        keep = W >= k_value
+        keep = torch.logical_and(keep, keep.transpose(-2, -1)) if mutual else torch.logical_or(keep, keep.transpose(-2, -1))
+        W = W * keep
+    elif mode != "HeatKernel":
+        raise NotImplementedError(mode)
     if graph is not None:
         W = W * graph
     deg = W.sum(dim=-1)
@@ -456,3 +463,48 @@ def svd_sign_flip(U, S, VT):
     SVT = S.unsqueeze(-1) * VT
     sign_left = torch.sum(torch.sign(SVT) * torch.square(SVT), dim=2)
     return torch.sign(sign_left).unsqueeze(1) * U
+
+
+def spatial_temporal_graph(N, tokens_per_frame, s_kernel=5, t_kernel=5):
+    """spectral.py:139-165: token i (frame t, grid row h, column w) is connected to the tokens of the frames t-ht..t+ht at
+    rows h-hs..h+hs and columns w-hs..w+hs that exist."""
+    side = int(tokens_per_frame ** 0.5)
+    frames = N // tokens_per_frame
+    g = torch.zeros(N, N, dtype=torch.bool)
+    ht, hs = t_kernel // 2, s_kernel // 2
+    for i in range(N):
+        t_, h_, w_ = i // tokens_per_frame, i % tokens_per_frame // side, i % tokens_per_frame % side
+        for t in range(max(t_ - ht, 0), min(t_ + ht, frames - 1) + 1):
+            for y in range(max(h_ - hs, 0), min(h_ + hs, side - 1) + 1):
+                for x in range(max(w_ - hs, 0), min(w_ + hs, side - 1) + 1):
+                    g[i, t * tokens_per_frame + y * side + x] = True
+    return g
+
+
+def literal_spectral_clustering(X, K, mode="HeatKernel", knn_k=10, metric="euclidean", threshold=1e-5, iter_limit=60,
+                                norm_p=1.0, correct_sign=False, split_size=8, sigma=2.5, graph=None):
+    """batch_spectral_clustering (spectral.py:17-75) with this host's LAPACK SVD as the decomposition - the reference's own
+    choice; its medoids are an exact target only where the K-th and (K+1)-th singular value are separated."""
+    B = X.shape[0]
+    L_sym, _ = spectral_laplacian(X, sigma, graph, mode, knn_k)
+    U, S, Vh = torch.linalg.svd(L_sym, full_matrices=False)
+    if correct_sign:
+        U = svd_sign_flip(U, S, Vh)
+    Q = U[:, :, -K:]
+    Q = Q / (Q.norm(p=2, dim=-1, keepdim=True) + 1e-6)
+    if split_size > 1 and B > split_size:
+        return literal_batch_kmedoids_with_split(Q, K, metric, threshold, iter_limit, True, norm_p, split_size)
+    return literal_batch_kmedoids(Q, K, metric, threshold, iter_limit, True, norm_p)
+
+
+def normalized_cut(W, assign, K):
+    """sum_k cut(C_k, rest) / vol(C_k) of a partition (the quantity spectral clustering relaxes), per problem; float64."""
+    W = W.double()
+    deg = W.sum(dim=-1)
+    out = torch.zeros(W.shape[0], dtype=torch.float64)
+    for k in range(K):
+        m = (assign == k).double()
+        vol = (deg * m).sum(dim=-1)
+        inside = torch.einsum("bi,bij,bj->b", m, W, m)
+        out += torch.where(vol > 0, (vol - inside) / vol.clamp_min(1e-300), torch.zeros_like(vol))
+    return out

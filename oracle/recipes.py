@@ -124,6 +124,39 @@ def grad_output(cfg):
     return fullmant(cfg["seed"] + 5000, (1 + Kp, cfg["B"] * cfg["T_new"], cfg["W"]))
 
 
+# N4 spectral fixtures: tokens around K well-separated centres, the groups being contiguous runs of the token index inside
+# every segment (so that the rank of any medoid of a group - the cluster label - does not depend on which member is picked).
+SPECTRAL_CASES = {
+    "planted_heat": dict(seed=61, B=2, T=4, T_new=2, n=16, W=32, K=4, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
+    "planted_knn_spg": dict(seed=62, B=2, T=6, T_new=2, n=16, W=32, K=6, sigma=2.0, graph="KNN", knn_k=0, spg=1, sep=6.0),
+    "planted_k5_odd": dict(seed=63, B=3, T=3, T_new=1, n=25, W=32, K=5, sigma=2.0, graph="HeatKernel", knn_k=0, sep=5.0),
+}
+
+
+def planted_tokens(cfg):
+    """x [1+n, B*T, W] fp32: patch token j = f*n + i of a segment lies at centre[j // (N/K)] (|centre_a - centre_b| >= sep)
+    plus noise of magnitude 0.05; CLS tokens are generic."""
+    rng = np.random.default_rng(cfg["seed"])
+    B, T, Tn, n, W, K = (cfg[k] for k in ("B", "T", "T_new", "n", "W", "K"))
+    fd = T // Tn
+    N = fd * n
+    assert N % K == 0
+    x = np.zeros((1 + n, B * T, W), dtype=np.float32)
+    x[0] = fullmant(cfg["seed"] + 1, (B * T, W))
+    for b in range(B):
+        for s_ in range(Tn):
+            centres = np.zeros((K, W), dtype=np.float32)
+            for k in range(K):
+                centres[k, (3 * k) % W] = cfg["sep"]                  # orthogonal axes: pairwise distance sep * sqrt(2)
+                centres[k, (3 * k + 1) % W] = 0.5 * k
+            for f in range(fd):
+                for i in range(n):
+                    j = f * n + i
+                    noise = (rng.integers(-64, 65, size=W).astype(np.float32) * np.float32(0.05 / 64.0))
+                    x[1 + i, b * T + s_ * fd + f] = centres[j // (N // K)] + noise
+    return x
+
+
 def variant_input(cfg):
     """x [1+n, B*T, W] fp32 for a VARIANT_CASES entry (+ cluster_embed [K,W], cls_multiplier [T] when asked)."""
     L, BT, W = 1 + cfg["n"], cfg["B"] * cfg["T"], cfg["W"]

@@ -575,7 +575,7 @@ def test_cluster_frame_embedding_is_a_parameter_the_forward_ignores(cl):
 
 
 def test_n2_unbuilt_variants_fail_loudly(cl):
-    for kw in (dict(algorithm="spectral"), dict(algorithm="token_shift"), dict(mean_residual=True)):
+    for kw in (dict(algorithm="temporal_shift"), dict(algorithm="token_shift"), dict(mean_residual=True)):
         with pytest.raises(NotImplementedError):
             cl.TokenClusterInter(**kw)
     mod = cl.TokenClusterInter(algorithm="sparse_sampling", cluster_num=20, before_block_frames=12, after_block_frames=3,

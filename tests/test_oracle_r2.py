@@ -77,3 +77,52 @@ def test_spectral_forward_pieces(g):
     np.testing.assert_allclose(Lg.numpy(), g["sp_lsym_graph"], rtol=0, atol=1e-6)
     U = co.svd_sign_flip(torch.from_numpy(g["sp_u"]), torch.from_numpy(g["sp_s"]), torch.from_numpy(g["sp_vh"]))
     assert np.array_equal(U.numpy(), g["sp_u_flipped"])
+
+
+# ------------------------------------------------------------------------------------------------ N4: spectral clustering
+SPG = np.load(os.path.join(os.path.dirname(__file__), "golden", "spectral_golden.npz"))
+
+
+def test_spectral_knn_graph_oracle_reproduces_reference():
+    """constructW(mode='KNN') + Laplacian, with and without the spatial-temporal mask (fixtures from the reference)."""
+    from oracle import cluster_oracle as co
+    from centerclip_amd.cluster.spectral import spatial_temporal_graph as product_graph
+    X = torch.from_numpy(SPG["knn_x"])
+    sigma, knn_k = float(SPG["knn_cfg"][0]), int(SPG["knn_cfg"][1])
+    mask = co.spatial_temporal_graph(48, 16, s_kernel=3, t_kernel=3)
+    assert np.array_equal(mask.numpy().astype(np.uint8), SPG["knn_graph_mask"])
+    # the product's vectorised construction of the same constant mask (host-side, built once per module)
+    for N, tpf, sk, tk in ((48, 16, 3, 3), (196, 49, 9, 7), (50, 16, 3, 3), (40, 9, 3, 5)):
+        assert torch.equal(product_graph(N, tpf, s_kernel=sk, t_kernel=tk), co.spatial_temporal_graph(N, tpf, sk, tk))
+    for tag, g in (("knn", None), ("knn_graph", mask)):
+        L, W = co.spectral_laplacian(X, sigma, g, mode="KNN", knn_k=knn_k)
+        assert np.array_equal(W.numpy(), SPG[f"{tag}_w"])
+        np.testing.assert_allclose(L.numpy(), SPG[f"{tag}_lsym"], rtol=0, atol=1e-6)
+
+
+def test_spectral_planted_partitions_oracle_reproduces_reference():
+    """The oracle's batch_spectral_clustering (this host's LAPACK, as the reference) on the planted-partition fixtures: the
+    same assignment as the reference module, every medoid in its own planted group, and the module output for both
+    aggregations."""
+    from oracle import cluster_oracle as co
+    from oracle.recipes import SPECTRAL_CASES, planted_tokens
+    for tag, cfg in SPECTRAL_CASES.items():
+        x = torch.from_numpy(planted_tokens(cfg))
+        T, Tn, n, K = cfg["T"], cfg["T_new"], cfg["n"], cfg["K"]
+        fd = T // Tn
+        tokens, _ = co.regroup_segments(x, T, Tn)
+        knn_k = int(5 * fd) if n < 100 else int(5 * fd + 5)
+        graph = co.spatial_temporal_graph(n * fd, n, s_kernel=9, t_kernel=7).float().unsqueeze(0) if cfg.get("spg") else None
+        asg, med = co.literal_spectral_clustering(tokens, K, cfg["graph"], knn_k, "euclidean", 1e-6, 100, 2.0, True, 16,
+                                                  cfg["sigma"], graph)
+        N = fd * n
+        planted = (torch.arange(N) // (N // K)).expand(tokens.shape[0], N)
+        assert torch.equal(asg, planted) and np.array_equal(SPG[f"{tag}_mean_assign"].astype(np.int64), planted.numpy())
+        assert torch.equal(med // (N // K), torch.arange(K).expand_as(med))
+        for name, agg in (("none", None), ("mean", "mean")):
+            ref_asg = torch.from_numpy(SPG[f"{tag}_{name}_assign"].astype(np.int64))
+            ref_med = torch.from_numpy(SPG[f"{tag}_{name}_medoids"].astype(np.int64))
+            y = co.literal_token_cluster_variant(x, T, Tn, K, "kmediods++", agg, assign=ref_asg, medoids=ref_med)
+            assert np.array_equal(y.numpy(), SPG[f"{tag}_{name}_out"]), (tag, name)
+        gap = SPG[f"{tag}_spectrum"]
+        assert (gap[:, 1] > 100 * gap[:, 2]).all()             # the K-th / (K+1)-th singular values are far apart

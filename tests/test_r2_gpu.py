@@ -704,8 +704,8 @@ def test_two_cluster_blocks_medoids_buffer(gc):
 def test_spectral_forward_pieces_match_reference(g):
     """N4 (forward pieces of cluster_algo 'spectral'): the normalised Laplacian of the heat-kernel graph - plain and with
     the spatial-temporal mask - within 2e-5 of the reference's, the SVD sign flip exact, the k-medoids tail on an
-    embedding, and batch_spectral_clustering end to end with a caller-supplied decomposition (the eigensolve itself has
-    no parity definition and is not built: without one the call raises)."""
+    embedding, and batch_spectral_clustering end to end with the built-in decomposition and with a caller-supplied one (the
+    decomposition itself: tests/test_spectral_gpu.py)."""
     from centerclip_amd.cluster.spectral import (batch_sign_flip_rasmus_bro, batch_spectral_clustering, spectral_laplacian,
                                                   spectral_embedding_kmedoids)
     X = torch.from_numpy(g["sp_x"]).to(DEV)
@@ -725,8 +725,8 @@ def test_spectral_forward_pieces_match_reference(g):
     ao, mo = co.literal_batch_kmedoids_with_split(Q.cpu(), K, "euclidean", 1e-6, 100, True, 2.0, Q.shape[0], True)
     Qn = (Q.cpu() / (Q.cpu().norm(dim=-1, keepdim=True) + 1e-6))
     assert abs(kmedoids_objective(Qn, m.cpu()) - kmedoids_objective(Qn, mo)) <= 0.01 * kmedoids_objective(Qn, mo)
-    with pytest.raises(NotImplementedError):
-        batch_spectral_clustering(X, K, sigma=sigma)
+    a1, m1 = batch_spectral_clustering(X, K, sigma=sigma, correct_sign=True, norm_p=2.0, threshold=1e-6, iter_limit=100)
+    assert a1.shape == (X.shape[0], X.shape[1]) and m1.shape == (X.shape[0], K) and bool((m1[:, 1:] > m1[:, :-1]).all())
     a2, m2 = batch_spectral_clustering(X, K, sigma=sigma, correct_sign=True, norm_p=2.0, threshold=1e-6, iter_limit=100,
                                        eigensolver=lambda L_: torch.linalg.svd(L_, full_matrices=False))
     assert a2.shape == (X.shape[0], X.shape[1]) and m2.shape == (X.shape[0], K) and bool((m2[:, 1:] > m2[:, :-1]).all())
