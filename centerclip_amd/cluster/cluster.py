@@ -181,20 +181,23 @@ class TokenClusterInter(torch.nn.Module):
         n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
         N = self.frame_duration * n
-        if self.algorithm == 'spectral' and torch.is_grad_enabled() and (
-                x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("autograd through cluster_algo 'spectral' is not built")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: the differentiable op (gradient of the gather / cluster means / CLS mean for the selection made in
             # the forward pass, which is a constant of the backward pass as in the reference: fast_kmeans.py:13,44)
             embed = self.cluster_embed.to(x.device).float().contiguous() if self.cluster_embedding else None
             mult = self.cls_multiplier.to(x.device).float().reshape(-1) if self.adaptive_cls else None
             ids = self._sparse_ids(N, x.device) if self.algorithm == 'sparse_sampling' else None
+            sp = (0.0, 0, 0, False, None)
+            if self.algorithm == 'spectral':
+                from .spectral import GRAPH_MODES
+                graph = self.spg[0].to(x.device).ne(0).to(torch.uint8).contiguous() if self.spg is not None else None
+                sp = (float(self.spectral_sigma), GRAPH_MODES[self.spectral_graph], int(self.spectral_knn_k),
+                      bool(self.svd_correct_sign), graph)
             out, medoids, _ = torch.ops.centerclip.token_cluster_train(
                 x, bool(frame_major), self.before_block_frames, self.after_block_frames, K, L.METRIC_IDS[self.distance],
                 float(self.norm_p), float(self.threshold), int(self.iter_limit), int(self.split_size), bool(self.pre_norm),
-                {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2}[self.algorithm],
-                0 if self.aggregation in [None, 'None'] else 1, embed, mult, ids)
+                {'kmediods++': 0, 'pooling': 1, 'sparse_sampling': 2, 'spectral': 3}[self.algorithm],
+                0 if self.aggregation in [None, 'None'] else 1, embed, mult, ids, *sp)
             self.last_medoids = medoids if medoids.numel() else None
             return out
         var, keep = self.variant(N, x.device)

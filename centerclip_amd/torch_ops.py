@@ -296,7 +296,9 @@ def _cluster_strides(shape, frame_major):
 def token_cluster_train(x: torch.Tensor, frame_major: bool, T: int, T_new: int, K: int, metric: int, norm_p: float,
                         threshold: float, iter_limit: int, split_size: int, pre_norm: bool, algorithm: int, aggregation: int,
                         cluster_embed: Optional[torch.Tensor], cls_mult: Optional[torch.Tensor],
-                        fixed_ids: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                        fixed_ids: Optional[torch.Tensor], spectral_sigma: float = 0.0, spectral_mode: int = 0,
+                        spectral_knn_k: int = 0, spectral_sign: bool = False,
+                        spectral_graph: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """token_cluster that also returns what its backward needs: medoids [T_new*B, K] and assign [T_new*B, fd*n] (both
     empty for 'pooling' / 'sparse_sampling').  Differentiable with respect to x, cluster_embed and cls_mult
     (torch.ops.centerclip.token_cluster_backward); the selection is a constant of the backward pass, as in the reference,
@@ -306,13 +308,14 @@ def token_cluster_train(x: torch.Tensor, frame_major: bool, T: int, T_new: int, 
     oshape = (B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W)
     out = _e(*oshape, like=x, dtype=torch.float32)
     _, _, _, o_tok, o_frame = _cluster_strides(oshape, frame_major)
-    kmed = algorithm == 0
+    kmed = algorithm in (0, 3)
     N = (T // T_new) * n
     med = _e(B * T_new if kmed else 0, K, like=x, dtype=torch.long)
     assign = _e(B * T_new if kmed else 0, N, like=x, dtype=torch.long)
-    var = _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids)
+    var = _variant(algorithm, aggregation, cluster_embed, cls_mult, fixed_ids,
+                   (spectral_sigma, spectral_mode, spectral_knn_k, spectral_sign, spectral_graph) if algorithm == 3 else None)
     lib = L.lib()
-    ws = L.workspace(lib.cc_cluster_workspace_bytes(B * T_new, N, W, int(pre_norm)), x.device)
+    ws = _cluster_ws(lib, B * T_new, N, W, pre_norm, K, algorithm, x.device)
     L.check(lib.cc_token_cluster_variant_f32(L.ptr(x), tok, frame, B, T, T_new, n, W, K, metric, float(norm_p),
                                              float(threshold), int(iter_limit), int(split_size), int(pre_norm),
                                              ctypes.byref(var), L.ptr(out), o_tok, o_frame,
@@ -323,11 +326,12 @@ def token_cluster_train(x: torch.Tensor, frame_major: bool, T: int, T_new: int, 
 
 @token_cluster_train.register_fake
 def _(x, frame_major, T, T_new, K, metric, norm_p, threshold, iter_limit, split_size, pre_norm, algorithm, aggregation,
-      cluster_embed, cls_mult, fixed_ids):
+      cluster_embed, cls_mult, fixed_ids, spectral_sigma=0.0, spectral_mode=0, spectral_knn_k=0, spectral_sign=False,
+      spectral_graph=None):
     BT, Lt, W, _, _ = _cluster_strides(x.shape, frame_major)
     B, n = BT // T, Lt - 1
     out = x.new_empty((B * T_new, 1 + K, W) if frame_major else (1 + K, B * T_new, W))
-    rows = B * T_new if algorithm == 0 else 0
+    rows = B * T_new if algorithm in (0, 3) else 0
     return out, x.new_empty((rows, K), dtype=torch.long), x.new_empty((rows, (T // T_new) * n), dtype=torch.long)
 
 
@@ -388,7 +392,8 @@ def _(grad_out, x, frame_major, T, T_new, K, algorithm, aggregation, medoids, as
 
 
 def _token_cluster_setup(ctx, inputs, output):
-    (x, frame_major, T, T_new, K, _m, _p, _t, _i, _s, _pn, algorithm, aggregation, cluster_embed, cls_mult, fixed_ids) = inputs
+    (x, frame_major, T, T_new, K, _m, _p, _t, _i, _s, _pn, algorithm, aggregation, cluster_embed, cls_mult, fixed_ids) = inputs[:16]
+    algorithm = 0 if algorithm == 3 else algorithm          # spectral: the backward is that of the gather / cluster means
     _, med, assign = output
     ctx.cfg = (frame_major, T, T_new, K, algorithm, aggregation)
     ctx.has = (cluster_embed is not None, cls_mult is not None, fixed_ids is not None)
@@ -408,7 +413,7 @@ def _token_cluster_bwd(ctx, grad_out, _gmed, _gassign):
     gx, ge, gm = torch.ops.centerclip.token_cluster_backward(grad_out.contiguous().float(), x, frame_major, T, T_new, K,
                                                              algorithm, aggregation, med, assign, cls_mult, fixed_ids,
                                                              want_embed, want_mult)
-    return (gx,) + (None,) * 12 + (ge if want_embed else None, gm if want_mult else None, None)
+    return (gx,) + (None,) * 12 + (ge if want_embed else None, gm if want_mult else None) + (None,) * 6
 
 
 token_cluster_train.register_autograd(_token_cluster_bwd, setup_context=_token_cluster_setup)

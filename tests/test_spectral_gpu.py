@@ -130,8 +130,15 @@ def test_spectral_module_on_planted_partitions(sg, tag):
     want = co.literal_token_cluster_variant(x.cpu(), T, Tn, K, "kmediods++", None, medoids=med,
                                             assign=torch.zeros(med.shape[0], N, dtype=torch.long))
     assert torch.equal(y.cpu(), want)
-    with pytest.raises(NotImplementedError):
-        mod(x.clone().requires_grad_(True))
+    # autograd: the selection is a constant of the backward pass, the gradient is that of the gather + CLS mean
+    xg = x.clone().requires_grad_(True)
+    yg, _ = mod(xg)
+    G = torch.randn_like(yg)
+    yg.backward(G)
+    xo = x.cpu().clone().requires_grad_(True)
+    co.literal_token_cluster_variant(xo, T, Tn, K, "kmediods++", None, medoids=mod.last_medoids.cpu(),
+                                     assign=torch.zeros(med.shape[0], N, dtype=torch.long)).backward(G.cpu())
+    assert torch.equal(xg.grad.cpu(), xo.grad)
 
 
 def test_spectral_generic_input_normalised_cut(sg):
