@@ -240,6 +240,20 @@ def cluster_bench(c, device, iters=30):
                               frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=alg_bytes))
 
 
+def spectral_cluster_bench(c, device):
+    """The same op with cluster_algo='spectral' (heat-kernel graph -> Laplacian -> batched Jacobi eigensolver -> k-medoids on
+    the embedding -> gather), one config's shape; eager launches between two events (the decomposition dominates: ms)."""
+    from centerclip_amd.cluster import TokenClusterInter
+    B, T, Tn, K, n = c["B"], c["T"], c["T_new"], c["K"], c["n"]
+    x = torch.randn(B * T, 1 + n, 768, device=device) * 0.05
+    mod = TokenClusterInter(algorithm="spectral", before_cluster_num=n, cluster_num=K, before_block_frames=T,
+                            after_block_frames=Tn, original_frame=T, threshold=1e-6, iter_limit=100, split_size=c["split"],
+                            norm_p=2.0, spectral_sigma=2.0)
+    ms = event_time_ms(lambda: mod.cluster_frame_major(x, keep_ids=False), 5)
+    return dict(ms_per_call=round(ms, 2), mtokens_per_s=round(B * T * n / ms / 1e3, 2), problems=B * Tn,
+                tokens_per_problem=(T // Tn) * n, launch="eager")
+
+
 def cluster_pmc_traffic():
     """HBM bytes of one cfg-2 token-cluster call = sum over its kernels, from the committed PMC passes (None if absent)."""
     import glob
@@ -479,6 +493,8 @@ def main():
                     dist.all_reduce(tt, op=dist.ReduceOp.SUM)
                     tc[name]["mtokens_per_s_all_ranks"] = round(float(tt), 2)
             extras["token_cluster"] = tc
+            if world == 1:
+                extras["token_cluster_spectral"] = {"cfg2": spectral_cluster_bench(CLUSTER_SHAPES["cfg2"], device)}
             extras["similarity_10k_x_1k"] = similarity_bench(device, world)
             if world > 1:
                 ms = event_time_ms(sink.gather, 50)
