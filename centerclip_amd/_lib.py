@@ -50,6 +50,8 @@ def _declare(lib):
     lib.cc_cluster_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.cc_token_norms_f32.argtypes = [vp, lay, i32, vp, vp, sz, vp]
     lib.cc_pairwise_distance_f32.argtypes = [vp, lay, i32, i32, f32, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.cc_pairwise_distance_cross_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, sz, vp]
+    lib.cc_pairwise_distance_cross_f32.restype = c.c_int
     lib.cc_kmedoids_from_dist_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.cc_batch_kmedoids_f32.argtypes = [vp, lay, i32, i32, i32, f32, f32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.cc_token_cluster_f32.argtypes = [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, i32,

@@ -15,16 +15,21 @@ def _as_batch(x):
 
 @torch.no_grad()
 def pairwise_distance(data1, data2, metric='euclidean', self_nearest=True, all_negative=False, p=2.0):
-    """Pairwise distance of a token set with itself -> [N, N] or [B, N, N] fp32.
+    """Pairwise distance -> [N1, N2] or [B, N1, N2] fp32, same arguments as the reference.
 
-    Same arguments as the reference.  The hot path only ever passes ``data2 is data1``
-    (fast_kmeans.py:61-62); cross-set distances are not built (NotImplementedError).
+    The hot path only ever passes ``data2 is data1`` (fast_kmeans.py:61-62): that case runs on the Gram kernel of the
+    cluster op; two different sets go through a plain tiled kernel (cc_pairwise_distance_cross_f32).
     Unknown metric -> NotImplementedError, as in the reference (cluster_utils.py:33).
     """
     if metric not in L.METRIC_IDS:
         raise NotImplementedError("{} metric is not implemented".format(metric))
     if data2 is not data1 and not (data1.shape == data2.shape and data1.data_ptr() == data2.data_ptr()):
-        raise NotImplementedError("centerclip_amd.pairwise_distance computes self-distances only (data2 must be data1)")
+        L.require_device(data1, data2)
+        a, squeeze = _as_batch(data1.float().contiguous())
+        b, _ = _as_batch(data2.float().contiguous())
+        dist = torch.ops.centerclip.pairwise_distance_cross(a, b, L.METRIC_IDS[metric], float(p), bool(all_negative),
+                                                            bool(self_nearest))
+        return dist[0] if squeeze else dist
     L.require_device(data1)
     x, squeeze = _as_batch(data1.float().contiguous())
     dist = torch.ops.centerclip.pairwise_distance(x, L.METRIC_IDS[metric], float(p), bool(all_negative), bool(self_nearest))

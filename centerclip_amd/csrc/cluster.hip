@@ -984,6 +984,73 @@ struct OuterSum {
     }
 };
 
+// pairwise_distance(data1, data2) for two DIFFERENT token sets (cluster_utils.py:8-43; the hot path only passes data1 twice):
+// one 16x16 output tile per workgroup, both row panels staged through LDS in 64-wide k chunks, plain fp32 VALU.
+//   euclidean, p = 2:  sqrt(max(|x|^2 + |y|^2 - 2 x.y, 0))   (ATen's cdist for more than 25 rows; direct below - same value to rounding)
+//   euclidean, p != 2: (sum |x - y|^p)^(1/p);   cosine: 1 - (x / (|x| + 1e-6)) . (y / (|y| + 1e-6))
+// gmax (optional): the maximum over the whole tensor, as ordered-uint keys (all_negative).
+__global__ __launch_bounds__(256) void cross_dist_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int N1,
+                                                         int N2, int W, int metric, float p, float* __restrict__ dist,
+                                                         unsigned* __restrict__ gmax) {
+    __shared__ float a[16][65], b[16][65];
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int bz = blockIdx.z, i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const float* X = x1 + (int64_t)bz * N1 * W;
+    const float* Y = x2 + (int64_t)bz * N2 * W;
+    const bool gram = metric == CC_METRIC_COSINE || p == 2.0f;
+    float dot = 0.f, nx = 0.f, ny = 0.f, lp = 0.f;
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            a[r][c] = (i0 + r < N1 && k0 + c < W) ? X[(int64_t)(i0 + r) * W + k0 + c] : 0.f;
+            b[r][c] = (j0 + r < N2 && k0 + c < W) ? Y[(int64_t)(j0 + r) * W + k0 + c] : 0.f;
+        }
+        __syncthreads();
+        const int kn = min(64, W - k0);
+        if (gram) {
+            for (int c = 0; c < kn; ++c) {
+                const float u = a[ti][c], v = b[tj][c];
+                dot += u * v; nx += u * u; ny += v * v;
+            }
+        } else if (p == 1.0f) {
+            for (int c = 0; c < kn; ++c) lp += fabsf(a[ti][c] - b[tj][c]);
+        } else {
+            for (int c = 0; c < kn; ++c) lp += powf(fabsf(a[ti][c] - b[tj][c]), p);
+        }
+        __syncthreads();
+    }
+    float d;
+    if (metric == CC_METRIC_COSINE) d = 1.0f - dot / ((sqrtf(nx) + 1e-6f) * (sqrtf(ny) + 1e-6f));
+    else if (p == 2.0f) d = sqrtf(fmaxf((nx + ny) - 2.f * dot, 0.f));
+    else d = (p == 1.0f) ? lp : powf(lp, 1.0f / p);
+    const bool in = i0 + ti < N1 && j0 + tj < N2;
+    if (in) dist[((int64_t)bz * N1 + i0 + ti) * N2 + j0 + tj] = d;
+    if (gmax) {
+        float m = in ? d : -__builtin_inff();
+        m = cc_wave_max(m);
+        if ((tid & 63) == 0) atomicMax(gmax, cc_float_to_ordered_uint(m));
+    }
+}
+
+// dis = dis - max(dis) - 1 (all_negative, :35-36), then dis[..., j, j] -= 1 for j < N2 (self_nearest, :38-41)
+__global__ __launch_bounds__(256) void cross_shift_kernel(float* __restrict__ dist, int P, int N1, int N2,
+                                                          const unsigned* __restrict__ gmax, int self_nearest) {
+    float mx = 0.f;
+    if (gmax) {
+        const unsigned u = *gmax;
+        mx = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+    const int64_t total = (int64_t)P * N1 * N2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx % N2);
+        const int i = (int)((idx / N2) % N1);
+        float v = dist[idx];
+        if (gmax) v = (v - mx) - 1.0f;
+        if (self_nearest && i == j) v -= 1.0f;
+        dist[idx] = v;
+    }
+}
+
 // One wave per output row.  mode 0: K medoid tokens (cluster.py:289; med_stride 0 = the same ids for every problem,
 // 'sparse_sampling' :326-343); mode 1: K cluster means (cluster.py:291-301:
 // sum(res_tmp * mask, dim=1) / sum(mask), empty cluster -> 0/0 = NaN as in the reference); mode 2: 'pooling'
@@ -1359,6 +1426,31 @@ int cc_pairwise_distance_f32(const float* x, const cc_token_layout* lay, int32_t
         }
         hipLaunchKernelGGL(shift_dist_kernel, dim3(blocks), dim3(256), 0, st, dist, P, N, c.chunkmax, chunk,
                            all_negative, self_nearest);
+        CC_LAUNCH_CHECK();
+    }
+    return CC_OK;
+}
+
+int cc_pairwise_distance_cross_f32(const float* x1, const float* x2, int32_t P, int32_t N1, int32_t N2, int32_t W,
+                                   int32_t metric, float p, int32_t all_negative, int32_t self_nearest, float* dist,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    if (!x1 || !x2 || !dist || P <= 0 || N1 <= 0 || N2 <= 0 || W <= 0) return CC_ERR_INVALID;
+    if (metric != CC_METRIC_EUCLIDEAN && metric != CC_METRIC_COSINE) return CC_ERR_UNSUPPORTED;
+    if (!(p > 0.f)) return CC_ERR_INVALID;
+    if (self_nearest && N2 > N1) return CC_ERR_INVALID;          // the reference indexes dis[..., j, j] for j < N2
+    if (all_negative && (!ws || ws_bytes < sizeof(unsigned))) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned* gmax = static_cast<unsigned*>(ws);
+    if (all_negative && hipMemsetAsync(gmax, 0, sizeof(unsigned), st) != hipSuccess) return CC_ERR_HIP;
+    const dim3 grid((N2 + 15) / 16, (N1 + 15) / 16, P);
+    hipLaunchKernelGGL(cross_dist_kernel, grid, dim3(256), 0, st, x1, x2, N1, N2, W, metric, p, dist,
+                       all_negative ? gmax : nullptr);
+    CC_LAUNCH_CHECK();
+    if (all_negative || self_nearest) {
+        const int64_t total = (int64_t)P * N1 * N2;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(cross_shift_kernel, dim3(blocks), dim3(256), 0, st, dist, P, N1, N2, all_negative ? gmax : nullptr,
+                           self_nearest);
         CC_LAUNCH_CHECK();
     }
     return CC_OK;

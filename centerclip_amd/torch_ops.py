@@ -484,6 +484,25 @@ def _(x, metric, p, all_negative, self_nearest):
     return x.new_empty((P, N, N))
 
 
+@custom_op(NS + "::pairwise_distance_cross", mutates_args=(), device_types="cuda")
+def pairwise_distance_cross(x1: torch.Tensor, x2: torch.Tensor, metric: int, p: float, all_negative: bool,
+                            self_nearest: bool) -> torch.Tensor:
+    """pairwise_distance(data1, data2, ...) for two different sets (cluster_utils.py:8-43): [P,N1,W], [P,N2,W] -> [P,N1,N2]."""
+    P, N1, W = x1.shape
+    N2 = x2.shape[1]
+    dist = _e(P, N1, N2, like=x1, dtype=torch.float32)
+    ws = L.workspace(256, x1.device)
+    L.check(L.lib().cc_pairwise_distance_cross_f32(L.ptr(x1), L.ptr(x2), P, N1, N2, W, metric, float(p), int(all_negative),
+                                                   int(self_nearest), L.ptr(dist), L.ptr(ws), ws.numel(), _st(x1)),
+            "cc_pairwise_distance_cross_f32")
+    return dist
+
+
+@pairwise_distance_cross.register_fake
+def _(x1, x2, metric, p, all_negative, self_nearest):
+    return x1.new_empty((x1.shape[0], x1.shape[1], x2.shape[1]))
+
+
 @custom_op(NS + "::token_norms", mutates_args=(), device_types="cuda")
 def token_norms(x: torch.Tensor) -> torch.Tensor:
     P, N, W = x.shape
@@ -837,7 +856,7 @@ def _(sim):
 OPS = ("contrastive_loss", "spectral_laplacian", "spectral_graph_laplacian", "spectral_embedding", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
        "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward", "token_apply_selection",
        "batch_kmedoids", "kmedoids_from_dist",
-       "pairwise_distance", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
+       "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",
        "rank_counts_cols")
 

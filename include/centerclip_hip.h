@@ -88,6 +88,13 @@ int cc_token_norms_f32(const float* x, const cc_token_layout* lay, int32_t W, fl
  *      of the whole tensor it is handed = one split chunk; pass P for a single call).
  *      norms_out (optional) [P,N] = L2 norm of every token (cluster_utils.py:93).
  */
+/* The same function for two DIFFERENT token sets: x1 [P,N1,W], x2 [P,N2,W] contiguous -> dist [P,N1,N2]; the all_negative
+ * shift uses the maximum of the whole tensor (cluster_utils.py:35-36), self_nearest lowers dist[.., j, j] for j < N2 (needs
+ * N2 <= N1, as the reference's indexing does).  Not on the retrieval path (the k-medoids only ever passes one set).
+ * ws: at least 4 bytes when all_negative. */
+int cc_pairwise_distance_cross_f32(const float* x1, const float* x2, int32_t P, int32_t N1, int32_t N2, int32_t W,
+                                   int32_t metric, float p, int32_t all_negative, int32_t self_nearest, float* dist,
+                                   void* ws, size_t ws_bytes, void* stream);
 int cc_pairwise_distance_f32(const float* x, const cc_token_layout* lay, int32_t W,
                              int32_t metric, float p, int32_t all_negative, int32_t self_nearest,
                              int32_t chunk, float* dist, float* norms_out,

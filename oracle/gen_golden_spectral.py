@@ -6,6 +6,7 @@
              (recipes.planted_tokens): with aggregation='mean' the module output depends on the partition only, which every
              correct eigensolver recovers; stored with the medoids / assignment batch_spectral_clustering returned and the
              singular values around the K-th (the gap that makes the case solver-independent)
+  xd_*       pairwise_distance(data1, data2) of two different token sets (recipes.CROSS_DIST_CASES)
   generic_*  a Gaussian input with the reference's assignment, for the normalised-cut comparison (no index target: the
              reference's own float64 run disagrees with it)
 
@@ -90,6 +91,14 @@ def main():
     asg, med = sp.batch_spectral_clustering(Xg, 8, mode='HeatKernel', metric='euclidean', threshold=1e-6, iter_limit=100,
                                             norm_p=2.0, correct_sign=True, split_size=16, sigma=2.0)
     out["generic_x"], out["generic_assign"], out["generic_medoids"] = Xg.numpy(), asg.numpy().astype(np.int16), med.numpy().astype(np.int16)
+    # ---- pairwise_distance(data1, data2) for two different token sets (cluster_utils.py:8-43)
+    import cluster.cluster_utils as cu
+    from recipes import CROSS_DIST_CASES, cross_dist_inputs
+    for tag, cfg in CROSS_DIST_CASES.items():
+        a, b = cross_dist_inputs(cfg)
+        d = cu.pairwise_distance(t(a), t(b), metric=cfg["metric"], self_nearest=cfg["self_nearest"],
+                                 all_negative=cfg["all_negative"], p=cfg["p"])
+        out[f"xd_{tag}"] = d.numpy()
     path = os.path.join(GOLD, "spectral_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

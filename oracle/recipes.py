@@ -157,6 +157,21 @@ def planted_tokens(cfg):
     return x
 
 
+# pairwise_distance(data1, data2) with two different sets: batched / 2-d, N1 != N2, every metric and flag
+CROSS_DIST_CASES = {
+    "l2_batched": dict(seed=71, shape1=(2, 40, 32), shape2=(2, 30, 32), metric="euclidean", p=2.0, self_nearest=True, all_negative=True),
+    "l2_plain": dict(seed=72, shape1=(3, 17, 48), shape2=(3, 17, 48), metric="euclidean", p=2.0, self_nearest=False, all_negative=False),
+    "l1_2d": dict(seed=73, shape1=(33, 20), shape2=(21, 20), metric="euclidean", p=1.0, self_nearest=True, all_negative=False),
+    "l3": dict(seed=74, shape1=(2, 18, 16), shape2=(2, 35, 16), metric="euclidean", p=3.0, self_nearest=False, all_negative=True),
+    "cos_batched": dict(seed=75, shape1=(2, 50, 64), shape2=(2, 28, 64), metric="cosine", p=2.0, self_nearest=True, all_negative=True),
+    "cos_2d": dict(seed=76, shape1=(9, 12), shape2=(31, 12), metric="cosine", p=2.0, self_nearest=False, all_negative=False),
+}
+
+
+def cross_dist_inputs(cfg):
+    return fullmant(cfg["seed"], cfg["shape1"], 21), fullmant(cfg["seed"] + 500, cfg["shape2"], 21)
+
+
 def variant_input(cfg):
     """x [1+n, B*T, W] fp32 for a VARIANT_CASES entry (+ cluster_embed [K,W], cls_multiplier [T] when asked)."""
     L, BT, W = 1 + cfg["n"], cfg["B"] * cfg["T"], cfg["W"]

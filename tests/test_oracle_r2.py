@@ -126,3 +126,13 @@ def test_spectral_planted_partitions_oracle_reproduces_reference():
             assert np.array_equal(y.numpy(), SPG[f"{tag}_{name}_out"]), (tag, name)
         gap = SPG[f"{tag}_spectrum"]
         assert (gap[:, 1] > 100 * gap[:, 2]).all()             # the K-th / (K+1)-th singular values are far apart
+
+
+def test_cross_set_pairwise_distance_oracle_reproduces_reference():
+    from oracle import cluster_oracle as co
+    from oracle.recipes import CROSS_DIST_CASES, cross_dist_inputs
+    for tag, cfg in CROSS_DIST_CASES.items():
+        a, b = cross_dist_inputs(cfg)
+        d = co.literal_pairwise_distance(torch.from_numpy(a), torch.from_numpy(b), cfg["metric"], cfg["self_nearest"],
+                                         cfg["all_negative"], cfg["p"])
+        np.testing.assert_allclose(d.numpy(), SPG[f"xd_{tag}"], rtol=0, atol=1e-5), tag

@@ -187,3 +187,19 @@ def test_spectral_block_inside_the_fused_encoder():
     ref = clo.visual_forward(sd, video.cpu(), T, cluster_plan={1: (2, 6)}, forced_medoids={1: med.cpu()})
     nrm = lambda v: v / v.norm(dim=-1, keepdim=True)
     assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+
+
+def test_cross_set_pairwise_distance_matches_reference(sg):
+    """pairwise_distance(data1, data2) with two different token sets (cluster_utils.py:8-43; not on the retrieval path):
+    batched and 2-d inputs, N1 != N2, Minkowski p in {1, 2, 3}, cosine, both flags - against the reference's outputs."""
+    from centerclip_amd.cluster import pairwise_distance
+    from oracle.recipes import CROSS_DIST_CASES, cross_dist_inputs
+    for tag, cfg in CROSS_DIST_CASES.items():
+        a, b = cross_dist_inputs(cfg)
+        d = pairwise_distance(dev(a), dev(b), metric=cfg["metric"], self_nearest=cfg["self_nearest"],
+                              all_negative=cfg["all_negative"], p=cfg["p"])
+        want = sg[f"xd_{tag}"]
+        assert tuple(d.shape) == want.shape, tag
+        np.testing.assert_allclose(d.cpu().numpy(), want, rtol=0, atol=2e-4 if cfg["p"] == 2.0 and cfg["metric"] == "euclidean" else 2e-5)
+    with pytest.raises(Exception):                                     # the reference's diagonal indexing needs N2 <= N1
+        pairwise_distance(dev(np.zeros((4, 8), np.float32)), dev(np.zeros((6, 8), np.float32)), self_nearest=True)
