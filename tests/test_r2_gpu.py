@@ -16,6 +16,7 @@ indices).
 """
 import math
 import os
+import sys
 from argparse import Namespace
 
 import numpy as np
@@ -762,3 +763,30 @@ def test_nccl_packed_all_gather_and_sharded_similarity():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "NCCL_WORKER_OK world=%d" % world in r.stdout
+
+
+def test_bench_line_contract_one_and_two_ranks():
+    """bench.py end to end on the device, small step counts: the N = 1 line carries the contract's keys with roofline and
+    cpu_baseline objects; `--gpus 2` launches its own two ranks (here sharing the one GPU over gloo, CC_BENCH_SHARE_GPU) and
+    reports n_gpus = 2 with the all-gather and the row-sharded similarity."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--min-seconds", "0.1"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    env2 = dict(env, CC_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--min-seconds", "0.1",
+                          "--no-cpu-baseline"], cwd=root, env=env2, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 32 and "feature_all_gather" in d2
+    assert d2["similarity_10k_x_1k"]["sharding"] != "single GPU" and "mtokens_per_s_all_ranks" in d2["token_cluster"]["cfg2"]
