@@ -153,7 +153,52 @@ def pmc_traffic(symbol):
     return None
 
 
-def gemm_roofline(c, device):
+def insitu_gemm_times(step, reps=6):
+    """Duration of every gemm_f16_kernel launch INSIDE the step, measured live with HIP events on the launch stream: the
+    library brackets each launch of the eagerly enqueued step with two events (cc_debug_gemm_timing_*; the whole step is
+    enqueued by one C call, far faster than the GPU drains it, so the launches run back to back between their real
+    neighbours as in the captured graph).  -> {symbol: dict(us, launches_per_step, flops_per_step, shapes)}; flops count
+    both problems of a paired launch (ViT carrier + text rider)."""
+    import ctypes
+    from centerclip_amd import _lib as L
+    lib = L.lib()
+    lib.cc_debug_gemm_timing_begin.argtypes = [ctypes.c_int]
+    lib.cc_debug_gemm_timing_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    assert lib.cc_debug_gemm_timing_begin(400 * reps) == 0
+    try:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        n = lib.cc_debug_gemm_timing_end()
+    us, info = ctypes.c_float(), (ctypes.c_int * 12)()
+    out = {}
+    for i in range(n):
+        assert lib.cc_debug_gemm_timing_read(i, ctypes.byref(us), info) == 0
+        bm, bn, wm, wn, epi, bk, m0, n0, k0, m1, n1, k1 = list(info)
+        sym = "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
+        e = out.setdefault(sym, dict(us=0.0, launches=0, flops=0.0, shapes={}))
+        e["us"] += us.value
+        e["launches"] += 1
+        e["flops"] += 2.0 * m0 * n0 * k0 + 2.0 * m1 * n1 * k1
+        key = "%dx%dx%d%s" % (m0, n0, k0, " + rider %dx%dx%d" % (m1, n1, k1) if m1 else "")
+        sh = e["shapes"].setdefault(key, [0, 0.0])
+        sh[0] += 1
+        sh[1] += us.value
+    lib.cc_debug_gemm_timing_begin(0)
+    for e in out.values():
+        e["avg_us"] = e["us"] / e["launches"]
+        e["tflops"] = e["flops"] / e["us"] / 1e6
+        e["launches_per_step"] = e["launches"] / reps
+        e["us_per_step"] = e["us"] / reps
+        e["shapes"] = {k: dict(launches_per_step=v[0] / reps, avg_us=round(v[1] / v[0], 2)) for k, v in e["shapes"].items()}
+    return out
+
+
+def gemm_roofline(c, device, insitu=None):
     """Time every distinct GEMM of one step alone (HIP events on the launch stream around replays of a hipGraph of
     back-to-back launches), group them by kernel symbol and return the symbol with the largest share of the step as the
     dominant kernel.  Algorithmic flops = 2*M*N*K."""
@@ -205,19 +250,34 @@ def gemm_roofline(c, device):
         s["flops"] += 2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"]
         s["launches"] += r["calls_per_step"]
         s["roles"].append(r["role"])
-    sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
-    tf = dom["flops"] / dom["us"] / 1e6
+    standalone = {k: dict(roles=v["roles"], step_share_us=round(v["us"], 1), tflops=round(v["flops"] / v["us"] / 1e6, 1),
+                          frac=round(v["flops"] / v["us"] / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)) for k, v in by_sym.items()}
+    if insitu:
+        # headline: the dominant symbol's launches as they run INSIDE the step (what rocprofv3 --kernel-trace --stats of
+        # this command averages too: profiles/*_bench_kernel_stats.*)
+        sym, dom = max(insitu.items(), key=lambda kv: kv[1]["us"])
+        tf, avg_us, n_l = dom["tflops"], dom["avg_us"], dom["launches_per_step"]
+        flops_per_launch, share = dom["flops"] / dom["launches"], dom["us_per_step"]
+        roles = standalone.get(sym, {}).get("roles", [])
+        how = "in situ: HIP events around every launch of the symbol inside the eagerly enqueued step"
+    else:
+        sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
+        tf, avg_us, n_l = dom["flops"] / dom["us"] / 1e6, dom["us"] / dom["launches"], dom["launches"]
+        flops_per_launch, share, roles = dom["flops"] / dom["launches"], dom["us"], dom["roles"]
+        how = "stand-alone: hipGraph of back-to-back launches of each shape (no text rider, no neighbours)"
     tr = pmc_traffic(sym)
-    roof = dict(bound="mfma", kernel=sym, roles=dom["roles"], achieved=round(tf, 1), peak=MFMA_F16_PEAK_TFLOPS,
-                unit="TFLOP/s", frac=round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+    roof = dict(bound="mfma", kernel=sym, roles=roles, achieved=round(tf, 1), peak=MFMA_F16_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=round(tf / MFMA_F16_PEAK_TFLOPS, 4), measured=how,
                 traffic=tr["hbm_bytes_per_launch"] if tr else None,
                 traffic_unit="bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE), from a committed profile - not measured in this run",
-                traffic_detail=tr, avg_launch_us=round(dom["us"] / dom["launches"], 2),
-                algorithmic_flops_per_launch=dom["flops"] / dom["launches"],
-                step_share_us=round(dom["us"], 1),
-                by_symbol={k: dict(roles=v["roles"], step_share_us=round(v["us"], 1),
-                                   tflops=round(v["flops"] / v["us"] / 1e6, 1),
-                                   frac=round(v["flops"] / v["us"] / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)) for k, v in by_sym.items()})
+                traffic_detail=tr, avg_launch_us=round(avg_us, 2), launches_per_step=n_l,
+                algorithmic_flops_per_launch=flops_per_launch,
+                step_share_us=round(share, 1),
+                by_symbol_in_situ={k: dict(avg_us=round(v["avg_us"], 2), launches_per_step=v["launches_per_step"],
+                                           step_share_us=round(v["us_per_step"], 1), tflops=round(v["tflops"], 1),
+                                           frac=round(v["tflops"] / MFMA_F16_PEAK_TFLOPS, 4), shapes=v["shapes"])
+                                   for k, v in (insitu or {}).items()},
+                by_symbol_stand_alone=standalone)
     gemm_us = sum(r["step_share_us"] for r in rows)
     gemm_flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"] for r in rows)
     return roof, rows, gemm_us, gemm_flops
@@ -299,7 +359,8 @@ def similarity_bench(device, world=1):
     return dict(pairs_per_s=round(Nt * Nv / ms * 1e3, 0), us_per_call=round(ms * 1e3, 1),
                 algorithmic_tflops=round(flops / ms / 1e9, 2), issued_f16_mfma_tflops=round(3 * flops / ms / 1e9, 2),
                 frac_of_f16_mfma_peak=round(3 * flops / ms / 1e9 / MFMA_F16_PEAK_TFLOPS / world, 4),
-                vs_exact_fp32_mfma_peak=round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS / world, 3),
+                algorithmic_bytes=int((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4),
+                frac_of_hbm_peak=round(((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4) / ms / 1e6 / HBM_PEAK_GBS / world, 4),
                 sharding="rows over %d ranks, videos all-gathered (%.1f MB)" % (world, Nv * E * 4 / 1e6) if world > 1 else "single GPU")
 
 
@@ -528,28 +589,21 @@ def main():
                                                                                   res["token_cluster"]["cfg2"]["mtokens_per_s"])
         if world == 1 and not a.no_extras:
             with torch.no_grad():
-                roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device)
+                roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device, insitu_gemm_times(step1))
                 res["roofline"] = roof
                 res["gemm_breakdown"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
                 res["gemm_time_share_of_step"] = round(gemm_us / (ms_per_step * 1e3), 3)
                 res["forward_algorithmic_tflops"] = round(gemm_flops * 1.0 / (ms_per_step * 1e-3) / 1e12, 1)
                 # the same step with the text tower on all 16 x 32 rows (caption compaction off), for transparency
-                from centerclip_amd import _lib as L_
-                L_.lib().cc_debug_set_text_compaction(0)
-                try:
+                with model.clip.row_policy(all_text_rows=True):
                     ms_dense = graph_time_ms(step1, launches=1, replays=20)
-                finally:
-                    L_.lib().cc_debug_set_text_compaction(1)
                 lens = (ids.argmax(dim=-1) + 1).float()
                 res["text_rows"] = {"policy": "captions compacted to their EOT on the device: tokens behind the EOT cannot reach the "
                                               "caption's feature (causal mask, EOT row projected) - features bit-identical to all rows",
                                     "rows_computed": int(lens.sum()), "rows_all": int(ids.numel()),
                                     "ms_per_step_all_rows": round(ms_dense, 3)}
-                L_.lib().cc_debug_set_last_block_rows(0)
-                try:
+                with model.clip.row_policy(all_last_block_rows=True):
                     ms_all12 = graph_time_ms(step1, launches=1, replays=20)
-                finally:
-                    L_.lib().cc_debug_set_last_block_rows(1)
                 res["last_block_rows"] = {"policy": "the last block of each tower computes out_proj / c_fc / c_proj for the rows its "
                                                     "projection head reads (CLS of every frame, EOT of every caption); features "
                                                     "agree with the all-rows form to the rounding of the fp16 intermediates (<= 2e-4 relative, tested)",

@@ -24,7 +24,7 @@ class VitModel(c.Structure):
                 ("cluster_frames", c.c_int32 * CC_MAX_LAYERS), ("cluster_tokens", c.c_int32 * CC_MAX_LAYERS),
                 ("cluster_metric", c.c_int32), ("cluster_norm_p", c.c_float), ("cluster_threshold", c.c_float),
                 ("cluster_iter_limit", c.c_int32), ("cluster_split_size", c.c_int32), ("cluster_pre_norm", c.c_int32),
-                ("cluster_variants", c.c_void_p)]
+                ("cluster_variants", c.c_void_p), ("row_policy", c.c_int32)]
 
 
 class Frames(c.Structure):
@@ -38,7 +38,10 @@ class TextModel(c.Structure):
                 ("vocab_size", c.c_int32), ("embed_dim", c.c_int32),
                 ("token_embedding", c.c_void_p), ("positional_embedding", c.c_void_p),
                 ("ln_final_weight", c.c_void_p), ("ln_final_bias", c.c_void_p), ("text_projection", c.c_void_p),
-                ("blocks", c.POINTER(BlockWeights))]
+                ("blocks", c.POINTER(BlockWeights)), ("row_policy", c.c_int32)]
+
+
+ROWS_ALL_TEXT, ROWS_ALL_LAST_BLOCK = 1, 2          # CC_ROWS_* (include/centerclip_hip.h)
 
 
 def declare(lib):
@@ -74,6 +77,8 @@ def declare(lib):
     lib.cc_rank_counts_f32.restype = c.c_int
     lib.cc_rank_counts_cols_f32.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp]
     lib.cc_rank_counts_cols_f32.restype = c.c_int
+    lib.cc_rank_counts_ref_f32.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp]
+    lib.cc_rank_counts_ref_f32.restype = c.c_int
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]

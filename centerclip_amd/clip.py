@@ -10,6 +10,7 @@ build_clip_model, load_clip_state_dict (local files).  Not built (out of the hot
 
 All compute goes through ``torch.ops.centerclip.*`` (torch_ops.py).
 """
+import contextlib
 import ctypes
 import torch
 from torch import nn
@@ -19,7 +20,7 @@ import os
 from . import _lib as L
 from . import ops
 from . import torch_ops as T
-from ._lib_clip import BlockWeights, TextModel, VitModel, CC_MAX_LAYERS
+from ._lib_clip import BlockWeights, TextModel, VitModel, CC_MAX_LAYERS, ROWS_ALL_TEXT, ROWS_ALL_LAST_BLOCK
 from .cluster import get_cluster_inter
 
 
@@ -236,11 +237,14 @@ class VisualTransformer(nn.Module):
         self.register_buffer("position_ids", torch.arange(self.positional_embedding.shape[0]).expand(1, -1))
         self._pack = _Pack()
         self.last_medoids = None
+        # False (shipped): block 12 computes out_proj / c_fc / c_proj for the CLS rows only (the rows ln_post + proj read);
+        # True: every row, as the reference does (cc_vit_model.row_policy, bench.py / the tests compare both)
+        self.all_last_block_rows = False
 
     # -- C-ABI model struct -----------------------------------------------------------------
     def _model(self):
         """-> handle of the packed cc_vit_model in the torch_ops registry (rebuilt when a parameter changes)."""
-        sig = _Pack.signature(self)
+        sig = _Pack.signature(self) + (("rows", bool(self.all_last_block_rows)),)
         pk = self._pack
         if pk.key == sig:
             return pk.handle
@@ -248,6 +252,7 @@ class VisualTransformer(nn.Module):
             T.release_model(pk.handle)
         pk.keep, pk.key = [], sig
         m = VitModel()
+        m.row_policy = ROWS_ALL_LAST_BLOCK if self.all_last_block_rows else 0
         m.layers, m.width, m.heads = self.transformer.layers, self.width, self.heads
         m.patch, m.resolution, m.embed_dim = self.patch_size, self.input_resolution, self.output_dim
         m.conv1_weight_f16 = pk.f16(self.conv1.weight.reshape(self.width, -1))
@@ -353,7 +358,35 @@ class CLIP(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]))
         self._text_pack = _Pack()
+        # row policies of the text tower (cc_text_model.row_policy): False (shipped) = rows up to each caption's EOT only /
+        # the last block on the EOT rows only; True = every row, as the reference computes them
+        self.all_text_rows = False
+        self.all_last_block_rows = False
         self.initialize_parameters()
+
+    @contextlib.contextmanager
+    def row_policy(self, all_text_rows=False, all_last_block_rows=False):
+        """Temporarily compute the rows nothing downstream reads, exactly as the reference does (both towers).  The policy is
+        part of the packed model (per model, no process state); a hipGraph captured inside the block keeps its policy."""
+        saved = (self.all_text_rows, self.all_last_block_rows, self.visual.all_last_block_rows)
+        self.all_text_rows, self.all_last_block_rows = bool(all_text_rows), bool(all_last_block_rows)
+        self.visual.all_last_block_rows = bool(all_last_block_rows)
+        try:
+            yield self
+        finally:
+            self.all_text_rows, self.all_last_block_rows, self.visual.all_last_block_rows = saved
+
+    def invalidate(self):
+        """Drop the packed device copies (fp16 operands, folded LayerNorms).  The packs are keyed on (data_ptr, _version)
+        of every parameter; writes through ``p.data`` do not bump ``_version`` - call this after such a write (or write
+        under ``torch.no_grad()`` instead, which is tracked)."""
+        for pk in (self._text_pack, self.visual._pack):
+            if pk.handle is not None:
+                T.release_model(pk.handle)
+            pk.key, pk.handle, pk.keep = None, None, []
+        for tr in (self.transformer, self.visual.transformer):
+            for blk in tr.resblocks:
+                blk._fold = None
 
     def initialize_parameters(self):
         """Same statistics as modules/clip.py:419-446."""
@@ -393,7 +426,8 @@ class CLIP(nn.Module):
     def _text_model(self):
         tower = nn.ModuleList([self.transformer, self.token_embedding, self.ln_final])
         sig = _Pack.signature(tower) + ((self.positional_embedding._version, self.text_projection._version,
-                                         self.positional_embedding.data_ptr(), self.text_projection.data_ptr()),)
+                                         self.positional_embedding.data_ptr(), self.text_projection.data_ptr(),
+                                         bool(self.all_text_rows), bool(self.all_last_block_rows)),)
         pk = self._text_pack
         if pk.key == sig:
             return pk.handle
@@ -401,6 +435,7 @@ class CLIP(nn.Module):
             T.release_model(pk.handle)
         pk.keep, pk.key = [], sig
         m = TextModel()
+        m.row_policy = (ROWS_ALL_TEXT if self.all_text_rows else 0) | (ROWS_ALL_LAST_BLOCK if self.all_last_block_rows else 0)
         m.layers, m.width, m.heads = self.transformer.layers, self.transformer.width, self.transformer.heads
         m.context_length, m.vocab_size, m.embed_dim = self.context_length, self.vocab_size, self.embed_dim
         m.token_embedding, m.positional_embedding = pk.f32(self.token_embedding.weight), pk.f32(self.positional_embedding)

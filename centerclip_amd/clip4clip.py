@@ -61,7 +61,8 @@ class CLIP4Clip(nn.Module):
         if override:
             model.clip.load_state_dict(override, strict=False)
         if getattr(task_config, "temperature_new", 0.0) > 1.0:
-            model.clip.logit_scale.data.fill_(task_config.temperature_new)
+            with torch.no_grad():                    # (tracked by the packs' version keys, unlike a .data write)
+                model.clip.logit_scale.fill_(task_config.temperature_new)
         return model
 
     # ------------------------------------------------------------------ forward (clip4clip.py:199-263)
@@ -127,8 +128,14 @@ class CLIP4Clip(nn.Module):
         sink.mask.copy_(video_mask)
         return sink
 
+    def invalidate(self):
+        """After a write through ``.data`` (not version-tracked): drop every cached copy of the parameters."""
+        self._ls_key = None
+        self.clip.invalidate()
+
     def _logit_scale_value(self):
-        """Python float of clip.logit_scale, cached per parameter version (no device->host sync per call)."""
+        """Python float of clip.logit_scale, cached per parameter version (no device->host sync per call).  Writes through
+        ``.data`` are not seen - use ``with torch.no_grad(): p.fill_()`` or call invalidate()."""
         p = self.clip.logit_scale
         key = (p.data_ptr(), p._version)
         if getattr(self, "_ls_key", None) != key:

@@ -11,13 +11,6 @@
 
 namespace {
 
-// debug hook (cc_debug_set_text_compaction, not part of the public ABI): 0 = run the text tower on all Bt * Lt rows, as the
-// reference does - bench.py reports the step both ways, tests compare the two forms bit for bit
-int g_text_compaction = 1;
-// debug hook (cc_debug_set_last_block_rows): 0 = the last block of each tower computes every row behind its attention,
-// as the reference does, instead of the rows the projection heads read
-int g_last_block_rows = 1;
-
 struct Carver {
     char* base;
     size_t off = 0;
@@ -296,7 +289,7 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     // Caption compaction (see TextEmbedArgs): the text tower runs on the rows up to each caption's EOT only - the launches
     // are sized for Bt * Lt rows, the kernels read the real count from the device, so nothing synchronises and a
     // captured graph stays valid for any batch.  Off when the caller wants the full hidden state.
-    const bool compact = tm && !text_hidden_out && Bt <= 256 && g_text_compaction;
+    const bool compact = tm && !text_hidden_out && Bt <= 256 && !(tm->row_policy & CC_ROWS_ALL_TEXT);
     BlockCtx cv{}, ct{};
     cv.slots0 = ct.slots0 = 1;
     if (tm) {
@@ -395,11 +388,11 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             return cc_gemm_rows_ok(Wd, Wd, EPI_F32_RESID_STATS) && cc_gemm_rows_ok(4 * Wd, Wd, EPI_F16_GELU_LN) &&
                    cc_gemm_rows_ok(Wd, 4 * Wd, EPI_F32_RESID_STATS);
         };
-        if (hv && i == vl - 1 && !hidden_out && g_last_block_rows && cv.L > 1 && few_rows_ok(W)) {
+        if (hv && i == vl - 1 && !hidden_out && !(vm->row_policy & CC_ROWS_ALL_LAST_BLOCK) && cv.L > 1 && few_rows_ok(W)) {
             cv.sel_rows = cv.nseq;
             cv.sel_step = cv.L;
         }
-        if (ht && ti == tl - 1 && compact && g_last_block_rows && few_rows_ok(tm->width)) {
+        if (ht && ti == tl - 1 && compact && !(tm->row_policy & CC_ROWS_ALL_LAST_BLOCK) && few_rows_ok(tm->width)) {
             ct.sel_rows = Bt;
             ct.sel_map = t.eot;
         }
@@ -428,16 +421,6 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
 }  // namespace
 
 extern "C" {
-
-int cc_debug_set_text_compaction(int on) {
-    g_text_compaction = on ? 1 : 0;
-    return CC_OK;
-}
-
-int cc_debug_set_last_block_rows(int on) {
-    g_last_block_rows = on ? 1 : 0;
-    return CC_OK;
-}
 
 size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T) {
     if (!m || B <= 0 || T <= 0 || m->patch <= 0 || m->resolution % m->patch) return 0;

@@ -513,11 +513,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     GEMM_STAMP(3);
 }
 
+extern "C" {
+// arm: up to `cap` launches from now on are bracketed by events (previous records are dropped); cap <= 0 disarms
+int cc_debug_gemm_timing_begin(int cap);
+// disarm; -> number of launches recorded
+int cc_debug_gemm_timing_end(void);
+// launch i: duration in microseconds (the stream must have been synchronised) + its 12-int record (see GemmTiming)
+int cc_debug_gemm_timing_read(int i, float* us_out, int* info12_out);
+}
+
 extern "C" int cc_debug_set_gemm_profile(long long* p) {   // debug only; p [workgroups, 4] int64 device memory or NULL
     return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &p, sizeof(p)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
 
 namespace {
+
+// Debug hook (cc_debug_gemm_timing_*, not part of the public ABI; process-wide, not thread-safe - a measurement aid for
+// bench.py): while armed, every launch of gemm_f16_kernel is bracketed by two HIP events recorded on the launch stream,
+// so that the duration of a kernel symbol can be read IN SITU - inside the eagerly launched step, between its real
+// neighbours - instead of from a stand-alone loop.  Never armed during graph capture.
+struct GemmTiming {
+    bool armed = false;
+    int count = 0, cap = 0;
+    hipEvent_t* ev = nullptr;          // [2 * cap]
+    int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK, M0, N0, K0, M1, N1, K1
+} g_timing;
 
 template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
@@ -532,7 +552,16 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
             configured = true;
         }
     }
+    const int tid = (g_timing.armed && g_timing.count < g_timing.cap) ? g_timing.count++ : -1;
+    if (tid >= 0) {
+        const bool two = total > pr.tiles0;
+        const int rec[12] = {BM, BN, WM, WN, EPI, BK, pr.p[0].M, pr.p[0].N, pr.p[0].K,
+                             two ? pr.p[1].M : 0, two ? pr.p[1].N : 0, two ? pr.p[1].K : 0};
+        memcpy(g_timing.info[tid], rec, sizeof(rec));
+        (void)hipEventRecord(g_timing.ev[2 * tid], st);
+    }
     hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), smem, st, pr);
+    if (tid >= 0) (void)hipEventRecord(g_timing.ev[2 * tid + 1], st);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -1007,6 +1036,37 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
     const int rc = cc_gemm_dispatch2(g, nullptr, EPI_F32_RESID_STATS, tile, static_cast<hipStream_t>(stream), slots);
     *slots_out = slots[0];
     return rc;
+}
+
+int cc_debug_gemm_timing_begin(int cap) {
+    if (g_timing.ev) {
+        for (int i = 0; i < 2 * g_timing.cap; ++i) (void)hipEventDestroy(g_timing.ev[i]);
+        delete[] g_timing.ev;
+        delete[] g_timing.info;
+        g_timing = GemmTiming{};
+    }
+    if (cap <= 0) return CC_OK;
+    g_timing.ev = new hipEvent_t[2 * cap];
+    g_timing.info = new int[cap][12];
+    for (int i = 0; i < 2 * cap; ++i)
+        if (hipEventCreate(&g_timing.ev[i]) != hipSuccess) return CC_ERR_HIP;
+    g_timing.cap = cap;
+    g_timing.armed = true;
+    return CC_OK;
+}
+
+int cc_debug_gemm_timing_end(void) {
+    g_timing.armed = false;
+    return g_timing.count;
+}
+
+int cc_debug_gemm_timing_read(int i, float* us_out, int* info12_out) {
+    if (i < 0 || i >= g_timing.count || !us_out || !info12_out) return CC_ERR_INVALID;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_timing.ev[2 * i], g_timing.ev[2 * i + 1]) != hipSuccess) return CC_ERR_HIP;
+    *us_out = ms * 1e3f;
+    memcpy(info12_out, g_timing.info[i], sizeof(int) * 12);
+    return CC_OK;
 }
 
 }  // extern "C"

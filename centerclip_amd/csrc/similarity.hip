@@ -394,13 +394,16 @@ int cc_loose_similarity_f32(const float* text, const float* visual, const int64_
 // under a stable descending sort.
 __global__ __launch_bounds__(256) void rank_counts_kernel(const float* __restrict__ sim, int rows, int cols,
                                                           int64_t row_stride, int64_t col_stride, int diag_offset,
-                                                          const int* __restrict__ gt_cols, int* __restrict__ counts) {
+                                                          const int* __restrict__ gt_cols, int* __restrict__ counts,
+                                                          const float* __restrict__ ref_vals) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const float* row = sim + (int64_t)i * row_stride;
     const int g = gt_cols ? gt_cols[i] : diag_offset + i;
-    const float d = row[(int64_t)g * col_stride];
+    // ref_vals: the value to rank against is handed in (row-sharded matrices: the ground-truth entry of a COLUMN lives
+    // in another rank's row block) instead of being read from the row itself
+    const float d = ref_vals ? ref_vals[i] : row[(int64_t)g * col_stride];
     int gt = 0, eq = 0, before = 0;
     for (int j = lane; j < cols; j += 64) {
         const float v = row[(int64_t)j * col_stride];
@@ -430,7 +433,16 @@ extern "C" int cc_rank_counts_cols_f32(const float* sim, int32_t rows, int32_t c
                                        int64_t col_stride, const int32_t* gt_cols, int32_t* counts3, void* stream) {
     if (!sim || !counts3 || !gt_cols || rows <= 0 || cols <= 0) return CC_ERR_INVALID;
     hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
-                       cols, row_stride, col_stride, 0, gt_cols, counts3);
+                       cols, row_stride, col_stride, 0, gt_cols, counts3, (const float*)nullptr);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+extern "C" int cc_rank_counts_ref_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
+                                      const float* ref_vals, int32_t* counts, void* stream) {
+    if (!sim || !counts || !ref_vals || rows <= 0 || cols <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
+                       cols, row_stride, col_stride, 0, (const int*)nullptr, counts, ref_vals);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -439,7 +451,7 @@ extern "C" int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, 
                                   int32_t diag_offset, int32_t* counts, void* stream) {
     if (!sim || !counts || rows <= 0 || cols <= 0 || diag_offset < 0 || diag_offset + rows > cols) return CC_ERR_INVALID;
     hipLaunchKernelGGL(rank_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), sim, rows,
-                       cols, row_stride, col_stride, diag_offset, (const int*)nullptr, counts);
+                       cols, row_stride, col_stride, diag_offset, (const int*)nullptr, counts, (const float*)nullptr);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -3,14 +3,17 @@
 
 * all_gather(*tensors) / AllGather: the per-step feature all-gathers + barrier of the reference
   (modules/utils.py:25-64 called at modules/clip4clip.py:351-355) packed into ONE all-gather of a byte buffer - the
-  messages are <= 2 MB (latency-bound over xGMI), so fewer, larger collectives.  Own-shard re-insert semantics as in
-  the reference (utils.py:56: ``gathered_tensor[rank] = tensor``).
+  messages are <= 2 MB (latency-bound over xGMI), so fewer, larger collectives.  Values as in the reference; the
+  reference also splices the INPUT tensor back into its rank's slot (utils.py:56) so that autograd reaches the local
+  shard - all_gather() returns plain gathered bytes (no autograd edge); use AllGather.apply for the differentiable form.
 * PackedFeatures: the same exchange with NO packing step at all - the encoders write their features straight into a
   preallocated record (visual | text | mask), one all_gather_into_tensor moves the records, and the similarity kernel
   reads the gathered records in place (cc_loose_similarity_grouped_f32).
 * shard_rows / gather_rows / sharded_similarity: the eval similarity matrix (main.py:502-534, rank-0 only in the
   reference) row-sharded over ranks: every rank keeps its text rows, receives all pooled video embeddings with one
   all-gather and computes its [Nt/G, Nv] row block with the HIP NT GEMM.
+* gather_varlen / all_gather_ints / all_reduce_: the exchange steps of the clip-sharded evaluation loop
+  (centerclip_amd/eval.py, eval_epoch(shard=True)).
 """
 import torch
 import torch.distributed as dist
@@ -31,8 +34,8 @@ def rank():
 def all_gather(*tensors):
     """Concatenate each tensor over ranks along dim 0 (rank order).  Tensors may differ in dtype and
     trailing shape but must have identical shapes on every rank.  Without an initialised process
-    group this is the identity (world size 1).  The own shard of every result is the input tensor's
-    data (utils.py:56)."""
+    group this is the identity (world size 1).  No autograd edge reaches the inputs (AllGather.apply is the
+    differentiable form, utils.py:25-44)."""
     if not is_dist() or dist.get_world_size() == 1:
         return tensors if len(tensors) > 1 else tensors[0]
     world = dist.get_world_size()
@@ -135,6 +138,44 @@ def gather_rows(local_rows, n_total):
         s, e = shard_rows(n_total, r, world)
         parts.append(out[r, :e - s])
     return torch.cat(parts, 0)
+
+
+def all_gather_ints(values, device):
+    """A few Python ints per rank -> list (rank order) of lists; identity without a process group."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return [list(values)]
+    world = dist.get_world_size()
+    mine = torch.as_tensor(list(values), dtype=torch.long, device=device)
+    out = torch.empty(world * mine.numel(), dtype=torch.long, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.view(world, -1).cpu().tolist()
+
+
+def gather_varlen(rows, tags):
+    """All-gather row blocks whose heights differ per rank (a rank may hold none): rows [n_r, ...], tags [n_r] (any
+    integer tensor travelling with the rows, e.g. dataset positions) -> (rows of all ranks concatenated in rank order,
+    their tags).  Two collectives: the heights, then one padded all_gather_into_tensor per tensor."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return rows, tags
+    world = dist.get_world_size()
+    heights = [h[0] for h in all_gather_ints([rows.shape[0]], rows.device)]
+    maxh = max(max(heights), 1)
+
+    def padded_gather(t):
+        pad = torch.zeros((maxh,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        out = torch.empty((world * maxh,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad)
+        out = out.view((world, maxh) + tuple(t.shape[1:]))
+        return torch.cat([out[r, :heights[r]] for r in range(world)], 0)
+    return padded_gather(rows.contiguous()), padded_gather(tags.to(rows.device).contiguous())
+
+
+def all_reduce_(t, op):
+    """In-place all-reduce ("sum" / "max") over the default group; identity without one."""
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+    return t
 
 
 def sharded_similarity(text_local, pooled_video_local, n_video_total, logit_mult, dot_fn=None):

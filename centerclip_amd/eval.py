@@ -1,12 +1,26 @@
-"""Mirror of the evaluation loop of ``main.py``: eval_epoch (:381-499, the feature-caching half and the metrics) and
-_run_on_single_gpu (:502-534, the similarity matrix).
+"""Mirror of the evaluation loop of ``main.py``: eval_epoch (:381-499 - feature caching, similarity matrix, retrieval
+metrics of both directions, single- and multi-sentence protocols) and _run_on_single_gpu (:502-534).
 
-The reference forms the [Nt, Nv] matrix as len(batch_list_t) x len(batch_list_v) small get_similarity_logits calls with a
-device->host copy each (3,969 of them for MSR-VTT at batch_size_val=16).  Here the cached features are concatenated on
-the device, the videos are pooled / normalised once (they were re-normalised for every text block), and the matrix is
-ONE exact-fp32 MFMA NT GEMM - or, with an initialised process group, this rank's row block of it (dist.sharded_similarity,
-row-sharded over the 8 GPUs of a node; the reference leaves ranks 1..7 idle during eval, main.py:232).  Every entry is
-what the block-by-block loop yields: pooling and the dot product are independent per (text, video) pair.
+Single process (default, ``shard=False`` - what the reference does: it evaluates on rank 0 only, main.py:232,251).  The
+reference forms the [Nt, Nv] matrix as (#text batches x #video batches) small get_similarity_logits calls with a
+device->host copy each (3,969 of them for MSR-VTT at batch_size_val=16).  Here the videos are pooled / normalised once
+per batch as they are cached, the cache is concatenated on the device and the matrix is ONE NT GEMM; the metrics are
+extracted on the device (centerclip_amd.metrics).  No collective is ever issued in this mode, so a ported main.py that
+keeps ``if is_master(): eval_epoch(...)`` does not deadlock under DDP.
+
+Clip-sharded (``shard=True``, EVERY rank calls it).  The encoders are > 99.9 % of the evaluation, so the
+dataset - not the GEMM - is what is sharded:
+  * batches are dealt round robin (batch b -> rank b % G) when every rank iterates the same loader, or taken as they come
+    when the loader carries a ``DistributedSampler(shuffle=False)`` (its padding duplicates are dropped);
+  * every rank keeps its text rows; the pooled + normalised video rows ([Nv, E], 2 MB for 1k videos) are all-gathered
+    once and put in dataset order;
+  * each rank forms its [Nt/G, Nv] row block with the HIP NT GEMM and ranks its rows on the device;
+  * text->video: the per-row counts (3 ints per sentence) are all-gathered;  video->text: the ground-truth entry of a
+    column lives in one rank's block - its values are summed into place with one all-reduce, every rank counts its rows
+    against them (cc_rank_counts_ref_f32) and the counts are all-reduced (multi-sentence: the per-(group, video) maxima
+    are all-reduced with MAX instead, utils/metrics.py:68-76).
+The [Nt, Nv] matrix never exists on one device and never travels.  A sharded loader in the single-process mode, or
+ranks disagreeing on the dataset size, raise instead of returning a silently wrong matrix.
 """
 import time
 
@@ -16,35 +30,64 @@ import torch
 from . import dist as ccdist
 from . import ops
 from . import torch_ops as T
-from .metrics import compute_metrics, tensor_text_to_video_metrics, tensor_video_to_text_sim
+from .metrics import metrics_from_counts, multi_sentence_metrics_from_counts
 
 
-def _similarity_matrix(model, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list):
-    """-> device tensor [Nt, Nv] (the full matrix; world > 1: computed row-sharded and gathered)."""
-    if hasattr(model, 'module'):
-        model = model.module
-    text = torch.cat([s.reshape(s.shape[0], -1) for s in batch_sequence_output_list], 0)     # [b, 1, D] -> [b, D]
-    first_v = batch_visual_output_list[0]
-    if first_v.dim() == 2:                       # eval with pre_visual_pooling: already pooled + normalised
-        pooled = torch.cat(batch_visual_output_list, 0)
-    else:
-        visual = torch.cat(batch_visual_output_list, 0)
-        masks = []
-        for (video_mask, *_tmp), v in zip(batch_list_v, batch_visual_output_list):
-            vm = video_mask.view(-1, video_mask.shape[-1])
-            if vm.shape[1] != v.shape[1]:
-                vm = model.get_video_mask_after_cluster(vm)
-            masks.append(vm)
-        pooled = ops.video_pool_normalize(visual, torch.cat(masks, 0))
-    tn = ops.normalize_rows(text)
-    mult = T.logit_multiplier(model._logit_scale_value())
-    world = ccdist.world_size()
-    if world == 1:
-        return ops.scaled_dot_nt(tn, pooled, mult)
-    # every rank holds the full cached features here (as rank 0 does in the reference); shard the rows of the matrix
-    s, e = ccdist.shard_rows(tn.shape[0])
-    block = ops.scaled_dot_nt(tn[s:e], pooled, mult)
-    return ccdist.gather_rows(block, tn.shape[0])
+class HipBackend:
+    """The device operations of the loop (the product path).  tests/test_dist_cpu.py swaps in a torch-CPU stand-in to run
+    the sharding / collective logic over gloo without a GPU."""
+    normalize_rows = staticmethod(ops.normalize_rows)
+    pool_normalize = staticmethod(ops.video_pool_normalize)
+    dot_nt = staticmethod(ops.scaled_dot_nt)
+
+    @staticmethod
+    def counts_cols(sim, gt_cols):
+        return torch.ops.centerclip.rank_counts_cols(sim.contiguous(), gt_cols)
+
+    @staticmethod
+    def counts_ref_columns(sim, ref_vals):
+        return torch.ops.centerclip.rank_counts_ref(sim, ref_vals.contiguous(), True)
+
+
+class _Cache:
+    """Features of the items this process encoded, with their positions in the dataset."""
+
+    def __init__(self):
+        self.text, self.text_pos, self.video, self.video_pos = [], [], [], []
+
+    def add_text(self, feats, pos):
+        self.text.append(feats.reshape(feats.shape[0], -1))
+        self.text_pos.append(pos)
+
+    def add_video(self, rows, pos):
+        self.video.append(rows)
+        self.video_pos.append(pos)
+
+    @staticmethod
+    def _cat(parts, width, device, dtype):
+        return torch.cat(parts, 0) if parts else torch.zeros((0, width), device=device, dtype=dtype)
+
+
+def _pooled_rows(core, visual_output, video_mask, be):
+    """[b, T', E] per-segment features + the loader's mask -> [b, E] pooled + normalised (clip4clip.py:305-316,357-360);
+    [b, E] inputs (eval with pre_visual_pooling) are already that."""
+    if visual_output.dim() == 2:
+        return visual_output
+    vm = video_mask.view(-1, video_mask.shape[-1])
+    if vm.shape[1] != visual_output.shape[1]:
+        vm = core.get_video_mask_after_cluster(vm)
+    return be.pool_normalize(visual_output.contiguous(), vm.contiguous())
+
+
+def _similarity_matrix(model, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list,
+                       backend=HipBackend):
+    """-> device tensor [Nt, Nv] from the cached per-batch lists (this process' cache only; no collective)."""
+    core = model.module if hasattr(model, 'module') else model
+    text = torch.cat([s.reshape(s.shape[0], -1) for s in batch_sequence_output_list], 0)
+    pooled = torch.cat([_pooled_rows(core, v, masks[0], backend)
+                        for v, masks in zip(batch_visual_output_list, batch_list_v)], 0)
+    mult = T.logit_multiplier(core._logit_scale_value())
+    return backend.dot_nt(backend.normalize_rows(text), pooled, mult)
 
 
 def _run_on_single_gpu(model, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list,
@@ -54,82 +97,176 @@ def _run_on_single_gpu(model, batch_list_t, batch_list_v, batch_sequence_output_
                               batch_visual_output_list).cpu().detach().numpy()
 
 
-def eval_epoch(model, test_dataloader, device, args=None, log=None):
-    """main.py:381-499: cache the features of every batch, form the similarity matrix, report R@1/5/10, MdR, MnR in both
-    directions (single- and multi-sentence protocols).  -> (R1, all_infer_time, info_str).
-    The metrics are extracted on the device (centerclip_amd.metrics); the matrix never travels to the host."""
+def _is_distributed_sampler(loader):
+    from torch.utils.data.distributed import DistributedSampler
+    return isinstance(getattr(loader, "sampler", None), DistributedSampler)
+
+
+def _item_positions(loader, world, rank, shard):
+    """-> (fn(batch index, batch size) -> LongTensor of dataset positions or None when the batch is another rank's,
+           dataset length or None)."""
+    if _is_distributed_sampler(loader):
+        if not shard:
+            raise RuntimeError("eval_epoch: the loader carries a DistributedSampler (every rank sees a different shard) but "
+                               "shard=False forms the matrix from this process' cache alone - pass shard=True on every "
+                               "rank, or evaluate on one rank with an unsharded loader as the reference does")
+        sampler = loader.sampler
+        if getattr(sampler, "shuffle", False):
+            raise RuntimeError("eval_epoch(shard=True) needs DistributedSampler(shuffle=False): retrieval metrics pair row i "
+                               "with video i")
+        order = torch.as_tensor(list(iter(sampler)), dtype=torch.long)
+        n = len(sampler.dataset)
+        seen = [0]
+
+        def positions(bid, b):
+            k = torch.arange(seen[0], seen[0] + b)
+            seen[0] += b
+            pos = order[k]
+            pos[k * sampler.num_replicas + sampler.rank >= n] = -1        # the sampler's padding repeats the head
+            return pos
+        return positions, n
+    seen = [0]
+
+    def positions(bid, b):
+        start = seen[0]
+        seen[0] += b
+        if shard and bid % world != rank:
+            return None
+        return torch.arange(start, start + b)
+    return positions, None
+
+
+def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend):
+    """main.py:381-499 -> (R1, all_infer_time, info_str).  ``shard=True``: clip-sharded over the ranks of the default
+    process group (module docstring) - every rank must call it and every rank returns the same numbers."""
     log = log or (lambda s: None)
-    multi_sentence_ = False
-    cut_off_points_, sentence_num_, video_num_ = [], -1, -1
+    be = backend
+    world, rank = (ccdist.world_size(), ccdist.rank()) if shard else (1, 0)
     ds = test_dataloader.dataset
-    if hasattr(ds, 'multi_sentence_per_video') and ds.multi_sentence_per_video:
-        multi_sentence_ = True
-        cut_off_points_ = [itm - 1 for itm in ds.cut_off_points]
-        sentence_num_, video_num_ = ds.sentence_num, ds.video_num
+    multi = bool(getattr(ds, 'multi_sentence_per_video', False))
+    last_sentence = None                   # multi-sentence protocol: dataset position of the last sentence of each video
+    if multi:
+        last_sentence = [c - 1 for c in ds.cut_off_points]
         log("Eval under the multi-sentence per video clip setting.")
-        log("sentence num: {}, video num: {}".format(sentence_num_, video_num_))
+        log("sentence num: {}, video num: {}".format(ds.sentence_num, ds.video_num))
+        video_of_last = {p: v for v, p in enumerate(last_sentence)}
     core = model.module if hasattr(model, 'module') else model
+    positions, n_items = _item_positions(test_dataloader, world, rank, shard)
+    cache = _Cache()
     model.eval()
+    t_start = time.time()
+    total = 0
     with torch.no_grad():
-        batch_list_t, batch_list_v = [], []
-        batch_sequence_output_list, batch_visual_output_list = [], []
-        total_video_num = 0
-        infer_start_t = time.time()
         for bid, batch in enumerate(test_dataloader):
-            batch = tuple(t.to(device) for t in batch)
-            input_ids, input_mask, segment_ids, video, video_mask = batch
-            if multi_sentence_:
-                b, *_t = video.shape
-                sequence_output = model(input_ids, segment_ids, input_mask)['sequence_output']
-                batch_sequence_output_list.append(sequence_output)
-                batch_list_t.append((input_mask, segment_ids,))
-                s_, e_ = total_video_num, total_video_num + b
-                filter_inds = [itm - s_ for itm in cut_off_points_ if itm >= s_ and itm < e_]
-                if len(filter_inds) > 0:
-                    video, video_mask = video[filter_inds, ...], video_mask[filter_inds, ...]
-                    visual_output = model(video=video, video_mask=video_mask)['visual_output']
-                    batch_visual_output_list.append(visual_output)
-                    batch_list_v.append((video_mask,))
-                total_video_num += b
-            else:
-                output = model(input_ids, segment_ids, input_mask, video, video_mask)
-                batch_sequence_output_list.append(output['sequence_output'])
-                batch_list_t.append((input_mask, segment_ids,))
-                batch_visual_output_list.append(output['visual_output'])
-                batch_list_v.append((video_mask,))
+            b = batch[0].shape[0]
+            pos = positions(bid, b)
+            total += b
+            if pos is None:
+                continue
+            keep = (pos >= 0).nonzero().flatten()
+            if keep.numel() == 0:
+                continue
+            if keep.numel() < b:                       # (only a DistributedSampler's padded tail)
+                batch, pos = tuple(t[keep] for t in batch), pos[keep]
+            input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
+            if not multi:
+                out = model(input_ids, segment_ids, input_mask, video, video_mask)
+                cache.add_text(out['sequence_output'], pos)
+                cache.add_video(_pooled_rows(core, out['visual_output'], video_mask, be), pos)
+                continue
+            cache.add_text(model(input_ids, segment_ids, input_mask)['sequence_output'], pos)
+            rows = [i for i, p in enumerate(pos.tolist()) if p in video_of_last]      # items that carry their clip's video
+            if rows:
+                vout = model(video=video[rows, ...], video_mask=video_mask[rows, ...])['visual_output']
+                cache.add_video(_pooled_rows(core, vout, video_mask[rows, ...], be),
+                                torch.as_tensor([video_of_last[int(pos[i])] for i in rows], dtype=torch.long))
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        all_infer_time = time.time() - infer_start_t
+        all_infer_time = time.time() - t_start
         log('The total model inference time of the program is {:.2f} Seconds\n'.format(all_infer_time))
         if args is not None and getattr(args, "inference_speed_test", False):
             return 0
-        sim = _similarity_matrix(core, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list)
-    if multi_sentence_:
-        log("before reshape, sim matrix size: {} x {}".format(sim.shape[0], sim.shape[1]))
-        cut_off_points2len_ = [itm + 1 for itm in cut_off_points_]
-        bounds = list(zip([0] + cut_off_points2len_[:-1], cut_off_points2len_))
-        max_length = max(e_ - s_ for s_, e_ in bounds)
-        sim3 = torch.full((len(bounds), max_length, sim.shape[1]), float("-inf"), device=sim.device)
-        for g, (s_, e_) in enumerate(bounds):
-            sim3[g, :e_ - s_] = sim[s_:e_]
-        log("after reshape, sim matrix size: {} x {} x {}".format(*sim3.shape))
-        tv_metrics = tensor_text_to_video_metrics(sim3)
-        vt_metrics = compute_metrics(tensor_video_to_text_sim(sim3))
+        n_text = n_items if n_items is not None else total
+        n_video = len(last_sentence) if multi else n_text
+        tv_metrics, vt_metrics, shape = _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world, be)
+    if multi:
+        log("sim matrix size: {} sentences x {} videos ({} groups)".format(shape[0], shape[1], n_video))
     else:
-        log("sim matrix size: {}, {}".format(sim.shape[0], sim.shape[1]))
-        tv_metrics = compute_metrics(sim)
-        vt_metrics = compute_metrics(sim.T)
-        log('\t Length-T: {}, Length-V:{}'.format(sim.shape[0], sim.shape[1]))
-    info_str = ["Text-to-Video:",
-                ' (metric) >>>  R@1: {:.1f} - R@5: {:.1f} - R@10: {:.1f} - Median R: {:.1f} - Mean R: {:.1f}'.format(
-                    tv_metrics['R1'], tv_metrics['R5'], tv_metrics['R10'], tv_metrics['MR'], tv_metrics['MeanR']),
-                "Video-to-Text:",
-                ' (metric) >>>  V2T$R@1: {:.1f} - V2T$R@5: {:.1f} - V2T$R@10: {:.1f} - V2T$Median R: {:.1f} - '
-                'V2T$Mean R: {:.1f}'.format(vt_metrics['R1'], vt_metrics['R5'], vt_metrics['R10'], vt_metrics['MR'],
-                                            vt_metrics['MeanR'])]
-    for info in info_str:
-        log(info)
+        log("sim matrix size: {}, {}".format(*shape))
+        log('\t Length-T: {}, Length-V:{}'.format(*shape))
+    fmt = ' (metric) >>>  {p}R@1: {:.1f} - {p}R@5: {:.1f} - {p}R@10: {:.1f} - {p}Median R: {:.1f} - {p}Mean R: {:.1f}'
+    keys = ('R1', 'R5', 'R10', 'MR', 'MeanR')
+    info_str = ["Text-to-Video:", fmt.format(*[tv_metrics[k] for k in keys], p=""),
+                "Video-to-Text:", fmt.format(*[vt_metrics[k] for k in keys], p="V2T$")]
+    for line in info_str:
+        log(line)
     return tv_metrics['R1'], all_infer_time, info_str
 
 
-__all__ = ["eval_epoch", "_run_on_single_gpu", "np"]
+def _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world, be):
+    """Row block of the similarity matrix for this process' text rows + the rank metrics of both directions.  world == 1:
+    the block is the whole matrix and no collective runs.  -> (tv_metrics, vt_metrics, (Nt, Nv))."""
+    text_pos = torch.cat(cache.text_pos) if cache.text_pos else torch.zeros(0, dtype=torch.long)
+    video_pos = torch.cat(cache.video_pos) if cache.video_pos else torch.zeros(0, dtype=torch.long)
+    E = (cache.text[0] if cache.text else cache.video[0]).shape[-1] if (cache.text or cache.video) else 0
+    if world > 1:                                       # ranks must agree on the geometry before any payload moves
+        sizes = ccdist.all_gather_ints([n_text, n_video, E, len(text_pos), len(video_pos)], device)
+        if len({tuple(s[:2]) for s in sizes}) != 1:
+            raise RuntimeError("eval_epoch(shard=True): ranks disagree on the dataset size %s" % (sizes,))
+        E = max(s[2] for s in sizes)
+        if sum(s[3] for s in sizes) != n_text or sum(s[4] for s in sizes) != n_video:
+            raise RuntimeError("eval_epoch(shard=True): the ranks' shards do not add up to the dataset (%s) - every rank "
+                               "must iterate the same unsharded loader or a DistributedSampler(shuffle=False)" % (sizes,))
+    text = _Cache._cat(cache.text, E, device, torch.float32)
+    local_video = _Cache._cat(cache.video, E, device, torch.float32)
+    # ---- exchange step: all pooled video rows, in dataset order
+    if world > 1:
+        rows, pos = ccdist.gather_varlen(local_video, video_pos.to(device))
+        video_all = torch.empty(n_video, E, device=device, dtype=torch.float32)
+        video_all[pos] = rows
+    else:
+        video_all = torch.empty_like(local_video)
+        video_all[video_pos.to(device)] = local_video
+    text_pos = text_pos.to(device)
+    if last_sentence is None:
+        gt_cols = text_pos
+    else:                                               # sentence at position p describes video #{cut points < p}
+        bounds = torch.as_tensor(last_sentence, device=device)
+        gt_cols = torch.searchsorted(bounds, text_pos)
+    mult = T.logit_multiplier(core._logit_scale_value())
+    nloc = text.shape[0]
+    block = be.dot_nt(be.normalize_rows(text), video_all, mult) if nloc else torch.zeros(0, n_video, device=device)
+    # ---- text -> video: rank of the ground-truth column in every local row
+    c3 = be.counts_cols(block, gt_cols.to(torch.int32)) if nloc else torch.zeros(0, 3, dtype=torch.int32, device=device)
+    truth = block.gather(1, gt_cols.view(-1, 1)).squeeze(1) if nloc else torch.zeros(0, device=device)
+    rec = torch.cat([text_pos.view(-1, 1).to(torch.float64), c3.to(torch.float64), truth.view(-1, 1).to(torch.float64)], 1)
+    if world > 1:
+        rec, _ = ccdist.gather_varlen(rec, text_pos)
+    order = torch.argsort(rec[:, 0])
+    rec = rec[order].cpu().numpy()
+    counts_tv, truth_all = rec[:, 1:4].astype(np.int64), rec[:, 4]
+    if last_sentence is None:
+        tv = metrics_from_counts(counts_tv[:, :2])
+        # ---- video -> text: column v against its ground-truth entry sim[v, v], owned by the rank that holds text row v
+        ref = torch.zeros(n_video, device=device)
+        ref[text_pos] = truth
+        if world > 1:
+            ccdist.all_reduce_(ref, "sum")
+        c2 = (be.counts_ref_columns(block, ref) if nloc else torch.zeros(n_video, 2, dtype=torch.int32, device=device)).long()
+        if world > 1:
+            ccdist.all_reduce_(c2, "sum")
+        vt = metrics_from_counts(c2)
+    else:
+        tv = multi_sentence_metrics_from_counts(counts_tv, np.isfinite(truth_all))
+        # ---- video -> text: best sentence of every group per video (utils/metrics.py:68-76), then ranks of the diagonal
+        best = torch.full((n_video, n_video), float("-inf"), device=device)              # [group, video]
+        if nloc:
+            clean = torch.where(block != block, torch.full_like(block, float("-inf")), block)
+            best.scatter_reduce_(0, gt_cols.view(-1, 1).expand(-1, n_video), clean, "amax", include_self=True)
+        if world > 1:
+            ccdist.all_reduce_(best, "max")
+        vt = metrics_from_counts(be.counts_cols(best.t().contiguous(), torch.arange(n_video, dtype=torch.int32, device=device))[:, :2])
+    return tv, vt, (n_text, n_video)
+
+
+__all__ = ["eval_epoch", "_run_on_single_gpu", "HipBackend", "np"]

@@ -57,8 +57,14 @@ def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10)):
     counts = torch.ops.centerclip.rank_counts_cols(x.view(G * Lmax, C), gt)
     truth = x.reshape(G * Lmax, C).gather(1, gt.long().unsqueeze(1)).squeeze(1)
     valid = torch.isfinite(truth).cpu().numpy()
-    c = counts.cpu().numpy().astype(np.int64)
-    ranks = (c[:, 0] + c[:, 2])[valid]
+    return multi_sentence_metrics_from_counts(counts.cpu().numpy(), valid, top_k)
+
+
+def multi_sentence_metrics_from_counts(counts3, valid, top_k=(1, 5, 10)):
+    """The dict tensor_text_to_video_metrics returns, from per-sentence (#greater, #equal, #equal before) counts and the
+    mask of real (non-padding, finite ground truth) sentences; the order of the sentences does not matter."""
+    c = np.asarray(counts3).astype(np.int64)
+    ranks = (c[:, 0] + c[:, 2])[np.asarray(valid, dtype=bool)]
     # the reference divides torch tensors here, i.e. in fp32 (metrics.py:58)
     res = {"R%d" % k: float(np.float32(np.sum(ranks < k) * 100) / np.float32(len(ranks))) for k in top_k}
     res["MedianR"] = float(np.sort(ranks + 1)[(len(ranks) - 1) // 2])          # torch.median: the lower middle value

@@ -837,6 +837,23 @@ def _(sim, gt_cols):
     return sim.new_empty((sim.shape[0], 3), dtype=torch.int32)
 
 
+@custom_op(NS + "::rank_counts_ref", mutates_args=(), device_types="cuda")
+def rank_counts_ref(sim: torch.Tensor, ref_vals: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """(#greater, #equal) than ref_vals[i] per row of sim (per COLUMN with transpose=True, through the strides): the
+    partial video->text counts of a row block of the similarity matrix (clip-sharded eval)."""
+    rows, cols = (sim.shape[1], sim.shape[0]) if transpose else sim.shape
+    rs, cs = (sim.stride(1), sim.stride(0)) if transpose else (sim.stride(0), sim.stride(1))
+    counts = _e(rows, 2, like=sim, dtype=torch.int32)
+    L.check(L.lib().cc_rank_counts_ref_f32(L.ptr(sim), rows, cols, rs, cs, L.ptr(ref_vals), L.ptr(counts), _st(sim)),
+            "cc_rank_counts_ref_f32")
+    return counts
+
+
+@rank_counts_ref.register_fake
+def _(sim, ref_vals, transpose):
+    return sim.new_empty((sim.shape[1] if transpose else sim.shape[0], 2), dtype=torch.int32)
+
+
 @custom_op(NS + "::contrastive_loss", mutates_args=(), device_types="cuda")
 def contrastive_loss(sim: torch.Tensor) -> torch.Tensor:
     """CrossEn(sim), CrossEn(sim.T) and their mean (modules/losses.py:8-18, clip4clip.py:250-253) -> [3] fp32."""
@@ -858,7 +875,7 @@ OPS = ("contrastive_loss", "spectral_laplacian", "spectral_graph_laplacian", "sp
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",
-       "rank_counts_cols")
+       "rank_counts_cols", "rank_counts_ref")
 
 
 def logit_multiplier(logit_scale):

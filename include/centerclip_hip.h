@@ -370,6 +370,12 @@ int cc_fold_layernorm_linear_f32(const float* weight, const float* bias, const f
 
 #define CC_MAX_LAYERS 32
 
+/* cc_vit_model.row_policy / cc_text_model.row_policy: compute rows whose values nothing downstream reads, exactly as the
+ * reference does (bench.py and the tests time / compare both forms; results agree bit for bit for the text rows and to the
+ * rounding of the fp16 intermediates for the last block). */
+#define CC_ROWS_ALL_TEXT        1   /* text tower: every token row, not only those up to each caption's EOT            */
+#define CC_ROWS_ALL_LAST_BLOCK  2   /* last block of the tower: every row behind the attention, not only CLS / EOT rows */
+
 /* VisualTransformer + the ln_post/proj tail of CLIP.encode_image (modules/clip.py:272-349,460-469) */
 typedef struct cc_vit_model {
     int32_t layers, width, heads, patch, resolution, embed_dim;
@@ -391,6 +397,9 @@ typedef struct cc_vit_model {
     /* optional HOST array [layers]: the TokenClusterInter variant of block i (N2); NULL = medoid gather
      * everywhere.  For CC_CLUSTER_POOLING cluster_tokens[i] must equal the incoming token count. */
     const struct cc_cluster_variant* cluster_variants;
+    /* CC_ROWS_* bits; 0 = the shipped policy (the last block computes out_proj / c_fc / c_proj for the rows the
+     * projection head reads).  Per model, not process state: two models with different policies can run side by side. */
+    int32_t row_policy;
 } cc_vit_model;
 
 /* Frame input descriptor for the *_frames entry points.  The reference's evaluation
@@ -431,6 +440,7 @@ typedef struct cc_text_model {
     const float* ln_final_weight; const float* ln_final_bias;
     const float* text_projection;         /* [W, embed_dim]    */
     const cc_block_weights* blocks;       /* HOST array [layers] */
+    int32_t row_policy;                   /* CC_ROWS_* bits; 0 = shipped policy */
 } cc_text_model;
 
 size_t cc_text_workspace_bytes(const cc_text_model* m, int32_t Bt, int32_t Lt);
@@ -539,6 +549,14 @@ int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, int64_t row
  * ground truth among its ties under a stable descending sort; the reference's argsort leaves that order open). */
 int cc_rank_counts_cols_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
                             const int32_t* gt_cols, int32_t* counts3, void* stream);
+
+/* The same against a reference value handed in per row (ref_vals [rows] fp32, device): counts [rows,2] = #entries of the
+ * row greater than / equal to ref_vals[i].  For the clip-sharded evaluation: a rank holds a ROW block
+ * [Nt/G, Nv] of the matrix of main.py:502-534; the video->text rank of video v counts, over all text rows, the entries of
+ * column v above the ground-truth entry, which lives in one rank's block - every rank counts its rows against the
+ * broadcast ground-truth values (swap the strides to walk columns) and the per-rank counts are summed. */
+int cc_rank_counts_ref_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
+                           const float* ref_vals, int32_t* counts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,10 @@ one process per GPU, backend nccl (= RCCL).  Checks, against data every rank can
   * dist.PackedFeatures: ONE all_gather_into_tensor of the preallocated records, logits read in place
   * dist.all_gather / AllGather (reference semantics, modules/utils.py:25-64) incl. the own-shard backward slice
   * dist.sharded_similarity with the HIP NT GEMM == the single-rank matrix
-Prints NCCL_WORKER_OK world=<n> on rank 0."""
+  * eval.eval_epoch(shard=True) (clip-sharded evaluation loop, HIP kernels + the collectives) == the single-process
+    eval_epoch on rank 0, single- and multi-sentence protocols
+``--share-gpu``: every rank uses cuda:0 and the collectives run over gloo (a 1-GPU box can still drive world 2 through the
+HIP-backed loop).  Prints NCCL_WORKER_OK world=<n> on rank 0."""
 import os
 import sys
 
@@ -23,11 +26,50 @@ def feats(rank, B, Tn, E):
     return vis, seq, mask
 
 
+class _Loader(list):
+    pass
+
+
+def sharded_eval_leg(rank, world, dev):
+    """Every rank: eval_epoch(shard=True) over the same list-backed loader (batches dealt round robin); rank 0 alone: the
+    single-process form (no collective).  Same R@1 and metric strings."""
+    from argparse import Namespace
+    import numpy as np
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd.eval import eval_epoch
+    from oracle.recipes import EVAL_CASES, eval_case_batches
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "r2_golden.npz"))
+    sd = {k[6:]: torch.from_numpy(g2[k].astype(np.float32) if g2[k].dtype == np.float16 else g2[k])
+          for k in g2.files if k.startswith("s1_sd/")}
+    cfg = g2["s1_cfg"]
+    T = int(cfg[11])
+    a = Namespace(cluster_inter=0, deep_cluster=0, cluster_algo='kmediods++', max_frames=T, target_frames_blocks=[T, T, T],
+                  cluster_num_blocks=[16, 6, 6], cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                  minkowski_norm_p=2.0, aggregation=None, pretrained_clip_name='ViT-B/32', pre_norm=False, loose_type=True,
+                  sim_header='meanP', linear_patch='2d', pre_visual_pooling=0)
+    model = CLIP4Clip.from_state_dict(sd, a).to(dev).eval()
+    for name in sorted(EVAL_CASES):
+        batches, attrs = eval_case_batches(EVAL_CASES[name], cfg)
+        loader = _Loader(batches)
+        loader.dataset = Namespace(**attrs)
+        got = eval_epoch(model, loader, dev, shard=True)
+        box = [eval_epoch(model, loader, dev) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        want = box[0]
+        assert abs(got[0] - want[0]) < 1e-9 and list(got[2]) == list(want[2]), (name, got, want)
+
+
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    share = "--share-gpu" in sys.argv
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if share:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     from centerclip_amd import ops
     from centerclip_amd.dist import AllGather, PackedFeatures, all_gather, gather_rows, shard_rows, sharded_similarity
     B, Tn, E = 16, 3, 512
@@ -62,6 +104,7 @@ def main():
     block = sharded_similarity(t[t0:t1], v[v0:v1], Nv, 2.0)
     full = gather_rows(block, Nt)
     assert torch.equal(full, ops.scaled_dot_nt(t, v, 2.0)), "sharded similarity"
+    sharded_eval_leg(rank, world, dev)
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

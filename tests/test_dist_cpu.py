@@ -145,3 +145,191 @@ def test_packed_features_single_process_is_a_view():
     pf.vis.fill_(2.0)
     assert pf.gather().data_ptr() == pf.send.data_ptr() and pf.recv is pf.send
     assert pf.vis.shape == (12, 8) and pf.seq.shape == (4, 8) and pf.mask.shape == (4, 3) and pf.mask.dtype == torch.long
+
+
+# ------------------------------------------------------------------------------------------------ clip-sharded eval loop
+class _TorchBackend:
+    """Torch-CPU stand-in for eval.HipBackend (same semantics as the HIP ops) so that the sharding / collective logic of
+    eval_epoch(shard=True) runs over gloo without a GPU.  Test infrastructure only."""
+
+    @staticmethod
+    def normalize_rows(x):
+        return x / x.norm(dim=-1, keepdim=True)
+
+    @staticmethod
+    def pool_normalize(v, m):
+        v = v / v.norm(dim=-1, keepdim=True)
+        m = m.to(torch.float).unsqueeze(-1)
+        s = m.sum(dim=1)
+        s[s == 0.] = 1.
+        v = (v * m).sum(dim=1) / s
+        return v / v.norm(dim=-1, keepdim=True)
+
+    @staticmethod
+    def dot_nt(a, b, mult):
+        return mult * a @ b.t()
+
+    @staticmethod
+    def counts_cols(sim, gt):
+        d = sim.gather(1, gt.long().view(-1, 1))
+        before = (sim == d) & (torch.arange(sim.shape[1])[None, :] < gt.long().view(-1, 1))
+        return torch.stack([(sim > d).sum(1), (sim == d).sum(1), before.sum(1)], 1).to(torch.int32)
+
+    @staticmethod
+    def counts_ref_columns(sim, ref):
+        return torch.stack([(sim > ref[None, :]).sum(0), (sim == ref[None, :]).sum(0)], 1).to(torch.int32)
+
+
+class _TableModel(torch.nn.Module):
+    """Stands in for CLIP4Clip: features are looked up from the inputs (ids carry a row number, 'frames' are features)."""
+
+    def __init__(self, E=8):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.table = torch.randn(64, E, generator=g)
+
+    def forward(self, input_ids=None, token_type_ids=None, attention_mask=None, video=None, video_mask=None):
+        out = {'sequence_output': None, 'visual_output': None}
+        if input_ids is not None:
+            out['sequence_output'] = self.table[input_ids.view(-1, input_ids.shape[-1])[:, 0]].unsqueeze(1)
+        if video is not None:
+            out['visual_output'] = video[:, 0].float()                  # [b, T, E]
+        return out
+
+    def get_video_mask_after_cluster(self, m):
+        return m
+
+    def _logit_scale_value(self):
+        return 0.5
+
+
+def _eval_dataset(multi, E=8, T=3):
+    """11 single-caption clips, or 5 clips with 3/1/4/2/3 sentences (13 items).  item = (ids, mask, seg, video, vmask)."""
+    g = torch.Generator().manual_seed(17)
+    sentences = [3, 1, 4, 2, 3] if multi else [1] * 11
+    videos = torch.randn(len(sentences), 1, T, E, generator=g)
+    vmask = torch.ones(len(sentences), 1, T, dtype=torch.long)
+    vmask[1, 0, T - 1] = 0
+    items = []
+    for v, ns in enumerate(sentences):
+        for _ in range(ns):
+            ids = torch.zeros(1, 4, dtype=torch.long)
+            ids[0, 0] = int(torch.randint(0, 64, (1,), generator=g))
+            items.append((ids, (ids >= 0).long(), torch.zeros_like(ids), videos[v], vmask[v]))
+    attrs = {}
+    if multi:
+        attrs = dict(multi_sentence_per_video=True, cut_off_points=list(torch.tensor(sentences).cumsum(0).tolist()),
+                     sentence_num=len(items), video_num=len(sentences))
+    return items, attrs
+
+
+class _Items(torch.utils.data.Dataset):
+    def __init__(self, items, attrs):
+        self.items = items
+        for k, v in attrs.items():
+            setattr(self, k, v)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def case_sharded_eval(rank, world):
+    """eval_epoch(shard=True) on 2 ranks == eval_epoch(shard=False) on one: batches dealt round robin over an unsharded
+    loader, and a DistributedSampler loader (11 / 13 items: the sampler pads, the padding must be dropped).  shard=False
+    issues no collective although a process group is up (rank 0 calls it alone), and refuses a DistributedSampler loader."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from centerclip_amd.eval import eval_epoch
+    model = _TableModel()
+    dev = torch.device("cpu")
+    ok = True
+    for multi in (False, True):
+        items, attrs = _eval_dataset(multi)
+        ds = _Items(items, attrs)
+        plain = DataLoader(ds, batch_size=3, shuffle=False)
+        want = None
+        if rank == 0:                                                # single-process form, called by ONE rank only
+            want = eval_epoch(model, plain, dev, backend=_TorchBackend)
+        box = [want]
+        dist.broadcast_object_list(box, src=0)
+        want = box[0]
+        got_rr = eval_epoch(model, plain, dev, shard=True, backend=_TorchBackend)
+        sharded = DataLoader(ds, batch_size=3, sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False))
+        got_ds = eval_epoch(model, sharded, dev, shard=True, backend=_TorchBackend)
+        for got in (got_rr, got_ds):
+            ok = ok and abs(got[0] - want[0]) < 1e-9 and list(got[2]) == list(want[2])
+        try:
+            eval_epoch(model, sharded, dev, backend=_TorchBackend)
+            ok = False
+        except RuntimeError as exc:
+            ok = ok and "DistributedSampler" in str(exc)
+    return bool(ok)
+
+
+def test_clip_sharded_eval_epoch_world2():
+    assert all(_run("case_sharded_eval").values())
+
+
+def test_eval_epoch_torch_backend_matches_numpy_reference_definition():
+    """The stand-in backend + the loop (world 1) against the metric definitions of utils/metrics.py restated in NumPy - so
+    that the world-2 comparison above is anchored to something independent of the loop itself."""
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from centerclip_amd.eval import eval_epoch
+    model = _TableModel()
+    items, attrs = _eval_dataset(False)
+    r1, _, info = eval_epoch(model, DataLoader(_Items(items, attrs), batch_size=4), torch.device("cpu"), backend=_TorchBackend)
+    text = torch.stack([model.table[it[0][0, 0]] for it in items])
+    vis = _TorchBackend.pool_normalize(torch.stack([it[3][0] for it in items]), torch.stack([it[4][0] for it in items]))
+    sim = (torch.exp(torch.tensor(0.5)) * _TorchBackend.normalize_rows(text) @ vis.t()).numpy()
+
+    def ranks(x):
+        sx = np.sort(-x, axis=1)
+        return np.where(sx - np.diag(-x)[:, None] == 0)[1]
+    ind_tv, ind_vt = ranks(sim), ranks(sim.T)
+    assert abs(r1 - 100.0 * np.mean(ind_tv == 0)) < 1e-9
+    assert info[1].endswith("Mean R: {:.1f}".format(np.mean(ind_tv) + 1)) and info[3].endswith("Mean R: {:.1f}".format(np.mean(ind_vt) + 1))
+
+
+@pytest.mark.parametrize("name", ["multi", "single"])
+def test_eval_epoch_metric_strings_against_reference_fixture(name):
+    """The loop's metric logic and string format against the reference's own eval_epoch output (tests/golden/r3_golden.npz):
+    the reference's similarity matrix is handed to the loop in place of its GEMM (torch stand-in backend; the HIP kernels are
+    pinned the same way in tests/test_r3_gpu.py)."""
+    import numpy as np
+    from argparse import Namespace
+    from centerclip_amd.eval import eval_epoch
+    from oracle.recipes import EVAL_CASES, eval_case_batches
+    here = os.path.dirname(os.path.abspath(__file__))
+    g3 = np.load(os.path.join(here, "golden", "r3_golden.npz"))
+    cfg = np.load(os.path.join(here, "golden", "r2_golden.npz"))["s1_cfg"]
+    batches, attrs = eval_case_batches(EVAL_CASES[name], cfg)
+    ref = torch.from_numpy(g3[f"ev_{name}_sim"])
+
+    class Model(torch.nn.Module):                       # any features: the matrix is supplied
+        def forward(self, input_ids=None, token_type_ids=None, attention_mask=None, video=None, video_mask=None):
+            out = {'sequence_output': None, 'visual_output': None}
+            if input_ids is not None:
+                out['sequence_output'] = torch.ones(input_ids.shape[0], 1, 4)
+            if video is not None:
+                out['visual_output'] = torch.ones(video.shape[0], video.shape[2], 4)
+            return out
+
+        def get_video_mask_after_cluster(self, m):
+            return m
+
+        def _logit_scale_value(self):
+            return 0.0
+
+    class Given(_TorchBackend):
+        dot_nt = staticmethod(lambda a, b, mult: ref.clone())
+
+    class Loader(list):
+        pass
+    loader = Loader(batches)
+    loader.dataset = Namespace(**attrs)
+    r1, _, info = eval_epoch(Model(), loader, torch.device("cpu"), backend=Given)
+    assert list(info) == [str(s) for s in g3[f"ev_{name}_info"]] and abs(r1 - float(g3[f"ev_{name}_r1"])) < 1e-4

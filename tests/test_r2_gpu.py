@@ -4,7 +4,7 @@
     with zeros, a fully masked clip), the training branch's loss values, CrossEn                   [S1, S2, N4]
   * block-level API: ResidualAttentionBlock.forward / Transformer.forward on LND activations, return_hidden,
     CLIP.forward                                                                                    [V2, boundary]
-  * the eval loop: the reference's call sequence main.py:430-449,511-524 against eval._run_on_single_gpu   [S3]
+  * the eval loop on a toy dataset (the reference-generated matrices are in tests/test_r3_gpu.py)               [S3]
   * similarity at the north-star size 10k x 1k (and a ragged 9,999 x 1,003) vs the oracle, + rank counts   [S3, N1]
   * pre_norm=True: reference fixture (bit-exact) and objective gap vs the oracle on generic floats   [C2]
   * folded LayerNorm on rows with |mean| / sigma = 10, 100 and 100x outlier channels                [V2]
@@ -229,9 +229,8 @@ def test_return_hidden_and_clip_forward(gc):
 
 def test_caption_compaction_is_bit_identical_to_all_rows(gc):
     """The text tower runs on the rows up to each caption's EOT (found on the device); the features equal the all-rows
-    run bit for bit - also for a caption without padding, one of length 1, both towers paired, and through the debug
-    switch that turns the compaction off."""
-    from centerclip_amd import _lib as L
+    run bit for bit - also for a caption without padding, one of length 1, both towers paired, and through the row
+    policy that turns the compaction off."""
     model, sd, T = small_clip(gc, cluster=True)
     CTX, VOCAB = int(gc["cfg"][5]), int(gc["cfg"][6])
     gen = torch.Generator().manual_seed(4)
@@ -243,25 +242,18 @@ def test_caption_compaction_is_bit_identical_to_all_rows(gc):
             ids[b, 1:ln - 1] = torch.randint(1, VOCAB - 2, (max(ln - 2, 0),), generator=gen)
         ids[b, ln - 1] = VOCAB - 1                                   # EOT = largest id, at position ln - 1
     ids = ids.to(DEV)
-    lib = L.lib()
     # (the last block's row selection is a separate saving with its own test; off here so that both forms run the same GEMMs)
-    assert lib.cc_debug_set_last_block_rows(0) == 0
-    try:
+    with model.row_policy(all_last_block_rows=True):
         feat = model.encode_text(ids)
         dense_feat, hidden = model.encode_text(ids, return_hidden=True)   # the all-rows path (hidden state requested)
         assert torch.equal(feat, dense_feat)
-        assert lib.cc_debug_set_text_compaction(0) == 0
-        try:
+        video = torch.from_numpy(gc["video"]).to(DEV)
+        with model.row_policy(all_text_rows=True, all_last_block_rows=True):
             off = model.encode_text(ids)
-            video = torch.from_numpy(gc["video"]).to(DEV)
             v_off, t_off = model.encode_pair(video, ids[:3], video_frame=T)
-        finally:
-            lib.cc_debug_set_text_compaction(1)
         assert torch.equal(feat, off)
         v_on, t_on = model.encode_pair(video, ids[:3], video_frame=T)
         assert torch.equal(t_on, t_off) and torch.equal(v_on, v_off)
-    finally:
-        lib.cc_debug_set_last_block_rows(1)
     ref = clo.text_forward(sd, ids.cpu())
     assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3
     # hidden rows behind the EOT exist in the all-rows run (the reference computes them too)
@@ -274,8 +266,6 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
     GEMMs (another K split, another partition of the LayerNorm partial sums), which can flip the rounding of an fp16
     intermediate (the QuickGELU output, the fp16 copy of the residual row): observed <= 8e-5 relative on a few rows, 5e-6
     typically; asserted at 2e-4, and both forms are equally far from the fp32 oracle (checked below for the text tower)."""
-    from centerclip_amd import _lib as L
-    lib = L.lib()
     for cluster in (True, False):
         model, sd, T = small_clip(gc, cluster=cluster)
         video = torch.from_numpy(gc["video"]).to(DEV)
@@ -283,18 +273,12 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
         v_sel, t_sel = model.encode_pair(video, ids, video_frame=T)
         only_v = model.encode_image(video, video_frame=T)[0]
         only_t = model.encode_text(ids)
-        assert lib.cc_debug_set_last_block_rows(0) == 0
-        try:
+        with model.row_policy(all_last_block_rows=True):
             v_all, t_all = model.encode_pair(video, ids, video_frame=T)
-        finally:
-            lib.cc_debug_set_last_block_rows(1)
         full_v, hid_v = model.encode_image(video, video_frame=T, return_hidden=True)
         # the towers in different modes (captions not compacted -> all text rows, CLS rows only on the visual side)
-        assert lib.cc_debug_set_text_compaction(0) == 0
-        try:
+        with model.row_policy(all_text_rows=True):
             v_mix, t_mix = model.encode_pair(video, ids, video_frame=T)
-        finally:
-            lib.cc_debug_set_text_compaction(1)
         for a, b in ((v_sel, v_all), (t_sel, t_all), (only_v, v_all), (only_t, t_all), (full_v, v_all), (v_mix, v_all),
                      (t_mix, t_all)):
             assert a.shape == b.shape and relerr(a.cpu(), b.cpu()) < 2e-4
@@ -311,11 +295,8 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
         ids[b, eot[b] + 1:] = 0
     ids = ids.to(DEV)
     v_sel, t_sel = model.encode_pair(video, ids, video_frame=T)
-    assert lib.cc_debug_set_last_block_rows(0) == 0
-    try:
+    with model.row_policy(all_last_block_rows=True):
         v_all, t_all = model.encode_pair(video, ids, video_frame=T)
-    finally:
-        lib.cc_debug_set_last_block_rows(1)
     assert v_sel.shape[0] == 70 and relerr(v_sel.cpu(), v_all.cpu()) < 2e-4 and relerr(t_sel.cpu(), t_all.cpu()) < 2e-4
     ref = nrm(clo.text_forward(sd, ids.cpu()))
     e_sel, e_all = (nrm(t_sel.cpu()) - ref).abs().max(), (nrm(t_all.cpu()) - ref).abs().max()
@@ -323,53 +304,7 @@ def test_last_block_runs_on_the_rows_the_heads_read(gc):
 
 
 # ------------------------------------------------------------------------------------------------ eval loop (S3)
-def test_run_on_single_gpu_follows_the_reference_call_sequence(g):
-    """main.py:430-449 (cache the features batch by batch) and :511-524 (get_similarity_logits per text-batch x video-batch
-    pair) executed verbatim against the mirror, compared with eval._run_on_single_gpu (one NT GEMM) and the oracle."""
-    from centerclip_amd.eval import _run_on_single_gpu
-    model = s1_model(g)
-    T = int(g["s1_cfg"][11])
-    gen = torch.Generator().manual_seed(9)
-    RES, CTX, VOCAB = int(g["s1_cfg"][1]), int(g["s1_cfg"][5]), int(g["s1_cfg"][6])
-    batches = []
-    for nb in (3, 3, 2):                                             # a ragged last batch
-        video = torch.randn(nb, 1, T, 3, RES, RES, generator=gen)
-        vmask = torch.ones(nb, 1, T, dtype=torch.long)
-        vmask[0, 0, 2:] = 0
-        ids = torch.zeros(nb, 1, CTX, dtype=torch.long)
-        for b in range(nb):
-            ln = int(torch.randint(4, CTX + 1, (1,), generator=gen))
-            ids[b, 0, 0], ids[b, 0, ln - 1] = VOCAB - 2, VOCAB - 1
-            ids[b, 0, 1:ln - 1] = torch.randint(1, VOCAB - 2, (ln - 2,), generator=gen)
-        batches.append((ids, (ids > 0).long(), torch.zeros_like(ids), video, vmask))
-    batch_list_t, batch_list_v, seq_list, vis_list = [], [], [], []
-    with torch.no_grad():
-        for batch in batches:                                        # main.py:430-449
-            input_ids, input_mask, segment_ids, video, video_mask = (t.to(DEV) for t in batch)
-            output = model(input_ids, segment_ids, input_mask, video, video_mask)
-            seq_list.append(output['sequence_output'])
-            batch_list_t.append((input_mask, segment_ids,))
-            vis_list.append(output['visual_output'])
-            batch_list_v.append((video_mask,))
-        sim_matrix = []                                              # main.py:511-524
-        for idx1, b1 in enumerate(batch_list_t):
-            input_mask, segment_ids, *_tmp = b1
-            sequence_output = seq_list[idx1]
-            each_row = []
-            for idx2, b2 in enumerate(batch_list_v):
-                video_mask, *_tmp = b2
-                visual_output = vis_list[idx2]
-                b1b2_logits, *_tmp = model.get_similarity_logits(sequence_output, visual_output, input_mask, video_mask)
-                each_row.append(b1b2_logits.cpu().detach().numpy())
-            sim_matrix.append(np.concatenate(tuple(each_row), axis=-1))
-        loop = np.concatenate(tuple(sim_matrix), axis=0)
-        one = _run_on_single_gpu(model, batch_list_t, batch_list_v, seq_list, vis_list)
-    assert isinstance(one, np.ndarray) and one.shape == loop.shape == (8, 8)
-    np.testing.assert_allclose(one, loop, rtol=0, atol=2e-5)
-    ref = clo.similarity_matrix_blocked([s.cpu() for s in seq_list], [v.cpu() for v in vis_list],
-                                        [model.get_video_mask_after_cluster(m[0].view(-1, T)).cpu() for m in batch_list_v],
-                                        float(s1_state_dict(g)["logit_scale"]))
-    np.testing.assert_allclose(one, ref.numpy(), rtol=0, atol=5e-5)
+# (the block-by-block similarity loop is checked against the reference's own matrix in tests/test_r3_gpu.py)
 
 
 class _ListLoader(list):
@@ -763,6 +698,13 @@ def test_nccl_packed_all_gather_and_sharded_similarity():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "NCCL_WORKER_OK world=%d" % world in r.stdout
+    if world == 1:
+        # one GPU: two ranks share it, collectives over gloo - the HIP-backed clip-sharded eval loop at world 2
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29578", script, "--share-gpu"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "NCCL_WORKER_OK world=2" in r.stdout
 
 
 def test_bench_line_contract_one_and_two_ranks():

@@ -1,0 +1,336 @@
+"""Round-3 parity tests on the MI355X (``-m gpu``), all through torch.ops.centerclip / the C ABI:
+
+  * THE STEP bench.py TIMES: bench.task_config / random_state_dict / synthetic_batch at cfg 2 (B = 16), CLIP4Clip.forward ->
+    get_similarity_logits captured into a hipGraph and replayed, caption compaction + the few-rows last block ON (as
+    shipped) and OFF, against oracle/clip_oracle.py at full width given the HIP path's own medoids            [S1, V1, T1]
+  * the same towers (encode_pair: text rider inside the ViT's launches) at the per-GPU shapes of cfg 3 / 4 / 5        [V1, T1]
+  * k-medoids on integer lattices at the per-GPU problem counts of cfg 3 / 4 / 5: several split chunks at the real N,
+    indices bit-exact against the reference's own output                                                     [C2, C5]
+  * eval._run_on_single_gpu against the matrix the reference's main._run_on_single_gpu produced from the same stored
+    features; eval_epoch against the reference's main.eval_epoch (matrix, R@1, metric strings)                 [S3, N1]
+
+Tolerances: north star - 1e-3 on L2-normalised embeddings / cosine similarities (x exp(logit_scale) on logits),
+bit-exact indices.  Fixtures: tests/golden/r3_golden.npz (oracle/gen_golden_r3.py, generated from the imported reference).
+"""
+import itertools
+import math
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as clo
+from oracle.recipes import EVAL_CASES, eval_case_batches, lattice, s3_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+R3 = os.path.join(HERE, "golden", "r3_golden.npz")
+R2 = os.path.join(HERE, "golden", "r2_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def g3():
+    return np.load(R3)
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return np.load(R2)
+
+
+def nrm(x):
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _captured(fn):
+    """Run fn eagerly (warm-up: allocations, model packing), capture it into a hipGraph, replay twice -> its outputs."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    return out, graph
+
+
+# ------------------------------------------------------------------------------------------------ the timed step
+@pytest.fixture(scope="module")
+def timed_step():
+    """bench.py's cfg-2 model, batch and step, + the oracle's answer for that batch given the HIP path's medoids."""
+    bench = _bench()
+    from centerclip_amd.clip4clip import CLIP4Clip
+    c = bench.CFG2
+    sd = bench.random_state_dict(c, seed=0)
+    model = CLIP4Clip.from_state_dict(dict(sd), bench.task_config(c)).to(DEV).eval()
+    ids, amask, video, vmask = bench.synthetic_batch(c, DEV, seed=100)
+    seg = torch.zeros_like(ids)
+
+    def step():
+        out = model(ids, seg, amask, video, vmask)
+        logits, *_ = model.get_similarity_logits(out["sequence_output"], out["visual_output"], amask, vmask)
+        return out["sequence_output"], out["visual_output"], logits
+
+    # the HIP path's own medoids (same kernels, ids kept): the oracle is evaluated "given identical medoid sets" 
+    model.clip.visual.keep_medoids = True
+    with torch.no_grad():
+        kept = [t.clone() for t in step()]
+    med = model.clip.visual.last_medoids.cpu()
+    model.clip.visual.keep_medoids = False
+    P = c["B"] * c["T_new"]
+    assert med.shape == (P, c["K"]) and bool((med[:, 1:] > med[:, :-1]).all()) and int(med.max()) < (c["T"] // c["T_new"]) * 49
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref = clo.clip4clip_forward(sd, ids.cpu(), video.cpu(), vmask.cpu(), c["T"], c["T_new"],
+                                    {c["cluster_block"] - 1: (c["T_new"], c["K"])}, float(sd["logit_scale"]),
+                                    forced_medoids={c["cluster_block"] - 1: med})
+    return dict(model=model, step=step, kept=kept, ref=ref, mult=math.exp(float(sd["logit_scale"])), c=c,
+                inputs=(ids, amask, video, vmask), bench=bench)
+
+
+def _check_step(out, ref, mult, what):
+    seq, vis, logits = (t.float().cpu() for t in out)
+    rseq, rvis, rlogits = ref
+    assert seq.shape == rseq.shape and vis.shape == rvis.shape and logits.shape == rlogits.shape
+    dt, dv = float((nrm(seq) - nrm(rseq)).abs().max()), float((nrm(vis) - nrm(rvis)).abs().max())
+    dl = float((logits - rlogits).abs().max())
+    print(f"[timed step, {what}] normalised embeddings: text {dt:.2e} visual {dv:.2e}; logits {dl:.2e} (x{mult:.2f})")
+    assert dt <= 1e-3 and dv <= 1e-3 and dl <= 1e-3 * mult
+
+
+def test_timed_step_hipgraph_replay_matches_oracle(timed_step):
+    """The exact object bench.py times - the cfg-2 step as a replayed hipGraph, paired towers, compacted captions, last
+    block on the rows the heads read - against the fp32 oracle (clip4clip.py:199-243,357-366)."""
+    ts = timed_step
+    with torch.no_grad():
+        out, graph = _captured(ts["step"])
+    _check_step(out, ts["ref"], ts["mult"], "hipGraph replay, row policies on")
+    # the replayed graph, the eager launches and the medoid-keeping form run the same kernels on the same data
+    for a, b in zip(out, ts["kept"]):
+        assert torch.equal(a, b)
+    # a second batch through the SAME captured graph (inputs refreshed in place, other caption lengths: the compaction
+    # offsets are computed on the device): identical to eager launches on that batch, no state leaks between replays
+    ids, amask, video, vmask = ts["inputs"]
+    saved = [t.clone() for t in ts["inputs"]]
+    fresh = ts["bench"].synthetic_batch(ts["c"], DEV, seed=321)
+    try:
+        for dst, src in zip(ts["inputs"], fresh):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [t.clone() for t in out]
+        with torch.no_grad():
+            eager = ts["step"]()
+        for a, b in zip(replayed, eager):
+            assert torch.equal(a, b)
+        assert not torch.equal(replayed[2], ts["kept"][2])
+    finally:
+        for dst, src in zip(ts["inputs"], saved):
+            dst.copy_(src)
+    del graph
+
+
+def test_timed_step_with_row_policies_off_matches_oracle_and_the_shipped_step(timed_step):
+    """Caption compaction and the few-rows last block switched off (every text row, every row of block 12): still within
+    the oracle's tolerance, text features bit-identical (compaction is exact), visual features within the rounding of the
+    fp16 intermediates of the shipped step."""
+    ts = timed_step
+    with torch.no_grad(), ts["model"].clip.row_policy(all_text_rows=True, all_last_block_rows=True):
+        out, graph = _captured(ts["step"])
+    _check_step(out, ts["ref"], ts["mult"], "hipGraph replay, row policies off")
+    seq_on, vis_on, log_on = ts["kept"]
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(out[0], seq_on) <= 2e-4 and rel(out[1], vis_on) <= 2e-4
+    assert float((out[2] - log_on).abs().max()) <= 2e-4 * ts["mult"]
+    del graph
+
+
+# ------------------------------------------------------------------------------------------------ cfg 3 / 4 / 5 towers
+PAIRED = {
+    # name: (patch, T, T_new, K, cluster block (1-based), B, words, model name)
+    "cfg3_msvd_12to4_b16": (32, 12, 4, 49, 7, 16, 32, 'ViT-B/32'),
+    "cfg4_activitynet_64to8_b8": (32, 64, 8, 49, 7, 8, 77, 'ViT-B/32'),
+    "cfg5_vitb16_12to4_k100_b4": (16, 12, 4, 100, 7, 4, 32, 'ViT-B/16'),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PAIRED))
+def test_paired_towers_at_per_gpu_shapes(name):
+    """encode_pair (both towers in one enqueue: the text problem rides in the ViT's launches) at the per-GPU batch of
+    BASELINE.json configs 3-5, full width, against the fp32 oracle given the HIP path's medoids.  Multi-chunk k-medoids
+    (P = B * T_new problems in split-size chunks) is part of the forward."""
+    from centerclip_amd.clip import CLIP
+    patch, T, T_new, K, cb, B, words, pname = PAIRED[name]
+    torch.manual_seed(31)
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=T,
+                     target_frames_blocks=[T] * (cb - 1) + [T_new] * (13 - cb), cluster_num_blocks=[K] * 12,
+                     cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100, minkowski_norm_p=2.0,
+                     pretrained_clip_name=pname, aggregation=None, pre_norm=False)
+    model = CLIP(512, 224, 12, 768, patch, 77, 49408, 512, 8, 12, video_frames=T, args=args)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.copy_(p_.half().float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    gen = torch.Generator().manual_seed(7)
+    video = torch.randn(B * T, 3, 224, 224, generator=gen)
+    ids = torch.zeros(B, words, dtype=torch.long)
+    for b in range(B):
+        ln = int(torch.randint(4, words + 1, (1,), generator=gen))
+        ids[b, 0], ids[b, ln - 1] = 49406, 49407
+        ids[b, 1:ln - 1] = torch.randint(1, 49405, (ln - 2,), generator=gen)
+    model.visual.keep_medoids = True
+    with torch.no_grad():
+        vfeat, tfeat = model.encode_pair(video.to(DEV), ids.to(DEV), video_frame=T)
+    med = model.visual.last_medoids.cpu()
+    model.visual.keep_medoids = False
+    n = (224 // patch) ** 2
+    assert med.shape == (B * T_new, K) and bool((med[:, 1:] > med[:, :-1]).all()) and int(med.max()) < (T // T_new) * n
+    with torch.no_grad():                                   # the shipped call (no medoid buffer) gives the same features
+        v2, t2 = model.encode_pair(video.to(DEV), ids.to(DEV), video_frame=T)
+    assert torch.equal(v2, vfeat) and torch.equal(t2, tfeat)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        vref = clo.visual_forward(sd, video, T, cluster_plan={cb - 1: (T_new, K)}, forced_medoids={cb - 1: med})
+        tref = clo.text_forward(sd, ids)
+    dv, dt = float((nrm(vfeat.cpu()) - nrm(vref)).abs().max()), float((nrm(tfeat.cpu()) - nrm(tref)).abs().max())
+    print(f"[{name}] normalised embeddings vs oracle: visual {dv:.2e} text {dt:.2e}")
+    assert vfeat.shape == vref.shape == (B * T_new, 512) and dv <= 1e-3 and dt <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ multi-chunk k-medoids
+P1M = ["p1m_cfg3", "p1m_cfg4", "p1m_cfg5", "p1m_ragged"]
+
+
+@pytest.mark.parametrize("tag", P1M)
+def test_p1_lattice_multi_chunk(g3, tag):
+    """Parity level P1 at the per-GPU problem counts: 16 / 4 / 4 split chunks (+ a ragged last chunk) at N = 147 / 392 /
+    588 / 196 - the chunk-wide distance maximum (cluster_utils.py:36) is taken per chunk, the reference's indices must be
+    reproduced bit for bit."""
+    from centerclip_amd import cluster as cl
+    seed, P, N, W, K, split, iters = [int(v) for v in g3[f"{tag}_cfg"]]
+    X = torch.from_numpy(lattice(seed, (P, N, W))).to(DEV)
+    a, m = cl.batch_fast_kmedoids_with_split(X, K, distance="euclidean", threshold=1e-6, iter_limit=iters,
+                                             id_sort=True, norm_p=2.0, split_size=split, pre_norm=False)
+    assert np.array_equal(m.cpu().numpy(), g3[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.cpu().numpy(), g3[f"{tag}_assign"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["cfg4 ActivityNet-shaped (per GPU)", "cfg5 ViT-B/16"])
+def test_cluster_shapes_bench_times_have_a_structural_check(name):
+    """The cfg-4 / cfg-5 token-cluster calls bench.py times (P = 64 problems, Gaussian tokens: parity level P3, no index
+    target): the contract every valid result obeys - sorted distinct medoids in range, CLS rows = segment means, every
+    output row a copy of the input row its medoid names."""
+    bench = _bench()
+    from centerclip_amd.cluster import TokenClusterInter
+    c = bench.CLUSTER_SHAPES[name]
+    B, T, Tn, K, n = c["B"], c["T"], c["T_new"], c["K"], c["n"]
+    W, fd = 768, c["T"] // c["T_new"]
+    x = torch.randn(B * T, 1 + n, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    mod = TokenClusterInter(before_cluster_num=n, cluster_num=K, before_block_frames=T, after_block_frames=Tn,
+                            original_frame=T, threshold=1e-6, iter_limit=100, split_size=c["split"], norm_p=2.0)
+    y = mod.cluster_frame_major(x, keep_ids=True).cpu()
+    med = mod.last_medoids.cpu()
+    assert y.shape == (B * Tn, 1 + K, W) and med.shape == (Tn * B, K)
+    assert bool((med[:, 1:] > med[:, :-1]).all()) and int(med.min()) >= 0 and int(med.max()) < fd * n
+    xs = x.cpu().view(B, Tn, fd, 1 + n, W)
+    tokens = xs[:, :, :, 1:, :].reshape(B, Tn, fd * n, W)
+    for b, s in itertools.product(range(B), range(Tn)):
+        ids_ = med[s * B + b]                                   # problem p = s*B + b (cluster.py:247-250)
+        assert torch.equal(y[b * Tn + s, 1:], tokens[b, s, ids_])
+    cls = xs[:, :, :, 0, :].mean(dim=2).reshape(B * Tn, W)
+    assert float((y[:, 0] - cls).abs().max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ S3: the eval loop
+def _small_model(g2, cluster_inter):
+    from centerclip_amd.clip4clip import CLIP4Clip
+    sd = {k[6:]: torch.from_numpy(g2[k].astype(np.float32) if g2[k].dtype == np.float16 else g2[k])
+          for k in g2.files if k.startswith("s1_sd/")}
+    cfg = g2["s1_cfg"]
+    T, T_new = int(cfg[11]), int(cfg[12])
+    a = Namespace(cluster_inter=cluster_inter, deep_cluster=0, cluster_algo='kmediods++', max_frames=T,
+                  target_frames_blocks=[4, T_new, T_new] if cluster_inter else [T, T, T], cluster_num_blocks=[16, 6, 6],
+                  cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100, minkowski_norm_p=2.0,
+                  aggregation=None, pretrained_clip_name='ViT-B/32', pre_norm=False, loose_type=True, sim_header='meanP',
+                  linear_patch='2d', pre_visual_pooling=0)
+    return CLIP4Clip.from_state_dict(sd, a).to(DEV).eval(), sd, cfg
+
+
+def test_run_on_single_gpu_against_the_reference_matrix(g2, g3):
+    """eval._run_on_single_gpu (ONE NT GEMM over the concatenated cache) against what the reference's own
+    main._run_on_single_gpu (main.py:502-534: a get_similarity_logits call + D2H copy per batch pair) made of the same
+    stored features - ragged batches, masks with the original frame count and zeros, a fully masked clip (NaN column)."""
+    from centerclip_amd.eval import _run_on_single_gpu
+    model, sd, cfg = _small_model(g2, cluster_inter=1)
+    seq_list, vis_list, list_t, list_v = s3_case(int(cfg[0]), int(cfg[11]), int(cfg[12]))
+    to = lambda ts: [tuple(t.to(DEV) for t in item) if isinstance(item, tuple) else item.to(DEV) for item in ts]
+    with torch.no_grad():
+        sim = _run_on_single_gpu(model, to(list_t), to(list_v), to(seq_list), to(vis_list))
+    ref = g3["s3_sim"]
+    assert isinstance(sim, np.ndarray) and sim.shape == ref.shape == (37, 21)
+    assert np.array_equal(np.isnan(sim), np.isnan(ref)) and np.isnan(ref[:, 5]).all()
+    mult = math.exp(float(sd["logit_scale"]))
+    ok = ~np.isnan(ref)
+    err = float(np.abs(sim[ok] - ref[ok]).max())
+    print(f"[S3] max |sim - reference| = {err:.2e} (logit multiplier {mult:.2f})")
+    assert err <= 5e-5 * mult
+    # the pairwise form of the same API agrees (one get_similarity_logits call per text batch x video batch)
+    with torch.no_grad():
+        blocks = [[model.get_similarity_logits(s.to(DEV), v.to(DEV), lt[0].to(DEV), lv[0].to(DEV))[0].cpu()
+                   for v, lv in zip(vis_list, list_v)] for s, lt in zip(seq_list, list_t)]
+    pairwise = torch.cat([torch.cat(row, dim=1) for row in blocks], dim=0).numpy()
+    assert float(np.abs(pairwise[ok] - sim[ok]).max()) <= 2e-5 * mult
+
+
+class _Loader(list):
+    pass
+
+
+@pytest.mark.parametrize("name", sorted(EVAL_CASES))
+def test_eval_epoch_against_the_reference(g2, g3, name):
+    """eval_epoch against the reference's own main.eval_epoch (main.py:381-499) on the same list-backed loader: the
+    similarity matrix within 1e-3 * exp(logit_scale), and - the fixture's rank metrics are stable under delta - R@1 and
+    the four metric strings character for character.  The metric kernels alone are pinned exactly by feeding them the
+    reference's matrix."""
+    from centerclip_amd import eval as ev
+    model, sd, cfg = _small_model(g2, cluster_inter=0)
+    batches, attrs = eval_case_batches(EVAL_CASES[name], cfg)
+    loader = _Loader(batches)
+    loader.dataset = Namespace(**attrs)
+    seen = {}
+
+    class Spy(ev.HipBackend):                                # the loop's NT GEMM, recorded
+        @staticmethod
+        def dot_nt(a, b, mult):
+            seen["sim"] = ev.HipBackend.dot_nt(a, b, mult)
+            return seen["sim"]
+    r1, t_inf, info = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy)
+    ref = g3[f"ev_{name}_sim"]
+    sim = seen["sim"].cpu().numpy()
+    mult = math.exp(float(sd["logit_scale"]))
+    err = float(np.abs(sim - ref).max())
+    print(f"[eval_epoch {name}] max |sim - reference| = {err:.2e}, delta {float(g3[f'ev_{name}_delta']):.2e}")
+    assert sim.shape == ref.shape and err <= 1e-3 * mult
+    assert err <= float(g3[f"ev_{name}_delta"]), "similarities outside the band in which the fixture's ranks are pinned"
+    assert abs(r1 - float(g3[f"ev_{name}_r1"])) < 1e-4 and t_inf > 0
+    assert list(info) == [str(s) for s in g3[f"ev_{name}_info"]]
+    # N1 alone, exactly: the reference's matrix through the device metric kernels -> the reference's strings
+    class Given(ev.HipBackend):
+        dot_nt = staticmethod(lambda a, b, mult: torch.from_numpy(ref).to(DEV))
+    r1b, _, info_b = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Given)
+    assert list(info_b) == [str(s) for s in g3[f"ev_{name}_info"]] and abs(r1b - float(g3[f"ev_{name}_r1"])) < 1e-4
