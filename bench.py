@@ -155,9 +155,9 @@ def pmc_traffic(symbol):
 
 def insitu_gemm_times(step, reps=6):
     """Duration of every gemm_f16_kernel launch INSIDE the step, measured live with HIP events on the launch stream: the
-    library brackets each launch of the eagerly enqueued step with two events (cc_debug_gemm_timing_*; the whole step is
-    enqueued by one C call, far faster than the GPU drains it, so the launches run back to back between their real
-    neighbours as in the captured graph).  -> {symbol: dict(us, launches_per_step, flops_per_step, shapes)}; flops count
+    library launches each of them with a start / stop event pair (hipExtLaunchKernelGGL, cc_debug_gemm_timing_*: the events
+    receive the dispatch's begin / end timestamps; the whole step is enqueued by one C call, far faster than the GPU drains
+    it, so the launches run back to back between their real neighbours as in the captured graph).  -> {symbol: dict(us, launches_per_step, flops_per_step, shapes)}; flops count
     both problems of a paired launch (ViT carrier + text rider)."""
     import ctypes
     from centerclip_amd import _lib as L
@@ -259,7 +259,8 @@ def gemm_roofline(c, device, insitu=None):
         tf, avg_us, n_l = dom["tflops"], dom["avg_us"], dom["launches_per_step"]
         flops_per_launch, share = dom["flops"] / dom["launches"], dom["us_per_step"]
         roles = standalone.get(sym, {}).get("roles", [])
-        how = "in situ: HIP events around every launch of the symbol inside the eagerly enqueued step"
+        how = ("in situ: every launch of the symbol inside the eagerly enqueued step carries a start / stop HIP event "
+               "(hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps)")
     else:
         sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
         tf, avg_us, n_l = dom["flops"] / dom["us"] / 1e6, dom["us"] / dom["launches"], dom["launches"]

@@ -44,6 +44,11 @@ struct GemmArgs {
     // c_proj run on those rows in place.
     int row_step;
     const int* row_map;
+    // EPI_F32 only: C = out_scale * (A W^T + bias) (0 = 1), and only columns n < n_valid are stored (0 = N; N itself must
+    // be a multiple of the tile width, so W carries rows up to N - their products are computed and dropped); ldc may be
+    // any value >= n_valid (unaligned rows fall back to scalar stores).  The similarity GEMM of similarity.hip.
+    float out_scale;
+    int n_valid;
 };
 
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the

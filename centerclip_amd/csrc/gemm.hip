@@ -15,6 +15,7 @@
 // bias + residual add -> fp32 in place (out_proj / c_proj), + positional embedding with the
 // patch-row -> token-row remap (conv1 as im2col GEMM, modules/clip.py:282,324-336).
 #include "cc_kernels.h"
+#include <hip/hip_ext.h>
 #include <cstring>
 #include <unistd.h>
 #include <cstdio>
@@ -422,9 +423,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // read, fp32 write, fp16 copy - covers a whole wave-tile row (WTN x 4 B = 256 B for the 128-wide tiles) instead of
     // 64-byte pieces of 16 different rows, and a row's LN statistics reduce over one DPP row of lanes.
     constexpr int LDF = WTN + 4;                                  // floats per staged row (272-byte rows for WTN = 64)
-    constexpr int LPRF = WTN / 4;                                 // lanes per row, 16 B each (16 or 8)
+    constexpr int LPRF_ACT = WTN / 4;                             // lanes that carry a row, 16 B each (16, 12 or 8)
+    constexpr int LPRF = LPRF_ACT <= 8 ? 8 : 16;                  // lane slots per row (48-wide wave tiles: 12 of 16)
     constexpr int RPP = 64 / LPRF, PASSES = 16 / RPP;             // rows per access, accesses per 16-row group
-    static_assert(OUT_F16 || LPRF == 16 || LPRF == 8, "fp32 epilogue geometry");
+    static_assert(OUT_F16 || LPRF_ACT == 16 || LPRF_ACT == 8 || (LPRF_ACT == 12 && EPI == EPI_F32), "fp32 epilogue geometry");
+    const bool flane_on = (LPRF == LPRF_ACT) || (lane % LPRF) < LPRF_ACT;
     static_assert(NWAVES * 16 * LDF * 4 <= 2 * (A_BYTES + B_BYTES), "fp32 epilogue strip fits the staging buffers");
     float* fstg = reinterpret_cast<float*>(smem) + wave * (16 * LDF);
     float* rowsh = reinterpret_cast<float*>(smem) + NWAVES * (16 * LDF);       // [BM] per-row shift (STATS with centring)
@@ -461,8 +464,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            const int m = out_row(i, ps);
-            float4 v = *reinterpret_cast<const float4*>(fstg + (ps * RPP + er) * LDF + ec);
+            const int m = flane_on ? out_row(i, ps) : g.M;         // (idle lane slots of a 48-wide wave tile store nothing)
+            float4 v = *reinterpret_cast<const float4*>(fstg + (ps * RPP + er) * LDF + (flane_on ? ec : 0));
             if (RESID) {
                 const float4 c = resv[i & 1][ps];
                 v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
@@ -501,7 +504,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + ncol;
                     *reinterpret_cast<float4*>(dst) = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
                 } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
+                    const float sc = g.out_scale != 0.f ? g.out_scale : 1.f;
+                    const int nv = g.n_valid > 0 ? g.n_valid : g.N;
+                    float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol;
+                    if (ncol + 3 < nv && (g.ldc & 3) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(sc * v.x, sc * v.y, sc * v.z, sc * v.w);
+                    } else {
+                        if (ncol < nv) dst[0] = sc * v.x;
+                        if (ncol + 1 < nv) dst[1] = sc * v.y;
+                        if (ncol + 2 < nv) dst[2] = sc * v.z;
+                        if (ncol + 3 < nv) dst[3] = sc * v.w;
+                    }
                 }
             }
         }
@@ -518,7 +531,8 @@ extern "C" {
 int cc_debug_gemm_timing_begin(int cap);
 // disarm; -> number of launches recorded
 int cc_debug_gemm_timing_end(void);
-// launch i: duration in microseconds (the stream must have been synchronised) + its 12-int record (see GemmTiming)
+// launch i (the stream must have been synchronised): *us_out = stop - start of the dispatch in microseconds; + the launch's
+// 12-int record (see GemmTiming)
 int cc_debug_gemm_timing_read(int i, float* us_out, int* info12_out);
 }
 
@@ -529,13 +543,15 @@ extern "C" int cc_debug_set_gemm_profile(long long* p) {   // debug only; p [wor
 namespace {
 
 // Debug hook (cc_debug_gemm_timing_*, not part of the public ABI; process-wide, not thread-safe - a measurement aid for
-// bench.py): while armed, every launch of gemm_f16_kernel is bracketed by two HIP events recorded on the launch stream,
-// so that the duration of a kernel symbol can be read IN SITU - inside the eagerly launched step, between its real
-// neighbours - instead of from a stand-alone loop.  Never armed during graph capture.
+// bench.py): while armed, every launch of gemm_f16_kernel goes through hipExtLaunchKernelGGL with a start and a stop
+// event, which receive the dispatch's own begin / end timestamps (what rocprofv3's kernel trace reads too) - so the
+// duration of a kernel symbol can be read IN SITU, inside the eagerly launched step between its real neighbours, instead
+// of from a stand-alone loop, and without the 2.5 - 5 us an event record of its own adds around a launch (measured: two
+// adjacent hipEventRecord calls are 5.3 us apart on this stream).  Never armed during graph capture.
 struct GemmTiming {
     bool armed = false;
     int count = 0, cap = 0;
-    hipEvent_t* ev = nullptr;          // [2 * cap]
+    hipEvent_t* ev = nullptr;          // [2 * cap]: kernel start, kernel stop
     int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK, M0, N0, K0, M1, N1, K1
 } g_timing;
 
@@ -558,10 +574,11 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
         const int rec[12] = {BM, BN, WM, WN, EPI, BK, pr.p[0].M, pr.p[0].N, pr.p[0].K,
                              two ? pr.p[1].M : 0, two ? pr.p[1].N : 0, two ? pr.p[1].K : 0};
         memcpy(g_timing.info[tid], rec, sizeof(rec));
-        (void)hipEventRecord(g_timing.ev[2 * tid], st);
+        hipExtLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), (unsigned)smem, st, g_timing.ev[2 * tid],
+                              g_timing.ev[2 * tid + 1], 0u, pr);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), smem, st, pr);
     }
-    hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), smem, st, pr);
-    if (tid >= 0) (void)hipEventRecord(g_timing.ev[2 * tid + 1], st);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -603,7 +620,7 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     }
 }
 
-// tiles whose wave tile is 48 columns wide exist for the fp16-output epilogues only
+// tiles whose wave tile is 48 columns wide exist for the fp16-output epilogues and the plain fp32 one
 template <int BM, int BN, int WM, int WN>
 int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     GemmPair pr{};
@@ -633,6 +650,7 @@ int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         case EPI_F16_GELU: return launch_one<BM, BN, WM, WN, EPI_F16_GELU>(pr, total, st);
         case EPI_F16_LN: return launch_one<BM, BN, WM, WN, EPI_F16_LN>(pr, total, st);
         case EPI_F16_GELU_LN: return launch_one<BM, BN, WM, WN, EPI_F16_GELU_LN>(pr, total, st);
+        case EPI_F32: return launch_one<BM, BN, WM, WN, EPI_F32>(pr, total, st);      // (the similarity GEMM)
         default: return CC_ERR_INVALID;
     }
 }
@@ -712,7 +730,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             if (g1->K % tile_bk(tile)) tile = 4;
         }
     }
-    if (tile == 7 && !epi_is_f16(epi)) return CC_ERR_INVALID;
+    if (tile == 7 && !epi_is_f16(epi) && epi != EPI_F32) return CC_ERR_INVALID;
     if ((g0.K % tile_bk(tile)) || (g1 && (g1->K % tile_bk(tile)))) return CC_ERR_INVALID;
     const int bn = tile_bn(tile);
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;

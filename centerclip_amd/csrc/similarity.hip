@@ -8,37 +8,98 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // rows [R, E] -> rows / |row|   (one wave per row)
-// Split form of a normalised value for the fp16 matrix cores (see dot_nt_kernel): hi = fp16(2^10 x), lo = fp16(2^10 x - hi)
+// Split form of a normalised value for the fp16 matrix cores: hi = fp16(2^10 x), lo = fp16(2^10 x - hi) - both in fp16's
+// normal range, 2^10 x = hi + lo to 22 bits.  A row is written as THREE planes side by side, [3E] halfs per row:
+//   text  side (A'):  [ hi | hi | lo ]        video side (B'):  [ hi | lo | hi ]
+// so that  A' . B'^T = hi.hi + hi.lo + lo.hi  is ONE fp16 GEMM with K = 3E on the main GEMM pipeline (gemm.hip), scaled
+// back by the exact factor 2^-20 in its epilogue; the dropped lo.lo term is 2^-22 relative (fp32 rounding level).
 struct SplitOut {
-    _Float16* hi;       // [R, E] or nullptr
-    _Float16* lo;
+    _Float16* hi;       // row-major [R, 3E] or nullptr
+    int E;
+    int b_side;         // 0: hi | hi | lo,  1: hi | lo | hi
 };
-__device__ __forceinline__ void split_put(const SplitOut& so, int64_t idx, float x) {
+__device__ __forceinline__ void split_put(const SplitOut& so, int64_t row, int e, float x) {
     const float sx = x * 1024.0f;
     const _Float16 h = (_Float16)sx;
-    so.hi[idx] = h;
-    so.lo[idx] = (_Float16)(sx - (float)h);
+    const _Float16 l = (_Float16)(sx - (float)h);
+    _Float16* p = so.hi + row * (3 * (int64_t)so.E) + e;
+    p[0] = h;
+    p[so.E] = so.b_side ? l : h;
+    p[2 * so.E] = so.b_side ? h : l;
 }
 
-__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                             SplitOut so, int R, int E) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
+typedef _Float16 sh8 __attribute__((ext_vector_type(8)));
+
+// one wave: row r of `in` -> row / |row| (fp32 `out`, optional) and / or its split planes.  The norm is summed exactly as
+// before (lane l takes elements l, l + 64, ... in order, then the wave sum), so every path that normalises a row yields
+// the same bits; the planes are then written from a second, lane-contiguous read of the row (an L1 hit) as 16-byte
+// stores - 2-byte stores strided over the wave were 24 partial-line store instructions per 512-wide row.
+__device__ __forceinline__ void normalize_row_wave(const float* __restrict__ in, float* __restrict__ out, const SplitOut& so,
+                                                   int r, int E, int lane) {
     const float* src = in + (int64_t)r * E;
     float s = 0.f;
     for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
     const float nrm = sqrtf(cc_wave_sum_fast(s));
+    if (so.hi && (E & 7) == 0) {
+        _Float16* p = so.hi + (int64_t)r * (3 * (int64_t)E);
+        for (int e0 = lane * 8; e0 < E; e0 += 512) {
+            const float4 a = *reinterpret_cast<const float4*>(src + e0), b = *reinterpret_cast<const float4*>(src + e0 + 4);
+            const float x[8] = {a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm, b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm};
+            sh8 H, Lo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float sx = x[u] * 1024.0f;
+                H[u] = (_Float16)sx;
+                Lo[u] = (_Float16)(sx - (float)H[u]);
+            }
+            *reinterpret_cast<sh8*>(p + e0) = H;
+            *reinterpret_cast<sh8*>(p + E + e0) = so.b_side ? Lo : H;
+            *reinterpret_cast<sh8*>(p + 2 * E + e0) = so.b_side ? H : Lo;
+            if (out) {
+                *reinterpret_cast<float4*>(out + (int64_t)r * E + e0) = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(out + (int64_t)r * E + e0 + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            }
+        }
+        return;
+    }
     for (int e = lane; e < E; e += 64) {
         const float v = src[e] / nrm;
         if (out) out[(int64_t)r * E + e] = v;
-        if (so.hi) split_put(so, (int64_t)r * E + e, v);
+        if (so.hi) split_put(so, r, e, v);
     }
+}
+
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             SplitOut so, int R, int E) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    normalize_row_wave(in, out, so, r, E, threadIdx.x & 63);
 }
 
 // rows that are normalised already -> split planes (the pre-pooled branch, where the video side arrives normalised)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, SplitOut so, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) split_put(so, i, in[i]);
+    if ((so.E & 7) == 0) {                                     // 8 consecutive elements per thread: 16-byte plane stores
+        const int E = so.E;
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += (int64_t)gridDim.x * 2048) {
+            const float4 a = *reinterpret_cast<const float4*>(in + i), b = *reinterpret_cast<const float4*>(in + i + 4);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            sh8 H, Lo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float sx = x[u] * 1024.0f;
+                H[u] = (_Float16)sx;
+                Lo[u] = (_Float16)(sx - (float)H[u]);
+            }
+            const int64_t r = i / E;
+            _Float16* p = so.hi + r * (3 * (int64_t)E) + (i - r * E);
+            *reinterpret_cast<sh8*>(p) = H;
+            *reinterpret_cast<sh8*>(p + E) = so.b_side ? Lo : H;
+            *reinterpret_cast<sh8*>(p + 2 * E) = so.b_side ? H : Lo;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        split_put(so, i / so.E, (int)(i % so.E), in[i]);
 }
 
 // visual [Bv, Tn, E], mask [Bv, Tn] int64 -> pooled [Bv, E]   (one wave per video)
@@ -48,12 +109,9 @@ struct VidAddr {
     int vg;
     int64_t vgs, mgs, mrs, mcs;
 };
-__global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
-                                                         const long long* __restrict__ mask, VidAddr ad,
-                                                         float* __restrict__ pooled, SplitOut so, int Bv, int Tn, int E) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= Bv) return;
+__device__ __forceinline__ void video_pool_wave(const float* __restrict__ visual, const long long* __restrict__ mask,
+                                                const VidAddr& ad, float* __restrict__ pooled, const SplitOut& so, int v,
+                                                int Tn, int E, int lane) {
     const int grp = v / ad.vg, loc = v - grp * ad.vg;
     visual += (int64_t)grp * ad.vgs + (int64_t)loc * Tn * E;
     mask += (int64_t)grp * ad.mgs + (int64_t)loc * ad.mrs;
@@ -92,8 +150,32 @@ __global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict
         if (e < E) {
             const float pv = acc[q] / nrm;
             if (pooled) pooled[(int64_t)v * E + e] = pv;
-            if (so.hi) split_put(so, (int64_t)v * E + e, pv);
+            if (so.hi) split_put(so, v, e, pv);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void video_pool_kernel(const float* __restrict__ visual,
+                                                         const long long* __restrict__ mask, VidAddr ad,
+                                                         float* __restrict__ pooled, SplitOut so, int Bv, int Tn, int E) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= Bv) return;
+    video_pool_wave(visual, mask, ad, pooled, so, v, Tn, E, threadIdx.x & 63);
+}
+
+// Both producers of the similarity GEMM's operands in ONE launch: workgroups [0, text_blocks) normalise 4 text rows each
+// (normalize_rows_kernel), the rest pool 4 videos each (video_pool_kernel) - two latency-bound launches become one.
+__global__ __launch_bounds__(256) void sim_prepare_kernel(const float* __restrict__ text, SplitOut ta, int Bt, int text_blocks,
+                                                          const float* __restrict__ visual, const long long* __restrict__ mask,
+                                                          VidAddr ad, float* __restrict__ pooled, SplitOut vb, int Bv, int Tn,
+                                                          int E) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x < text_blocks) {
+        const int r = blockIdx.x * 4 + w;
+        if (r < Bt) normalize_row_wave(text, nullptr, ta, r, E, lane);
+    } else {
+        const int v = ((int)blockIdx.x - text_blocks) * 4 + w;
+        if (v < Bv) video_pool_wave(visual, mask, ad, pooled, vb, v, Tn, E, lane);
     }
 }
 
@@ -177,107 +259,33 @@ __global__ __launch_bounds__(256) void loose_similarity_small_kernel(const float
     }
 }
 
-// C[i][j] = mult * sum_k A[i][k] B[j][k]; 64x64 tile per workgroup.
-// Arithmetic as in the Gram kernel of cluster.hip: each normalised fp32 value x (|x| <= 1) was split by its producer
-// (normalize_rows_kernel / video_pool_kernel / split_rows_kernel) into hi = fp16(2^10 x) and lo = fp16(2^10 x - hi) -
-// both in fp16's normal range, 2^10 x = hi + lo to 22 bits - and the dot product is accumulated in fp32 as
-// hi.hi + hi.lo + lo.hi on the fp16 matrix cores (16x the rate of the exact-fp32 MFMA the first version used and was
-// bound by), then scaled back by the exact factor 2^-20.  The dropped lo.lo term is 2^-22 relative: fp32 rounding level.
-// Splitting once per row instead of in every tile keeps the tile's staging a pure copy: the four operand planes go
-// HBM -> LDS by LDS-DMA (16 B per lane, chunks XOR-swizzled through the source address as in gemm.hip).
-#define ST 64
-#define SKK 64
-typedef _Float16 sh8 __attribute__((ext_vector_type(8)));
-#define SPLANE (ST * SKK)
-__device__ __forceinline__ void sim_glds16(const _Float16* g, _Float16* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// The NT product itself: cc_gemm_dispatch (gemm.hip) on the concatenated planes - 256 / 128-row tiles staged by LDS-DMA,
+// XOR-swizzled LDS, the half-shifted main loop - with the fp32 epilogue scaling by mult * 2^-20 and dropping the columns
+// beyond Bv (the video rows are padded to the tile width inside the workspace; what the padding rows hold is never stored).
+// Round 2 ran a 64x64-tile kernel of its own here (12 MFMAs per 8 fragment reads, 2,512 workgroups: 67 us for 10k x 1k,
+// bound by neither the matrix pipe nor memory).
+// Tile for the [Bt, Bv] product: large problems run ONE round of 8-wave tiles, 256x256 or 256x192 - whichever covers
+// the matrix in a round with less work per tile (10k x 1k: 160 tiles of 256x256 leave 96 CUs idle, 240 tiles of 256x192
+// do 3/4 of the work each: 43 -> 33 us); everything else is left to the dispatcher's own choice.
+static inline int sim_tile(int Bt, int Bv, int* bn_out) {
+    const long mt = (Bt + 255) / 256, t256 = mt * ((Bv + 255) / 256), t192 = mt * ((Bv + 191) / 192);
+    *bn_out = 256;
+    if (t256 < 128) return 0;
+    const long c256 = (t256 + 255) / 256 * 4, c192 = (t192 + 255) / 256 * 3;        // rounds x relative tile work
+    if (c192 < c256) { *bn_out = 192; return 7; }
+    return 5;
 }
-__global__ __launch_bounds__(256) void dot_nt_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
-                                                     const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
-                                                     float* __restrict__ C, int M, int N, int K, int ldc, float mult) {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][SPLANE];      // [buffer][Ah, Al, Bh, Bl]
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // staging: LDS chunk idx (16 B) = q*256 + tid -> row idx / 8, position idx % 8; source chunk = position ^ (row & 7)
-    const _Float16* src[4][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int idx = q * 256 + tid, r = idx >> 3, c = (idx & 7) ^ (r & 7);
-        const int64_t ra = (int64_t)min(ti * ST + r, M - 1) * K + c * 8, rb = (int64_t)min(tj * ST + r, N - 1) * K + c * 8;
-        src[0][q] = Ah + ra; src[1][q] = Al + ra; src[2][q] = Bh + rb; src[3][q] = Bl + rb;
-    }
-    auto stage = [&](int buf, int kt) {
-#pragma unroll
-        for (int pl = 0; pl < 4; ++pl)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) sim_glds16(src[pl][q] + kt * SKK, &lds[buf][pl][(q * 4 + wave) * 512]);
-    };
-    const int wr = wave >> 1, wc = wave & 1;
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = K / SKK;                                    // K % 64 == 0 (checked by the launcher)
-    stage(0, 0);
-    __syncthreads();
-    const int g = lane >> 4, l15 = lane & 15;
-    auto frag = [&](const _Float16* pl, int row, int ks) {     // 8 consecutive k of `row` at k = ks*32 + g*8
-        return *reinterpret_cast<const sh8*>(pl + row * SKK + ((((ks << 2) | g) ^ (row & 7)) << 3));
-    };
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const int ar = wr * 32 + l15, br = wc * 32 + l15;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const sh8 a0h = frag(lds[buf][0], ar, ks), a0l = frag(lds[buf][1], ar, ks);
-            const sh8 a1h = frag(lds[buf][0], ar + 16, ks), a1l = frag(lds[buf][1], ar + 16, ks);
-            const sh8 b0h = frag(lds[buf][2], br, ks), b0l = frag(lds[buf][3], br, ks);
-            const sh8 b1h = frag(lds[buf][2], br + 16, ks), b1l = frag(lds[buf][3], br + 16, ks);
-            // B fragment as the first operand: a lane then owns 4 consecutive j of one i (16-byte stores)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a0h, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a0l, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0l, a0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a0h, acc[0][1], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a0l, acc[0][1], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1l, a0h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a1h, acc[1][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0h, a1l, acc[1][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0l, a1h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a1h, acc[1][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1h, a1l, acc[1][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1l, a1h, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const float sc = mult * 9.5367431640625e-07f;              // 2^-20: undo the two 2^10 operand scalings (exact)
-#pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
-        const int i = ti * ST + wr * 32 + fm * 16 + l15;
-        if (i >= M) continue;
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-            const int j = tj * ST + wc * 32 + fn * 16 + g * 4;
-            float* dst = C + (int64_t)i * ldc + j;
-            const f32x4 v = acc[fm][fn];
-            if (j + 3 < N && ((ldc & 3) == 0)) {
-                *reinterpret_cast<float4*>(dst) = make_float4(sc * v[0], sc * v[1], sc * v[2], sc * v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (j + e < N) dst[e] = sc * v[e];
-            }
-        }
-    }
+// rows of the video-side planes inside the workspace: room for either tile width
+static inline size_t sim_rows_pad(int Bv) {
+    const size_t p256 = ((size_t)Bv + 255) / 256 * 256, p192 = ((size_t)Bv + 191) / 192 * 192;
+    return p256 > p192 ? p256 : p192;
 }
 
 extern "C" {
 
 size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E) {
     if (Bt <= 0 || Bv <= 0 || E <= 0) return 0;
-    return cc_align_up((size_t)Bt * E * 4, 256) + cc_align_up((size_t)Bv * E * 4, 256);
+    return cc_align_up((size_t)Bt * E * 6, 256) + cc_align_up(sim_rows_pad(Bv) * E * 6, 256);
 }
 
 static int video_pool_launch(const float* visual, const int64_t* video_mask, const VidAddr& ad, int32_t Bv,
@@ -293,33 +301,38 @@ static int video_pool_launch(const float* visual, const int64_t* video_mask, con
 int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
                                 float* pooled, void* stream) {
     const VidAddr ad{Bv > 0 ? Bv : 1, 0, 0, Tn, 1};
-    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, SplitOut{nullptr, nullptr}, stream);
+    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, SplitOut{nullptr, 0, 0}, stream);
 }
 
 /* rows [R, E] -> rows / |row| (the text half of _loose_similarity, modules/clip4clip.py:361-362) */
 int cc_normalize_rows_f32(const float* in, float* out, int32_t R, int32_t E, void* stream) {
     if (!in || !out || R <= 0 || E <= 0) return CC_ERR_INVALID;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
-                       SplitOut{nullptr, nullptr}, R, E);
+                       SplitOut{nullptr, 0, 0}, R, E);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
-// split planes of the text rows ([Bt,E] hi | lo) and the video rows ([Bv,E] hi | lo) inside the similarity workspace
-// (cc_similarity_workspace_bytes = (Bt + Bv) * E floats, each region exactly the size of its two fp16 planes)
+// concatenated planes of the text rows ([Bt, 3E]) and the video rows ([pad(Bv), 3E]) inside the similarity workspace
 static void sim_planes(void* ws, int Bt, int Bv, int E, SplitOut& ta, SplitOut& vb) {
     _Float16* t = static_cast<_Float16*>(ws);
-    ta = SplitOut{t, t + (size_t)Bt * E};
-    _Float16* v = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 4, 256));
-    vb = SplitOut{v, v + (size_t)Bv * E};
+    ta = SplitOut{t, E, 0};
+    _Float16* v = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + cc_align_up((size_t)Bt * E * 6, 256));
+    vb = SplitOut{v, E, 1};
 }
 
 static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int Bv, int E, float mult, float* logits,
                              int ldl, hipStream_t st) {
-    dim3 grid((Bv + ST - 1) / ST, (Bt + ST - 1) / ST);
-    hipLaunchKernelGGL(dot_nt_kernel, grid, dim3(256), 0, st, ta.hi, ta.lo, vb.hi, vb.lo, logits, Bt, Bv, E, ldl, mult);
-    CC_LAUNCH_CHECK();
-    return CC_OK;
+    GemmArgs g{};
+    g.A = ta.hi;
+    g.W = vb.hi;
+    g.C = logits;
+    int bn = 256;
+    const int tile = sim_tile(Bt, Bv, &bn);
+    g.M = Bt; g.N = (Bv + bn - 1) / bn * bn; g.K = 3 * E; g.ldc = ldl;
+    g.n_valid = Bv;
+    g.out_scale = mult * 9.5367431640625e-07f;                // 2^-20: undo the two 2^10 operand scalings (exact)
+    return cc_gemm_dispatch(g, EPI_F32, tile, st);
 }
 
 int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv, int32_t E, float mult, float* logits,
@@ -330,9 +343,9 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
     SplitOut ta, vb;
     sim_planes(ws, Bt, Bv, E, ta, vb);
     const int64_t na = (int64_t)Bt * E, nb = (int64_t)Bv * E;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((na + 255) / 256 < 4096 ? (na + 255) / 256 : 4096)), dim3(256), 0, st, a, ta, na);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((na + 2047) / 2048 < 4096 ? (na + 2047) / 2048 : 4096)), dim3(256), 0, st, a, ta, na);
     CC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((nb + 255) / 256 < 4096 ? (nb + 255) / 256 : 4096)), dim3(256), 0, st, b, vb, nb);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((nb + 2047) / 2048 < 4096 ? (nb + 2047) / 2048 : 4096)), dim3(256), 0, st, b, vb, nb);
     CC_LAUNCH_CHECK();
     return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, st);
 }
@@ -357,10 +370,11 @@ int cc_loose_similarity_grouped_f32(const float* text, const float* visual, cons
     // text rows: normalise -> split planes; videos: pool + normalise -> split planes (+ fp32 pooled_out); then the GEMM
     SplitOut ta, vb;
     sim_planes(ws, Bt, Bv, E, ta, vb);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((Bt + 3) / 4), dim3(256), 0, st, text, (float*)nullptr, ta, Bt, E);
+    if (E > 1024 || Tn <= 0) return E > 1024 ? CC_ERR_UNSUPPORTED : CC_ERR_INVALID;
+    const int tb = (Bt + 3) / 4;
+    hipLaunchKernelGGL(sim_prepare_kernel, dim3(tb + (Bv + 3) / 4), dim3(256), 0, st, text, ta, Bt, tb, visual,
+                       reinterpret_cast<const long long*>(video_mask), ad, pooled_out, vb, Bv, Tn, E);
     CC_LAUNCH_CHECK();
-    int rc = video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled_out, vb, stream);
-    if (rc) return rc;
     return dot_planes_launch(ta, vb, Bt, Bv, E, expf(logit_scale), logits, ldl, st);
 }
 

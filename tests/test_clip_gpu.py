@@ -69,7 +69,8 @@ def test_linear_f16_epilogues(M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K", [(9600, 2304, 768), (300, 192, 64), (1000, 1536, 512), (257, 768, 3072)])
 def test_linear_f16_tile_256x192(M, N, K):
-    """tile 7 (256 x 192, 48-column wave tiles) exists for the fp16-output epilogues only; the auto choice picks it for
+    """tile 7 (256 x 192, 48-column wave tiles) exists for the fp16-output epilogues and the plain fp32 one (the similarity
+    GEMM of similarity.hip); the auto choice picks it for
     in_proj at M = 9,600 and must agree with the forced 256 x 256 / 128 x 128 results bit for bit (same k order)."""
     from centerclip_amd import ops
     gen = torch.Generator().manual_seed(7 * M + N + K)
@@ -85,9 +86,11 @@ def test_linear_f16_tile_256x192(M, N, K):
     y = ops.linear_f16(ad, wd, bd, "f16_gelu", tile=7)
     assert relerr(y.float().cpu(), ref * torch.sigmoid(1.702 * ref)) < 2e-3
     assert torch.equal(y, ops.linear_f16(ad, wd, bd, "f16_gelu", tile=4))
-    for epi in ("f32", "f32_resid"):
-        with pytest.raises(RuntimeError, match="invalid"):
-            ops.linear_f16(ad, wd, bd, epi, out=torch.zeros(M, N, device=DEV), tile=7)
+    y32 = ops.linear_f16(ad, wd, bd, "f32", out=torch.zeros(M, N, device=DEV), tile=7)      # 12 of 16 lane slots per row
+    assert torch.equal(y32, ops.linear_f16(ad, wd, bd, "f32", out=torch.zeros(M, N, device=DEV), tile=4))
+    assert relerr(y32.cpu(), ref) < 2e-5
+    with pytest.raises(RuntimeError, match="invalid"):
+        ops.linear_f16(ad, wd, bd, "f32_resid", out=torch.zeros(M, N, device=DEV), tile=7)
     with pytest.raises(RuntimeError, match="invalid"):
         ops.linear_f16(ad[:, :64].contiguous(), wd[:128, :64].contiguous(), None, "f16", tile=7)     # 128 % 192
     # folded LayerNorm through the same tile
