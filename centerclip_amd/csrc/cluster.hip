@@ -447,8 +447,11 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 }
 
 // ============================================================================ K2
-// One 256-thread workgroup per problem; the whole selection (KKZ init, assignment / update
-// iterations, ascending sort, final assignment) runs inside it with no host round trip.
+// One 1024-thread workgroup (16 waves) per problem; the whole selection (KKZ init, assignment / update
+// iterations, ascending sort, final assignment) runs inside it with no host round trip.  The staged distance matrix
+// takes a whole CU's LDS anyway (154 KB at N = 196), so the workgroup may as well own all of the CU's wave slots:
+// staging, the assignment (4 threads per token) and the output phases use all 16 waves; the KKZ chain - K dependent
+// arg-max / row-fold steps - runs on ONE wave with no barrier at all (rounds 1-2: four waves meeting in LDS once per step).
 // Everything here is latency-bound dependent work on a 38-346 K-entry matrix, so the kernel is
 // organised to keep >= 4-8 independent LDS/L2 loads in flight per lane and to avoid LDS
 // crossbar shuffles on the critical path (wave arg-max = 4 DPP steps + readlane, ties resolved
@@ -459,7 +462,7 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 // each member closes; a candidate then walks its cluster's list with branch-free level partials
 // and the medoid falls out of a 64-bit LDS min over (key(sum), token).
 //
-// LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | cmask K*E u64 | med K i32 | asg, order, mem N u16 | cnt K | off K+1 u16
+// LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | med K i32 | asg, order N u16
 #define SEL_MAX_E 16   /* N <= 1023: ATen's row sum folds its accumulators once (pass 16) below 1024 terms */
 #define SEL_MAX_N 1023
 
@@ -504,27 +507,34 @@ __device__ __forceinline__ float sel_and(float x, int m) { return __int_as_float
 struct SelSmem {
     float* D;
     unsigned long long* best;   // per cluster: (ordered key of the smallest row sum) << 32 | token, via ds_min_u64
-    unsigned long long* cmask;  // per cluster: membership bits in summation-rank space
     int* med;
     unsigned short* asg;        // token -> cluster
     unsigned short* order;      // summation rank -> token (see sum_rank)
+    unsigned short* prev;       // token -> cluster one iteration ago
+    unsigned short* list;       // candidates of the clusters whose member set changed (the only ones whose row sums can differ)
+    unsigned char* dirty;       // per cluster: member set changed in this iteration
+    int* count;                 // length of list
+    // member-list form of the update step (D in global memory only, see the kernel)
+    unsigned long long* cmask;  // per cluster: membership bits in summation-rank space
     unsigned short* mem;        // tokens grouped by cluster, each group in summation-rank order
     unsigned short* cnt;        // members per cluster
     unsigned short* off;        // K + 1 group offsets into mem
-    unsigned long long* kkz;    // [2][4] per-wave (key, index) pairs of the KKZ arg-max
 };
 
 static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
-    const int E = (N + 63) / 64;
     size_t b = 0;
     if (in_lds) b += cc_align_up((size_t)N * N * 4, 8);
-    b += (size_t)K * 8;                         // best
-    b += (size_t)K * E * 8;                     // cmask
+    b += cc_align_up((size_t)K * 8, 128);       // best (>= 64 B: the chunk-max reduction parks 16 ints at the start)
     b += cc_align_up((size_t)K * 4, 8);         // med
-    b += 3 * cc_align_up((size_t)N * 2, 8);     // asg, order, mem
-    b += cc_align_up((size_t)K * 2, 8);         // cnt
-    b += cc_align_up((size_t)(K + 1) * 2, 8);   // off
-    b += 64;                                    // kkz
+    b += 4 * cc_align_up((size_t)N * 2, 8);     // asg, order, prev, list
+    b += cc_align_up((size_t)K, 8) + 8;         // dirty, count
+    if (!in_lds) {
+        const int E = (N + 63) / 64;
+        b += (size_t)K * E * 8;                     // cmask
+        b += cc_align_up((size_t)N * 2, 8);         // mem
+        b += cc_align_up((size_t)K * 2, 8);         // cnt
+        b += cc_align_up((size_t)(K + 1) * 2, 8);   // off
+    }
     return cc_align_up(b, 16);
 }
 
@@ -549,14 +559,32 @@ __device__ __forceinline__ unsigned cc_wave_umin(unsigned v) {
 }
 
 // NE = compile-time number of 64-token chunks (N <= 64*NE): the KKZ loop is fully unrolled, branch free
+// What K3 (reduce_tokens_kernel) needs to produce the output rows; kmedoids_select_kernel takes one too and, for the
+// shipped variant (medoid gather, W % 32 == 0), writes its problem's 1 + K output rows itself right after the selection -
+// the ids never leave LDS and the separate gather launch (10 us of the 99 us op in the step) disappears.
+struct GatherDesc {
+    const float* x; int64_t in_tok, in_frame;
+    int B, T, T_new, n, W, K, mode;
+    const long long* medoids; int med_stride;
+    const long long* assign;
+    const float* cluster_embed;
+    const float* cls_mult;
+    float* out; int64_t out_tok, out_frame;
+    _Float16* h16; float* stats; float* shift;
+};
+template <bool LEFT>
+__device__ void reduce_row_wave(const GatherDesc& g, int row, int lane, const int* med_lds);
+
+#define SEL_WAVES 16
+#define SEL_THREADS (64 * SEL_WAVES)
 template <bool IN_LDS, int NE>
-__global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __restrict__ dist_in, float* dist_rw,
+__global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const float* __restrict__ dist_in, float* dist_rw,
                                                               const float* __restrict__ norms,
                                                               const int* __restrict__ chunkmax, int slots_pp, int chunk,
                                                               int apply_shift, int N, int K, int iter_limit,
                                                               int id_sort, long long* __restrict__ medoids_out,
                                                               long long* __restrict__ assign_out,
-                                                              int* __restrict__ iters_out) {
+                                                              int* __restrict__ iters_out, GatherDesc gd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int E = (N + 63) >> 6;
     SelSmem s;
@@ -564,15 +592,18 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         unsigned char* q = smem_raw;
         s.D = reinterpret_cast<float*>(q);
         if (IN_LDS) q += cc_align_up((size_t)N * N * 4, 8);
-        s.best = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * 8;
-        s.cmask = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * E * 8;
+        s.best = reinterpret_cast<unsigned long long*>(q); q += cc_align_up((size_t)K * 8, 128);
         s.med = reinterpret_cast<int*>(q); q += cc_align_up((size_t)K * 4, 8);
         s.asg = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
         s.order = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.prev = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.list = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.dirty = reinterpret_cast<unsigned char*>(q); q += cc_align_up((size_t)K, 8);
+        s.count = reinterpret_cast<int*>(q); q += 8;
+        s.cmask = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * E * 8;      // (the four below: !IN_LDS only)
         s.mem = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
         s.cnt = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)K * 2, 8);
-        s.off = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)(K + 1) * 2, 8);
-        s.kkz = reinterpret_cast<unsigned long long*>(q);
+        s.off = reinterpret_cast<unsigned short*>(q);
     }
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -591,11 +622,14 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         int* red = reinterpret_cast<int*>(smem_raw);
         const int c0 = (p / chunk) * chunk, c1 = min((int)gridDim.x, c0 + chunk);
         int m = (int)0x80000000;
-        for (int64_t q = (int64_t)c0 * slots_pp + tid; q < (int64_t)c1 * slots_pp; q += 256) m = max(m, chunkmax[q]);
+        for (int64_t q = (int64_t)c0 * slots_pp + tid; q < (int64_t)c1 * slots_pp; q += SEL_THREADS) m = max(m, chunkmax[q]);
         m = cc_wave_imax(m);
         if (lane == 0) red[wave] = m;
         __syncthreads();
-        shift_mx = cc_ordered_int_to_float(max(max(red[0], red[1]), max(red[2], red[3])));
+        int mm = red[0];
+#pragma unroll
+        for (int w = 1; w < SEL_WAVES; ++w) mm = max(mm, red[w]);
+        shift_mx = cc_ordered_int_to_float(mm);
         __syncthreads();                                       // red[] is the start of the staged D / of best[]
     }
     if (IN_LDS) {
@@ -606,16 +640,16 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
             const float4* src4 = reinterpret_cast<const float4*>(Dg);
             float4* dst4 = reinterpret_cast<float4*>(dst);
             const int total4 = total >> 2;
-            for (int i0 = tid; i0 < total4; i0 += 256 * 8) {
+            for (int i0 = tid; i0 < total4; i0 += SEL_THREADS * 8) {
                 float4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * 256;
+                    const int idx = i0 + u * SEL_THREADS;
                     v[u] = idx < total4 ? src4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * 256;
+                    const int idx = i0 + u * SEL_THREADS;
                     if (idx < total4) {
                         if (apply_shift) {
                             v[u].x = (v[u].x - mx) - 1.0f; v[u].y = (v[u].y - mx) - 1.0f;
@@ -626,16 +660,16 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
                 }
             }
         } else {
-            for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+            for (int i0 = tid; i0 < total; i0 += SEL_THREADS * 8) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * 256;
+                    const int idx = i0 + u * SEL_THREADS;
                     v[u] = idx < total ? Dg[idx] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * 256;
+                    const int idx = i0 + u * SEL_THREADS;
                     if (idx < total) dst[idx] = apply_shift ? (v[u] - mx) - 1.0f : v[u];
                 }
             }
@@ -645,7 +679,7 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         __syncthreads();
         if (apply_shift) {
             float* dd = IN_LDS ? s.D : (dist_rw + base);
-            for (int i = tid; i < N; i += 256) dd[(int64_t)i * N + i] -= 1.0f;
+            for (int i = tid; i < N; i += SEL_THREADS) dd[(int64_t)i * N + i] -= 1.0f;
             __threadfence_block();
         }
         __syncthreads();
@@ -661,71 +695,84 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
 #define DREAD(i, j) (IN_LDS ? s.D[(i) * N + (j)] : dread_global((i), (j)))
     SEL_STAMP(1);
 
-    for (int j = tid; j < N; j += 256) s.order[sum_rank(j, N)] = (unsigned short)j;
+    for (int j = tid; j < N; j += SEL_THREADS) s.order[sum_rank(j, N)] = (unsigned short)j;
 
-    // ---- KKZ init (cluster_utils.py:93,106-118) on all four waves: thread t owns tokens t, t + 256, ...; the running
-    // minimum lives in registers as order-preserving uint keys.  Per step: wave arg-max = DPP max + ballots (lowest
-    // index wins ties), the four (key, index) pairs meet in LDS (one barrier; the slots are double-buffered so that a
-    // step's writes never race the previous step's reads), every thread takes the best pair and folds the new medoid's
-    // row into its minimum.  (One wave doing all of it took ~990 cycles per step: 4 LDS rows + 4 ballots in a chain.)
-    {
-        constexpr int NT = (NE + 3) / 4;
-        unsigned nearest[NT];
+    // ---- KKZ init (cluster_utils.py:93,106-118) on ONE wave: lane l owns the TPL consecutive tokens from l * TPL, the
+    // running minimum lives in registers as order-preserving uint keys.  Per step: first maximum inside the lane, wave
+    // maximum by DPP, lowest lane holding it by one ballot (token order = lane order, so that is the lowest index, as
+    // torch.max / argmax resolve ties), its slot by one readlane; then the new medoid's row is folded into the minimum
+    // - the lane's TPL entries are contiguous (one ds_read_b128 at N = 196).  No barrier, no LDS exchange in the chain:
+    // ~300 cycles per step at N = 196 against 780 for the four-wave form.
+    if (wave == 0) {
+        constexpr int TPL = NE;
+        // (the running minimum is kept as plain floats: v_max / v_min / v_cmp_eq order finite floats as torch.max / min do,
+        //  -0 == +0 included, and save the 3-instruction key conversion per element that sat in the dependent chain)
+        float nearest[TPL];
         const float* nr = norms + (int64_t)p * N;
+        const int n0 = lane * TPL;
+        const float NEG = -__builtin_inff();                   // padding tokens never win
 #pragma unroll
-        for (int e = 0; e < NT; ++e) {
-            const int n = tid + 256 * e;
-            nearest[e] = (n < N) ? cc_float_to_ordered_uint(nr[n]) : 0u;   // 0 < key of any float
-        }
-        unsigned long long* red = s.kkz;
+        for (int e = 0; e < TPL; ++e) nearest[e] = (n0 + e < N) ? nr[n0 + e] : NEG;
         for (int i = 0; i < K; ++i) {
-            unsigned loc = nearest[0];
+            float loc = nearest[0];
+            int slot = 0;
 #pragma unroll
-            for (int e = 1; e < NT; ++e) loc = max(loc, nearest[e]);
-            const unsigned mx = cc_wave_umax(loc);
-            int m = -1;
-#pragma unroll
-            for (int e = 0; e < NT; ++e) {
-                const unsigned long long b = __ballot(nearest[e] == mx);
-                if (m < 0 && b) m = 256 * e + 64 * wave + __ffsll((long long)b) - 1;
+            for (int e = 1; e < TPL; ++e)
+                if (nearest[e] > loc) { loc = nearest[e]; slot = e; }
+            float mx = fmaxf(loc, cc_dpp_f32<0xB1>(loc));
+            mx = fmaxf(mx, cc_dpp_f32<0x4E>(mx));
+            mx = fmaxf(mx, cc_dpp_f32<0x141>(mx));
+            mx = fmaxf(mx, cc_dpp_f32<0x140>(mx));
+            {
+                const int iv = __float_as_int(mx);
+                const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+                const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+                mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
             }
-            // (a wave that owns only padding reports key 0 and loses against every real key)
-            if (lane == 0)
-                red[(i & 1) * 4 + wave] = ((unsigned long long)mx << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)m);
-            __syncthreads();
-            unsigned long long best = red[(i & 1) * 4];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const unsigned long long o = red[(i & 1) * 4 + w];
-                best = o > best ? o : best;
-            }
-            m = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
-            if (tid == 0) s.med[i] = m;
-#pragma unroll
-            for (int e = 0; e < NT; ++e) {
-                const int n = tid + 256 * e;
-                if (n < N) {
-                    const unsigned kd = cc_float_to_ordered_uint(DREAD(m, n));
-                    nearest[e] = (i == 0) ? kd : min(nearest[e], kd);
+            const int src = __ffsll((long long)__ballot(loc == mx)) - 1;
+            const int m = src * TPL + __builtin_amdgcn_readlane(slot, src);
+            if (lane == 0) s.med[i] = m;
+            bool done = false;
+            if constexpr (IN_LDS && TPL == 4) {
+                if ((N & 3) == 0) {                              // 16-byte aligned rows: one wide LDS read
+                    const float4 r = *reinterpret_cast<const float4*>(s.D + m * N + min(n0, N - 4));
+                    if (n0 < N) {
+                        nearest[0] = (i == 0) ? r.x : fminf(nearest[0], r.x);
+                        nearest[1] = (i == 0) ? r.y : fminf(nearest[1], r.y);
+                        nearest[2] = (i == 0) ? r.z : fminf(nearest[2], r.z);
+                        nearest[3] = (i == 0) ? r.w : fminf(nearest[3], r.w);
+                    }
+                    done = true;
                 }
+            }
+            if (!done) {
+                float r[TPL];
+#pragma unroll
+                for (int e = 0; e < TPL; ++e) r[e] = DREAD(m, min(n0 + e, N - 1));
+#pragma unroll
+                for (int e = 0; e < TPL; ++e)
+                    if (n0 + e < N) nearest[e] = (i == 0) ? r[e] : fminf(nearest[e], r[e]);
             }
         }
     }
     __syncthreads();
     SEL_STAMP(2);
 
-    // a_n = first argmin_k D[m_k, n]  (fast_kmeans.py:75-76); 8 medoid rows in flight per lane
+    // a_n = first argmin_k D[m_k, n]  (fast_kmeans.py:75-76).  Four threads per token: thread part q scans the contiguous
+    // medoid range [q * ceil(K/4), ...) with 8 rows in flight and keeps its first minimum; the quad then keeps the smaller
+    // value, the lower cluster id on equal values - the first minimum over all K, as torch.min resolves ties.
     auto assign_step = [&](bool build_masks) {
-        if (build_masks)                                             // the masks are rebuilt with LDS atomics below
-            for (int q = tid; q < K * E; q += 256) s.cmask[q] = 0ull;
-        for (int e = 0; e < 4; ++e) {
-            const int n = tid + 256 * e;
-            if (e * 256 >= N) break;                                 // uniform
+        if (!IN_LDS && build_masks)                                  // the masks are rebuilt with LDS atomics below
+            for (int q = tid; q < K * E; q += SEL_THREADS) s.cmask[q] = 0ull;
+        const int part = tid & 3, kq = (K + 3) >> 2;
+        const int kb = part * kq, ke = min(K, kb + kq);
+        for (int nb = 0; nb < N; nb += SEL_THREADS / 4) {            // uniform trip count
+            const int n = nb + (tid >> 2);
             const int nn = min(n, N - 1);
-            float best = DREAD(s.med[0], nn);
-            int a = 0;
-            int k = 1;
-            for (; k + 8 <= K; k += 8) {
+            float best = __builtin_inff();
+            int a = K;                                               // (an empty part never wins: D is finite)
+            int k = kb;
+            for (; k + 8 <= ke; k += 8) {
                 int mk[8];
                 float v[8];
 #pragma unroll
@@ -734,19 +781,25 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
                 for (int u = 0; u < 8; ++u) v[u] = DREAD(mk[u], nn);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (v[u] < best) { best = v[u]; a = k + u; }
+                    if (v[u] < best || a == K) { best = v[u]; a = k + u; }
             }
-            for (; k < K; ++k) {
+            for (; k < ke; ++k) {
                 const float v = DREAD(s.med[k], nn);
-                if (v < best) { best = v; a = k; }
+                if (v < best || a == K) { best = v; a = k; }
             }
-            if (n < N) s.asg[n] = (unsigned short)a;
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oa = __shfl_xor(a, o, 64);
+                if (oa < K && (a == K || ob < best || (ob == best && oa < a))) { best = ob; a = oa; }
+            }
+            if (n < N && part == 0) s.asg[n] = (unsigned short)a;
         }
-        if (build_masks) {
+        if (!IN_LDS && build_masks) {
             // membership bit masks in summation-rank space: bit t of cluster k  <-  token order[t] belongs to k.
             // One ds_or_b64 per token (OR commutes: deterministic) instead of K ballots per wave.
             __syncthreads();
-            for (int t = tid; t < N; t += 256)
+            for (int t = tid; t < N; t += SEL_THREADS)
                 atomicOr(&s.cmask[(size_t)s.asg[s.order[t]] * E + (t >> 6)], 1ull << (t & 63));
         }
     };
@@ -759,13 +812,29 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         assign_step(true);
         __syncthreads();
         if (prof) tq1 = (long long)__builtin_readcyclecounter();
+        // Incremental update: s_i depends only on the member set of i's cluster, so a cluster that neither gained nor lost
+        // a token since the last iteration keeps its medoid (its best[] entry stays) - only the candidates of the clusters
+        // that changed are re-evaluated.  Bit for bit what the full recomputation yields; after the first iteration a
+        // handful of clusters move per iteration, and the last iteration (nothing moves) costs an assignment only.
+        for (int k = tid; k < K; k += SEL_THREADS) s.dirty[k] = (it == 0) ? 1 : 0;
+        if (tid == 0) *s.count = 0;
+        __syncthreads();
+        for (int n = tid; n < N; n += SEL_THREADS) {
+            const unsigned short a = s.asg[n], pa = s.prev[n];
+            if (it > 0 && a != pa) { s.dirty[a] = 1; s.dirty[pa] = 1; }
+            s.prev[n] = a;
+        }
+        __syncthreads();
+        if constexpr (!IN_LDS) {
+        // D in global memory (N > 197): the member-list form - a dense walk reads N^2 entries per iteration from L2,
+        // the lists only sum_c |c|^2 (measured at N = 588: 65 k against 37 k cycles per iteration)
         // group the tokens by cluster, each group in summation-rank order: counts -> offsets -> scatter
-        for (int k = tid; k < K; k += 256) {
+        for (int k = tid; k < K; k += SEL_THREADS) {
             const unsigned long long* cm = s.cmask + (size_t)k * E;
             int n = 0;
             for (int w = 0; w < E; ++w) n += __popcll(cm[w]);
             s.cnt[k] = (unsigned short)n;
-            s.best[k] = ~0ull;
+            if (s.dirty[k]) s.best[k] = ~0ull;
         }
         __syncthreads();
         if (wave == 0) {                                       // exclusive prefix sum of the counts: wave scan, 64 at a time
@@ -790,7 +859,7 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         auto tree_code = [&](int j) {
             return ((j & 7) << 4) | (j >= rest ? 2 : ((((j >> 3) & 3) << 2) | (j >> 9)));
         };
-        for (int t = tid; t < N; t += 256) {
+        for (int t = tid; t < N; t += SEL_THREADS) {
             const int j = s.order[t];
             const int a = s.asg[j];
             const unsigned long long* cm = s.cmask + (size_t)a * E;
@@ -820,8 +889,9 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
         // c = current run of passes, P = accumulator (k,l), R = lane l, F = total.  Closing a level adds it to its
         // parent; closing an empty level adds an exact zero, so the level logic is branch-free selects.  The
         // medoid (fast_kmeans.py:82: argmin, lowest index on ties) is a 64-bit LDS min over (key(s_i), i).
-        for (int i = tid; i < N; i += 256) {
+        for (int i = tid; i < N; i += SEL_THREADS) {
             const int cl = s.asg[i];
+            if (!s.dirty[cl]) continue;
             const int b0 = s.off[cl], b1 = s.off[cl + 1];
             float c = 0.f, P = 0.f, R = 0.f, F = 0.f;
             for (int q = b0; q < b1; q += 8) {
@@ -854,8 +924,116 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
             atomicMin(&s.best[cl], ((unsigned long long)cc_float_to_ordered_uint(F) << 32) | (unsigned)i);
         }
         __syncthreads();
+        } else {
+        for (int k = tid; k < K; k += SEL_THREADS)
+            if (s.dirty[k]) s.best[k] = ~0ull;
+        for (int n = tid; n < N; n += SEL_THREADS)
+            if (s.dirty[s.asg[n]]) s.list[atomicAdd(s.count, 1)] = (unsigned short)n;     // (order is irrelevant to the min below)
+        __syncthreads();
+        if (prof) tq2 = (long long)__builtin_readcyclecounter();
+        // s_i = sum_j D[i,j] * [a_j == a_i]  (fast_kmeans.py:81-82, equivalence 2) in the association of ATen's CPU row sum
+        // (see sum_rank).  That sum is a fixed TREE, not a chain: 32 accumulators P_kl (lane l = j % 8, accumulator
+        // k = (j / 8) % 4), each a sequential sum over the passes it of x[32 it + 8 k + l] (passes 0-15 and 16-31 apart,
+        // then added; the up to three vectors behind the last full pass join accumulator 0), then
+        // R_l = ((P_0l + P_1l) + P_2l) + P_3l and total = (((tail + R_0) + R_1) ... + R_7), tail = the N % 8 trailing
+        // scalars summed first.  The 32 accumulators are independent chains over the passes, walked DENSELY (masked-out
+        // terms are exact zeros and x + 0 = x, so adding them is the reference's own arithmetic): depth <= 32 + 3 + 7 + 8
+        // dependent adds instead of one per member, no member lists, no per-cluster masks (rounds 1-2: a thread per
+        // candidate walking its cluster's member list through branch-free level partials - 9.3 k of the 17.3 k cycles of
+        // an iteration at N = 196, set by the largest cluster).  The medoid (fast_kmeans.py:82: argmin,
+        // lowest index on ties) is a 64-bit LDS min over (key(s_i), i).
+        {
+            // 8 lanes per candidate: lane l owns the four accumulators P_0l..P_3l - four independent chains over the passes -
+            // forms R_l itself, and the eight R_l meet through one round of lane shuffles; 128 candidates in flight, waves
+            // whose eight slots lie behind the end of the list skip the pass.  (A 32-lane form - one accumulator per lane -
+            // measured 18.5 k cycles per iteration at N = 196: seven dependent passes of shuffles; a 2-lane form with wide
+            // reads 12.5 k: four-way bank conflicts between rows 196 floats apart; this one 9.2 k for all 196 candidates.)
+            const int lq = tid & 7, slot = tid >> 3;
+            const int M = *s.count;
+            if (N >= 8) {
+                const int vec_end = N & ~7, vs = N >> 3, passes = vs >> 2, nleft = vs & 3, ntail = N - vec_end;
+                for (int i0 = 0; i0 < M; i0 += SEL_THREADS / 8) {      // uniform trip count
+                    if (i0 + wave * 8 >= M) continue;                  // wave-uniform
+                    const int idx = i0 + slot;
+                    const int i = s.list[min(idx, M - 1)];
+                    const int cl = s.asg[i];
+                    float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int p0 = min(passes, 16);
+#pragma unroll 2
+                    for (int it2 = 0; it2 < p0; ++it2) {
+                        float d[4];
+                        int a4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = 32 * it2 + 8 * k + lq;
+                            d[k] = s.D[i * N + j];
+                            a4[k] = s.asg[j];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c0[k] += (a4[k] == cl) ? d[k] : 0.f;
+                    }
+#pragma unroll 2
+                    for (int it2 = 16; it2 < passes; ++it2) {
+                        float d[4];
+                        int a4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = 32 * it2 + 8 * k + lq;
+                            d[k] = s.D[i * N + j];
+                            a4[k] = s.asg[j];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c1[k] += (a4[k] == cl) ? d[k] : 0.f;
+                    }
+                    float P[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) P[k] = (passes > 16) ? c0[k] + c1[k] : c0[k];
+                    for (int v = 0; v < nleft; ++v) {                  // the vectors behind the last full pass join accumulator 0
+                        const int j = 32 * passes + 8 * v + lq;
+                        const float d = s.D[i * N + j];
+                        P[0] += ((int)s.asg[j] == cl) ? d : 0.f;
+                    }
+                    const float R = ((P[0] + P[1]) + P[2]) + P[3];     // R_l
+                    float F = 0.f;                                     // tail scalars first (every lane of the group: same value)
+                    float dt[7];
+                    int at[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) {
+                        const int j = min(vec_end + t, N - 1);
+                        dt[t] = s.D[i * N + j];
+                        at[t] = s.asg[j];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 7; ++t)
+                        if (t < ntail) F += (at[t] == cl) ? dt[t] : 0.f;
+                    const int base = (tid & 63) & ~7;
+                    float r8[8];
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) r8[l] = __shfl(R, base + l, 64);
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) F += r8[l];
+                    if (lq == 0 && idx < M)
+                        atomicMin(&s.best[cl], ((unsigned long long)cc_float_to_ordered_uint(F) << 32) | (unsigned)i);
+                }
+            } else {
+                // N < 8 is ATen's scalar path: the terms strictly in summation-rank order (x0, the scalars from 4 on, x1..x3)
+                for (int q = tid; q < M; q += SEL_THREADS) {
+                    const int i = s.list[q];
+                    const int cl = s.asg[i];
+                    float F = 0.f;
+                    for (int t = 0; t < N; ++t) {
+                        const int j = s.order[t];
+                        const float d = DREAD(i, j);
+                        F += (s.asg[j] == cl) ? d : 0.f;
+                    }
+                    atomicMin(&s.best[cl], ((unsigned long long)cc_float_to_ordered_uint(F) << 32) | (unsigned)i);
+                }
+            }
+        }
+        __syncthreads();
+        }
         int changed = 0;
-        for (int k = tid; k < K; k += 256) {
+        for (int k = tid; k < K; k += SEL_THREADS) {
             const unsigned long long b = s.best[k];
             const int bi = (b == ~0ull) ? 0 : (int)(unsigned)(b & 0xFFFFFFFFull);   // empty cluster -> 0, as argmin
             changed |= (bi != s.med[k]);                                             // over an all-zero row
@@ -868,34 +1046,32 @@ __global__ __launch_bounds__(256) void kmedoids_select_kernel(const float* __res
     }
     SEL_STAMP(3);
 
-    if (id_sort) {                              // fast_kmeans.py:90-94
-        int mine[4], rank[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = tid + 256 * e;
-            mine[e] = 0; rank[e] = 0;
-            if (k < K) {
-                mine[e] = s.med[k];
-                int r = 0;
-                for (int q = 0; q < K; ++q) {
-                    const int o = s.med[q];
-                    r += (o < mine[e] || (o == mine[e] && q < k)) ? 1 : 0;
-                }
-                rank[e] = r;
+    if (id_sort) {                              // fast_kmeans.py:90-94 (K <= SEL_MAX_N < SEL_THREADS: one medoid per thread)
+        int mine = 0, rank = 0;
+        if (tid < K) {
+            mine = s.med[tid];
+            for (int q = 0; q < K; ++q) {
+                const int o = s.med[q];
+                rank += (o < mine || (o == mine && q < tid)) ? 1 : 0;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (tid + 256 * e < K) s.med[rank[e]] = mine[e];
+        if (tid < K) s.med[rank] = mine;
         __syncthreads();
         if (assign_out) assign_step(false);
         __syncthreads();
     }
-    for (int k = tid; k < K; k += 256) medoids_out[(int64_t)p * K + k] = s.med[k];
+    for (int k = tid; k < K; k += SEL_THREADS) medoids_out[(int64_t)p * K + k] = s.med[k];
     if (assign_out)
-        for (int n = tid; n < N; n += 256) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
+        for (int n = tid; n < N; n += SEL_THREADS) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
     if (iters_out && tid == 0) iters_out[p] = iters;
+    if (gd.out) {
+        // K3 folded in: problem p = segment sgm of clip b (p = sgm * B + b, cluster.py:247-250) -> output frame b * T_new + sgm;
+        // one wave per output row (CLS mean, K medoid tokens), ids straight from LDS (s.med is final and barrier-visible)
+        const int b = p % gd.B, sgm = p / gd.B, Lout = 1 + K;
+        const int row0 = (b * gd.T_new + sgm) * Lout;
+        for (int l = wave; l < Lout; l += SEL_WAVES) reduce_row_wave<false>(gd, row0 + l, lane, s.med);
+    }
     SEL_STAMP(4);
     if (prof && tid == 0) {
         prof[(int64_t)blockIdx.x * 16 + 5] = iters;
@@ -1058,19 +1234,20 @@ __global__ __launch_bounds__(256) void cross_shift_kernel(float* __restrict__ di
 // of the segment's CLS tokens (cluster.py:307-308), optionally scaled per frame (adaptive_cls, :244-245);
 // cluster_embed [K,W] is added to rows 1..K (:304-305).
 template <bool LEFT>
-__global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restrict__ x, int64_t in_tok, int64_t in_frame,
-                                                            int B, int T, int T_new, int n, int W, int K, int mode,
-                                                            const long long* __restrict__ medoids, int med_stride,
-                                                            const long long* __restrict__ assign,
-                                                            const float* __restrict__ cluster_embed,
-                                                            const float* __restrict__ cls_mult,
-                                                            float* __restrict__ out, int64_t out_tok, int64_t out_frame,
-                                                            _Float16* __restrict__ h16, float* __restrict__ stats,
-                                                            float* __restrict__ shift) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ void reduce_row_wave(const GatherDesc& gd, int row, int lane, const int* med_lds) {
+    const float* __restrict__ x = gd.x;
+    const int64_t in_tok = gd.in_tok, in_frame = gd.in_frame, out_tok = gd.out_tok, out_frame = gd.out_frame;
+    const int B = gd.B, T = gd.T, T_new = gd.T_new, n = gd.n, W = gd.W, K = gd.K, mode = gd.mode;
+    const long long* __restrict__ medoids = gd.medoids;
+    const int med_stride = gd.med_stride;
+    const long long* __restrict__ assign = gd.assign;
+    const float* __restrict__ cluster_embed = gd.cluster_embed;
+    const float* __restrict__ cls_mult = gd.cls_mult;
+    float* __restrict__ out = gd.out;
+    _Float16* __restrict__ h16 = gd.h16;
+    float* __restrict__ stats = gd.stats;
+    float* __restrict__ shift = gd.shift;
     const int Lout = (mode == 2) ? 1 + n : 1 + K;
-    if (row >= B * T_new * Lout) return;
     // optional by-products for the fused forward (the next block's folded ln_1): fp16 copy of the output row at
     // h16[row][W], centred on the row mean (see layernorm_row in transformer.hip), its (sum, sum of squares) and the mean.
     // The mean needs the whole row: every lane re-reads the elements it has just written (same lane, program order).
@@ -1131,7 +1308,7 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
     const int p = sgm * B + b, k = l - 1;
     const float* emb = cluster_embed ? cluster_embed + (int64_t)k * W : nullptr;
     if (mode == 0) {
-        const int j = (int)medoids[(int64_t)p * med_stride + k];
+        const int j = med_lds ? med_lds[k] : (int)medoids[(int64_t)p * med_stride + k];
         const int f = j / n, i = j - f * n;
         const float* src = seg0 + (int64_t)(1 + i) * in_tok + (int64_t)f * in_frame;
         for (int w = lane * 4; w < W; w += 256) {
@@ -1179,7 +1356,41 @@ __global__ __launch_bounds__(256) void reduce_tokens_kernel(const float* __restr
     finish();
 }
 
+template <bool LEFT>
+__global__ __launch_bounds__(256) void reduce_tokens_kernel(GatherDesc gd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Lout = (gd.mode == 2) ? 1 + gd.n : 1 + gd.K;
+    if (row >= gd.B * gd.T_new * Lout) return;
+    reduce_row_wave<LEFT>(gd, row, threadIdx.x & 63, nullptr);
+}
+
 // ============================================================================ host side
+static GatherDesc gather_desc(const float* x, int64_t in_tok, int64_t in_frame, int B, int T, int T_new, int n, int W, int K,
+                              int mode, const long long* medoids, int med_stride, const long long* assign,
+                              const float* cluster_embed, const float* cls_mult, float* out, int64_t out_tok,
+                              int64_t out_frame, _Float16* h16, float* stats, float* shift) {
+    GatherDesc g{};
+    g.x = x; g.in_tok = in_tok; g.in_frame = in_frame;
+    g.B = B; g.T = T; g.T_new = T_new; g.n = n; g.W = W; g.K = K; g.mode = mode;
+    g.medoids = medoids; g.med_stride = med_stride; g.assign = assign;
+    g.cluster_embed = cluster_embed; g.cls_mult = cls_mult;
+    g.out = out; g.out_tok = out_tok; g.out_frame = out_frame;
+    g.h16 = h16; g.stats = stats; g.shift = shift;
+    return g;
+}
+
+// K3 as a launch of its own (one wave per output row)
+static void launch_reduce_tokens(hipStream_t st, const float* x, int64_t in_tok, int64_t in_frame, int B, int T, int T_new,
+                                 int n, int W, int K, int mode, const long long* medoids, int med_stride,
+                                 const long long* assign, const float* cluster_embed, const float* cls_mult, float* out,
+                                 int64_t out_tok, int64_t out_frame, _Float16* h16, float* stats, float* shift) {
+    const GatherDesc g = gather_desc(x, in_tok, in_frame, B, T, T_new, n, W, K, mode, medoids, med_stride, assign,
+                                     cluster_embed, cls_mult, out, out_tok, out_frame, h16, stats, shift);
+    const int rows = B * T_new * ((mode == 2) ? 1 + n : 1 + K);
+    if (W & 31) hipLaunchKernelGGL(reduce_tokens_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, g);
+}
+
 namespace {
 
 struct ClusterWs {
@@ -1338,7 +1549,9 @@ int run_distance_sq(const float* x, cc_token_layout lay, int W, const ClusterWs&
 
 int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int slots_pp, int chunk,
                int apply_shift, int P, int N, int K, int iter_limit, int id_sort, long long* med, long long* assign,
-               int* iters, hipStream_t st) {
+               int* iters, hipStream_t st, const GatherDesc* gather = nullptr) {
+    GatherDesc gd{};
+    if (gather) gd = *gather;
     const size_t lds_limit = 160 * 1024;
     const bool in_lds = sel_smem_bytes(N, K, true) <= lds_limit;
     const size_t smem = sel_smem_bytes(N, K, in_lds);
@@ -1350,8 +1563,8 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
         if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return CC_ERR_HIP;                                                                                         \
-        hipLaunchKernelGGL(kern, dim3(P), dim3(256), smem, st, dist_in, dist_rw, norms, chunkmax, slots_pp, chunk, apply_shift, \
-                           N, K, iter_limit, id_sort, med, assign, iters);                                            \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(SEL_THREADS), smem, st, dist_in, dist_rw, norms, chunkmax, slots_pp, chunk, apply_shift, \
+                           N, K, iter_limit, id_sort, med, assign, iters, gd);                                        \
     } while (0)
     if (in_lds) {
         if (ne <= 1) SEL_LAUNCH(true, 1);
@@ -1467,10 +1680,10 @@ int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, 
                       static_cast<hipStream_t>(stream));
 }
 
-int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K, int32_t metric,
-                          float norm_p, float threshold, int32_t iter_limit, int32_t id_sort, int32_t split_size,
-                          int32_t pre_norm, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
-                          size_t ws_bytes, void* stream) {
+static int batch_kmedoids_impl(const float* x, const cc_token_layout* lay, int32_t W, int32_t K, int32_t metric,
+                               float norm_p, float threshold, int32_t iter_limit, int32_t id_sort, int32_t split_size,
+                               int32_t pre_norm, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
+                               size_t ws_bytes, void* stream, const GatherDesc* gather) {
     // Stop test: every problem iterates to its fixed point (medoids unchanged), which gives the final state of the
     // reference's chunk-mean test (fast_kmeans.py:85-88) whenever the threshold is below the distance between any two
     // distinct tokens.  A loose threshold would stop the reference earlier: refused instead of silently ignored.
@@ -1488,7 +1701,15 @@ int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W,
     int rc = run_distance(x, *lay, W, metric, norm_p, split_size, pre_norm, c, st);
     if (rc != CC_OK) return rc;
     return run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, iter_limit, id_sort,
-                      reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st);
+                      reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st, gather);
+}
+
+int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K, int32_t metric,
+                          float norm_p, float threshold, int32_t iter_limit, int32_t id_sort, int32_t split_size,
+                          int32_t pre_norm, int64_t* medoids, int64_t* assign, int32_t* iters, void* ws,
+                          size_t ws_bytes, void* stream) {
+    return batch_kmedoids_impl(x, lay, W, K, metric, norm_p, threshold, iter_limit, id_sort, split_size, pre_norm, medoids,
+                               assign, iters, ws, ws_bytes, stream, nullptr);
 }
 
 // *_rows: the public entry plus the by-products the fused forward wants from the same launch - row_h16 [rows][W] fp16
@@ -1505,8 +1726,7 @@ int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame
     if (!rows_layout_ok(row_h16, row_stats, W, 1 + K, out_tok_stride, out_frame_stride)) return CC_ERR_INVALID;
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
-    const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+    launch_reduce_tokens( static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(medoids), K,
                        (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
                        out_frame_stride, row_h16, row_stats, row_shift);
@@ -1531,8 +1751,7 @@ int cc_token_aggregate_f32(const float* x, int64_t in_tok_stride, int64_t in_fra
     float* const row_shift = nullptr;
     if ((T % T_new) || (W & 3) || ((in_tok_stride | in_frame_stride | out_tok_stride | out_frame_stride) & 3))
         return CC_ERR_INVALID;
-    const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+    launch_reduce_tokens( static_cast<hipStream_t>(stream), x,
                        in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 1, (const long long*)nullptr, 0,
                        reinterpret_cast<const long long*>(assign), var ? var->cluster_embed : nullptr,
                        var ? var->cls_multiplier : nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats,
@@ -1553,8 +1772,7 @@ int cc_token_apply_selection_f32(const float* x, int64_t in_tok_stride, int64_t 
     _Float16* const row_h16 = nullptr;
     float* const row_stats = nullptr;
     float* const row_shift = nullptr;
-    const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0,
+    launch_reduce_tokens(
                        static_cast<hipStream_t>(stream), x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, mean ? 1 : 0,
                        mean ? (const long long*)nullptr : reinterpret_cast<const long long*>(medoids), mean ? 0 : K,
                        mean ? reinterpret_cast<const long long*>(assign) : (const long long*)nullptr,
@@ -1579,8 +1797,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int fd = T / T_new;
     if (var->algorithm == CC_CLUSTER_POOLING) {                 // no selection: every token = mean over the segment's frames
-        const int rows = B * T_new * (1 + n);
-        hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+        launch_reduce_tokens( st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, n, 2, (const long long*)nullptr, 0, (const long long*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, out, out_tok_stride, out_frame_stride, row_h16, row_stats,
                            row_shift);
@@ -1589,8 +1806,7 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
     }
     if (var->algorithm == CC_CLUSTER_SPARSE_SAMPLING) {         // fixed ids shared by every problem, then gather + CLS mean
         if (!var->fixed_ids || K <= 0) return CC_ERR_INVALID;
-        const int rows = B * T_new * (1 + K);
-        hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride,
+        launch_reduce_tokens( st, x, in_tok_stride, in_frame_stride,
                            B, T, T_new, n, W, K, 0, reinterpret_cast<const long long*>(var->fixed_ids), 0,
                            (const long long*)nullptr, (const float*)nullptr, (const float*)nullptr, out, out_tok_stride,
                            out_frame_stride, row_h16, row_stats, row_shift);
@@ -1635,12 +1851,18 @@ int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t
                                    (split_size > 1 && P > split_size) ? split_size : P, 1, med, asg_q, iters, sw.km, sw.km_bytes,
                                    stream);
     } else {
-        rc = cc_batch_kmedoids_f32(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
-                                   pre_norm, med, asg, iters, ws, ws_bytes, stream);
+        // the shipped variant: the selection kernel writes the output rows itself (K3 folded into K2's tail)
+        const bool fold = !mean && (W & 31) == 0;
+        const GatherDesc gd = gather_desc(x, in_tok_stride, in_frame_stride, B, T, T_new, n, W, K, 0,
+                                          reinterpret_cast<const long long*>(med), K, (const long long*)nullptr,
+                                          var->cluster_embed, var->cls_multiplier, out, out_tok_stride, out_frame_stride,
+                                          row_h16, row_stats, row_shift);
+        rc = batch_kmedoids_impl(x + in_tok_stride, &lay, W, K, metric, norm_p, threshold, iter_limit, 1, split_size,
+                                 pre_norm, med, asg, iters, ws, ws_bytes, stream, fold ? &gd : nullptr);
+        if (rc == CC_OK && fold) return CC_OK;
     }
     if (rc != CC_OK) return rc;
-    const int rows = B * T_new * (1 + K);
-    hipLaunchKernelGGL((W & 31) ? reduce_tokens_kernel<true> : reduce_tokens_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, in_tok_stride, in_frame_stride, B,
+    launch_reduce_tokens( st, x, in_tok_stride, in_frame_stride, B,
                        T, T_new, n, W, K, mean ? 1 : 0, reinterpret_cast<const long long*>(med), K,
                        reinterpret_cast<const long long*>(asg), var->cluster_embed, var->cls_multiplier, out,
                        out_tok_stride, out_frame_stride, row_h16, row_stats, row_shift);
