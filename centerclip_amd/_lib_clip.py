@@ -66,6 +66,10 @@ def declare(lib):
     lib.cc_head_project_f32.restype = c.c_int
     lib.cc_contrastive_loss_f32.argtypes = [vp, i32, i64, i64, vp, vp, sz, vp]
     lib.cc_contrastive_loss_f32.restype = c.c_int
+    lib.cc_contrastive_grad_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.cc_contrastive_grad_workspace_bytes.restype = sz
+    lib.cc_contrastive_loss_grad_f32.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_contrastive_loss_grad_f32.restype = c.c_int
     lib.cc_normalize_rows_f32.argtypes = [vp, vp, i32, i32, vp]
     lib.cc_normalize_rows_f32.restype = c.c_int
     lib.cc_loose_similarity_grouped_f32.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, f32, vp, i32,

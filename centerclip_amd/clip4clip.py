@@ -3,8 +3,9 @@ CLIP4Clip.from_pretrained (local checkpoint), forward, get_sequence_output, get_
 get_similarity_logits, _loose_similarity, get_video_mask_after_cluster - same signatures and return conventions
 (SURVEY.md §8b, rows S1/S2).  All compute goes through ``torch.ops.centerclip.*``.
 
-Training mode returns the reference's loss VALUES (feature all-gather -> logits -> symmetric CrossEn,
-clip4clip.py:245-262) without a backward - gradients / the optimiser are out of scope.
+Training mode returns the reference's loss (feature all-gather -> logits -> symmetric CrossEn, clip4clip.py:245-262),
+differentiable with respect to the features and logit_scale; the towers have no backward (encoder backward,
+DDP gradient all-reduce and the optimiser are out of scope).
 Not built: seqTransf / tightTransf heads, weight download.
 """
 import torch
@@ -14,8 +15,9 @@ from . import _lib as L
 from . import ops
 from . import torch_ops as T
 from .clip import build_clip_model, load_clip_state_dict, zero_scalar
-from .dist import all_gather
-from .losses import symmetric_contrastive_loss
+from . import dist as ccdist
+from .dist import AllGather, all_gather
+from .losses import contrastive_loss
 
 
 class CLIP4Clip(nn.Module):
@@ -101,11 +103,15 @@ class CLIP4Clip(nn.Module):
             else:                                    # clip4clip.py:238-243: normalise, masked mean, normalise
                 output_dict['visual_output'] = ops.video_pool_normalize(visual_output, video_mask)
         if self.training:
-            # loss values of the reference's training branch (clip4clip.py:245-262); forward only
-            with torch.no_grad():
-                sim_matrix, *_tmp = self.get_similarity_logits(sequence_output, visual_output, attention_mask,
-                                                               video_mask, shaped=True)
-                sim_loss, _, _ = symmetric_contrastive_loss(sim_matrix)
+            # the reference's training branch (clip4clip.py:245-262): features of all ranks -> logits -> symmetric CrossEn.
+            # The loss is differentiable with respect to the features and logit_scale (losses.contrastive_loss: forward and
+            # gradient in one kernel chain); the towers have no backward here, so the gradient edge ends at
+            # sequence_output / visual_output (detached leaves unless the caller made them require grad).
+            seq, vis, vmask = sequence_output.contiguous(), visual_output.contiguous(), video_mask.contiguous()
+            if ccdist.world_size() > 1:
+                seq, vis = AllGather.apply(seq), AllGather.apply(vis)
+                vmask = all_gather(vmask)
+            sim_loss, _, _ = contrastive_loss(seq, vis, vmask, self.clip.logit_scale, self._logit_scale_value())
             output_dict['loss'] = sim_loss + cluster_loss
             output_dict['cluster_loss'] = cluster_loss
             output_dict['sim_loss'] = sim_loss

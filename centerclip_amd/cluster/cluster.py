@@ -145,6 +145,14 @@ class TokenClusterInter(torch.nn.Module):
             self._sparse_key, self._sparse_val = key, torch.from_numpy(offsets).long().to(device)
         return self._sparse_val
 
+    def _spg_mask(self, device):
+        """uint8 [N, N] form of the spatial-temporal graph the kernels read, built once per device."""
+        key = str(device)
+        cache = self.__dict__.setdefault("_spg_u8", {})
+        if key not in cache:
+            cache[key] = self.spg[0].to(device).ne(0).to(torch.uint8).contiguous()
+        return cache[key]
+
     def variant(self, N, device):
         """-> (cc_cluster_variant for this module, tensors it points to)."""
         var = L.ClusterVariant()
@@ -165,7 +173,7 @@ class TokenClusterInter(torch.nn.Module):
             var.spectral_sigma, var.spectral_graph_mode = float(self.spectral_sigma), GRAPH_MODES[self.spectral_graph]
             var.spectral_knn_k, var.spectral_correct_sign = int(self.spectral_knn_k), int(bool(self.svd_correct_sign))
             if self.spg is not None:
-                keep.append(self.spg[0].to(device).ne(0).to(torch.uint8).contiguous())
+                keep.append(self._spg_mask(device))
                 var.spectral_graph = keep[-1].data_ptr()
         return var, keep
 
@@ -181,7 +189,7 @@ class TokenClusterInter(torch.nn.Module):
         n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
         N = self.frame_duration * n
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
             # training: the differentiable op (gradient of the gather / cluster means / CLS mean for the selection made in
             # the forward pass, which is a constant of the backward pass as in the reference: fast_kmeans.py:13,44)
             embed = self.cluster_embed.to(x.device).float().contiguous() if self.cluster_embedding else None
@@ -190,7 +198,7 @@ class TokenClusterInter(torch.nn.Module):
             sp = (0.0, 0, 0, False, None)
             if self.algorithm == 'spectral':
                 from .spectral import GRAPH_MODES
-                graph = self.spg[0].to(x.device).ne(0).to(torch.uint8).contiguous() if self.spg is not None else None
+                graph = self._spg_mask(x.device) if self.spg is not None else None
                 sp = (float(self.spectral_sigma), GRAPH_MODES[self.spectral_graph], int(self.spectral_knn_k),
                       bool(self.svd_correct_sign), graph)
             out, medoids, _ = torch.ops.centerclip.token_cluster_train(

@@ -2356,7 +2356,9 @@ int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int3
     if (!in_lds && (!ws || ws_bytes < cc_spectral_embedding_workspace_bytes(P, N))) return CC_ERR_WORKSPACE;
     const size_t smem = (in_lds ? (size_t)N * N * 4 : 0) + (size_t)N * 8 + 64;
     const int max_sweeps = 30;
-    const float tol = 1e-6f;
+    // stop when every pair's |gamma| / sqrt(alpha beta) is below the rounding floor of a length-N fp32 dot product (a fixed
+    // 1e-6 sits under that floor for N >~ 70: the loop could then run to max_sweeps without ever meeting it)
+    const float tol = fmaxf(1e-6f, 0.25f * (float)N * 1.1920929e-7f);
 #define EIG_LAUNCH(MAXR, INLDS)                                                                                        \
     do {                                                                                                               \
         auto kern = sym_eig_jacobi_kernel<MAXR, INLDS>;                                                                \

@@ -522,3 +522,245 @@ extern "C" int cc_contrastive_loss_f32(const float* sim, int32_t n, int64_t row_
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
+
+// ============================================================================ N4: the training tail with its gradient
+// loss = (CrossEn(S) + CrossEn(S^T)) / 2,  S = exp(logit_scale) * t_hat p_hat^T  (modules/clip4clip.py:245-262,357-366,
+// modules/losses.py:8-18), t_hat = t / |t|, p = sum_f m_f (v_f / |v_f|) / max(sum_f m_f, 1), p_hat = p / |p|.
+// What torch.autograd derives for it (g = the incoming gradient of the loss, c = exp(logit_scale), n = batch):
+//   G = dL/dS = g / (2n) * (softmax_rows(S) + softmax_cols(S) - 2 I)          d logit_scale = sum_ij G_ij S_ij
+//   d t_hat = c G p_hat              d t = (d t_hat - t_hat (t_hat . d t_hat)) / |t|
+//   d p_hat = c G^T t_hat            d p = (d p_hat - p_hat (p_hat . d p_hat)) / |p|
+//   d vhat_f = d p * m_f / den       d v_f = (d vhat_f - vhat_f (vhat_f . d vhat_f)) / |v_f|
+// Everything fp32 in fixed summation orders (one wave per row, lane-strided partial sums + the shuffle tree): no atomics,
+// the same bits on every run.  n is a training batch (<= a few hundred): the n x n x E products are one wave per output row.
+namespace {
+
+struct CtrWs {
+    float* that;   // [n, E]
+    float* phat;   // [n, E]
+    float* tn;     // [n]  |t|
+    float* pn;     // [n]  |p|
+    float* den;    // [n]  max(sum mask, 1)
+    float* vn;     // [n, Tn]  |v_f|
+    float* S;      // [n, n]
+    float* nce;    // [2n]  rows | cols
+    float* G;      // [n, n]
+    float* dls;    // [n]  per-row partial of d logit_scale
+    size_t total;
+};
+
+CtrWs ctr_carve(void* ws, int n, int Tn, int E) {
+    CtrWs c{};
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + off) : nullptr;
+        off += cc_align_up(floats * sizeof(float), 256);
+        return p;
+    };
+    c.that = take((size_t)n * E); c.phat = take((size_t)n * E);
+    c.tn = take(n); c.pn = take(n); c.den = take(n); c.vn = take((size_t)n * Tn);
+    c.S = take((size_t)n * n); c.nce = take(2 * (size_t)n); c.G = take((size_t)n * n); c.dls = take(n);
+    c.total = off;
+    return c;
+}
+
+// one wave per row: [0, n) text rows, [n, 2n) videos
+__global__ __launch_bounds__(256) void ctr_prepare_kernel(const float* __restrict__ text, const float* __restrict__ visual,
+                                                          const long long* __restrict__ mask, int64_t mrs, int64_t mcs, int n,
+                                                          int Tn, int E, CtrWs w) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= 2 * n) return;
+    if (r < n) {
+        const float* src = text + (int64_t)r * E;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
+        const float nrm = sqrtf(cc_wave_sum(s));
+        for (int e = lane; e < E; e += 64) w.that[(int64_t)r * E + e] = src[e] / nrm;
+        if (lane == 0) w.tn[r] = nrm;
+        return;
+    }
+    const int v = r - n;
+    float cnt = 0.f;
+    for (int t = 0; t < Tn; ++t) cnt += (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];
+    if (cnt == 0.f) cnt = 1.f;                    // "avoid zero divide", clip4clip.py:313
+    float sp = 0.f;
+    for (int e = lane; e < E; e += 64) w.phat[(int64_t)v * E + e] = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        const float* src = visual + ((int64_t)v * Tn + t) * E;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s = fmaf(src[e], src[e], s);
+        const float nrm = sqrtf(cc_wave_sum(s));
+        const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];
+        for (int e = lane; e < E; e += 64) w.phat[(int64_t)v * E + e] += (src[e] / nrm) * mk;   // (same lane re-reads its own element)
+        if (lane == 0) w.vn[(int64_t)v * Tn + t] = nrm;
+    }
+    for (int e = lane; e < E; e += 64) {
+        const float p = w.phat[(int64_t)v * E + e] / cnt;
+        w.phat[(int64_t)v * E + e] = p;
+        sp = fmaf(p, p, sp);
+    }
+    const float pn = sqrtf(cc_wave_sum(sp));
+    for (int e = lane; e < E; e += 64) w.phat[(int64_t)v * E + e] /= pn;
+    if (lane == 0) { w.pn[v] = pn; w.den[v] = cnt; }
+}
+
+// S[i][j] = c * that_i . phat_j: one wave per (i, j)
+__global__ __launch_bounds__(256) void ctr_sim_kernel(CtrWs w, int n, int E, float c) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (int64_t)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    const float* a = w.that + (int64_t)i * E;
+    const float* b = w.phat + (int64_t)j * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s = fmaf(a[e], b[e], s);
+    s = cc_wave_sum(s);
+    if (lane == 0) w.S[idx] = c * s;
+}
+
+// G_ij = g/(2n) (exp(S_ij - lse_row_i) + exp(S_ij - lse_col_j) - 2 [i == j]); row partial of sum_ij G_ij S_ij.  One wave per row.
+__global__ __launch_bounds__(256) void ctr_grad_sim_kernel(CtrWs w, int n, float g) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float lse_r = w.nce[i] + w.S[(int64_t)i * n + i];            // nce_i = lse_i - S_ii (cross_entropy_rows_kernel)
+    const float k = g / (2.0f * (float)n);
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float s = w.S[(int64_t)i * n + j];
+        const float lse_c = w.nce[n + j] + w.S[(int64_t)j * n + j];
+        const float gij = k * ((expf(s - lse_r) + expf(s - lse_c)) - (i == j ? 2.0f : 0.0f));
+        w.G[(int64_t)i * n + j] = gij;
+        acc = fmaf(gij, s, acc);
+    }
+    acc = cc_wave_sum(acc);
+    if (lane == 0) w.dls[i] = acc;
+}
+
+// one wave per output row: [0, n) d_text rows, [n, 2n) videos (all Tn frames), row 2n: d logit_scale
+__global__ __launch_bounds__(256) void ctr_grad_feat_kernel(const float* __restrict__ visual, const long long* __restrict__ mask,
+                                                            int64_t mrs, int64_t mcs, int n, int Tn, int E, float c, CtrWs w,
+                                                            float* __restrict__ d_text, float* __restrict__ d_visual,
+                                                            float* __restrict__ d_ls) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int MAXE = 16;                                           // E <= 1024
+    if (r == 2 * n) {
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += w.dls[i];
+        s = cc_wave_sum(s);
+        if (lane == 0) *d_ls = s;                                      // dS/d logit_scale = S
+        return;
+    }
+    if (r > 2 * n) return;
+    float d[MAXE];
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) d[q] = 0.f;
+    if (r < n) {                                                       // d that_i = c sum_j G_ij phat_j
+        for (int j = 0; j < n; ++j) {
+            const float gij = w.G[(int64_t)r * n + j];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const int e = lane + 64 * q;
+                if (e < E) d[q] = fmaf(gij, w.phat[(int64_t)j * E + e], d[q]);
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            d[q] *= c;
+            if (e < E) dot = fmaf(w.that[(int64_t)r * E + e], d[q], dot);
+        }
+        dot = cc_wave_sum(dot);
+        const float inv = 1.0f / w.tn[r];
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            if (e < E) d_text[(int64_t)r * E + e] = (d[q] - w.that[(int64_t)r * E + e] * dot) * inv;
+        }
+        return;
+    }
+    const int v = r - n;                                               // d phat_v = c sum_i G_iv that_i
+    for (int i = 0; i < n; ++i) {
+        const float giv = w.G[(int64_t)i * n + v];
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            if (e < E) d[q] = fmaf(giv, w.that[(int64_t)i * E + e], d[q]);
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int e = lane + 64 * q;
+        d[q] *= c;
+        if (e < E) dot = fmaf(w.phat[(int64_t)v * E + e], d[q], dot);
+    }
+    dot = cc_wave_sum(dot);
+    const float invp = 1.0f / w.pn[v], den = w.den[v];
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int e = lane + 64 * q;
+        if (e < E) d[q] = (d[q] - w.phat[(int64_t)v * E + e] * dot) * invp;      // d p
+    }
+    for (int t = 0; t < Tn; ++t) {
+        const float* src = visual + ((int64_t)v * Tn + t) * E;
+        const float mk = (float)mask[(int64_t)v * mrs + (int64_t)t * mcs];
+        const float nrm = w.vn[(int64_t)v * Tn + t];
+        float dv[MAXE], vh[MAXE];
+        float dt = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            vh[q] = e < E ? src[e] / nrm : 0.f;
+            dv[q] = d[q] * mk / den;                                   // d vhat_f
+            dt = fmaf(vh[q], dv[q], dt);
+        }
+        dt = cc_wave_sum(dt);
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = lane + 64 * q;
+            if (e < E) d_visual[((int64_t)v * Tn + t) * E + e] = (dv[q] - vh[q] * dt) / nrm;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cc_contrastive_grad_workspace_bytes(int32_t n, int32_t Tn, int32_t E) {
+    if (n <= 0 || Tn <= 0 || E <= 0) return 0;
+    return ctr_carve(nullptr, n, Tn, E).total;
+}
+
+extern "C" int cc_contrastive_loss_grad_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                            int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
+                                            float logit_scale, float grad_scale, float* loss3, float* d_text, float* d_visual,
+                                            float* d_logit_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!text || !visual || !video_mask || !loss3 || !d_text || !d_visual || !d_logit_scale) return CC_ERR_INVALID;
+    if (n <= 0 || Tn <= 0 || E <= 0) return CC_ERR_INVALID;
+    if (E > 1024) return CC_ERR_UNSUPPORTED;
+    const CtrWs w = ctr_carve(ws, n, Tn, E);
+    if (!ws || ws_bytes < w.total) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float c = expf(logit_scale);
+    const long long* mk = reinterpret_cast<const long long*>(video_mask);
+    hipLaunchKernelGGL(ctr_prepare_kernel, dim3((2 * n + 3) / 4), dim3(256), 0, st, text, visual, mk, mask_row_stride,
+                       mask_col_stride, n, Tn, E, w);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctr_sim_kernel, dim3((unsigned)(((int64_t)n * n + 3) / 4)), dim3(256), 0, st, w, n, E, c);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.S, n, (int64_t)n, (int64_t)1, w.nce);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.S, n, (int64_t)1, (int64_t)n, w.nce + n);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(contrastive_mean_kernel, dim3(1), dim3(256), 0, st, w.nce, n, loss3);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctr_grad_sim_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w, n, grad_scale);
+    CC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctr_grad_feat_kernel, dim3((2 * n + 1 + 3) / 4), dim3(256), 0, st, visual, mk, mask_row_stride,
+                       mask_col_stride, n, Tn, E, c, w, d_text, d_visual, d_logit_scale);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}

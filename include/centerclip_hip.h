@@ -534,6 +534,19 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
 int cc_contrastive_loss_f32(const float* sim, int32_t n, int64_t row_stride, int64_t col_stride, float* loss3,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* N4 - the training branch's loss WITH its gradient (modules/clip4clip.py:245-262, 357-366; modules/losses.py:8-18): from the
+ * features as the towers return them - text [n, E], visual [n, Tn, E] (per-segment), video_mask [n, Tn] int64 (element
+ * strides) - forms S = exp(logit_scale) * normalise(text) . normalise(masked mean of per-frame-normalised visual)^T,
+ * loss3 = (CrossEn(S), CrossEn(S^T), their mean) and, for an incoming gradient grad_scale of loss3[2], what torch.autograd
+ * yields for it: d_text [n, E], d_visual [n, Tn, E], d_logit_scale [1].  fp32, fixed summation orders (deterministic).
+ * The towers have no backward in this library (encoder backward and DDP all-reduce are out of scope):
+ * this is the gradient a caller feeds into its own backward of the encoders.  E <= 1024. */
+size_t cc_contrastive_grad_workspace_bytes(int32_t n, int32_t Tn, int32_t E);
+int cc_contrastive_loss_grad_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                 int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
+                                 float logit_scale, float grad_scale, float* loss3, float* d_text, float* d_visual,
+                                 float* d_logit_scale, void* ws, size_t ws_bytes, void* stream);
+
 /* N1 - the rank extraction of compute_metrics (utils/metrics.py:11-26) on the device: for row i with
  * ground-truth column g = diag_offset + i, counts[2i] = #{j: sim[i,j] > sim[i,g]} and counts[2i+1] =
  * #{j: sim[i,j] == sim[i,g]} (>= 1).  The reference's rank list `ind` is the concatenation over rows of

@@ -207,3 +207,24 @@ def clip4clip_train_loss(sd, ids, video, video_mask, max_frames, final_frames, c
     """The loss of the training branch at world size 1 (clip4clip.py:245-262): (CrossEn(sim) + CrossEn(sim^T)) / 2."""
     _, _, sim = clip4clip_forward(sd, ids, video, video_mask, max_frames, final_frames, cluster_plan, logit_scale)
     return (cross_en(sim) + cross_en(sim.t())) / 2
+
+
+def contrastive_loss_and_grads(sequence_output, visual_output, video_mask, logit_scale):
+    """The training branch's loss (clip4clip.py:245-262) and torch.autograd's gradients of it with respect to
+    sequence_output, visual_output and logit_scale -> (loss3 [CrossEn(S), CrossEn(S^T), mean], d_seq, d_vis, d_logit_scale)."""
+    seq = sequence_output.detach().clone().float().requires_grad_(True)
+    vis = visual_output.detach().clone().float().requires_grad_(True)
+    ls = torch.tensor(float(logit_scale), requires_grad=True)
+    v = vis / vis.norm(dim=-1, keepdim=True)
+    m = video_mask.to(torch.float).unsqueeze(-1)
+    den = torch.sum(m, dim=1, dtype=torch.float)
+    den = torch.where(den == 0., torch.ones_like(den), den)
+    v = torch.sum(v * m, dim=1) / den
+    v = v / v.norm(dim=-1, keepdim=True)
+    t = seq.reshape(seq.shape[0], -1)
+    t = t / t.norm(dim=-1, keepdim=True)
+    sim = ls.exp() * torch.matmul(t, v.t())
+    l1, l2 = cross_en(sim), cross_en(sim.t())
+    loss = (l1 + l2) / 2
+    loss.backward()
+    return torch.stack([l1.detach(), l2.detach(), loss.detach()]), seq.grad, vis.grad, ls.grad

@@ -6,6 +6,8 @@
   s3_*   the reference's own main._run_on_single_gpu (main.py:502-534) on stored features: ragged text / video batches,
          video masks with the ORIGINAL frame count (so get_similarity_logits applies get_video_mask_after_cluster,
          clip4clip.py:417-418,436-447), zeros in the masks.                                              [§8c row S3]
+  lg_*   the training branch's loss on the reference's own module and torch.autograd's gradients of it with respect to
+         sequence_output, visual_output and logit_scale (clip4clip.py:245-262, losses.py:8-18)             [§8f N4]
   ev_*   the reference's own main.eval_epoch (main.py:381-499) over a list-backed loader with the small random-weight
          model of r2_golden.npz (token clustering off, so no medoid choice enters): single-sentence and multi-sentence
          protocols -> similarity matrix, R@1, the metric strings.                                         [§8c rows S3, N1]
@@ -31,7 +33,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
 from gen_golden_clip import _import_reference, ref_args  # noqa: E402
-from recipes import lattice, dyadic, EVAL_CASES, eval_case_batches, s3_case  # noqa: E402
+from recipes import lattice, dyadic, EVAL_CASES, eval_case_batches, s3_case, loss_grad_case  # noqa: E402
 
 # name: (seed, P, N, W, K, split, iter_limit)
 P1_MULTI = {
@@ -170,8 +172,41 @@ def _metric_values(rmain, sim, ds_attrs):
     return tuple(round(float(d[k]), 6) for d in (tv, vt) for k in ("R1", "R5", "R10", "MR", "MeanR"))
 
 
+def gen_loss_grad(out):
+    """N4: the training branch's loss and what torch.autograd makes of it on the reference's own module
+    (clip4clip.py:245-262: get_similarity_logits in training mode -> CrossEn both ways): gradients with respect to
+    sequence_output, visual_output and clip.logit_scale.  all_gather needs a process group: world-size-1 gloo."""
+    import torch.distributed as dist
+    rmain, rc4c = _import_main()
+    import modules.losses as rl
+    model, cfg = _small_model(rc4c, cluster_inter=1)
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+    E, T_new = int(cfg[0]), int(cfg[12])
+    for tag, n, scale in (("lg_a", 6, 2.0), ("lg_b", 33, 3.5)):
+        seq, vis, vmask = loss_grad_case(tag, n, T_new, E)
+        seq_t = torch.from_numpy(seq).requires_grad_(True)
+        vis_t = torch.from_numpy(vis).requires_grad_(True)
+        with torch.no_grad():
+            model.clip.logit_scale.fill_(scale)
+        model.clip.logit_scale.grad = None
+        model.train()
+        sim, *_ = model.get_similarity_logits(seq_t, vis_t, torch.ones(n, 1, 4, dtype=torch.long), torch.from_numpy(vmask),
+                                              shaped=True)
+        l1, l2 = rl.CrossEn()(sim), rl.CrossEn()(sim.T)
+        loss = (l1 + l2) / 2
+        loss.backward()
+        model.eval()
+        out[f"{tag}_loss3"] = np.array([l1.item(), l2.item(), loss.item()], dtype=np.float32)
+        out[f"{tag}_dseq"], out[f"{tag}_dvis"] = seq_t.grad.numpy(), vis_t.grad.numpy()
+        out[f"{tag}_dls"] = np.float32(model.clip.logit_scale.grad.item())
+        out[f"{tag}_scale"] = np.float32(scale)
+        print(tag, "loss", out[f"{tag}_loss3"], "dls", out[f"{tag}_dls"], flush=True)
+
+
 if __name__ == "__main__":
     out = {}
+    gen_loss_grad(out)
     gen_s3(out)
     gen_eval(out)
     gen_p1_multi(out)

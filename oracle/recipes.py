@@ -296,3 +296,17 @@ def eval_case_batches(case, cfg):
         attrs = dict(multi_sentence_per_video=True, cut_off_points=list(np.cumsum(sentences)),
                      sentence_num=len(items), video_num=nvid)
     return batches, attrs
+
+
+def loss_grad_case(tag, n, T_new, E):
+    """Features for the lg_* fixtures (training loss + gradients): sequence_output [n,1,E], visual_output [n,T_new,E] with
+    generic full-mantissa values, video_mask [n,T_new] with zeros (never a fully masked clip: the loss would be NaN)."""
+    seed = 700 + sum(ord(ch) for ch in tag)
+    seq = fullmant(seed, (n, 1, E), 21)
+    vis = fullmant(seed + 1, (n, T_new, E), 21)
+    rng = np.random.default_rng(seed + 2)
+    vmask = np.ones((n, T_new), dtype=np.int64)
+    for v in range(n):
+        if v % 3 == 1 and T_new > 1:
+            vmask[v, rng.integers(1, T_new)] = 0
+    return seq, vis, vmask

@@ -10,7 +10,7 @@ import torch
 
 from oracle import clip_oracle as clo
 from oracle import cluster_oracle as co
-from oracle.recipes import EVAL_CASES, eval_case_batches, lattice, s3_case
+from oracle.recipes import EVAL_CASES, eval_case_batches, lattice, loss_grad_case, s3_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -73,3 +73,17 @@ def test_eval_epoch_matrix_oracle(g3, small, name):
     ref = g3[f"ev_{name}_sim"]
     assert sim.shape == ref.shape
     assert float(np.abs(sim - ref).max()) <= 2e-5 * math.exp(float(sd["logit_scale"]))
+
+
+@pytest.mark.parametrize("tag,n", [("lg_a", 6), ("lg_b", 33)])
+def test_contrastive_loss_gradients_oracle(g3, small, tag, n):
+    """The oracle's loss + gradients == the reference module's own (get_similarity_logits in training mode -> CrossEn both
+    ways -> autograd), clip4clip.py:245-262."""
+    sd, cfg = small
+    seq, vis, vmask = loss_grad_case(tag, n, int(cfg[12]), int(cfg[0]))
+    loss3, dseq, dvis, dls = clo.contrastive_loss_and_grads(torch.from_numpy(seq), torch.from_numpy(vis), torch.from_numpy(vmask),
+                                                            float(g3[f"{tag}_scale"]))
+    assert np.allclose(loss3.numpy(), g3[f"{tag}_loss3"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(dseq.numpy(), g3[f"{tag}_dseq"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(dvis.numpy(), g3[f"{tag}_dvis"], rtol=1e-5, atol=1e-8)
+    assert abs(float(dls) - float(g3[f"{tag}_dls"])) <= 1e-5 * max(1.0, abs(float(g3[f"{tag}_dls"])))

@@ -334,3 +334,59 @@ def test_eval_epoch_against_the_reference(g2, g3, name):
         dot_nt = staticmethod(lambda a, b, mult: torch.from_numpy(ref).to(DEV))
     r1b, _, info_b = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Given)
     assert list(info_b) == [str(s) for s in g3[f"ev_{name}_info"]] and abs(r1b - float(g3[f"ev_{name}_r1"])) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ N4: loss gradient
+@pytest.mark.parametrize("tag,n", [("lg_a", 6), ("lg_b", 33)])
+def test_contrastive_loss_gradients_against_reference_autograd(g2, g3, tag, n):
+    """losses.contrastive_loss (cc_contrastive_loss_grad_f32) against the reference module's own loss and torch.autograd's
+    gradients of it (clip4clip.py:245-262 -> losses.py:8-18) for sequence_output, visual_output and logit_scale; the
+    incoming gradient scales them; repeated calls give the same bits (fixed summation orders, no atomics)."""
+    from centerclip_amd.losses import contrastive_loss
+    from oracle.recipes import loss_grad_case
+    cfg = g2["s1_cfg"]
+    seq, vis, vmask = loss_grad_case(tag, n, int(cfg[12]), int(cfg[0]))
+    scale = float(g3[f"{tag}_scale"])
+    seq_t = torch.from_numpy(seq).to(DEV).requires_grad_(True)
+    vis_t = torch.from_numpy(vis).to(DEV).requires_grad_(True)
+    ls = torch.tensor(scale, device=DEV, requires_grad=True)
+    loss, l1, l2 = contrastive_loss(seq_t, vis_t, torch.from_numpy(vmask).to(DEV), ls)
+    (3.0 * loss).backward()
+    ref3 = g3[f"{tag}_loss3"]
+    assert abs(float(l1) - ref3[0]) <= 2e-5 and abs(float(l2) - ref3[1]) <= 2e-5 and abs(float(loss) - ref3[2]) <= 2e-5
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    e_seq, e_vis = rel(seq_t.grad.cpu().numpy() / 3.0, g3[f"{tag}_dseq"]), rel(vis_t.grad.cpu().numpy() / 3.0, g3[f"{tag}_dvis"])
+    e_ls = abs(float(ls.grad) / 3.0 - float(g3[f"{tag}_dls"])) / max(1.0, abs(float(g3[f"{tag}_dls"])))
+    print(f"[loss grad {tag}] rel err d_seq {e_seq:.1e} d_vis {e_vis:.1e} d_logit_scale {e_ls:.1e}")
+    assert e_seq <= 1e-4 and e_vis <= 1e-4 and e_ls <= 1e-4
+    assert seq_t.grad.shape == seq_t.shape and vis_t.grad.shape == vis_t.shape
+    # the oracle agrees as well (pins the test's own reference path)
+    o3, odseq, odvis, odls = clo.contrastive_loss_and_grads(torch.from_numpy(seq), torch.from_numpy(vis), torch.from_numpy(vmask), scale)
+    assert rel(seq_t.grad.cpu().numpy() / 3.0, odseq.numpy()) <= 1e-4 and rel(vis_t.grad.cpu().numpy() / 3.0, odvis.numpy()) <= 1e-4
+    # determinism
+    seq2 = torch.from_numpy(seq).to(DEV).requires_grad_(True)
+    loss2, _, _ = contrastive_loss(seq2, vis_t.detach(), torch.from_numpy(vmask).to(DEV), ls.detach())
+    loss2.backward()
+    assert torch.equal(loss2.detach(), loss.detach()) and torch.equal(seq2.grad * 3.0, seq_t.grad)
+
+
+def test_training_forward_returns_a_differentiable_loss(g2):
+    """CLIP4Clip.forward in training mode: 'loss' carries a grad_fn and its backward reaches logit_scale (the towers have no
+    backward: the feature gradients stop at sequence_output / visual_output); value = the eval-mode logits' symmetric CrossEn."""
+    from centerclip_amd.losses import symmetric_contrastive_loss
+    model, sd, cfg = _small_model(g2, cluster_inter=1)
+    g = np.load(R2)
+    ids, amask = torch.from_numpy(g["s1_ids"]).to(DEV), torch.from_numpy(g["s1_amask"]).to(DEV)
+    video = torch.from_numpy(g["s1_video"]).to(DEV)
+    vmask = torch.from_numpy(g["s1_train_vmask"]).to(DEV)
+    model.train()
+    out = model(ids, torch.zeros_like(ids), amask, video, vmask)
+    assert out["loss"].requires_grad and out["loss"].grad_fn is not None
+    out["loss"].backward()
+    assert model.clip.logit_scale.grad is not None and bool(torch.isfinite(model.clip.logit_scale.grad))
+    model.eval()
+    with torch.no_grad():
+        logits, _ = model.get_similarity_logits(out["sequence_output"], out["visual_output"], amask, vmask)
+        want, _, _ = symmetric_contrastive_loss(logits)
+    assert abs(float(out["sim_loss"]) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
+    assert abs(float(out["loss"]) - float(g["s1_train_loss"])) <= 2e-3          # (own medoids; the fixture test pins it tighter)
