@@ -37,3 +37,9 @@ mod = TokenClusterInter(before_cluster_num=49, cluster_num=49, before_block_fram
 for _ in range(5):
     mod.cluster_frame_major(x)
 torch.cuda.synchronize()
+# the similarity tail at the north-star size (prepare kernel + the GEMM on the concatenated planes)
+t = torch.randn(10000, 512, device="cuda"); v = torch.randn(1000, 3, 512, device="cuda")
+m = torch.ones(1000, 3, dtype=torch.long, device="cuda")
+for _ in range(5):
+    ops.loose_similarity(t, v, m, 1.0)
+torch.cuda.synchronize()

@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(out, "p1", "**", "*counter_collection.csv"), rec
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
-    if not any(s in k for s in ("gemm_f16", "gram_dist", "kmedoids", "dot_nt")):
+    if not any(s in k for s in ("gemm_f16", "gram_dist", "kmedoids", "sim_prepare")):
         continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
     gui = m.get("GRBM_GUI_ACTIVE", 0.0)

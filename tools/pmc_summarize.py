@@ -15,7 +15,7 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         res[k][which + "_raw_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
 OURS = ("gemm_f16_kernel", "kmedoids_select", "gram_dist", "lp_dist", "reduce_tokens", "token_norm", "attention_",
-        "im2col", "dot_nt", "row_stats", "layernorm_kernel", "head_project")
+        "im2col", "sim_prepare", "row_stats", "layernorm_kernel", "head_project")
 summary = {}
 for k, v in res.items():
     if not any(s in k for s in OURS):        # torch's own fill / randn kernels of the driver script are not ours
