@@ -24,7 +24,7 @@ class VitModel(c.Structure):
                 ("cluster_frames", c.c_int32 * CC_MAX_LAYERS), ("cluster_tokens", c.c_int32 * CC_MAX_LAYERS),
                 ("cluster_metric", c.c_int32), ("cluster_norm_p", c.c_float), ("cluster_threshold", c.c_float),
                 ("cluster_iter_limit", c.c_int32), ("cluster_split_size", c.c_int32), ("cluster_pre_norm", c.c_int32),
-                ("cluster_variants", c.c_void_p), ("row_policy", c.c_int32)]
+                ("cluster_variants", c.c_void_p), ("row_policy", c.c_int32), ("conv2_weight_f16", c.c_void_p)]
 
 
 class Frames(c.Structure):

@@ -2,11 +2,11 @@
 same class / method names, forward signatures and state-dict keys, executed by
 the HIP encoders of libcenterclip_hip.so through the C ABI.  No PyTorch compute fallback.
 
-Built: VisualTransformer (ViT-B/32, ViT-B/16, linear_patch '2d'), the text Transformer,
+Built: VisualTransformer (ViT-B/32, ViT-B/16, linear_patch '2d' and '3d'), the text Transformer,
 ResidualAttentionBlock.forward / Transformer.forward on LND activations (composed from the op-level
 entry points), CLIP.encode_image / encode_text (incl. return_hidden=True), CLIP.forward,
 build_clip_model, load_clip_state_dict (local files).  Not built (out of the hot path, SURVEY §2.1
-#2): ModifiedResNet, linear_patch='3d', weight download.
+#2): ModifiedResNet, weight download.
 
 All compute goes through ``torch.ops.centerclip.*`` (torch_ops.py).
 """
@@ -125,15 +125,16 @@ class ResidualAttentionBlock(nn.Module):
         """(x [L, N, W] LND, video_frame, cluster_loss) -> same tuple   (clip.py:228-253)"""
         x, video_frame, cluster_loss = x_tuple
         L.require_device(x)
+        res_x = None
         if self.tokencluster_inter is not None:                 # place 1, before the self-attention (clip.py:236-242)
             x, res_x = self.tokencluster_inter(x)
-            if res_x is not None:
-                raise NotImplementedError("mean_residual is not built")
         Lq, N, W = x.shape
         M = Lq * N
         w = self._folded()
-        h = x.float().contiguous().view(M, W).clone()           # the residual stream (updated in place below)
-        h16, st, sh = ops.row_stats(h)
+        xin = x.float().contiguous().view(M, W)
+        h16, st, sh = ops.row_stats(xin)                        # ln_1 reads the clustered x ...
+        # ... and the residual stream (updated in place below) starts from x, or from the frame means (mean_residual, :242)
+        h = (xin if res_x is None else res_x.float().contiguous().view(M, W)).clone()
         qkv = ops.linear_ln_f16(h16, w["in_w"], w["in_c1"], w["in_c2"], st, 1, eps=self.ln_1.eps)
         att = ops.attention_f16(qkv, N, Lq, self.n_head, causal=self.attn_mask is not None, seq_rows=1, tok_rows=N)
         h16, st1, slots1, _ = ops.linear_resid_stats_f16(att, w["out_w"], w["out_b"], h, shift_in=sh,
@@ -220,8 +221,6 @@ class VisualTransformer(nn.Module):
                  video_frames=None, args=None):
         super().__init__()
         assert linear_patch in ['2d', '3d']
-        if linear_patch != '2d':
-            raise NotImplementedError("linear_patch='3d' is not built")
         self.input_resolution, self.patch_size, self.output_dim, self.width = input_resolution, patch_size, output_dim, width
         self.heads = heads
         self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
@@ -234,6 +233,9 @@ class VisualTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self.linear_patch = linear_patch
         self.video_frames = video_frames
+        if linear_patch == '3d':                     # clip.py:296-299: Conv3d over (t, h, w), kernel (3, p, p), zero padding 1 along t
+            self.conv2 = nn.Conv3d(3, width, kernel_size=(3, patch_size, patch_size), stride=(1, patch_size, patch_size),
+                                   padding=(1, 0, 0), bias=False)
         self.register_buffer("position_ids", torch.arange(self.positional_embedding.shape[0]).expand(1, -1))
         self._pack = _Pack()
         self.last_medoids = None
@@ -256,6 +258,8 @@ class VisualTransformer(nn.Module):
         m.layers, m.width, m.heads = self.transformer.layers, self.width, self.heads
         m.patch, m.resolution, m.embed_dim = self.patch_size, self.input_resolution, self.output_dim
         m.conv1_weight_f16 = pk.f16(self.conv1.weight.reshape(self.width, -1))
+        if self.linear_patch == '3d':                # [W, 3(c), 3(t), p, p] flattened = the im2col row order of the 3-d gather
+            m.conv2_weight_f16 = pk.f16(self.conv2.weight.reshape(self.width, -1))
         m.class_embedding, m.positional_embedding = pk.f32(self.class_embedding), pk.f32(self.positional_embedding)
         m.ln_pre_weight, m.ln_pre_bias = pk.f32(self.ln_pre.weight), pk.f32(self.ln_pre.bias)
         m.ln_post_weight, m.ln_post_bias = pk.f32(self.ln_post.weight), pk.f32(self.ln_post.bias)
@@ -272,6 +276,9 @@ class VisualTransformer(nn.Module):
                 m.cluster_frames[i], m.cluster_tokens[i] = tc.after_block_frames, tc.cluster_num
                 if tc.algorithm == 'pooling' and tc.cluster_num != tokens:
                     raise ValueError("'pooling' keeps the token count: cluster_num_blocks[%d] must be %d" % (i, tokens))
+                if getattr(tc, "mean_residual", False):
+                    raise NotImplementedError("mean_residual is built for the module / block-level forwards, not inside the "
+                                              "fused encoder")
                 variants[i], keep = tc.variant(tc.frame_duration * tokens, dev)     # N2: per-block variant
                 pk.keep.extend(keep)
                 any_variant = any_variant or not tc.is_default_variant
@@ -320,7 +327,11 @@ class VisualTransformer(nn.Module):
         BT = x.shape[0]
         T_ = video_frame if video_frame and video_frame > 0 else 1
         has_cluster = any(b.tokencluster_inter is not None for b in self.transformer.resblocks)
-        if not has_cluster:
+        if self.linear_patch == '3d':
+            assert video_frame and video_frame > 0, "linear_patch='3d' needs video_frame (clip.py:307)"
+            if x.dtype == torch.uint8:
+                raise NotImplementedError("uint8 frames are built for linear_patch='2d' only")
+        elif not has_cluster:
             T_ = 1
         assert BT % T_ == 0
         if forced_medoids is not None:
@@ -457,7 +468,9 @@ class CLIP(nn.Module):
         image = image.contiguous()
         ids = text.to(torch.long).contiguous()
         T_ = video_frame if video_frame and video_frame > 0 else 1
-        if not any(b.tokencluster_inter is not None for b in vis.transformer.resblocks):
+        if vis.linear_patch == '3d':
+            assert video_frame and video_frame > 0, "linear_patch='3d' needs video_frame (clip.py:307)"
+        elif not any(b.tokencluster_inter is not None for b in vis.transformer.resblocks):
             T_ = 1
         B = image.shape[0] // T_
         forced = getattr(vis, "forced_medoids", None)       # test hook ("given identical medoid sets")

@@ -27,6 +27,8 @@ class CLIP4Clip(nn.Module):
         self.loose_type = bool(getattr(task_config, "loose_type", True))
         self.linear_patch = getattr(task_config, "linear_patch", '2d')
         self.sim_header = getattr(task_config, "sim_header", 'meanP')
+        if self.linear_patch not in ('2d', '3d'):
+            raise ValueError("linear_patch must be '2d' or '3d'")
         if self.sim_header != "meanP" or not self.loose_type:
             raise NotImplementedError("only sim_header='meanP' with loose_type is built (all shipped scripts use it)")
         self.cluster_inter = getattr(task_config, "cluster_inter", 0)
@@ -60,6 +62,12 @@ class CLIP4Clip(nn.Module):
         clip_state_dict = load_clip_state_dict(name, pretrained_dir=task_config.pretrained_dir)
         model = cls(clip_state_dict, task_config)
         override = {k[len("clip."):]: v for k, v in state_dict.items() if k.startswith("clip.")}
+        if model.linear_patch == '3d' and "visual.conv2.weight" not in override and "visual.conv2.weight" not in clip_state_dict:
+            # the reference's initialisation trick (clip4clip.py:46-76): conv2 = conv1 in the centre time slice, zeros around
+            w1 = override.get("visual.conv1.weight", clip_state_dict["visual.conv1.weight"]).float()
+            w2 = torch.zeros_like(model.clip.visual.conv2.weight)
+            w2[:, :, (w2.shape[2] - 1) // 2] = w1
+            override["visual.conv2.weight"] = w2
         if override:
             model.clip.load_state_dict(override, strict=False)
         if getattr(task_config, "temperature_new", 0.0) > 1.0:

@@ -1,6 +1,6 @@
 """Mirror of modules/cluster/cluster.py: get_cluster_inter (:15-63) and TokenClusterInter (:66-352) for the
 algorithms 'kmediods++' and 'spectral' (aggregation None or mean, cluster_embedding, adaptive_cls), 'pooling' and
-'sparse_sampling' in eval mode.  Differentiable with respect to x, cluster_embed and cls_multiplier
+'sparse_sampling' (eval: fixed ids; training: the reference's random ids), mean_residual.  Differentiable with respect to x, cluster_embed and cls_multiplier
 (torch.ops.centerclip.token_cluster_train / token_cluster_backward, cc_token_cluster_backward_f32)."""
 import numpy as np
 import torch
@@ -41,6 +41,26 @@ def get_cluster_inter(width, block_id, args=None):
                              transformer_width=width, pre_norm=getattr(args, 'pre_norm', False))
 
 
+class _GatherGiven(torch.autograd.Function):
+    """Medoid-token gather + per-segment CLS mean for GIVEN ids (training-mode sparse_sampling), differentiable in x."""
+
+    @staticmethod
+    def forward(ctx, x, medoids, frame_major, T, T_new, K):
+        ctx.save_for_backward(x, medoids)
+        ctx.cfg = (frame_major, T, T_new, K)
+        empty = torch.empty(0, 1, dtype=torch.long, device=x.device)
+        return torch.ops.centerclip.token_apply_selection(x, frame_major, T, T_new, K, 0, medoids, empty, None, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, medoids = ctx.saved_tensors
+        frame_major, T, T_new, K = ctx.cfg
+        empty = torch.empty(0, 1, dtype=torch.long, device=x.device)
+        gx, _, _ = torch.ops.centerclip.token_cluster_backward(g.contiguous(), x, frame_major, T, T_new, K, 0, 0, medoids, empty,
+                                                               None, None, False, False)
+        return gx, None, None, None, None, None
+
+
 class TokenClusterInter(torch.nn.Module):
     """Token clustering between transformer blocks: T frames -> T_new segments, the fd*n patch
     tokens of a segment -> K medoid tokens (ascending ids), CLS = mean of the segment's CLS.
@@ -51,8 +71,9 @@ class TokenClusterInter(torch.nn.Module):
     `cluster_frame_embed` load) and the forward does not use it (its use is commented out, :283-285).
     'spectral' (cluster.py:262-272): the selection comes from spectral clustering of the segment's tokens (graph Laplacian,
     batched Jacobi eigensolver, k-medoids on the embedding - all on the device, cluster/spectral.py), the rest is shared.
-    The shift algorithms and mean_residual (not reachable from the reference's arguments) raise NotImplementedError at
-    construction.
+    'sparse_sampling' in training mode draws the reference's random ids (same NumPy calls, per segment).  mean_residual
+    (not reachable from the reference's arguments) is built for the module / block-level forwards.  The shift algorithms
+    raise NotImplementedError at construction.
     """
 
     def __init__(self, algorithm='kmediods++', block_id=1, before_cluster_num=49, cluster_num=49,
@@ -67,8 +88,6 @@ class TokenClusterInter(torch.nn.Module):
         if algorithm not in ('kmediods++', 'pooling', 'sparse_sampling', 'spectral'):
             raise NotImplementedError("centerclip_amd builds cluster_algo 'kmediods++', 'spectral', 'pooling' and "
                                       "'sparse_sampling' (got %r)" % algorithm)
-        if mean_residual:
-            raise NotImplementedError("mean_residual is not built")
         kmed = algorithm in ('kmediods++', 'spectral')                            # cluster.py:240 (shared branch)
         self.cluster_embedding = bool(cluster_embedding) if kmed else False      # cluster.py:154-156
         self.adaptive_cls = bool(adaptive_cls) if kmed else False
@@ -98,6 +117,9 @@ class TokenClusterInter(torch.nn.Module):
         self.split_size = split_size
         self.norm_p = norm_p
         self.pre_norm = pre_norm
+        # cluster.py:228-237: the residual connection of the block becomes the mean over each segment's frames of EVERY
+        # token (needs an unchanged token count); module / block-level forwards only - not inside the fused encoder
+        self.mean_residual = bool(mean_residual)
         self.last_medoids = None
         # cluster_algo 'spectral' (cluster.py:142-152,174-182)
         self.spectral_graph = spectral_graph
@@ -125,15 +147,48 @@ class TokenClusterInter(torch.nn.Module):
                          keep_ids=keep_ids)
 
     def forward(self, x):
-        """x [1+n, B*T, W] (LND) -> (x' [1+K, B*T_new, W], None)   (cluster.py:206,350-352)"""
+        """x [1+n, B*T, W] (LND) -> (x' [1+K, B*T_new, W], residual_x or None)   (cluster.py:206,350-352)"""
         Lt, BT, W = x.shape
-        return self._run(x, tok_stride=BT * W, frame_stride=W, BT=BT, Lt=Lt, W=W, frame_major=False), None
+        residual_x = None
+        if self.mean_residual:                       # cluster.py:228-235 = the 'pooling' reduction of the same tensor
+            assert Lt == self.cluster_num + 1
+            residual_x = self._pool_frames(x)
+        return self._run(x, tok_stride=BT * W, frame_stride=W, BT=BT, Lt=Lt, W=W, frame_major=False), residual_x
+
+    def _pool_frames(self, x):
+        """[1+n, B*T, W] -> [1+n, B*T_new, W]: every token (CLS included) averaged over its segment's frames."""
+        L.require_device(x)
+        x = x.float().contiguous()
+        n = x.shape[0] - 1
+        op = torch.ops.centerclip.token_cluster_train if (torch.is_grad_enabled() and x.requires_grad) else None
+        if op is not None:
+            out, _, _ = op(x, False, self.before_block_frames, self.after_block_frames, n, 0, 2.0, 1e-6, 0, 16, False, 1, 0,
+                           None, None, None, 0.0, 0, 0, False, None)
+            return out
+        out, _ = torch.ops.centerclip.token_cluster(x, False, self.before_block_frames, self.after_block_frames, n, 0, 2.0,
+                                                    1e-6, 0, 16, False, 1, 0, None, None, None, False)
+        return out
+
+    def _sparse_ids_random(self, N, segments):
+        """token_sparse_sampling(cluster_num, N, random_shift=True) (cluster_utils.py:150-162), drawn once per segment as the
+        reference's loop does (cluster.py:332-336), with the same NumPy calls in the same order - the same global NumPy seed
+        gives the same ids.  -> int64 [segments, K] (host)."""
+        K = self.cluster_num
+        rows = []
+        for _ in range(segments):
+            avg = N // K
+            if avg > 0:
+                off = np.multiply(list(range(K)), avg) + np.random.randint(avg, size=K)
+            elif N > K:
+                off = np.sort(np.random.choice(N, K, replace=False))
+            else:
+                off = np.clip(np.arange(0, K), 0, N)
+            rows.append(np.asarray(off, dtype=np.int64))
+        return torch.from_numpy(np.stack(rows))
 
     def _sparse_ids(self, N, device):
         """token_sparse_sampling(cluster_num, N, random_shift=False) (cluster_utils.py:136-170, eval branch):
         centres of cluster_num equal segments of the N tokens; the same ids for every problem."""
-        if self.training:
-            raise NotImplementedError("sparse_sampling draws random ids in training mode; only eval is built")
         key = (N, str(device))
         if getattr(self, "_sparse_key", None) != key:
             K = self.cluster_num
@@ -189,6 +244,13 @@ class TokenClusterInter(torch.nn.Module):
         n = Lt - 1
         K = n if self.algorithm == 'pooling' else self.cluster_num
         N = self.frame_duration * n
+        if self.algorithm == 'sparse_sampling' and self.training:
+            # random ids per segment, shared by the clips (cluster.py:332-336): a gather with given ids - problem p = s*B + b
+            B = BT // self.before_block_frames
+            ids = self._sparse_ids_random(N, self.after_block_frames)                       # [T_new, K]
+            med = ids.to(x.device).repeat_interleave(B, dim=0).contiguous()                 # [T_new*B, K]
+            self.last_medoids = med
+            return _GatherGiven.apply(x, med, bool(frame_major), self.before_block_frames, self.after_block_frames, K)
         if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
             # training: the differentiable op (gradient of the gather / cluster means / CLS mean for the selection made in
             # the forward pass, which is a constant of the backward pass as in the reference: fast_kmeans.py:13,44)

@@ -107,6 +107,7 @@ struct AttArgs {
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
 int cc_launch_im2col(const cc_frames& frames, _Float16* A, int F, int res, int p, hipStream_t st);
+int cc_launch_im2col3d(const cc_frames& frames, _Float16* A, int F, int T, int res, int p, hipStream_t st);   // linear_patch '3d'
 int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st);
 // ln_pre (args as cc_launch_layernorm2, fp32 output) and the text embedding in one launch
 int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hipStream_t st);

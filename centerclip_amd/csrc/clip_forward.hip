@@ -45,7 +45,7 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
     Carver c(ws);
     const int g = m->resolution / m->patch, n = g * g, L0 = n + 1, W = m->width;
     const size_t F = (size_t)B * T, M0 = F * L0;
-    v.im2col = c.take<_Float16>(F * n * 3 * m->patch * m->patch);
+    v.im2col = c.take<_Float16>(F * n * (m->conv2_weight_f16 ? 9 : 3) * m->patch * m->patch);
     v.h = c.take<float>(M0 * W);
     v.h2 = c.take<float>(M0 * W);
     v.h16 = c.take<_Float16>(M0 * W);
@@ -303,14 +303,16 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         W = vm->width;
         tokens = n;
         // patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
-        rc = cc_launch_im2col(*video, v.im2col, F, vm->resolution, vm->patch, st);
+        const bool patch3d = vm->conv2_weight_f16 != nullptr;      // linear_patch '3d' (clip.py:306-317)
+        rc = patch3d ? cc_launch_im2col3d(*video, v.im2col, F, T, vm->resolution, vm->patch, st)
+                     : cc_launch_im2col(*video, v.im2col, F, vm->resolution, vm->patch, st);
         if (rc) return rc;
         GemmArgs ga{};
         ga.A = v.im2col;
-        ga.W = static_cast<const _Float16*>(vm->conv1_weight_f16);
+        ga.W = static_cast<const _Float16*>(patch3d ? vm->conv2_weight_f16 : vm->conv1_weight_f16);
         ga.C = v.h;
         ga.pos = vm->positional_embedding;
-        ga.M = F * n; ga.N = W; ga.K = 3 * vm->patch * vm->patch; ga.ldc = W;
+        ga.M = F * n; ga.N = W; ga.K = (patch3d ? 9 : 3) * vm->patch * vm->patch; ga.ldc = W;
         ga.patch_n = n;
         rc = cc_gemm_dispatch(ga, EPI_F32_PATCH, 0, st);
         if (rc) return rc;

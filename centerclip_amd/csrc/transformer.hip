@@ -475,6 +475,33 @@ __global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict
     }
 }
 
+// linear_patch = '3d' (modules/clip.py:296-317, Conv3d kernel (3, p, p), stride (1, p, p), padding (1, 0, 0)) as GEMM:
+// A[f*n + pi][c*3*p*p + kt*p*p + kh*p + kw] = video[f + kt - 1][c][ph*p+kh][pw*p+kw] when frame f + kt - 1 belongs to the same
+// clip of T frames, else 0 (the zero padding along t).
+__global__ __launch_bounds__(256) void im2col3d_f16_kernel(const float* __restrict__ video, _Float16* __restrict__ A,
+                                                           int F, int T, int res, int p) {
+    const int g = res / p, n = g * g, pp = p * p, Kc = 9 * pp;
+    const int64_t total = (int64_t)F * n * Kc / 8;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t e = idx * 8;
+        const int k = (int)(e % Kc);
+        const int64_t row = e / Kc;
+        const int f = (int)(row / n), pi = (int)(row - (int64_t)f * n);
+        const int ph = pi / g, pw = pi - ph * g;
+        const int c = k / (3 * pp), kt = (k / pp) % 3, rem = k % pp, kh = rem / p, kw = rem - kh * p;
+        const int ft = (f % T) + kt - 1;
+        h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ft >= 0 && ft < T) {
+            const float* src = video + (((int64_t)(f + kt - 1) * 3 + c) * res + (ph * p + kh)) * res + pw * p + kw;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            o = h8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                   (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        }
+        *reinterpret_cast<h8*>(A + e) = o;
+    }
+}
+
 // N3: the same patch gather from uint8 frames, with the loader's normalisation fused in.  Per sample exactly the
 // reference's three fp32 operations, in its order: u/255 (transforms.py:166), - mean, / std (torchvision normalize),
 // all IEEE (no reciprocal, no contraction possible between them), so the fp16 patch matrix is bit-identical to the
@@ -866,6 +893,16 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
     return CC_OK;
 }
 
+
+int cc_launch_im2col3d(const cc_frames& fr, _Float16* A, int F, int T, int res, int p, hipStream_t st) {
+    if ((p & 7) || res % p || !fr.data || T <= 0 || F % T) return CC_ERR_INVALID;
+    if (fr.format != CC_FRAMES_F32_CHW) return CC_ERR_UNSUPPORTED;          // uint8 frames: '2d' patches only
+    const int64_t total = (int64_t)F * (res / p) * (res / p) * 9 * p * p / 8;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col3d_f16_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(fr.data), A, F, T, res, p);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
 
 int cc_launch_im2col(const cc_frames& fr, _Float16* A, int F, int res, int p, hipStream_t st) {
     if ((p & 7) || res % p || !fr.data) return CC_ERR_INVALID;

@@ -400,6 +400,10 @@ typedef struct cc_vit_model {
     /* CC_ROWS_* bits; 0 = the shipped policy (the last block computes out_proj / c_fc / c_proj for the rows the
      * projection head reads).  Per model, not process state: two models with different policies can run side by side. */
     int32_t row_policy;
+    /* linear_patch = '3d' (modules/clip.py:296-317): the patch embedding is a Conv3d over (t, h, w) with kernel (3, p, p),
+     * stride (1, p, p) and zero padding 1 along t - frame t of a clip sees frames t-1, t, t+1 of the SAME clip.
+     * conv2_weight_f16 [W, 3*3*p*p] = the Conv3d weight [W, 3(c), 3(t), p, p] flattened; NULL = '2d' (conv1). */
+    const void* conv2_weight_f16;
 } cc_vit_model;
 
 /* Frame input descriptor for the *_frames entry points.  The reference's evaluation

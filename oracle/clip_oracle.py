@@ -74,7 +74,8 @@ def resblock(x, sd, pre, heads, causal):
     return x + h @ sd[pre + "mlp.c_proj.weight"].float().t() + sd[pre + "mlp.c_proj.bias"].float()
 
 
-def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_medoids=None, return_hidden=False):
+def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_medoids=None, return_hidden=False,
+                   linear_patch='2d'):
     """VisualTransformer.forward + the ln_post/proj tail of CLIP.encode_image
     (clip.py:304-349,460-469).  video [B*T,3,H,W]; cluster_plan {block_index(0-based): (T_new, K)};
     cluster_cfg dict(distance, threshold, iter_limit, norm_p, split_size, pre_norm[, algorithm, aggregation]).
@@ -85,7 +86,12 @@ def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_med
     p = sd["visual.conv1.weight"].shape[-1]
     heads = W // 64
     layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
-    x = F.conv2d(video.float(), sd["visual.conv1.weight"].float(), stride=p)          # clip.py:324
+    if linear_patch == '3d':                                                           # clip.py:306-319
+        x3 = video.float().reshape(-1, T, video.shape[-3], video.shape[-2], video.shape[-1]).permute(0, 2, 1, 3, 4)
+        x3 = F.conv3d(x3, sd["visual.conv2.weight"].float(), stride=(1, p, p), padding=(1, 0, 0)).permute(0, 2, 1, 3, 4)
+        x = x3.reshape(-1, x3.shape[-3], x3.shape[-2], x3.shape[-1])
+    else:
+        x = F.conv2d(video.float(), sd["visual.conv1.weight"].float(), stride=p)      # clip.py:324
     x = x.reshape(x.shape[0], W, -1).permute(0, 2, 1)                                  # [BT, n, W]
     cls = sd["visual.class_embedding"].float().expand(x.shape[0], 1, W)
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"].float()         # :334-336

@@ -8,6 +8,8 @@
          clip4clip.py:417-418,436-447), zeros in the masks.                                              [§8c row S3]
   lg_*   the training branch's loss on the reference's own module and torch.autograd's gradients of it with respect to
          sequence_output, visual_output and logit_scale (clip4clip.py:245-262, losses.py:8-18)             [§8f N4]
+  mr_* / ss_train_*  TokenClusterInter with mean_residual / sparse_sampling in training mode            [§8f N2]
+  p3d_*  CLIP.encode_image with linear_patch='3d' (Conv3d patch embedding, clip.py:296-317)                 [§8a V1]
   ev_*   the reference's own main.eval_epoch (main.py:381-499) over a list-backed loader with the small random-weight
          model of r2_golden.npz (token clustering off, so no medoid choice enters): single-sentence and multi-sentence
          protocols -> similarity matrix, R@1, the metric strings.                                         [§8c rows S3, N1]
@@ -33,7 +35,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
 from gen_golden_clip import _import_reference, ref_args  # noqa: E402
-from recipes import lattice, dyadic, EVAL_CASES, eval_case_batches, s3_case, loss_grad_case  # noqa: E402
+from recipes import lattice, dyadic, EVAL_CASES, eval_case_batches, s3_case, loss_grad_case, conv3d_patch_weight, PATCH3D_SEED, MINOR_SEED  # noqa: E402
 
 # name: (seed, P, N, W, K, split, iter_limit)
 P1_MULTI = {
@@ -172,6 +174,50 @@ def _metric_values(rmain, sim, ds_attrs):
     return tuple(round(float(d[k]), 6) for d in (tv, vt) for k in ("R1", "R5", "R10", "MR", "MeanR"))
 
 
+def gen_cluster_minor(out):
+    """The two TokenClusterInter branches round 2 refused: mean_residual (cluster.py:228-237: the block's residual = frame
+    means of every token) and sparse_sampling in training mode (random ids per segment, cluster_utils.py:150-162 with the
+    global NumPy generator seeded here)."""
+    sys.path.insert(0, os.path.join("/root/reference", "modules"))
+    import cluster.cluster as cc
+    B, T, T_new, n, W = 2, 4, 2, 16, 32
+    x = torch.from_numpy(lattice(MINOR_SEED, (1 + n, B * T, W)))
+    mod = cc.TokenClusterInter(algorithm="kmediods++", block_id=3, before_cluster_num=n, cluster_num=n, before_block_frames=T,
+                               after_block_frames=T_new, original_frame=T, distance="euclidean", threshold=1e-6,
+                               iter_limit=100, id_sort=True, aggregation=None, split_size=16, norm_p=2.0,
+                               mean_residual=True, transformer_width=W)
+    y, res = mod(x)
+    out["mr_out"], out["mr_residual"] = y.contiguous().numpy(), res.contiguous().numpy()
+    K = 5
+    mod = cc.TokenClusterInter(algorithm="sparse_sampling", block_id=3, before_cluster_num=n, cluster_num=K,
+                               before_block_frames=T, after_block_frames=T_new, original_frame=T, transformer_width=W).train()
+    np.random.seed(MINOR_SEED)
+    y, res = mod(x)
+    assert res is None
+    out["ss_train_out"] = y.contiguous().numpy()
+    print("cluster minor", tuple(out["mr_out"].shape), tuple(out["mr_residual"].shape), tuple(y.shape), flush=True)
+
+
+def gen_patch3d(out):
+    """linear_patch='3d' (clip.py:296-317): the reference's CLIP with the Conv3d patch embedding, small model of
+    r2_golden.npz + a seeded conv2 weight -> image features of 2 clips x 4 frames (no token clustering)."""
+    rclip, rc4c, rcc, rmetrics = _import_reference()
+    g2 = np.load(os.path.join(GOLD, "r2_golden.npz"))
+    sd = {k[6:]: torch.from_numpy(g2[k].astype(np.float32) if g2[k].dtype == np.float16 else g2[k])
+          for k in g2.files if k.startswith("s1_sd/")}
+    E, RES, P, VW, VL, CTX, VOCAB, TW, TH, TL, B, T, T_new = [int(v) for v in g2["s1_cfg"]]
+    model = rclip.CLIP(E, RES, VL, VW, P, CTX, VOCAB, TW, TH, TL, linear_patch='3d', video_frames=T, args=None).float().eval()
+    model.load_state_dict(sd, strict=False)
+    w2 = torch.from_numpy(conv3d_patch_weight(PATCH3D_SEED, (VW, 3, 3, P, P)))
+    with torch.no_grad():
+        model.visual.conv2.weight.copy_(w2)
+    video = torch.from_numpy(dyadic(PATCH3D_SEED + 1, (2 * T, 3, RES, RES)))
+    with torch.no_grad():
+        feats, _ = model.encode_image(video, video_frame=T)
+    out["p3d_feats"] = feats.float().numpy()
+    print("patch3d", tuple(feats.shape), flush=True)
+
+
 def gen_loss_grad(out):
     """N4: the training branch's loss and what torch.autograd makes of it on the reference's own module
     (clip4clip.py:245-262: get_similarity_logits in training mode -> CrossEn both ways): gradients with respect to
@@ -206,10 +252,12 @@ def gen_loss_grad(out):
 
 if __name__ == "__main__":
     out = {}
+    gen_patch3d(out)
     gen_loss_grad(out)
     gen_s3(out)
     gen_eval(out)
     gen_p1_multi(out)
+    gen_cluster_minor(out)               # (these two put /root/reference/modules on sys.path: after everything that imports `utils`)
     path = os.path.join(GOLD, "r3_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -310,3 +310,13 @@ def loss_grad_case(tag, n, T_new, E):
         if v % 3 == 1 and T_new > 1:
             vmask[v, rng.integers(1, T_new)] = 0
     return seq, vis, vmask
+
+
+def conv3d_patch_weight(seed, shape):
+    """fp16-representable Conv3d weights for the linear_patch='3d' fixture: integers in [-2048, 2048] / 2^15."""
+    r = np.random.default_rng(seed).integers(-2048, 2049, size=shape)
+    return (r.astype(np.float32) * np.float32(2.0 ** -15)).astype(np.float32)
+
+
+PATCH3D_SEED = 901        # linear_patch='3d' fixture (p3d_* of r3_golden.npz)
+MINOR_SEED = 911          # mean_residual / training-mode sparse_sampling fixtures (mr_*, ss_train_*)

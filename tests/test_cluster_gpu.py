@@ -575,10 +575,8 @@ def test_cluster_frame_embedding_is_a_parameter_the_forward_ignores(cl):
 
 
 def test_n2_unbuilt_variants_fail_loudly(cl):
-    for kw in (dict(algorithm="temporal_shift"), dict(algorithm="token_shift"), dict(mean_residual=True)):
+    """(mean_residual and training-mode sparse_sampling were refused until round 3: tests/test_r3_gpu.py pins them to the
+    reference now.)  The shift ablations stay unbuilt, and mean_residual cannot enter the fused encoder."""
+    for kw in (dict(algorithm="temporal_shift"), dict(algorithm="token_shift")):
         with pytest.raises(NotImplementedError):
             cl.TokenClusterInter(**kw)
-    mod = cl.TokenClusterInter(algorithm="sparse_sampling", cluster_num=20, before_block_frames=12, after_block_frames=3,
-                               transformer_width=32).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        mod(dev(lattice(1, (50, 12, 32))))

@@ -128,7 +128,7 @@ def test_s1_training_branch_loss_values(g):
     model.clip.visual.forced_medoids = torch.from_numpy(g["s1_medoids"])
     out = model(ids, torch.zeros_like(ids), amask, video, vmask)
     assert abs(float(out["loss"].detach()) - float(g["s1_train_loss"])) <= 3e-3
-    assert abs(float(out["sim_loss"]) - float(g["s1_train_sim_loss"])) <= 3e-3 and float(out["cluster_loss"]) == 0.0
+    assert abs(float(out["sim_loss"].detach()) - float(g["s1_train_sim_loss"])) <= 3e-3 and float(out["cluster_loss"]) == 0.0
     sim = torch.from_numpy(g["n4_sim"]).to(DEV)
     got = [float(CrossEn()(sim)), float(CrossEn()(sim.t()))]
     np.testing.assert_allclose(got, g["n4_crossen"], rtol=0, atol=2e-6)

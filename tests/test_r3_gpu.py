@@ -390,3 +390,63 @@ def test_training_forward_returns_a_differentiable_loss(g2):
         want, _, _ = symmetric_contrastive_loss(logits)
     assert abs(float(out["sim_loss"]) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
     assert abs(float(out["loss"]) - float(g["s1_train_loss"])) <= 2e-3          # (own medoids; the fixture test pins it tighter)
+
+
+# ------------------------------------------------------------------------------------------------ minor branches
+def test_linear_patch_3d_against_reference(g2, g3):
+    """linear_patch='3d' (clip.py:296-317): Conv3d patch embedding (frame t sees t-1, t, t+1 of its clip, zero padded) as a
+    9*p*p-deep im2col GEMM, against the reference's CLIP.encode_image on the same weights; and CLIP4Clip.from_pretrained's
+    initialisation trick (conv2 = conv1 in the centre slice) reproduces the '2d' features."""
+    from centerclip_amd.clip import CLIP
+    from oracle.recipes import PATCH3D_SEED, conv3d_patch_weight, dyadic
+    E, RES, P, VW, VL, CTX, VOCAB, TW, TH, TL, B, T, T_new = [int(v) for v in g2["s1_cfg"]]
+    sd = {k[6:]: torch.from_numpy(g2[k].astype(np.float32) if g2[k].dtype == np.float16 else g2[k])
+          for k in g2.files if k.startswith("s1_sd/")}
+    model = CLIP(E, RES, VL, VW, P, CTX, VOCAB, TW, TH, TL, linear_patch='3d', video_frames=T, args=None)
+    model.load_state_dict(sd, strict=False)
+    w2 = torch.from_numpy(conv3d_patch_weight(PATCH3D_SEED, (VW, 3, 3, P, P)))
+    with torch.no_grad():
+        model.visual.conv2.weight.copy_(w2)
+    model = model.to(DEV).eval()
+    video = torch.from_numpy(dyadic(PATCH3D_SEED + 1, (2 * T, 3, RES, RES)))
+    feats, _ = model.encode_image(video.to(DEV), video_frame=T)
+    ref = torch.from_numpy(g3["p3d_feats"])
+    assert feats.shape == ref.shape and float((nrm(feats.cpu()) - nrm(ref)).abs().max()) <= 1e-3
+    sd3 = dict(sd)
+    sd3["visual.conv2.weight"] = w2
+    oref = clo.visual_forward(sd3, video, T, linear_patch='3d')
+    assert float((nrm(feats.cpu()) - nrm(oref)).abs().max()) <= 1e-3
+    # centre-slice inflation == the 2-d patch embedding
+    with torch.no_grad():
+        model.visual.conv2.weight.zero_()
+        model.visual.conv2.weight[:, :, 1] = model.visual.conv1.weight
+    f3, _ = model.encode_image(video.to(DEV), video_frame=T)
+    m2 = CLIP(E, RES, VL, VW, P, CTX, VOCAB, TW, TH, TL, linear_patch='2d', video_frames=T, args=None)
+    m2.load_state_dict(sd, strict=False)
+    f2, _ = m2.to(DEV).eval().encode_image(video.to(DEV), video_frame=T)
+    assert float((f3 - f2).abs().max()) <= 1e-5 * float(f2.abs().max())
+
+
+def test_mean_residual_and_training_sparse_sampling_against_reference(g3):
+    """TokenClusterInter(mean_residual=True) -> (x', residual_x) and algorithm='sparse_sampling' in training mode (the
+    reference's random ids: same NumPy calls under the same seed) against the reference module's outputs, bit for bit."""
+    from centerclip_amd.cluster import TokenClusterInter
+    from oracle.recipes import MINOR_SEED
+    B, T, T_new, n, W = 2, 4, 2, 16, 32
+    x = torch.from_numpy(lattice(MINOR_SEED, (1 + n, B * T, W))).to(DEV)
+    mod = TokenClusterInter(algorithm="kmediods++", block_id=3, before_cluster_num=n, cluster_num=n, before_block_frames=T,
+                            after_block_frames=T_new, original_frame=T, distance="euclidean", threshold=1e-6, iter_limit=100,
+                            split_size=16, norm_p=2.0, mean_residual=True, transformer_width=W).to(DEV).eval()
+    y, res = mod(x)
+    assert np.array_equal(y.cpu().numpy(), g3["mr_out"]) and np.array_equal(res.cpu().numpy(), g3["mr_residual"])
+    K = 5
+    mod = TokenClusterInter(algorithm="sparse_sampling", block_id=3, before_cluster_num=n, cluster_num=K, before_block_frames=T,
+                            after_block_frames=T_new, original_frame=T, transformer_width=W).to(DEV).train()
+    np.random.seed(MINOR_SEED)
+    xg = x.clone().requires_grad_(True)
+    y, res = mod(xg)
+    assert res is None and np.array_equal(y.detach().cpu().numpy(), g3["ss_train_out"])
+    y.sum().backward()                                    # gather + CLS mean: every picked token gets 1, every CLS 1 / fd
+    g = xg.grad.cpu()
+    assert float(g[0].min()) == float(g[0].max()) == 1.0 / (T // T_new)
+    assert float(g[1:].sum()) == float(B * T_new * K * W)
