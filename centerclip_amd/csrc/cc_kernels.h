@@ -90,6 +90,9 @@ struct TextEmbedArgs {
     int* seq_off;
     int* seq_len;
     int* m_total;
+    // rows of tok_emb; 0 = unchecked.  Ids outside [0, vocab) are clamped instead of read out of bounds (nn.Embedding raises
+    // for them; an enqueue-only C entry point cannot, and a wild read takes the process down with a memory fault).
+    int vocab;
 };
 // fp16 copy + (sum, sumsq) of fp32 rows (one wave per row); rows contiguous with stride W
 int cc_launch_row_stats(const float* h, _Float16* h16, float* stats, float* shift, int rows, int W, hipStream_t st);

@@ -331,7 +331,8 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         if (tm)
             te = TextEmbedArgs{reinterpret_cast<const long long*>(ids), tm->token_embedding, tm->positional_embedding,
                                t.h, t.eot, Bt, Lt, tm->width, t.h16, t.st0, t.sh0,
-                               compact ? t.seq_off : nullptr, compact ? t.seq_len : nullptr, compact ? t.mcount : nullptr};
+                               compact ? t.seq_off : nullptr, compact ? t.seq_len : nullptr, compact ? t.mcount : nullptr,
+                               tm->vocab_size};
         rc = (vm && tm) ? cc_launch_pre_stage(a, te, 1e-5f, st)
                         : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;

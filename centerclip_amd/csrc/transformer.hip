@@ -610,7 +610,8 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
         if (t > my_eot) return;
         row = off + t;
     }
-    const long long id = ids[src_row];
+    long long id = ids[src_row];
+    if (e.vocab > 0) id = id < 0 ? 0 : (id >= e.vocab ? e.vocab - 1 : id);
     const float* src = e.tok_emb + (int64_t)id * W;
     float4 v[4];
     float tot = 0.f;

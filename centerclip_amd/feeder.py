@@ -1,0 +1,62 @@
+"""Host -> device staging for the retrieval forward: the step the kernels are timed on takes batches that are already in
+HBM; a loader hands over pinned host tensors.  ``DeviceFeeder`` keeps ``depth`` device-resident copies of a batch and fills
+them on a COPY STREAM while the encoders work on the previous batch, so that the resident-input rate is reachable from a
+loader: with the decoder's uint8 frames (N3: 1.8 MB per 12-frame clip, the normalisation runs inside the patch gather) a
+16-clip batch is 29 MB = ~0.5 ms of PCIe Gen5 under 2.1 ms of compute.
+
+    feeder = DeviceFeeder(device, depth=2)
+    for slot, (ids, mask, video_u8, vmask) in feeder(loader):      # tensors of slot `slot`, valid until the next iteration
+        out = model(ids, seg, mask, video_u8, vmask)                # (a hipGraph per slot works: the addresses are stable)
+
+Ordering: the compute stream waits for the slot's copy event before it reads the slot; the copy stream waits for the
+event the compute stream records when it is done with the slot before it overwrites it.  No host synchronisation.
+PyTorch streams / events / ``Tensor.copy_(non_blocking=True)`` only: plumbing, no kernels of its own.
+"""
+import torch
+
+
+class DeviceFeeder:
+    def __init__(self, device, depth=2):
+        assert depth >= 2, "double buffering needs two slots"
+        self.device = torch.device(device)
+        self.depth = depth
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.slots = [None] * depth
+        self.ready = [torch.cuda.Event() for _ in range(depth)]      # slot filled
+        self.free = [torch.cuda.Event() for _ in range(depth)]       # slot no longer read by the compute stream
+        self._used = [False] * depth
+
+    def _fill(self, k, host_batch):
+        host_batch = tuple(host_batch)
+        if self.slots[k] is None or any(tuple(d.shape) != tuple(h.shape) or d.dtype != h.dtype
+                                        for d, h in zip(self.slots[k], host_batch)):
+            self.slots[k] = tuple(torch.empty(h.shape, dtype=h.dtype, device=self.device) for h in host_batch)
+        with torch.cuda.stream(self.copy_stream):
+            if self._used[k]:
+                self.copy_stream.wait_event(self.free[k])
+            for d, h in zip(self.slots[k], host_batch):
+                d.copy_(h, non_blocking=True)                        # asynchronous only from pinned memory
+            self.ready[k].record(self.copy_stream)
+
+    def __call__(self, host_batches):
+        """Iterate over (slot index, device tensors) for an iterable of host batches (tuples of CPU tensors, ideally pinned)."""
+        it = iter(host_batches)
+        filled = []
+        for k in range(self.depth):                                  # prime every slot
+            try:
+                self._fill(k, next(it))
+                filled.append(k)
+            except StopIteration:
+                break
+        while filled:
+            k = filled.pop(0)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.ready[k])
+            yield k, self.slots[k]
+            self.free[k].record(cur)                                 # everything the consumer enqueued on `cur` so far
+            self._used[k] = True
+            try:
+                self._fill(k, next(it))
+                filled.append(k)
+            except StopIteration:
+                pass

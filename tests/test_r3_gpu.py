@@ -450,3 +450,61 @@ def test_mean_residual_and_training_sparse_sampling_against_reference(g3):
     g = xg.grad.cpu()
     assert float(g[0].min()) == float(g[0].max()) == 1.0 / (T // T_new)
     assert float(g[1:].sum()) == float(B * T_new * K * W)
+
+
+# ------------------------------------------------------------------------------------------------ host -> device staging
+def test_device_feeder_overlapped_staging_gives_the_resident_results(g2):
+    """feeder.DeviceFeeder: batches staged from pinned host memory on a copy stream (two slots) give bit for bit the features
+    of the same batches placed on the device by hand - also when the consumer is a hipGraph captured per slot."""
+    from centerclip_amd.feeder import DeviceFeeder
+    model, sd, cfg = _small_model(g2, cluster_inter=1)
+    RES, CTX, VOCAB, T = int(cfg[1]), int(cfg[5]), int(cfg[6]), int(cfg[11])
+    gen = torch.Generator().manual_seed(3)
+    host = []
+    for i in range(5):
+        ids = torch.zeros(3, CTX, dtype=torch.long)
+        for b in range(3):
+            ln = int(torch.randint(4, CTX + 1, (1,), generator=gen))
+            ids[b, 0], ids[b, ln - 1] = VOCAB - 2, VOCAB - 1
+            ids[b, 1:ln - 1] = torch.randint(1, VOCAB - 2, (ln - 2,), generator=gen)
+        u8 = torch.randint(0, 256, (3, 1, T, RES, RES, 3), dtype=torch.uint8, generator=gen)
+        host.append((ids.pin_memory(), u8.pin_memory(), torch.ones(3, 1, T, dtype=torch.long).pin_memory()))
+
+    def run(ids, video, vmask):
+        out = model(ids, torch.zeros_like(ids), (ids > 0).long(), video, vmask)
+        return out["sequence_output"], out["visual_output"]
+
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in run(*(h.to(DEV) for h in hb))) for hb in host]
+        feeder = DeviceFeeder(DEV, depth=2)
+        got = [tuple(t.clone() for t in run(*bufs)) for _, bufs in feeder(host)]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # one captured graph per slot
+        graphs, got2 = {}, []
+        for k, bufs in DeviceFeeder(DEV, depth=2)(host):
+            if k not in graphs:
+                run(*bufs)
+                torch.cuda.synchronize()
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    outs = run(*bufs)
+                graphs[k] = (gph, outs)
+            graphs[k][0].replay()
+            got2.append(tuple(t.clone() for t in graphs[k][1]))
+        for a, b in zip(got2, want):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_out_of_range_token_ids_do_not_fault(g2):
+    """An id outside [0, vocab) (uninitialised buffer, corrupt loader output) is clamped by the embedding kernel instead of
+    reading out of bounds - the enqueue-only C path cannot raise as nn.Embedding does, and a wild read kills the process."""
+    model, sd, cfg = _small_model(g2, cluster_inter=0)
+    CTX, VOCAB = int(cfg[5]), int(cfg[6])
+    ids = torch.full((2, CTX), 2 ** 40, dtype=torch.long)
+    ids[1] = -7
+    ids[:, 3] = VOCAB - 1
+    feats = model.clip.encode_text(ids.to(DEV))
+    torch.cuda.synchronize()
+    assert feats.shape == (2, int(cfg[0])) and bool(torch.isfinite(feats).all())
