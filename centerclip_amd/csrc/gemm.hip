@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // Co-resident 4-wave workgroups: raising the wave priority over its MFMA block keeps the other workgroup's VMEM /
     // LDS instructions from being issued between them (measured: 1832 -> 1713-1763 cycles per k-step for the 128-wide
     // tiles; the single-workgroup 256x256 tile loses 7 % with it, so it is keyed on the loop form below).
-    constexpr bool MMA_PRIO = !((NWAVES == 8) || (BM == 64 && BN == 64));
+        constexpr bool MMA_PRIO = !((NWAVES == 8) || (BM == 64 && BN == 64));
     auto mma = [&](const h8 (&af)[MI], const h8 (&bf)[NI]) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     };
     // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
-    // plain order is faster (1832 vs 2033) - the co-resident workgroup already fills the LDS-latency gap.
-    constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
+    // plain order is faster (1832 vs 2033; re-measured in round 3 with the pinned phase-start wait: 1,468-1,572 vs 1,560-1,705)
+    // - the co-resident workgroup already fills the LDS-latency gap.
+        constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
     if constexpr (BK > GEMM_BK) {
         // Deep k-step (BK = 128, the 64x64 tile only): the small tile is bound by the latency of the LDS-DMA round trip,
         // one per k-step and workgroup (~900 cycles for 8 MFMAs per wave at BK = 64) - twice the bytes per stage halves

@@ -9,7 +9,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     lib = L.lib()
     lib.cc_debug_set_gemm_profile.argtypes = [ctypes.c_void_p]
     for M, N, K, epi, tile in [(9600, 3072, 768, "f16", 5), (9600, 2304, 768, "f16", 7), (9600, 768, 3072, "f32_resid", 6),
-                               (8192, 8192, 4096, "f16", 5)]:
+                               (8192, 8192, 4096, "f16", 5),
+                               (2400, 2304, 768, "f16", 1), (2400, 3072, 768, "f16_gelu", 1), (9408, 768, 3072, "f32", 1)]:
         a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
         out = torch.zeros(M, N, device="cuda", dtype=torch.float16 if epi.startswith("f16") else torch.float32)
         for _ in range(3): ops.linear_f16(a, w, None, epi, out=out, tile=tile)
