@@ -353,7 +353,8 @@ def test_contrastive_loss_gradients_against_reference_autograd(g2, g3, tag, n):
     loss, l1, l2 = contrastive_loss(seq_t, vis_t, torch.from_numpy(vmask).to(DEV), ls)
     (3.0 * loss).backward()
     ref3 = g3[f"{tag}_loss3"]
-    assert abs(float(l1) - ref3[0]) <= 2e-5 and abs(float(l2) - ref3[1]) <= 2e-5 and abs(float(loss) - ref3[2]) <= 2e-5
+    assert abs(float(l1.detach()) - ref3[0]) <= 2e-5 and abs(float(l2.detach()) - ref3[1]) <= 2e-5
+    assert abs(float(loss.detach()) - ref3[2]) <= 2e-5
     rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
     e_seq, e_vis = rel(seq_t.grad.cpu().numpy() / 3.0, g3[f"{tag}_dseq"]), rel(vis_t.grad.cpu().numpy() / 3.0, g3[f"{tag}_dvis"])
     e_ls = abs(float(ls.grad) / 3.0 - float(g3[f"{tag}_dls"])) / max(1.0, abs(float(g3[f"{tag}_dls"])))
