@@ -111,6 +111,12 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 
 int cc_launch_im2col(const cc_frames& frames, _Float16* A, int F, int res, int p, hipStream_t st);
 int cc_launch_im2col3d(const cc_frames& frames, _Float16* A, int F, int T, int res, int p, hipStream_t st);   // linear_patch '3d'
+
+// eig.hip: direct symmetric eigensolver for the K smallest eigenpairs (N <= 196, K <= 64, 2K <= N), see the file header
+bool cc_sym_eig_tridiag_supports(int N, int K);
+size_t cc_sym_eig_tridiag_ws_bytes(int P, int N);
+int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int correct_sign, float* Q, int ldq, float* evals,
+                              int* sweeps_out, void* ws, size_t ws_bytes, hipStream_t st);
 int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st);
 // ln_pre (args as cc_launch_layernorm2, fp32 output) and the text embedding in one launch
 int cc_launch_pre_stage(const LnArgs& ln, const TextEmbedArgs& te, float eps, hipStream_t st);

@@ -11,6 +11,7 @@
 // (modules/cluster/fast_kmeans.py:65,81) are never materialised: the update step walks
 // per-cluster member lists (SURVEY §8a equivalence 2).
 #include "cc_common.h"
+#include "cc_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -2342,8 +2343,13 @@ int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, 
 
 size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N) {
     if (P <= 0 || N <= 0) return 0;
+    if (N <= 196) return cc_sym_eig_tridiag_ws_bytes(P, N);      // the direct solver's band scratch (eig.hip)
     return N <= 201 ? 256 : cc_align_up((size_t)P * N * N * sizeof(float), 256);
 }
+
+// DEBUG hook (declared in no header, process-wide): 1 = always the Jacobi kernel, 0 = the direct solver where it applies.
+static int g_force_jacobi = 0;
+void cc_debug_set_eig_jacobi(int on) { g_force_jacobi = on; }
 
 int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
                               float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
@@ -2352,6 +2358,8 @@ int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int3
     if (N > 640) return CC_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ldq > K && hipMemsetAsync(Q, 0, (size_t)P * N * ldq * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
+    if (!g_force_jacobi && cc_sym_eig_tridiag_supports(N, K))    // tridiagonalisation + bisection + inverse iteration
+        return cc_launch_sym_eig_tridiag(laplacian, P, N, K, correct_sign, Q, ldq, eigenvalues, sweeps_out, ws, ws_bytes, st);
     const bool in_lds = N <= 201;
     if (!in_lds && (!ws || ws_bytes < cc_spectral_embedding_workspace_bytes(P, N))) return CC_ERR_WORKSPACE;
     const size_t smem = (in_lds ? (size_t)N * N * 4 : 0) + (size_t)N * 8 + 64;

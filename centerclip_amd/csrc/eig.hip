@@ -1,0 +1,626 @@
+// Direct symmetric eigensolver for the decomposition step of batch_spectral_clustering (reference: modules/cluster/
+// spectral.py:54-61 takes the K trailing left singular vectors of L_sym from torch.linalg.svd = the eigenvectors of the K
+// smallest eigenvalues).  The one-sided Jacobi kernel in cluster.hip decomposes the whole N x N matrix (8-10 sweeps of N/2
+// dependent rounds); this one does the work the K wanted pairs need, one workgroup of 16 waves per problem:
+//
+//   A  L_sym (symmetrised on load) -> LDS
+//   B  Householder tridiagonalisation T = Q^T L Q in fp32, ONE pass over the trailing block per reflector (the rank-2
+//      update of reflector k-1 and the matrix-vector product for reflector k fused), two barriers per step; the reflectors
+//      stay in row k of the matrix and are then packed to the front of the LDS region, which frees the rest of it
+//   C  eigenvalues of T in fp64: Sturm counts by the three-term recurrence (no division), 8 lanes per wanted eigenvalue,
+//      9-section steps from the Gershgorin interval down to 1e-13 |T|
+//   D  eigenvectors of T in fp64: inverse iteration, one lane per eigenvalue (Gaussian elimination with partial pivoting
+//      on the shifted tridiagonal; the bands of U stream through a global scratch, lane-contiguous), and after every solve
+//      a modified Gram-Schmidt pass over ALL K vectors in eigenvalue order (16 lanes per vector, vector in registers, the
+//      pivot vector broadcast through LDS: one barrier per vector)
+//   E  back-transformation z = H_0 ... H_{N-3} y in fp32 in the same lanes (reflectors read from LDS, no barrier)
+//   F  the reference's column order (eigenvalue ascending -> column K-1-k), sign rule of batch_sign_flip_rasmus_bro
+//
+// Why C and D run in fp64 although T is only an fp32-accurate image of L: Gram-Schmidt amplifies whatever the solved
+// vectors carry outside the wanted invariant subspace by the condition number of the solved block, and with shifts known to
+// fp32 (1e-7 |T|) a cluster whose spacing is comparable to that (planted partitions: eigenvalue 0 of multiplicity K up to
+// the coupling between the parts) gives blocks of condition 1e2 - 1e4, i.e. residuals of 1e-4 (measured, oracle/
+// probe_tridiag.py).  As a matrix of exact numbers T has simple eigenvalues; with shifts accurate to 1e-13 |T| every solve is
+// dominated by its own eigenvector, the block is orthogonal to rounding before it is orthogonalised, and the fp32 floor is
+// what remains: residual |L q - lambda q| <= 4e-7, orthonormal to 1.3e-6, eigenvalues within 5e-7 of a float64 eigh over
+// heat-kernel / KNN / planted-partition Laplacians (coupling 0 ... 1e-3, identical blocks) at N = 196, K = 49.
+// Scope: the matrix in LDS next to 10 KB of vectors (N <= 196) and packed reflectors + K fp64 vectors in its place
+// afterwards (K = 49 at N = 196), K <= 64; other shapes keep the Jacobi kernel.
+#include "cc_common.h"
+#include "cc_kernels.h"
+
+namespace {
+
+constexpr int TD_WAVES = 16;
+constexpr int TD_THREADS = 64 * TD_WAVES;
+constexpr int TD_ITERS = 2;                 // inverse iterations (one reaches the floor on every probe matrix)
+constexpr int TD_SECTIONS = 14;             // 9-section steps: 9^14 = 2e13
+constexpr double TD_EPS64 = 2.220446049250313e-16;
+
+__device__ __forceinline__ float td_row16_sum(float v) {
+    v += cc_dpp_f32<0xB1>(v);
+    v += cc_dpp_f32<0x4E>(v);
+    v += cc_dpp_f32<0x141>(v);
+    v += cc_dpp_f32<0x140>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ double td_dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double td_row16_sum(double v) {
+    v += td_dpp_f64<0xB1>(v);
+    v += td_dpp_f64<0x4E>(v);
+    v += td_dpp_f64<0x141>(v);
+    v += td_dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double td_row16_max(double v) {
+    v = fmax(v, td_dpp_f64<0xB1>(v));
+    v = fmax(v, td_dpp_f64<0x4E>(v));
+    v = fmax(v, td_dpp_f64<0x141>(v));
+    v = fmax(v, td_dpp_f64<0x140>(v));
+    return v;
+}
+// max over the 8 lanes of an aligned octet (quad swaps + the mirror inside an 8-lane half row)
+__device__ __forceinline__ double td_oct_max(double v) {
+    v = fmax(v, td_dpp_f64<0xB1>(v));
+    v = fmax(v, td_dpp_f64<0x4E>(v));
+    v = fmax(v, td_dpp_f64<0x141>(v));
+    return v;
+}
+
+// Number of eigenvalues of T below x: sign changes of p_0 = 1, p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}; ds[i] = (d_i,
+// e_i^2 clamped away from 0 so that an exact zero of p cannot stick).  A zero counts as positive, which gives the same
+// total as LAPACK's pivot replacement.  Rescaled by the exponent of p every 8 steps.
+__device__ __forceinline__ int td_sturm(const double2* __restrict__ ds, int N, double x) {
+    double p0 = 1.0, p1 = ds[0].x - x;
+    int c = p1 < 0.0 ? 1 : 0;
+    double e2 = ds[0].y;
+    int i = 1;
+    double2 nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nxt[u] = ds[min(1 + u, N - 1)];
+    for (; i + 8 <= N; i += 8) {                                 // blocks of 8 rows, the next block's loads in flight
+        double2 cur[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = ds[min(i + 8 + u, N - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double pn = (cur[u].x - x) * p1 - e2 * p0;
+            c += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
+            p0 = p1; p1 = pn; e2 = cur[u].y;
+        }
+        const int ex = __builtin_amdgcn_frexp_exp(p1 != 0.0 ? p1 : p0);
+        p1 = __builtin_amdgcn_ldexp(p1, -ex);
+        p0 = __builtin_amdgcn_ldexp(p0, -ex);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {                                // tail (< 8 rows): nxt holds rows i, i + 1, ...
+        if (i + u < N) {
+            const double pn = (nxt[u].x - x) * p1 - e2 * p0;
+            c += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
+            p0 = p1; p1 = pn; e2 = nxt[u].y;
+        }
+    }
+    return c;
+}
+
+__device__ __forceinline__ double td_start_value(unsigned i, unsigned k) {
+    unsigned h = i * 0x9E3779B1u + k * 0x85EBCA77u + 0x165667B1u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return (double)(h >> 8) * (1.0 / 8388608.0) - 1.0;
+}
+
+__device__ __forceinline__ int td_pack_offset(int k, int N) { return (k * (2 * N - 3 - k)) >> 1; }
+
+// Back-transformation, reflectors kr whose first non-zero element f = kr + 1 lies in pair slot T0 (f in [32 T0, 32 T0 + 31]):
+// slots below T0 are all-zero and skipped statically, slot T0 takes the (0 ... 0, 1, v ...) boundary, the rest is plain.
+template <int MAXT, int T0>
+__device__ __forceinline__ void td_back_range(float2 (&y)[MAXT], const float* __restrict__ R, const float* __restrict__ tau,
+                                              int N, int g) {
+    const int khi = min(N - 3, 32 * T0 + 30), klo = max(0, 32 * T0 - 1);
+    for (int kr = khi; kr >= klo; --kr) {
+        const float tk = tau[kr];
+        if (tk == 0.f) continue;
+        const int f = kr + 1;
+        const float* rk = R + td_pack_offset(kr, N) - (kr + 2);          // rk[j] = v_j for j >= kr + 2, v_f = 1
+        float2 v[MAXT];
+        float s;
+        {
+            const int i0 = 2 * g + 32 * T0, i1 = i0 + 1;
+            float a = rk[max(i0, f + 1)], b = rk[max(i1, f + 1)];        // (clamped: never in front of the packed row)
+            a = i0 > f ? a : (i0 == f ? 1.f : 0.f);
+            b = i1 > f ? b : (i1 == f ? 1.f : 0.f);
+            a = i0 < N ? a : 0.f; b = i1 < N ? b : 0.f;
+            v[T0] = make_float2(a, b);
+            s = a * y[T0].x + b * y[T0].y;
+        }
+#pragma unroll
+        for (int t = T0 + 1; t < MAXT; ++t) {
+            const int i0 = 2 * g + 32 * t;
+            float a = rk[i0], b = rk[i0 + 1];
+            a = i0 < N ? a : 0.f; b = i0 + 1 < N ? b : 0.f;      // (MAXT is sized for a range of N)
+            v[t] = make_float2(a, b);
+            s = fmaf(a, y[t].x, s);
+            s = fmaf(b, y[t].y, s);
+        }
+        s = td_row16_sum(s) * tk;
+#pragma unroll
+        for (int t = T0; t < MAXT; ++t) { y[t].x -= s * v[t].x; y[t].y -= s * v[t].y; }
+    }
+}
+template <int MAXT, int T0>
+__device__ __forceinline__ void td_back_all(float2 (&y)[MAXT], const float* __restrict__ R, const float* __restrict__ tau,
+                                            int N, int g) {
+    td_back_range<MAXT, T0>(y, R, tau, N, g);
+    if constexpr (T0 > 0) td_back_all<MAXT, T0 - 1>(y, R, tau, N, g);
+}
+
+// MAXT = ceil(N / 32): a vector of length N over the 16 lanes of a DPP row, lane g holds the pairs (2g + 32t, 2g + 32t + 1)
+template <int MAXT>
+__global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float* __restrict__ Lsym, double* __restrict__ bands,
+                                                                     float* __restrict__ Q, float* __restrict__ evals,
+                                                                     int* __restrict__ sweeps_out, int N, int K, int KP, int ldq,
+                                                                     int correct_sign, long long* __restrict__ prof) {
+    extern __shared__ __align__(16) unsigned char td_smem[];
+    const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int LD = (N + 3) & ~3;                                 // row pitch of the matrix in LDS (16-byte rows)
+    float* A = reinterpret_cast<float*>(td_smem);                // [N][LD]
+    float* tau = A + N * LD;                                     // [LD]
+    float* es = tau + LD;                                        // [max(2 LD, 256)]: e and 1 / (x0 - beta); later lam, shf
+    float* e = es;
+    float* scl = es + LD;
+    float4* vwx = reinterpret_cast<float4*>(es + max(2 * LD, 256));   // [LD] (v_j, w_j, next x_j, -) of the tridiagonalisation
+    float* part = reinterpret_cast<float*>(vwx + LD);            // [1024] matvec partials; (d, e^2); pivot vectors
+    double2* de = reinterpret_cast<double2*>(vwx);               // afterwards: [LD] (d_i, e_i)
+    double* lam = reinterpret_cast<double*>(es);                 //             [64] eigenvalues (ascending)
+    double* shf = lam + 64;                                      //             [64] shifts of the inverse iteration
+    const float* Lp = Lsym + (int64_t)p * N * N;
+    int stamp = 0;
+#define TD_STAMP() do { if (prof && p == 0 && tid == 0) prof[stamp] = (long long)wall_clock64(); ++stamp; } while (0)
+    TD_STAMP();
+
+    // ---- A: load, symmetrised; (v, w) = 0 and x = row 0 for the first pass ----------------------------------------------
+    for (int idx = tid; idx < N * LD; idx += TD_THREADS) {
+        const int i = idx / LD, j = idx - i * LD;
+        A[idx] = j < N ? 0.5f * (Lp[(int64_t)i * N + j] + Lp[(int64_t)j * N + i]) : 0.f;
+    }
+    for (int j = tid; j < LD; j += TD_THREADS)
+        vwx[j] = make_float4(0.f, 0.f, (j >= 1 && j < N) ? 0.5f * (Lp[j] + Lp[(int64_t)j * N]) : 0.f, 0.f);
+    __syncthreads();
+    TD_STAMP();                                                  // 1: loaded
+
+    // ---- B: Householder tridiagonalisation -------------------------------------------------------------------------
+    // One pass over the trailing block per reflector: the pass of step k applies reflector k-1 (S -= v w^T + w v^T on rows /
+    // columns >= k) and, on the values it has just produced, accumulates t = S x_k over rows >= k+1, where x_k = row k after
+    // that update - known beforehand from row k, v and w, so wave 0 prepared it with the previous reflector.  Then wave 0
+    // alone: |x|, beta, tau, p = tau S v from t and column k+1 (v = s (x - beta e_1): S v = s (t - beta S e_1)), w, and
+    // the next x.  Two barriers and one read + one write of the block per step.
+    // Lane = (row phase rs, column quad qd): 16 lanes read 256 contiguous bytes of a row (ds_read_b128, conflict-free),
+    // a wave covers 4 rows x 64 columns per iteration; waves = 64-column groups x 4 row chunks.
+    const int rs = lane >> 4, qd = lane & 15;
+    const int qlast = (N - 1) >> 2;
+    long long t_pass = 0, t_p2 = 0, t_bar = 0;
+    for (int k = 0; k <= N - 2; ++k) {
+        const long long c_a = prof ? (long long)wall_clock64() : 0;
+        const int q0 = k >> 2;
+        const int nq = qlast - q0 + 1;
+        const int cqg = nq > 48 ? 4 : (nq > 32 ? 3 : (nq > 16 ? 2 : 1));
+        int cq, ch;
+        if (cqg == 4) { cq = wave & 3; ch = wave >> 2; }
+        else if (cqg == 3) { ch = (wave * 11) >> 5; cq = wave - 3 * ch; }
+        else if (cqg == 2) { cq = wave & 1; ch = wave >> 1; }
+        else { cq = 0; ch = wave; }
+        const int rpc = (((N - k + 3) >> 2) + 3) & ~3;           // rows per chunk: ceil(m / 4) rounded to the 4 row phases
+        const int q4 = q0 + (cq << 4) + qd;
+        const bool on = ch < 4 && q4 <= qlast;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+            const int jb = k + ch * rpc, je = min(jb + rpc, N);
+            const float4 c0 = vwx[4 * q4], c1 = vwx[4 * q4 + 1], c2 = vwx[4 * q4 + 2], c3 = vwx[4 * q4 + 3];
+            float* col = A + 4 * q4;
+#pragma unroll 2
+            for (int j = jb + rs; j < je; j += 4) {
+                float4 a = *reinterpret_cast<const float4*>(col + j * LD);
+                const float4 o = vwx[j];
+                a.x -= o.x * c0.y + o.y * c0.x;
+                a.y -= o.x * c1.y + o.y * c1.x;
+                a.z -= o.x * c2.y + o.y * c2.x;
+                a.w -= o.x * c3.y + o.y * c3.x;
+                *reinterpret_cast<float4*>(col + j * LD) = a;
+                acc.x = fmaf(a.x, o.z, acc.x);
+                acc.y = fmaf(a.y, o.z, acc.y);
+                acc.z = fmaf(a.z, o.z, acc.z);
+                acc.w = fmaf(a.w, o.z, acc.w);
+            }
+        }
+        if (ch < 4) {                                            // (wave-uniform)
+            acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+            acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+            acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+            acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+            if (on && rs == 0) *reinterpret_cast<float4*>(part + (ch << 8) + (((cq << 4) + qd) << 2)) = acc;
+        }
+        const long long c_b = prof ? (long long)wall_clock64() : 0;
+        __syncthreads();
+        const long long c_c = prof ? (long long)wall_clock64() : 0;
+        t_pass += c_b - c_a; t_bar += c_c - c_b;
+        if (k == N - 2) break;                                   // the last pass only applies reflector N-3
+        if (wave == 0) {
+            const int f = k + 1;                                 // first column of reflector k
+            const int cbase = q0 << 2;
+            const int tmax = (N - f + 63) >> 6;
+            float xv[4], tv[4], cv[4];
+            float sig = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xv[t] = 0.f; tv[t] = 0.f; cv[t] = 0.f;
+                if (t < tmax) {                                  // (uniform)
+                    const int i = min(f + lane + 64 * t, N - 1), o = i - cbase;
+                    const bool in = f + lane + 64 * t < N;
+                    const float x = vwx[i].z, c = A[f * LD + i];
+                    const float tt = (part[o] + part[256 + o]) + (part[512 + o] + part[768 + o]);
+                    xv[t] = in ? x : 0.f; tv[t] = in ? tt : 0.f; cv[t] = in ? c : 0.f;
+                    sig = fmaf(xv[t], (lane + 64 * t) > 0 ? xv[t] : 0.f, sig);
+                }
+            }
+            sig = cc_wave_sum_fast(sig);
+            const float x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xv[0])));
+            float vv[4], ww[4];
+            float beta = x0, tk = 0.f, s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { vv[t] = 0.f; ww[t] = 0.f; }
+            if (sig != 0.f) {                                    // else nothing to annihilate: H_k = I
+                const float n2 = fmaf(x0, x0, sig);
+                float rn = __builtin_amdgcn_rsqf(n2);
+                rn = rn * (1.5f - 0.5f * n2 * rn * rn);          // one Newton step: 1 / |x| to rounding
+                const float nrm = n2 * rn;
+                beta = x0 >= 0.f ? -nrm : nrm;
+                const float dd = x0 - beta;                      // same sign as x0: no cancellation
+                float rd = __builtin_amdgcn_rcpf(dd);
+                rd = rd * (2.f - dd * rd);
+                s = rd;
+                // tau = (beta - x0) / beta = 2 / |v|^2, |v|^2 = 1 + s^2 sig: H = I - tau v v^T is orthogonal iff tau |v|^2 = 2
+                const float vn = fmaf(s * s, sig, 1.f);
+                float rv = __builtin_amdgcn_rcpf(vn);
+                rv = rv * (2.f - vn * rv);
+                tk = 2.f * rv;
+                const float ts = tk * s;
+                float gam = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < tmax) {
+                        vv[t] = (lane + 64 * t) == 0 ? 1.f : s * xv[t];      // (0 beyond N: x = 0 there)
+                        ww[t] = ts * (tv[t] - beta * cv[t]);               // p
+                        gam = fmaf(ww[t], vv[t], gam);
+                    }
+                }
+                gam = cc_wave_sum_fast(gam);
+                const float hc = 0.5f * tk * gam;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ww[t] -= hc * vv[t];
+            }
+            const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ww[0])));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ii = lane + 64 * t, i = f + ii;
+                if (t < tmax && i < N) {                         // .z: row k+1 after this reflector = the next x
+                    vwx[i] = make_float4(vv[t], ww[t], ii == 0 ? 0.f : cv[t] - ww[t] - w0 * vv[t], 0.f);
+                    // the reflector that is stored must be the x that tau and s were computed from, not the row the pass
+                    // produced: the two differ by rounding of terms far larger than a nearly decoupled row (planted
+                    // partitions: 1e-4 relative), and H = I - tau v v^T is orthogonal only for the v that tau belongs to
+                    A[k * LD + i] = xv[t];
+                }
+            }
+            if (lane == 0) { vwx[k] = make_float4(0.f, 0.f, 0.f, 0.f); e[k] = beta; tau[k] = tk; scl[k] = s; }
+        }
+        if (prof) t_p2 += (long long)wall_clock64() - c_c;
+        __syncthreads();
+    }
+    // the tridiagonal in fp64 (vwx is no longer read); e_{N-2} is what the last pass left
+    {
+        double2 mine_de[1];
+        const int i = tid;
+        if (i < N) {
+            const float ei = i < N - 2 ? e[i] : (i == N - 2 ? A[(N - 2) * LD + N - 1] : 0.f);
+            mine_de[0] = make_double2((double)A[i * LD + i], (double)ei);
+        }
+        __syncthreads();                                         // (N <= 196 < 1024: one element per thread)
+        if (i < N) de[i] = mine_de[0];
+    }
+    __syncthreads();
+    TD_STAMP();                                                  // 2: tridiagonal
+    if (prof && p == 0 && tid == 0) { prof[16] = t_pass; prof[17] = t_bar; prof[18] = t_p2; }
+
+    // ---- pack the reflectors (row k, columns k+2.., scaled) to the front of the region ---------------------------------
+    const int T = ((N - 1) * (N - 2)) >> 1;
+    {
+        constexpr int MAXP = 19;                                 // ceil(T / 1024) at N = 196
+        float reg[MAXP];
+#pragma unroll
+        for (int r = 0; r < MAXP; ++r) {
+            const int q = tid + TD_THREADS * r;
+            reg[r] = 0.f;
+            if (q < T) {
+                const float b2 = (float)(2 * N - 3);
+                int kq = (int)((b2 - sqrtf(fmaxf(b2 * b2 - 8.f * (float)q, 0.f))) * 0.5f);
+                kq = max(0, min(kq, N - 3));
+                while (kq < N - 3 && td_pack_offset(kq + 1, N) <= q) ++kq;
+                while (kq > 0 && td_pack_offset(kq, N) > q) --kq;
+                reg[r] = A[kq * LD + kq + 2 + (q - td_pack_offset(kq, N))] * scl[kq];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXP; ++r) {
+            const int q = tid + TD_THREADS * r;
+            if (q < T) A[q] = reg[r];
+        }
+    }
+    const float* R = A;
+    double* Y = reinterpret_cast<double*>(A + ((T + 3) & ~3));   // [N][KP]
+    double2* ds = reinterpret_cast<double2*>(part);              // [LD] (d_i, max(e_i^2, tiny)) for the Sturm counts
+    for (int i = tid; i < N; i += TD_THREADS) { const double2 t = de[i]; ds[i] = make_double2(t.x, fmax(t.y * t.y, 1e-280)); }
+    __syncthreads();
+    TD_STAMP();                                                  // 3: reflectors packed
+
+    // ---- C: eigenvalues (fp64) -----------------------------------------------------------------------------------------
+    double glo = 1.0e300, ghi = -1.0e300;
+    for (int i = lane; i < N; i += 64) {
+        const double r = (i > 0 ? fabs(de[i - 1].y) : 0.0) + fabs(de[i].y);     // (e_{N-1} = 0)
+        glo = fmin(glo, de[i].x - r);
+        ghi = fmax(ghi, de[i].x + r);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { glo = fmin(glo, __shfl_xor(glo, o, 64)); ghi = fmax(ghi, __shfl_xor(ghi, o, 64)); }
+    const double tnorm = fmax(fmax(fabs(glo), fabs(ghi)), 1e-300);
+    glo -= 4.0 * TD_EPS64 * tnorm * (double)N;
+    ghi += 4.0 * TD_EPS64 * tnorm * (double)N;
+    if (tid < 8 * K) {                                           // 8 lanes per wanted eigenvalue
+        const int kb = tid >> 3, gb = tid & 7;
+        double lo = glo, hi = ghi;
+        for (int it = 0; it < TD_SECTIONS; ++it) {
+            const double x = lo + (hi - lo) * ((double)(gb + 1) * (1.0 / 9.0));
+            const bool below = td_sturm(ds, N, x) <= kb;
+            lo = td_oct_max(below ? x : lo);
+            hi = -td_oct_max(below ? -hi : -x);
+        }
+        if (gb == 0) lam[kb] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    TD_STAMP();                                                  // 4: eigenvalues
+
+    // ---- D: eigenvectors of T (fp64) -------------------------------------------------------------------------------------
+    if (tid == 0) {
+        // numerically equal eigenvalues get distinct shifts (LAPACK's dstein: 10 ulps of |T|) so that their factorisations
+        // differ; the Gram-Schmidt pass makes a basis of the eigenspace out of the solutions
+        const double sep = 10.0 * TD_EPS64 * tnorm;
+        double prev = lam[0];
+        shf[0] = prev;
+        for (int q = 1; q < K; ++q) {
+            prev = fmax(lam[q], prev + sep);
+            shf[q] = prev;
+        }
+    }
+    for (int idx = tid; idx < N * KP; idx += TD_THREADS) {
+        const int i = idx / KP, c = idx - i * KP;
+        Y[idx] = td_start_value((unsigned)i, (unsigned)c);
+    }
+    __syncthreads();
+    const double tiny = TD_EPS64 * tnorm;
+    double* U0 = bands + (int64_t)p * 3 * N * KP;                 // 1 / pivot
+    double* U1 = U0 + (int64_t)N * KP;
+    double* U2 = U1 + (int64_t)N * KP;
+    const int k = tid >> 4, g = tid & 15;                        // 16 lanes per wanted vector
+    const bool mine = k < K;
+    double2 y[MAXT];
+    double* qbuf = reinterpret_cast<double*>(part);              // 2 x [256] pivot vector (ds is no longer read)
+    for (int it = 0; it < TD_ITERS; ++it) {
+        if (tid < K) {                                           // (T - shift) x = y, lane = eigenvalue
+            const int c = tid;
+            const double sh = shf[c];
+            double2 cur = de[0], nx = de[1];                     // rows i and i + 1 of T; the loads run one row ahead
+            double nr = Y[KP + c];
+            double a = cur.x - sh, b = cur.y, cc = 0.0, r = Y[c];
+            for (int i = 0; i < N - 1; ++i) {
+                const int i2 = min(i + 2, N - 1);
+                const double2 nx2 = de[i2];
+                const double nr2 = Y[i2 * KP + c];
+                const double na = cur.y, nb = nx.x - sh, nc = nx.y;                 // (e_{N-1} = 0)
+                const bool sw = fabs(na) > fabs(a);
+                double pa = sw ? na : a;
+                const double pb = sw ? nb : b, pc = sw ? nc : cc, pr = sw ? nr : r;
+                const double qa = sw ? a : na, qb = sw ? b : nb, qc = sw ? cc : nc, qr = sw ? r : nr;
+                if (fabs(pa) < tiny) pa = pa < 0.0 ? -tiny : tiny;
+                const double ip = 1.0 / pa;
+                const double ml = qa * ip;
+                U0[i * KP + c] = ip; U1[i * KP + c] = pb; U2[i * KP + c] = pc;
+                Y[i * KP + c] = pr;
+                a = qb - ml * pb; b = qc - ml * pc; cc = 0.0; r = qr - ml * pr;
+                cur = nx; nx = nx2; nr = nr2;
+            }
+            if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;
+            double x1 = r / a, x2 = 0.0;
+            Y[(N - 1) * KP + c] = x1;
+            // back substitution in blocks of 4 rows, the next block's bands (global) and right-hand sides in flight
+            double by[4], b0[4], b1[4], b2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = max(N - 2 - u, 0);
+                by[u] = Y[i * KP + c]; b0[u] = U0[i * KP + c]; b1[u] = U1[i * KP + c]; b2[u] = U2[i * KP + c];
+            }
+            for (int ib = N - 2; ib >= 0; ib -= 4) {
+                double cy[4], c0[4], c1[4], c2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { cy[u] = by[u]; c0[u] = b0[u]; c1[u] = b1[u]; c2[u] = b2[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = max(ib - 4 - u, 0);
+                    by[u] = Y[i * KP + c]; b0[u] = U0[i * KP + c]; b1[u] = U1[i * KP + c]; b2[u] = U2[i * KP + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ib - u >= 0) {
+                        const double x = (cy[u] - c1[u] * x1 - c2[u] * x2) * c0[u];
+                        Y[(ib - u) * KP + c] = x;
+                        x2 = x1; x1 = x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        TD_STAMP();                                              // 5, 7: solve
+        if (mine) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int i0 = 2 * g + 32 * t;
+                y[t].x = i0 < N ? Y[i0 * KP + k] : 0.0;
+                y[t].y = i0 + 1 < N ? Y[(i0 + 1) * KP + k] : 0.0;
+            }
+            double mx = 0.0;                                     // keep the numbers small: a solve grows a vector by up to 1 / tiny
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) mx = fmax(mx, fmax(fabs(y[t].x), fabs(y[t].y)));
+            mx = td_row16_max(mx);
+            const double im = mx > 0.0 ? 1.0 / mx : 0.0;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) { y[t].x *= im; y[t].y *= im; }
+        }
+        for (int kk = 0; kk < K; ++kk) {                         // modified Gram-Schmidt, right-looking
+            double* qb = qbuf + (kk & 1) * 256;
+            if (mine && k == kk) {
+                double n2 = 0.0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) n2 = fma(y[t].x, y[t].x, fma(y[t].y, y[t].y, n2));
+                n2 = td_row16_sum(n2);
+                const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int i0 = 2 * g + 32 * t;
+                    y[t].x *= inv; y[t].y *= inv;
+                    if (i0 < N) *reinterpret_cast<double2*>(qb + i0) = y[t];     // (the pad element of an odd N is 0)
+                }
+            }
+            __syncthreads();
+            if (mine && k > kk) {
+                double2 qv[MAXT];
+                double cf = 0.0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int i0 = 2 * g + 32 * t;
+                    qv[t] = i0 < N ? *reinterpret_cast<const double2*>(qb + i0) : make_double2(0.0, 0.0);
+                    cf = fma(qv[t].x, y[t].x, fma(qv[t].y, y[t].y, cf));
+                }
+                cf = td_row16_sum(cf);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) { y[t].x -= cf * qv[t].x; y[t].y -= cf * qv[t].y; }
+            }
+        }
+        TD_STAMP();                                              // 6, 8: Gram-Schmidt
+        if (it + 1 < TD_ITERS) {
+            if (mine) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int i0 = 2 * g + 32 * t;
+                    if (i0 < N) Y[i0 * KP + k] = y[t].x;
+                    if (i0 + 1 < N) Y[(i0 + 1) * KP + k] = y[t].y;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- E: back-transformation (fp32) ----------------------------------------------------------------------------------
+    float2 z[MAXT];
+    if (mine) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) z[t] = make_float2((float)y[t].x, (float)y[t].y);
+        td_back_all<MAXT, MAXT - 1>(z, R, tau, N, g);
+    }
+    __syncthreads();                                             // every group is done with Y / the pivot buffers
+    TD_STAMP();                                                  // 9: back-transformed
+
+    // ---- F: column order and sign of the reference, coalesced store ------------------------------------------------------
+    float* Yf = reinterpret_cast<float*>(Y);                     // [N][KP] fp32 staging
+    if (mine) {
+        float sg = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const float u0 = z[t].x, u1 = z[t].y;
+            sg += (u0 > 0.f ? 1.f : (u0 < 0.f ? -1.f : 0.f)) * (u0 * u0) + (u1 > 0.f ? 1.f : (u1 < 0.f ? -1.f : 0.f)) * (u1 * u1);
+        }
+        sg = td_row16_sum(sg);
+        const float flip = correct_sign ? (sg > 0.f ? 1.f : (sg < 0.f ? -1.f : 0.f)) : 1.f;
+        const int col = K - 1 - k;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int i0 = 2 * g + 32 * t;
+            if (i0 < N) Yf[i0 * KP + col] = z[t].x * flip;
+            if (i0 + 1 < N) Yf[(i0 + 1) * KP + col] = z[t].y * flip;
+        }
+        if (g == 0 && evals) evals[(int64_t)p * K + col] = (float)lam[k];
+    }
+    __syncthreads();
+    float* Qp = Q + (int64_t)p * N * ldq;
+    for (int idx = tid; idx < N * K; idx += TD_THREADS) {
+        const int i = idx / K, c = idx - i * K;
+        Qp[(int64_t)i * ldq + c] = Yf[i * KP + c];
+    }
+    if (tid == 0 && sweeps_out) sweeps_out[p] = 0;               // a direct method: no sweeps
+    TD_STAMP();                                                  // 10: stored
+#undef TD_STAMP
+}
+
+size_t td_smem_bytes(int N) {
+    const size_t LD = (size_t)((N + 3) & ~3);
+    const size_t es = 2 * LD > 256 ? 2 * LD : 256;
+    return ((size_t)N * LD + LD + es + 4 * LD + 1024) * sizeof(float);
+}
+
+long long* g_td_prof = nullptr;
+
+}  // namespace
+
+// DEBUG hook (declared in no header, process-wide): wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries.
+extern "C" void cc_debug_set_eig_profile(long long* dev_buf) { g_td_prof = dev_buf; }
+
+bool cc_sym_eig_tridiag_supports(int N, int K) {
+    if (N < 3 || N > 196 || K < 1 || K > 64 || K > N) return false;
+    const int KP = K | 1, LD = (N + 3) & ~3;
+    const int T = ((N - 1) * (N - 2)) >> 1;
+    // the packed reflectors (fp32) and the K vectors (fp64) take the place of the matrix
+    return (size_t)((T + 3) & ~3) * 4 + (size_t)N * KP * 8 <= (size_t)N * LD * 4 && td_smem_bytes(N) <= 160 * 1024;
+}
+
+size_t cc_sym_eig_tridiag_ws_bytes(int P, int N) {               // three fp64 bands of U for K <= 64 lanes per problem
+    return cc_align_up((size_t)P * 3 * N * 65 * sizeof(double), 256);
+}
+
+int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int correct_sign, float* Q, int ldq, float* evals,
+                              int* sweeps_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!cc_sym_eig_tridiag_supports(N, K)) return CC_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < cc_sym_eig_tridiag_ws_bytes(P, N)) return CC_ERR_WORKSPACE;
+    const int KP = K | 1;
+    const size_t smem = td_smem_bytes(N);
+#define TD_LAUNCH(MAXT)                                                                                                 \
+    do {                                                                                                               \
+        auto kern = sym_eig_tridiag_kernel<MAXT>;                                                                      \
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
+            return CC_ERR_HIP;                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(TD_THREADS), smem, st, laplacian, static_cast<double*>(ws), Q, evals,    \
+                           sweeps_out, N, K, KP, ldq, correct_sign, g_td_prof);                                        \
+    } while (0)
+    if (N <= 64) TD_LAUNCH(2);
+    else if (N <= 128) TD_LAUNCH(4);
+    else TD_LAUNCH(7);
+#undef TD_LAUNCH
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
