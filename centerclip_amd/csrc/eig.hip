@@ -7,8 +7,8 @@
 //   B  Householder tridiagonalisation T = Q^T L Q in fp32, ONE pass over the trailing block per reflector (the rank-2
 //      update of reflector k-1 and the matrix-vector product for reflector k fused), two barriers per step; the reflectors
 //      stay in row k of the matrix and are then packed to the front of the LDS region, which frees the rest of it
-//   C  eigenvalues of T in fp64: Sturm counts by the three-term recurrence (no division), 8 lanes per wanted eigenvalue,
-//      9-section steps from the Gershgorin interval down to 1e-13 |T|
+//   C  eigenvalues of T in fp64: Sturm counts by the three-term recurrence (no division), 4 lanes per wanted eigenvalue,
+//      5-section steps from the Gershgorin interval down to 1e-13 |T|
 //   D  eigenvectors of T in fp64: inverse iteration, one lane per eigenvalue (Gaussian elimination with partial pivoting
 //      on the shifted tridiagonal; the bands of U stream through a global scratch, lane-contiguous), and after every solve
 //      a modified Gram-Schmidt pass over ALL K vectors in eigenvalue order (16 lanes per vector, vector in registers, the
@@ -33,8 +33,8 @@ namespace {
 
 constexpr int TD_WAVES = 16;
 constexpr int TD_THREADS = 64 * TD_WAVES;
-constexpr int TD_ITERS = 2;                 // inverse iterations (one reaches the floor on every probe matrix)
-constexpr int TD_SECTIONS = 14;             // 9-section steps: 9^14 = 2e13
+constexpr int TD_ITERS = 1;                 // inverse iterations: with fp64 shifts one reaches the fp32 floor (probe: 76 matrices)
+constexpr int TD_SECTIONS = 19;             // 5-section steps: 5^19 = 2e13
 constexpr double TD_EPS64 = 2.220446049250313e-16;
 
 __device__ __forceinline__ float td_row16_sum(float v) {
@@ -43,6 +43,13 @@ __device__ __forceinline__ float td_row16_sum(float v) {
     v += cc_dpp_f32<0x141>(v);
     v += cc_dpp_f32<0x140>(v);
     return v;
+}
+// x[l] + x[l^16] + x[l^32] + x[l^48] in every lane: the gfx950 row / half swaps instead of two ds_bpermute round trips
+__device__ __forceinline__ float td_sum_rows(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 template <int CTRL>
 __device__ __forceinline__ double td_dpp_f64(double x) {
@@ -64,51 +71,68 @@ __device__ __forceinline__ double td_row16_max(double v) {
     v = fmax(v, td_dpp_f64<0x140>(v));
     return v;
 }
-// max over the 8 lanes of an aligned octet (quad swaps + the mirror inside an 8-lane half row)
-__device__ __forceinline__ double td_oct_max(double v) {
-    v = fmax(v, td_dpp_f64<0xB1>(v));
-    v = fmax(v, td_dpp_f64<0x4E>(v));
-    v = fmax(v, td_dpp_f64<0x141>(v));
-    return v;
-}
 
 // Number of eigenvalues of T below x: sign changes of p_0 = 1, p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}; ds[i] = (d_i,
-// e_i^2 clamped away from 0 so that an exact zero of p cannot stick).  A zero counts as positive, which gives the same
-// total as LAPACK's pivot replacement.  Rescaled by the exponent of p every 8 steps.
+// e_i^2 clamped away from 0 so that an exact zero of p cannot stick), readable up to index N + 15.  A zero counts as positive,
+// which gives the same total as LAPACK's pivot replacement.  Per row: add, mul, fma and one v_alignbit that shifts the sign
+// of p into a mask; the changes are counted per 8 rows (popcount of mask ^ mask >> 1), where p is also rescaled by its
+// exponent.  Two register sets of 8 rows alternate so that the next rows are in flight while 8 are consumed.
+#define TD_STURM_ROW(R)                                                       \
+    {                                                                          \
+        const double pn = ((R).x - x) * p1 - e2 * p0;                          \
+        m = __builtin_amdgcn_alignbit(m, (unsigned)__double2hiint(pn), 31);    \
+        p0 = p1; p1 = pn; e2 = (R).y;                                          \
+    }
+#define TD_STURM_CLOSE()                                                      \
+    {                                                                          \
+        c += __builtin_popcount((m ^ (m >> 1)) & 0xFFu);                       \
+        const int ex = __builtin_amdgcn_frexp_exp(p1 != 0.0 ? p1 : p0);        \
+        p1 = __builtin_amdgcn_ldexp(p1, -ex);                                  \
+        p0 = __builtin_amdgcn_ldexp(p0, -ex);                                  \
+    }
 __device__ __forceinline__ int td_sturm(const double2* __restrict__ ds, int N, double x) {
     double p0 = 1.0, p1 = ds[0].x - x;
-    int c = p1 < 0.0 ? 1 : 0;
+    unsigned m = (unsigned)__double2hiint(p1) >> 31;             // bit 0 = sign of the latest p; the sign of p_0 is 0
+    int c = (int)m;
     double e2 = ds[0].y;
+    double2 ra[8], rb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ra[u] = ds[1 + u];
     int i = 1;
-    double2 nxt[8];
+    while (i + 16 <= N) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) nxt[u] = ds[min(1 + u, N - 1)];
-    for (; i + 8 <= N; i += 8) {                                 // blocks of 8 rows, the next block's loads in flight
-        double2 cur[8];
+        for (int u = 0; u < 8; ++u) rb[u] = ds[i + 8 + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < 8; ++u) TD_STURM_ROW(ra[u])
+        TD_STURM_CLOSE()
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = ds[min(i + 8 + u, N - 1)];
+        for (int u = 0; u < 8; ++u) ra[u] = ds[i + 16 + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double pn = (cur[u].x - x) * p1 - e2 * p0;
-            c += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
-            p0 = p1; p1 = pn; e2 = cur[u].y;
-        }
-        const int ex = __builtin_amdgcn_frexp_exp(p1 != 0.0 ? p1 : p0);
-        p1 = __builtin_amdgcn_ldexp(p1, -ex);
-        p0 = __builtin_amdgcn_ldexp(p0, -ex);
+        for (int u = 0; u < 8; ++u) TD_STURM_ROW(rb[u])
+        TD_STURM_CLOSE()
+        i += 16;
+    }
+    if (i + 8 <= N) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rb[u] = ds[i + 8 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) TD_STURM_ROW(ra[u])
+        TD_STURM_CLOSE()
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ra[u] = rb[u];
+        i += 8;
     }
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {                                // tail (< 8 rows): nxt holds rows i, i + 1, ...
+    for (int u = 0; u < 7; ++u) {                                // tail (< 8 rows): ra holds rows i, i + 1, ...
         if (i + u < N) {
-            const double pn = (nxt[u].x - x) * p1 - e2 * p0;
-            c += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
-            p0 = p1; p1 = pn; e2 = nxt[u].y;
+            TD_STURM_ROW(ra[u])
+            c += (int)((m ^ (m >> 1)) & 1u);
         }
     }
     return c;
 }
+#undef TD_STURM_ROW
+#undef TD_STURM_CLOSE
 
 __device__ __forceinline__ double td_start_value(unsigned i, unsigned k) {
     unsigned h = i * 0x9E3779B1u + k * 0x85EBCA77u + 0x165667B1u;
@@ -138,7 +162,7 @@ __device__ __forceinline__ void td_back_range(float2 (&y)[MAXT], const float* __
             float a = rk[max(i0, f + 1)], b = rk[max(i1, f + 1)];        // (clamped: never in front of the packed row)
             a = i0 > f ? a : (i0 == f ? 1.f : 0.f);
             b = i1 > f ? b : (i1 == f ? 1.f : 0.f);
-            a = i0 < N ? a : 0.f; b = i1 < N ? b : 0.f;
+            if (32 * T0 + 32 > N) { a = i0 < N ? a : 0.f; b = i1 < N ? b : 0.f; }      // (uniform: MAXT covers a range of N)
             v[T0] = make_float2(a, b);
             s = a * y[T0].x + b * y[T0].y;
         }
@@ -146,7 +170,7 @@ __device__ __forceinline__ void td_back_range(float2 (&y)[MAXT], const float* __
         for (int t = T0 + 1; t < MAXT; ++t) {
             const int i0 = 2 * g + 32 * t;
             float a = rk[i0], b = rk[i0 + 1];
-            a = i0 < N ? a : 0.f; b = i0 + 1 < N ? b : 0.f;      // (MAXT is sized for a range of N)
+            if (32 * t + 32 > N) { a = i0 < N ? a : 0.f; b = i0 + 1 < N ? b : 0.f; }
             v[t] = make_float2(a, b);
             s = fmaf(a, y[t].x, s);
             s = fmaf(b, y[t].y, s);
@@ -187,13 +211,22 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
 #define TD_STAMP() do { if (prof && p == 0 && tid == 0) prof[stamp] = (long long)wall_clock64(); ++stamp; } while (0)
     TD_STAMP();
 
-    // ---- A: load, symmetrised; (v, w) = 0 and x = row 0 for the first pass ----------------------------------------------
+    // ---- A: load (coalesced), symmetrise in LDS; (v, w) = 0 and x = row 0 for the first pass ------------------------------
     for (int idx = tid; idx < N * LD; idx += TD_THREADS) {
         const int i = idx / LD, j = idx - i * LD;
-        A[idx] = j < N ? 0.5f * (Lp[(int64_t)i * N + j] + Lp[(int64_t)j * N + i]) : 0.f;
+        A[idx] = j < N ? Lp[(int64_t)i * N + j] : 0.f;
     }
-    for (int j = tid; j < LD; j += TD_THREADS)
-        vwx[j] = make_float4(0.f, 0.f, (j >= 1 && j < N) ? 0.5f * (Lp[j] + Lp[(int64_t)j * N]) : 0.f, 0.f);
+    __syncthreads();
+    for (int idx = tid; idx < N * LD; idx += TD_THREADS) {       // the thread of (i, j), j > i, owns the pair
+        const int i = idx / LD, j = idx - i * LD;
+        if (j > i && j < N) {
+            const float mij = 0.5f * (A[idx] + A[j * LD + i]);
+            A[idx] = mij;
+            A[j * LD + i] = mij;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < LD; j += TD_THREADS) vwx[j] = make_float4(0.f, 0.f, (j >= 1 && j < N) ? A[j] : 0.f, 0.f);
     __syncthreads();
     TD_STAMP();                                                  // 1: loaded
 
@@ -204,23 +237,69 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
     // alone: |x|, beta, tau, p = tau S v from t and column k+1 (v = s (x - beta e_1): S v = s (t - beta S e_1)), w, and
     // the next x.  Two barriers and one read + one write of the block per step.
     // Lane = (row phase rs, column quad qd): 16 lanes read 256 contiguous bytes of a row (ds_read_b128, conflict-free),
-    // a wave covers 4 rows x 64 columns per iteration; waves = 64-column groups x 4 row chunks.
+    // a wave covers 4 rows x 64 columns per iteration; waves = 64-column groups x row chunks.
     const int rs = lane >> 4, qd = lane & 15;
     const int qlast = (N - 1) >> 2;
     long long t_pass = 0, t_p2 = 0, t_bar = 0;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0: x_k and v_k of the step, element f + lane + 64 t
+    float r_beta = 0.f, r_tk = 0.f, r_s = 0.f;
+    bool r_on = false;
     for (int k = 0; k <= N - 2; ++k) {
         const long long c_a = prof ? (long long)wall_clock64() : 0;
+        // wave 0, ahead of its share of the pass: everything of reflector k that only needs x_k (known since the previous
+        // step) - |x|, beta, tau, s, v - so that after the barrier only t and column k+1 are missing
+        if (wave == 0 && k < N - 2) {
+            const int f = k + 1;
+            const int tmax = (N - f + 63) >> 6;
+            float sig = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xv[t] = 0.f;
+                if (t < tmax) {                                  // (uniform)
+                    const int ii = lane + 64 * t;
+                    const float x = vwx[min(f + ii, N - 1)].z;
+                    xv[t] = f + ii < N ? x : 0.f;
+                    sig = fmaf(xv[t], ii > 0 ? xv[t] : 0.f, sig);
+                }
+            }
+            sig = cc_wave_sum_fast(sig);
+            const float x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xv[0])));
+            r_beta = x0; r_tk = 0.f; r_s = 0.f; r_on = sig != 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vv[t] = 0.f;
+            if (r_on) {                                          // else nothing to annihilate: H_k = I
+                const float n2 = fmaf(x0, x0, sig);
+                float rn = __builtin_amdgcn_rsqf(n2);
+                rn = rn * (1.5f - 0.5f * n2 * rn * rn);          // one Newton step: 1 / |x| to rounding
+                const float nrm = n2 * rn;
+                r_beta = x0 >= 0.f ? -nrm : nrm;
+                const float dd = x0 - r_beta;                    // same sign as x0: no cancellation
+                float rd = __builtin_amdgcn_rcpf(dd);
+                rd = rd * (2.f - dd * rd);
+                r_s = rd;
+                // tau = (beta - x0) / beta = 2 / |v|^2, |v|^2 = 1 + s^2 sig: H = I - tau v v^T is orthogonal iff tau |v|^2 = 2
+                const float vn = fmaf(r_s * r_s, sig, 1.f);
+                float rv = __builtin_amdgcn_rcpf(vn);
+                rv = rv * (2.f - vn * rv);
+                r_tk = 2.f * rv;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < tmax) vv[t] = (lane + 64 * t) == 0 ? 1.f : r_s * xv[t];      // (0 beyond N: x = 0 there)
+            }
+        }
         const int q0 = k >> 2;
         const int nq = qlast - q0 + 1;
         const int cqg = nq > 48 ? 4 : (nq > 32 ? 3 : (nq > 16 ? 2 : 1));
-        int cq, ch;
-        if (cqg == 4) { cq = wave & 3; ch = wave >> 2; }
-        else if (cqg == 3) { ch = (wave * 11) >> 5; cq = wave - 3 * ch; }
+        int cq, ch;                                              // waves = 64-column groups x 4 row chunks (more chunks were
+        if (cqg == 4) { cq = wave & 3; ch = wave >> 2; }         // measured slower: the per-wave overhead of a step outweighs
+        else if (cqg == 3) { ch = (wave * 11) >> 5; cq = wave - 3 * ch; }   // the shorter row loops, and wave 0 sums more partials)
         else if (cqg == 2) { cq = wave & 1; ch = wave >> 1; }
         else { cq = 0; ch = wave; }
+        const int chunks = 4;
         const int rpc = (((N - k + 3) >> 2) + 3) & ~3;           // rows per chunk: ceil(m / 4) rounded to the 4 row phases
+        const int stride = 256;
         const int q4 = q0 + (cq << 4) + qd;
-        const bool on = ch < 4 && q4 <= qlast;
+        const bool on = ch < chunks && q4 <= qlast;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (on) {
             const int jb = k + ch * rpc, je = min(jb + rpc, N);
@@ -241,12 +320,10 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
                 acc.w = fmaf(a.w, o.z, acc.w);
             }
         }
-        if (ch < 4) {                                            // (wave-uniform)
-            acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
-            acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
-            acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
-            acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
-            if (on && rs == 0) *reinterpret_cast<float4*>(part + (ch << 8) + (((cq << 4) + qd) << 2)) = acc;
+        if (ch < chunks) {                                       // (wave-uniform)
+            acc.x = td_sum_rows(acc.x); acc.y = td_sum_rows(acc.y);      // over the 4 row phases (lanes l, l^16, l^32, l^48)
+            acc.z = td_sum_rows(acc.z); acc.w = td_sum_rows(acc.w);
+            if (on && rs == 0) *reinterpret_cast<float4*>(part + ch * stride + (((cq << 4) + qd) << 2)) = acc;
         }
         const long long c_b = prof ? (long long)wall_clock64() : 0;
         __syncthreads();
@@ -257,56 +334,26 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
             const int f = k + 1;                                 // first column of reflector k
             const int cbase = q0 << 2;
             const int tmax = (N - f + 63) >> 6;
-            float xv[4], tv[4], cv[4];
-            float sig = 0.f;
+            float ww[4], cv[4];
+            float gam = 0.f;
+            const float ts = r_tk * r_s;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                xv[t] = 0.f; tv[t] = 0.f; cv[t] = 0.f;
+                ww[t] = 0.f; cv[t] = 0.f;
                 if (t < tmax) {                                  // (uniform)
                     const int i = min(f + lane + 64 * t, N - 1), o = i - cbase;
                     const bool in = f + lane + 64 * t < N;
-                    const float x = vwx[i].z, c = A[f * LD + i];
+                    const float c = A[f * LD + i];
                     const float tt = (part[o] + part[256 + o]) + (part[512 + o] + part[768 + o]);
-                    xv[t] = in ? x : 0.f; tv[t] = in ? tt : 0.f; cv[t] = in ? c : 0.f;
-                    sig = fmaf(xv[t], (lane + 64 * t) > 0 ? xv[t] : 0.f, sig);
+                    cv[t] = in ? c : 0.f;
+                    ww[t] = in ? ts * (tt - r_beta * c) : 0.f;   // p = tau S v (0 when there is no reflector: ts = 0)
+                    gam = fmaf(ww[t], vv[t], gam);
                 }
             }
-            sig = cc_wave_sum_fast(sig);
-            const float x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xv[0])));
-            float vv[4], ww[4];
-            float beta = x0, tk = 0.f, s = 0.f;
+            gam = cc_wave_sum_fast(gam);
+            const float hc = 0.5f * r_tk * gam;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { vv[t] = 0.f; ww[t] = 0.f; }
-            if (sig != 0.f) {                                    // else nothing to annihilate: H_k = I
-                const float n2 = fmaf(x0, x0, sig);
-                float rn = __builtin_amdgcn_rsqf(n2);
-                rn = rn * (1.5f - 0.5f * n2 * rn * rn);          // one Newton step: 1 / |x| to rounding
-                const float nrm = n2 * rn;
-                beta = x0 >= 0.f ? -nrm : nrm;
-                const float dd = x0 - beta;                      // same sign as x0: no cancellation
-                float rd = __builtin_amdgcn_rcpf(dd);
-                rd = rd * (2.f - dd * rd);
-                s = rd;
-                // tau = (beta - x0) / beta = 2 / |v|^2, |v|^2 = 1 + s^2 sig: H = I - tau v v^T is orthogonal iff tau |v|^2 = 2
-                const float vn = fmaf(s * s, sig, 1.f);
-                float rv = __builtin_amdgcn_rcpf(vn);
-                rv = rv * (2.f - vn * rv);
-                tk = 2.f * rv;
-                const float ts = tk * s;
-                float gam = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t < tmax) {
-                        vv[t] = (lane + 64 * t) == 0 ? 1.f : s * xv[t];      // (0 beyond N: x = 0 there)
-                        ww[t] = ts * (tv[t] - beta * cv[t]);               // p
-                        gam = fmaf(ww[t], vv[t], gam);
-                    }
-                }
-                gam = cc_wave_sum_fast(gam);
-                const float hc = 0.5f * tk * gam;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) ww[t] -= hc * vv[t];
-            }
+            for (int t = 0; t < 4; ++t) ww[t] -= hc * vv[t];
             const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ww[0])));
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
                     A[k * LD + i] = xv[t];
                 }
             }
-            if (lane == 0) { vwx[k] = make_float4(0.f, 0.f, 0.f, 0.f); e[k] = beta; tau[k] = tk; scl[k] = s; }
+            if (lane == 0) { vwx[k] = make_float4(0.f, 0.f, 0.f, 0.f); e[k] = r_beta; tau[k] = r_tk; scl[k] = r_s; }
         }
         if (prof) t_p2 += (long long)wall_clock64() - c_c;
         __syncthreads();
@@ -340,34 +387,39 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
     if (prof && p == 0 && tid == 0) { prof[16] = t_pass; prof[17] = t_bar; prof[18] = t_p2; }
 
     // ---- pack the reflectors (row k, columns k+2.., scaled) to the front of the region ---------------------------------
+    // wave w takes rows w, w + 16, ...; everything is read into registers before anything is written
     const int T = ((N - 1) * (N - 2)) >> 1;
     {
-        constexpr int MAXP = 19;                                 // ceil(T / 1024) at N = 196
-        float reg[MAXP];
+        constexpr int MAXR = 13;                                 // ceil(194 / 16) rows per wave at N = 196
+        float reg[MAXR][4];
 #pragma unroll
-        for (int r = 0; r < MAXP; ++r) {
-            const int q = tid + TD_THREADS * r;
-            reg[r] = 0.f;
-            if (q < T) {
-                const float b2 = (float)(2 * N - 3);
-                int kq = (int)((b2 - sqrtf(fmaxf(b2 * b2 - 8.f * (float)q, 0.f))) * 0.5f);
-                kq = max(0, min(kq, N - 3));
-                while (kq < N - 3 && td_pack_offset(kq + 1, N) <= q) ++kq;
-                while (kq > 0 && td_pack_offset(kq, N) > q) --kq;
-                reg[r] = A[kq * LD + kq + 2 + (q - td_pack_offset(kq, N))] * scl[kq];
+        for (int r = 0; r < MAXR; ++r) {
+            const int kr = wave + 16 * r;
+            const float sc = kr <= N - 3 ? scl[kr] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = kr + 2 + lane + 64 * t;
+                reg[r][t] = (kr <= N - 3 && j < N) ? A[kr * LD + j] * sc : 0.f;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < MAXP; ++r) {
-            const int q = tid + TD_THREADS * r;
-            if (q < T) A[q] = reg[r];
+        for (int r = 0; r < MAXR; ++r) {
+            const int kr = wave + 16 * r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = kr + 2 + lane + 64 * t;
+                if (kr <= N - 3 && j < N) A[td_pack_offset(kr, N) + lane + 64 * t] = reg[r][t];
+            }
         }
     }
     const float* R = A;
     double* Y = reinterpret_cast<double*>(A + ((T + 3) & ~3));   // [N][KP]
     double2* ds = reinterpret_cast<double2*>(part);              // [LD] (d_i, max(e_i^2, tiny)) for the Sturm counts
-    for (int i = tid; i < N; i += TD_THREADS) { const double2 t = de[i]; ds[i] = make_double2(t.x, fmax(t.y * t.y, 1e-280)); }
+    for (int i = tid; i < N + 24 && i < 256; i += TD_THREADS) {  // (rows beyond N are loaded ahead, never used)
+        const double2 t = i < N ? de[i] : make_double2(0.0, 0.0);
+        ds[i] = make_double2(t.x, fmax(t.y * t.y, 1e-280));
+    }
     __syncthreads();
     TD_STAMP();                                                  // 3: reflectors packed
 
@@ -383,14 +435,16 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
     const double tnorm = fmax(fmax(fabs(glo), fabs(ghi)), 1e-300);
     glo -= 4.0 * TD_EPS64 * tnorm * (double)N;
     ghi += 4.0 * TD_EPS64 * tnorm * (double)N;
-    if (tid < 8 * K) {                                           // 8 lanes per wanted eigenvalue
-        const int kb = tid >> 3, gb = tid & 7;
+    if (tid < 4 * K) {                                           // 4 lanes per wanted eigenvalue: one wave per SIMD, the
+        const int kb = tid >> 2, gb = tid & 3;                   // recurrence is a dependent chain (latency, not throughput)
         double lo = glo, hi = ghi;
         for (int it = 0; it < TD_SECTIONS; ++it) {
-            const double x = lo + (hi - lo) * ((double)(gb + 1) * (1.0 / 9.0));
+            const double x = lo + (hi - lo) * ((double)(gb + 1) * 0.2);
             const bool below = td_sturm(ds, N, x) <= kb;
-            lo = td_oct_max(below ? x : lo);
-            hi = -td_oct_max(below ? -hi : -x);
+            double a = below ? x : lo, b = below ? -hi : -x;
+            a = fmax(a, td_dpp_f64<0xB1>(a)); a = fmax(a, td_dpp_f64<0x4E>(a));      // over the quad
+            b = fmax(b, td_dpp_f64<0xB1>(b)); b = fmax(b, td_dpp_f64<0x4E>(b));
+            lo = a; hi = -b;
         }
         if (gb == 0) lam[kb] = 0.5 * (lo + hi);
     }
@@ -439,7 +493,9 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
                 const double pb = sw ? nb : b, pc = sw ? nc : cc, pr = sw ? nr : r;
                 const double qa = sw ? a : na, qb = sw ? b : nb, qc = sw ? cc : nc, qr = sw ? r : nr;
                 if (fabs(pa) < tiny) pa = pa < 0.0 ? -tiny : tiny;
-                const double ip = 1.0 / pa;
+                double ip = __builtin_amdgcn_rcp(pa);              // v_rcp_f64 + two Newton steps (the IEEE sequence is twice
+                ip = fma(fma(-pa, ip, 1.0), ip, ip);                // as long, and this is the dependent chain of the loop)
+                ip = fma(fma(-pa, ip, 1.0), ip, ip);
                 const double ml = qa * ip;
                 U0[i * KP + c] = ip; U1[i * KP + c] = pb; U2[i * KP + c] = pc;
                 Y[i * KP + c] = pr;
