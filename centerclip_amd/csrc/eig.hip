@@ -192,12 +192,12 @@ template <int MAXT>
 __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float* __restrict__ Lsym, double* __restrict__ bands,
                                                                      float* __restrict__ Q, float* __restrict__ evals,
                                                                      int* __restrict__ sweeps_out, int N, int K, int KP, int ldq,
-                                                                     int correct_sign, long long* __restrict__ prof) {
+                                                                     int correct_sign, int areg, long long* __restrict__ prof) {
     extern __shared__ __align__(16) unsigned char td_smem[];
     const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int LD = (N + 3) & ~3;                                 // row pitch of the matrix in LDS (16-byte rows)
-    float* A = reinterpret_cast<float*>(td_smem);                // [N][LD]
-    float* tau = A + N * LD;                                     // [LD]
+    float* A = reinterpret_cast<float*>(td_smem);                // [N][LD]; later packed reflectors + K fp64 vectors (areg floats)
+    float* tau = A + areg;                                       // [LD]
     float* es = tau + LD;                                        // [max(2 LD, 256)]: e and 1 / (x0 - beta); later lam, shf
     float* e = es;
     float* scl = es + LD;
@@ -268,20 +268,14 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
 #pragma unroll
             for (int t = 0; t < 4; ++t) vv[t] = 0.f;
             if (r_on) {                                          // else nothing to annihilate: H_k = I
-                const float n2 = fmaf(x0, x0, sig);
-                float rn = __builtin_amdgcn_rsqf(n2);
-                rn = rn * (1.5f - 0.5f * n2 * rn * rn);          // one Newton step: 1 / |x| to rounding
-                const float nrm = n2 * rn;
+                // correctly rounded sqrt / divisions: a one-sided error of an ulp in tau makes every H_k non-orthogonal in the
+                // same direction and the eigenvalues drift by 20 ulps of |L| (measured with rcp + Newton); this runs ahead of
+                // the pass, off the critical path
+                const float nrm = sqrtf(fmaf(x0, x0, sig));
                 r_beta = x0 >= 0.f ? -nrm : nrm;
-                const float dd = x0 - r_beta;                    // same sign as x0: no cancellation
-                float rd = __builtin_amdgcn_rcpf(dd);
-                rd = rd * (2.f - dd * rd);
-                r_s = rd;
+                r_s = 1.f / (x0 - r_beta);                       // same sign as x0: no cancellation
                 // tau = (beta - x0) / beta = 2 / |v|^2, |v|^2 = 1 + s^2 sig: H = I - tau v v^T is orthogonal iff tau |v|^2 = 2
-                const float vn = fmaf(r_s * r_s, sig, 1.f);
-                float rv = __builtin_amdgcn_rcpf(vn);
-                rv = rv * (2.f - vn * rv);
-                r_tk = 2.f * rv;
+                r_tk = 2.f / fmaf(r_s * r_s, sig, 1.f);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (t < tmax) vv[t] = (lane + 64 * t) == 0 ? 1.f : r_s * xv[t];      // (0 beyond N: x = 0 there)
@@ -309,10 +303,14 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
             for (int j = jb + rs; j < je; j += 4) {
                 float4 a = *reinterpret_cast<const float4*>(col + j * LD);
                 const float4 o = vwx[j];
-                a.x -= o.x * c0.y + o.y * c0.x;
-                a.y -= o.x * c1.y + o.y * c1.x;
-                a.z -= o.x * c2.y + o.y * c2.x;
-                a.w -= o.x * c3.y + o.y * c3.x;
+                {   // both products rounded before they are added: v_j w_i + w_j v_i is then the same number at (j, i) and
+                    // (i, j) and the block stays symmetric to the bit (with an fma it drifts, and t = S^T x != S x)
+#pragma clang fp contract(off)
+                    a.x -= o.x * c0.y + o.y * c0.x;
+                    a.y -= o.x * c1.y + o.y * c1.x;
+                    a.z -= o.x * c2.y + o.y * c2.x;
+                    a.w -= o.x * c3.y + o.y * c3.x;
+                }
                 *reinterpret_cast<float4*>(col + j * LD) = a;
                 acc.x = fmaf(a.x, o.z, acc.x);
                 acc.y = fmaf(a.y, o.z, acc.y);
@@ -633,10 +631,17 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
 #undef TD_STAMP
 }
 
-size_t td_smem_bytes(int N) {
+// floats of the big region: the matrix, later the packed reflectors (fp32) + K vectors (fp64)
+size_t td_region_floats(int N, int K) {
+    const size_t LD = (size_t)((N + 3) & ~3), KP = (size_t)(K | 1);
+    const size_t T = ((size_t)(N - 1) * (N - 2)) >> 1;
+    const size_t after = ((T + 3) & ~(size_t)3) + 2 * (size_t)N * KP;
+    return (((size_t)N * LD > after ? (size_t)N * LD : after) + 3) & ~(size_t)3;
+}
+size_t td_smem_bytes(int N, int K) {
     const size_t LD = (size_t)((N + 3) & ~3);
     const size_t es = 2 * LD > 256 ? 2 * LD : 256;
-    return ((size_t)N * LD + LD + es + 4 * LD + 1024) * sizeof(float);
+    return (td_region_floats(N, K) + LD + es + 4 * LD + 1024) * sizeof(float);
 }
 
 long long* g_td_prof = nullptr;
@@ -648,10 +653,7 @@ extern "C" void cc_debug_set_eig_profile(long long* dev_buf) { g_td_prof = dev_b
 
 bool cc_sym_eig_tridiag_supports(int N, int K) {
     if (N < 3 || N > 196 || K < 1 || K > 64 || K > N) return false;
-    const int KP = K | 1, LD = (N + 3) & ~3;
-    const int T = ((N - 1) * (N - 2)) >> 1;
-    // the packed reflectors (fp32) and the K vectors (fp64) take the place of the matrix
-    return (size_t)((T + 3) & ~3) * 4 + (size_t)N * KP * 8 <= (size_t)N * LD * 4 && td_smem_bytes(N) <= 160 * 1024;
+    return td_smem_bytes(N, K) <= 160 * 1024;                    // (N = 196: K <= 49)
 }
 
 size_t cc_sym_eig_tridiag_ws_bytes(int P, int N) {               // three fp64 bands of U for K <= 64 lanes per problem
@@ -663,7 +665,8 @@ int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int c
     if (!cc_sym_eig_tridiag_supports(N, K)) return CC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < cc_sym_eig_tridiag_ws_bytes(P, N)) return CC_ERR_WORKSPACE;
     const int KP = K | 1;
-    const size_t smem = td_smem_bytes(N);
+    const size_t smem = td_smem_bytes(N, K);
+    const int areg = (int)td_region_floats(N, K);
 #define TD_LAUNCH(MAXT)                                                                                                 \
     do {                                                                                                               \
         auto kern = sym_eig_tridiag_kernel<MAXT>;                                                                      \
@@ -671,7 +674,7 @@ int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int c
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return CC_ERR_HIP;                                                                                         \
         hipLaunchKernelGGL(kern, dim3(P), dim3(TD_THREADS), smem, st, laplacian, static_cast<double*>(ws), Q, evals,    \
-                           sweeps_out, N, K, KP, ldq, correct_sign, g_td_prof);                                        \
+                           sweeps_out, N, K, KP, ldq, correct_sign, areg, g_td_prof);                                        \
     } while (0)
     if (N <= 64) TD_LAUNCH(2);
     else if (N <= 128) TD_LAUNCH(4);

@@ -1,18 +1,36 @@
-"""Dev probe (CPU, numpy fp32): the numerics of the direct eigensolver planned for the spectral path - Householder
-tridiagonalisation, multi-section Sturm bisection for the K smallest eigenvalues, inverse iteration with one shift per
-vector and a Gram-Schmidt pass over ALL K vectors per iteration, back-transformation - on the kinds of L_sym the module
-produces (heat kernel, KNN, planted partitions with numerically multiple eigenvalues).  Prints the worst residual,
-orthogonality defect and eigenvalue error against a float64 eigh.  Test infrastructure only; nothing imports this.
+"""Numerical specification (CPU, numpy) of the direct eigensolver of the spectral path - centerclip_amd/csrc/eig.hip - and the
+probe that chose its precisions.  Test infrastructure only: tests/test_oracle_tridiag.py pins it against the reference's
+fixtures; nothing in the product imports it.
+
+The algorithm (what the kernel does, phase by phase, in the same precisions):
+  B  Householder tridiagonalisation in fp32, fused form: the pass of step k applies reflector k-1 and accumulates S x_k,
+     x_k (row k after that update) being known analytically beforehand; the STORED reflector is that analytic x_k
+  C  eigenvalues of T in fp64: Sturm counts (three-term recurrence), multi-section from the Gershgorin interval
+  D  eigenvectors of T in fp64: one inverse iteration per eigenvalue from a hashed start vector (Gaussian elimination with
+     partial pivoting), modified Gram-Schmidt over all K vectors in eigenvalue order
+  E  back-transformation in fp32
+
+Run as a script it prints, over heat-kernel / KNN / planted-partition Laplacians, the worst residual / orthogonality defect /
+eigenvalue error against a float64 eigh for (a) this algorithm, (b) phases C and D in fp32 with 1-3 iterations (the first
+design: Gram-Schmidt amplifies the out-of-subspace part of the solved block by its condition number, 1e2 - 1e4 when the
+spacing inside a cluster is comparable to the fp32 shift accuracy -> residuals of 1e-4 on planted partitions), and (c) the
+fused tridiagonalisation with the reflector taken from the updated row instead of the analytic x (1e-4 on nearly
+decoupled matrices: tau belongs to the analytic x).
 """
 import sys
 import numpy as np
 
 f32 = np.float32
-EPS = f32(1.1920929e-7)
+f64 = np.float64
+
+
+def _eps(dt):
+    return dt(np.finfo(dt).eps)
 
 
 def tridiagonalise(A):
-    """A symmetric fp32 [N,N] (destroyed) -> d [N], e [N-1], reflectors H [N-2][N] (v with v[k+1] = 1), tau [N-2]."""
+    """Textbook fp32 Householder (matrix-vector product, then rank-2 update).  A symmetric [N,N] -> d, e, H (v with
+    v[k+1] = 1), tau."""
     N = A.shape[0]
     A = A.astype(f32).copy()
     H = np.zeros((max(N - 2, 0), N), f32)
@@ -26,7 +44,7 @@ def tridiagonalise(A):
         d[k] = A[k, k]
         if sig == 0:
             e[k] = x0
-            continue                                             # tau = 0: H_k = I
+            continue
         nrm = f32(np.sqrt(x0 * x0 + sig))
         beta = -nrm if x0 >= 0 else nrm
         t = f32((beta - x0) / beta)
@@ -47,99 +65,141 @@ def tridiagonalise(A):
     return d, e, H, tau
 
 
-def sturm_count(d, e2, x, pivmin):
-    """number of eigenvalues < x, for an array of shifts x (fp32 arithmetic, the kernel's recurrence)."""
-    x = np.asarray(x, f32)
+def tridiagonalise_fused(L, store_analytic=True):
+    """The kernel's form (eig.hip phase B): one pass per reflector; p = tau S v from t = S x and column k+1
+    (v = s (x - beta e_1)); tau = 2 / (1 + s^2 |x_rest|^2).  store_analytic=False keeps the updated row as the reflector
+    (the variant that fails on nearly decoupled matrices)."""
+    N = L.shape[0]
+    A = L.astype(f32).copy()
+    v = np.zeros(N, f32); w = np.zeros(N, f32); xn = np.zeros(N, f32)
+    xn[1:] = A[0, 1:]
+    e = np.zeros(N - 1, f32); tau = np.zeros(max(N - 2, 0), f32); scl = np.zeros(max(N - 2, 0), f32)
+    for k in range(N - 1):
+        S = A[k:, k:]
+        S -= (np.outer(v[k:], w[k:]) + np.outer(w[k:], v[k:])).astype(f32)
+        t = np.zeros(N, f32)
+        t[k:] = (xn[k:, None] * S).sum(axis=0).astype(f32)
+        if k == N - 2:
+            break
+        f = k + 1
+        x = xn[f:].copy(); c = A[f, f:].copy(); tt = t[f:]
+        sig = f32(np.dot(x[1:], x[1:])); x0 = x[0]
+        vv = np.zeros(N - f, f32); ww = np.zeros(N - f, f32)
+        beta = x0; tk = f32(0); s = f32(0)
+        if sig != 0:
+            nrm = f32(np.sqrt(f32(x0 * x0 + sig)))
+            beta = -nrm if x0 >= 0 else nrm
+            s = f32(1) / f32(x0 - beta)
+            tk = f32(2) / f32(f32(1) + s * s * sig)
+            vv = (s * x).astype(f32); vv[0] = 1
+            ww = (tk * s * (tt - beta * c)).astype(f32)
+            gam = f32(np.dot(ww, vv))
+            ww = (ww - f32(0.5) * tk * gam * vv).astype(f32)
+        w0 = ww[0]
+        xnn = (c - ww - w0 * vv).astype(f32); xnn[0] = 0
+        v[:] = 0; w[:] = 0; xn[:] = 0
+        v[f:] = vv; w[f:] = ww; xn[f:] = xnn
+        e[k] = beta; tau[k] = tk; scl[k] = s
+        if store_analytic:
+            A[k, f:] = x
+    d = np.diag(A).copy()
+    e[N - 2] = A[N - 2, N - 1]
+    H = np.zeros((max(N - 2, 0), N), f32)
+    for k in range(N - 2):
+        H[k, k + 1] = 1
+        H[k, k + 2:] = A[k, k + 2:] * scl[k]
+    return d, e, H, tau
+
+
+def sturm_count(d, e2, x):
+    """number of eigenvalues below x for an array of shifts (the division form; the kernel's three-term recurrence counts
+    the same sign changes)."""
+    dt = d.dtype.type
+    tinyp = dt(1e-280 if dt is f64 else 1e-30)
+    x = np.asarray(x, dt)
     q = d[0] - x
-    q = np.where(np.abs(q) < pivmin, -pivmin, q).astype(f32)
+    q = np.where(np.abs(q) < tinyp, -tinyp, q)
     cnt = (q < 0).astype(np.int32)
     for i in range(1, len(d)):
-        q = (d[i] - x - e2[i - 1] / q).astype(f32)
-        q = np.where(np.abs(q) < pivmin, -pivmin, q).astype(f32)
+        q = d[i] - x - e2[i - 1] / q
+        q = np.where(np.abs(q) < tinyp, -tinyp, q)
         cnt += q < 0
     return cnt
 
 
-def bisect(d, e, K, first=1024, lanes=16, steps=5):
+def bisect(d, e, K, lanes=4, steps=19):
+    """multi-section: `lanes` shifts per eigenvalue and step, from the Gershgorin interval."""
+    dt = d.dtype.type
     N = len(d)
-    e2 = (e * e).astype(f32)
+    e2 = e * e
     ae = np.abs(e)
-    r = np.zeros(N, f32); r[:-1] += ae; r[1:] += ae
-    lo, hi = f32((d - r).min()), f32((d + r).max())
+    r = np.zeros(N, dt); r[:-1] += ae; r[1:] += ae
+    lo, hi = (d - r).min(), (d + r).max()
     span = max(abs(lo), abs(hi))
-    lo, hi = f32(lo - 2 * EPS * span * N), f32(hi + 2 * EPS * span * N)
-    pivmin = f32(max(1e-30, float(e2.max()) * 1.1754944e-38 / EPS))
-    pivmin = f32(max(pivmin, 1e-30))
-    xs = (lo + (hi - lo) * (np.arange(1, first + 1, dtype=f32) / f32(first + 1))).astype(f32)
-    cnt = sturm_count(d, e2, xs, pivmin)
-    los, his = np.full(K, lo, f32), np.full(K, hi, f32)
-    for k in range(K):
-        below = np.nonzero(cnt <= k)[0]
-        above = np.nonzero(cnt > k)[0]
-        if len(below): los[k] = xs[below].max()
-        if len(above): his[k] = xs[above].min()
+    lo, hi = dt(lo - 4 * _eps(dt) * span * N), dt(hi + 4 * _eps(dt) * span * N)
+    los, his = np.full(K, lo, dt), np.full(K, hi, dt)
+    frac = np.arange(1, lanes + 1, dtype=dt) / dt(lanes + 1)
+    ks = np.arange(K)[:, None]
     for _ in range(steps):
-        frac = (np.arange(1, lanes + 1, dtype=f32) / f32(lanes + 1))
-        X = (los[:, None] + (his - los)[:, None] * frac[None, :]).astype(f32)
-        C = sturm_count(d, e2, X.reshape(-1), pivmin).reshape(K, lanes)
-        for k in range(K):
-            b = C[k] <= k
-            if b.any(): los[k] = max(los[k], X[k][b].max())
-            if (~b).any(): his[k] = min(his[k], X[k][~b].min())
-    return ((los + his) * f32(0.5)).astype(f32), pivmin
+        X = los[:, None] + (his - los)[:, None] * frac[None, :]
+        C = sturm_count(d, e2, X.reshape(-1)).reshape(K, lanes)
+        below = C <= ks
+        los = np.maximum(los, np.where(below, X, -np.inf).max(axis=1)).astype(dt)
+        his = np.minimum(his, np.where(~below, X, np.inf).min(axis=1)).astype(dt)
+    return ((los + his) * dt(0.5)).astype(dt)
 
 
 def solve_shifted(d, e, lam, B, tiny):
-    """(T - lam_k) y_k = b_k for every column k, Gaussian elimination with partial pivoting on the tridiagonal, fp32,
-    one column = one lane (vectorised over k).  Tiny pivots are replaced (the system is singular on purpose)."""
+    """(T - lam_k) y_k = b_k for every column k: Gaussian elimination with partial pivoting on the tridiagonal, one column =
+    one lane.  Tiny pivots are replaced (the system is singular on purpose)."""
+    dt = d.dtype.type
     N, K = B.shape
-    u0 = np.zeros((N, K), f32); u1 = np.zeros((N, K), f32); u2 = np.zeros((N, K), f32)
-    y = B.astype(f32).copy()
-    a = (d[0] - lam).astype(f32)                                  # current row: (a, b, 0 | rhs r)
-    b = np.full(K, e[0], f32) if N > 1 else np.zeros(K, f32)
-    c = np.zeros(K, f32)
+    u0 = np.zeros((N, K), dt); u1 = np.zeros((N, K), dt); u2 = np.zeros((N, K), dt)
+    y = B.astype(dt).copy()
+    a = d[0] - lam
+    b = np.full(K, e[0], dt) if N > 1 else np.zeros(K, dt)
+    c = np.zeros(K, dt)
     r = y[0].copy()
     for i in range(N - 1):
-        # next row: (e_i, d_{i+1} - lam, e_{i+1})
-        na = np.full(K, e[i], f32)
-        nb = (d[i + 1] - lam).astype(f32)
-        nc = np.full(K, e[i + 1] if i + 2 < N else 0, f32)
+        na = np.full(K, e[i], dt)
+        nb = d[i + 1] - lam
+        nc = np.full(K, e[i + 1] if i + 2 < N else 0, dt)
         nr = y[i + 1].copy()
         swap = np.abs(na) > np.abs(a)
         pa = np.where(swap, na, a); pb = np.where(swap, nb, b); pc = np.where(swap, nc, c); pr = np.where(swap, nr, r)
         qa = np.where(swap, a, na); qb = np.where(swap, b, nb); qc = np.where(swap, c, nc); qr = np.where(swap, r, nr)
-        pa = np.where(np.abs(pa) < tiny, np.where(pa < 0, -tiny, tiny), pa).astype(f32)
-        m = (qa / pa).astype(f32)
+        pa = np.where(np.abs(pa) < tiny, np.where(pa < 0, -tiny, tiny), pa)
+        m = qa / pa
         u0[i], u1[i], u2[i], y[i] = pa, pb, pc, pr
-        a = (qb - m * pb).astype(f32)
-        b = (qc - m * pc).astype(f32)
-        c = np.zeros(K, f32)
-        r = (qr - m * pr).astype(f32)
-    a = np.where(np.abs(a) < tiny, np.where(a < 0, -tiny, tiny), a).astype(f32)
+        a = qb - m * pb
+        b = qc - m * pc
+        c = np.zeros(K, dt)
+        r = qr - m * pr
+    a = np.where(np.abs(a) < tiny, np.where(a < 0, -tiny, tiny), a)
     u0[N - 1] = a; y[N - 1] = r
-    x = np.zeros((N, K), f32)
+    x = np.zeros((N, K), dt)
     x[N - 1] = y[N - 1] / u0[N - 1]
     if N > 1:
         x[N - 2] = (y[N - 2] - u1[N - 2] * x[N - 1]) / u0[N - 2]
     for i in range(N - 3, -1, -1):
-        x[i] = ((y[i] - u1[i] * x[i + 1] - u2[i] * x[i + 2]) / u0[i]).astype(f32)
-    return x
+        x[i] = (y[i] - u1[i] * x[i + 1] - u2[i] * x[i + 2]) / u0[i]
+    return x.astype(dt)
 
 
 def mgs(Y):
-    """right-looking modified Gram-Schmidt over the columns, in order, fp32."""
-    Y = Y.astype(f32).copy()
+    """right-looking modified Gram-Schmidt over the columns, in order."""
+    Y = Y.copy()
     K = Y.shape[1]
     for k in range(K):
-        n = f32(np.sqrt(np.dot(Y[:, k], Y[:, k])))
+        n = np.sqrt(np.dot(Y[:, k], Y[:, k]))
         Y[:, k] = Y[:, k] / n
         if k + 1 < K:
-            c = (Y[:, k] @ Y[:, k + 1:]).astype(f32)
-            Y[:, k + 1:] -= np.outer(Y[:, k], c).astype(f32)
+            c = Y[:, k] @ Y[:, k + 1:]
+            Y[:, k + 1:] -= np.outer(Y[:, k], c)
     return Y
 
 
-def start_vectors(N, K):
+def start_vectors(N, K, dt=f64):
     """the kernel's start vectors: an integer hash of (row, column) mapped to [-1, 1)."""
     i = np.arange(N, dtype=np.uint64)[:, None]; k = np.arange(K, dtype=np.uint64)[None, :]
     M = np.uint64(0xFFFFFFFF)
@@ -147,67 +207,63 @@ def start_vectors(N, K):
     h ^= h >> np.uint64(15); h = (h * np.uint64(0x2C1B3C6D)) & M
     h ^= h >> np.uint64(12); h = (h * np.uint64(0x297A2D39)) & M
     h ^= h >> np.uint64(15)
-    return ((h >> np.uint64(8)).astype(f32) * f32(1.0 / 8388608.0) - f32(1.0)).astype(f32)
+    return ((h >> np.uint64(8)).astype(f64) * (1.0 / 8388608.0) - 1.0).astype(dt)
 
 
-def inverse_iteration(d, e, lam, iters=3, seed=1):
+def inverse_iteration(d, e, lam, iters=1, sep_ulps=10):
+    dt = d.dtype.type
     N, K = len(d), len(lam)
-    Y = start_vectors(N, K)
-    nrm = f32(max(np.abs(d).max(), np.abs(e).max()))
-    tiny = f32(EPS * nrm)
-    # shifts of numerically equal eigenvalues are spread by a few ulps of |T| (LAPACK sstein does the same): equal shifts
-    # would make every lane of a cluster converge to the same dominant direction
-    sh = lam.astype(f32).copy()
-    sep = f32(10) * EPS * nrm
-    for k in range(1, K):
-        if sh[k] - sh[k - 1] < sep: sh[k] = sh[k - 1] + sep
+    Y = start_vectors(N, K, dt)
+    nrm = dt(max(np.abs(d).max(), np.abs(e).max()))
+    tiny = dt(_eps(dt) * nrm)
+    sh = lam.astype(dt).copy()
+    sep = dt(sep_ulps) * _eps(dt) * nrm
+    for k in range(1, K):                                         # numerically equal eigenvalues: distinct shifts (LAPACK stein)
+        sh[k] = max(sh[k], sh[k - 1] + sep)
     for _ in range(iters):
         Y = solve_shifted(d, e, sh, Y, tiny)
-        sc = np.abs(Y).max(axis=0)
-        Y = (Y / sc).astype(f32)
-        Y = mgs(Y)
+        Y = (Y / np.abs(Y).max(axis=0)).astype(dt)
+        Y = mgs(Y).astype(dt)
     return Y
 
 
 def back_transform(H, tau, Y):
     Z = Y.astype(f32).copy()
     for k in range(H.shape[0] - 1, -1, -1):
-        if tau[k] == 0: continue
+        if tau[k] == 0:
+            continue
         v = H[k]
         s = (v @ Z).astype(f32)
         Z -= np.outer(v, tau[k] * s).astype(f32)
     return Z
 
 
-def smallest_eigenpairs(L, K, iters=3):
-    d, e, H, tau = tridiagonalise(L)
-    lam, _ = bisect(d, e, K)
-    Y = inverse_iteration(d, e, lam, iters)
-    Z = back_transform(H, tau, Y)
-    return lam, Z
+def smallest_eigenpairs(L, K, high=True, iters=1, fused=True, store_analytic=True):
+    """The K smallest eigenpairs of the symmetric L: (eigenvalues ascending [K] fp32, vectors [N,K] fp32).  high = phases C
+    and D in fp64 (the kernel); False = fp32 (the first design)."""
+    if fused:
+        d, e, H, tau = tridiagonalise_fused(L, store_analytic)
+    else:
+        d, e, H, tau = tridiagonalise(L)
+    dt = f64 if high else f32
+    dd, ee = d.astype(dt), e.astype(dt)
+    lam = bisect(dd, ee, K, lanes=4 if high else 16, steps=19 if high else 9)
+    Y = inverse_iteration(dd, ee, lam, iters)
+    return lam.astype(f32), back_transform(H, tau, Y)
 
 
-def report(name, Ls, K, iters=3):
-    worst = [0, 0, 0, 0]
-    for L in Ls:
-        L = L.astype(f32)
-        lam, Z = smallest_eigenpairs(L, K, iters)
-        Ld = L.astype(np.float64); Zd = Z.astype(np.float64)
-        ref, V = np.linalg.eigh(Ld)
-        res = np.abs(Ld @ Zd - Zd * lam[None, :].astype(np.float64)).max()
-        orth = np.abs(Zd.T @ Zd - np.eye(K)).max()
-        everr = np.abs(lam.astype(np.float64) - ref[:K]).max()
-        gap = ref[K] - ref[K - 1] if K < len(ref) else 1.0
-        proj = np.abs(Zd @ Zd.T - V[:, :K] @ V[:, :K].T).max() if gap > 1e-3 else 0.0
-        worst = [max(worst[0], res), max(worst[1], orth), max(worst[2], everr), max(worst[3], proj)]
-    print(f"{name:40s} residual {worst[0]:.2e}  orth {worst[1]:.2e}  eigenvalue err {worst[2]:.2e}  projector {worst[3]:.2e}")
+def quality(L, lam, Z):
+    K = Z.shape[1]
+    Ld = L.astype(f64); Zd = Z.astype(f64)
+    ref = np.linalg.eigvalsh(Ld)
+    res = np.abs(Ld @ Zd - Zd * lam[None, :].astype(f64)).max()
+    orth = np.abs(Zd.T @ Zd - np.eye(K)).max()
+    return res, orth, np.abs(lam.astype(f64) - ref[:K]).max()
 
 
-def heat_lsym(X, sigma):
+def heat_w(X, sigma):
     n1 = (X * X).sum(-1, keepdims=True)
-    d2 = n1 + n1.T - 2 * X @ X.T
-    W = np.exp(-d2 / (2 * sigma ** 2))
-    return W
+    return np.exp(-(n1 + n1.T - 2 * X @ X.T) / (2 * sigma ** 2))
 
 
 def lsym(W):
@@ -223,30 +279,39 @@ def knn(W, k, mutual=False):
     return W * keep
 
 
+def planted(rng, N, parts, leak, permute):
+    W = np.full((N, N), leak, f64)
+    b = N // parts
+    for c in range(parts):
+        blk = rng.uniform(0.5, 1.0, (b, b)); W[c * b:(c + 1) * b, c * b:(c + 1) * b] = 0.5 * (blk + blk.T)
+    if permute:
+        p = rng.permutation(N); W = W[p][:, p]
+    return lsym(W)
+
+
+def probe_matrices(rng, N=196, K=49):
+    mats = [("heat kernel", lsym(heat_w(rng.standard_normal((N, 64)).astype(f32) * 0.25, 2.0))),
+            ("KNN", lsym(knn(heat_w(rng.standard_normal((N, 64)).astype(f32) * 0.25, 2.0), 10)))]
+    for leak in (0.0, 1e-8, 1e-6, 1e-4, 1e-3):
+        for perm in (False, True):
+            mats.append((f"planted {K} x {N // K}, coupling {leak:g}{', permuted' if perm else ''}", planted(rng, N, K, leak, perm)))
+    return mats
+
+
 if __name__ == "__main__":
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    N, K = (int(a) for a in sys.argv[1:3]) if len(sys.argv) > 2 else (196, 49)
     rng = np.random.default_rng(0)
-    g = np.load("tests/golden/spectral_golden.npz")
-    report("fixture knn_lsym (48, K=6)", list(g["knn_lsym"]), 6, iters)
-    report("fixture knn_graph_lsym (48, K=6)", list(g["knn_graph_lsym"]), 6, iters)
-    mats = [lsym(heat_lsym(rng.standard_normal((196, 64)).astype(f32) * 0.25, 2.0)) for _ in range(3)]
-    report("heat kernel N=196 K=49", mats, 49, iters)
-    mats = [lsym(knn(heat_lsym(rng.standard_normal((196, 64)).astype(f32) * 0.25, 2.0), 10)) for _ in range(3)]
-    report("KNN N=196 K=49", mats, 49, iters)
-    mats = [lsym(heat_lsym(rng.standard_normal((196, 768)).astype(f32) * 0.08, 2.0)) for _ in range(2)]
-    report("heat kernel N=196 D=768 K=49", mats, 49, iters)
-    # planted partitions: K disconnected (or nearly) blocks -> eigenvalue 0 of multiplicity K
-    for leak in (0.0, 1e-6, 1e-3):
-        mats = []
-        for _ in range(2):
-            W = np.full((196, 196), leak, np.float64)
-            for b in range(49):
-                blk = rng.uniform(0.5, 1.0, (4, 4)); blk = 0.5 * (blk + blk.T)
-                W[4 * b:4 * b + 4, 4 * b:4 * b + 4] = blk
-            perm = rng.permutation(196)
-            mats.append(lsym(W[perm][:, perm]))
-        report(f"planted 49 x 4, leak {leak:g}", mats, 49, iters)
-    mats = [lsym(heat_lsym(rng.standard_normal((64, 32)).astype(f32) * 0.35, 2.0)) for _ in range(3)]
-    report("heat kernel N=64 K=8", mats, 8, iters)
-    mats = [np.eye(20, dtype=f32), np.diag(np.arange(20)).astype(f32) / 10]
-    report("diagonal N=20 K=5", mats, 5, iters)
+    mats = probe_matrices(rng, N, K)
+    variants = [("kernel: fused fp32 | fp64, 1 iteration | fp32", dict()),
+                ("phases C, D in fp32, 1 iteration", dict(high=False, iters=1)),
+                ("phases C, D in fp32, 3 iterations", dict(high=False, iters=3)),
+                ("reflector = updated row (not the analytic x)", dict(store_analytic=False))]
+    for name, kw in variants:
+        worst = [0.0, 0.0, 0.0]; where = ["", "", ""]
+        for tag, L in mats:
+            q = quality(L, *smallest_eigenpairs(L, K, **kw))
+            for j in range(3):
+                if q[j] > worst[j]:
+                    worst[j], where[j] = q[j], tag
+        print(f"{name:48s} residual {worst[0]:.1e} ({where[0]}) | orth {worst[1]:.1e} ({where[1]}) | eigenvalue {worst[2]:.1e}",
+              flush=True)
