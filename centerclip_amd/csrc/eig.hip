@@ -19,8 +19,8 @@
 // Why C and D run in fp64 although T is only an fp32-accurate image of L: Gram-Schmidt amplifies whatever the solved
 // vectors carry outside the wanted invariant subspace by the condition number of the solved block, and with shifts known to
 // fp32 (1e-7 |T|) a cluster whose spacing is comparable to that (planted partitions: eigenvalue 0 of multiplicity K up to
-// the coupling between the parts) gives blocks of condition 1e2 - 1e4, i.e. residuals of 1e-4 (measured, oracle/
-// probe_tridiag.py).  As a matrix of exact numbers T has simple eigenvalues; with shifts accurate to 1e-13 |T| every solve is
+// the coupling between the parts) gives blocks of condition 1e2 - 1e4, i.e. residuals of 1e-4 (measured: DESIGN.md,
+// spectral decomposition).  As a matrix of exact numbers T has simple eigenvalues; with shifts accurate to 1e-13 |T| every solve is
 // dominated by its own eigenvector, the block is orthogonal to rounding before it is orthogonalised, and the fp32 floor is
 // what remains: residual |L q - lambda q| <= 4e-7, orthonormal to 1.3e-6, eigenvalues within 5e-7 of a float64 eigh over
 // heat-kernel / KNN / planted-partition Laplacians (coupling 0 ... 1e-3, identical blocks) at N = 196, K = 49.
