@@ -3,8 +3,9 @@
     constructW ('HeatKernel' or 'KNN' [+ spatial_temporal_graph])  ->  normalised Laplacian  ->  the K eigenvectors with the
     smallest eigenvalues  ->  batch_sign_flip_rasmus_bro  ->  row-normalise  ->  k-medoids on them
 
-The decomposition (the reference: the trailing K left singular vectors of a fp32 LAPACK SVD of L_sym) is a batched
-one-sided Jacobi solver (cc_spectral_embedding_f32).  What "the same result" can mean for it: eigenpairs to working
+The decomposition (the reference: the trailing K left singular vectors of a fp32 LAPACK SVD of L_sym) is
+cc_spectral_embedding_f32: for N <= 196 a direct solver (Householder tridiagonalisation, fp64 Sturm multi-section and
+inverse iteration for the K wanted pairs, back-transformation), else a batched one-sided Jacobi solver.  What "the same result" can mean for it: eigenpairs to working
 precision and the reference's singular values to 1e-5 - yes; the same *vectors* only up to sign and, where eigenvalues
 coincide to rounding, up to a rotation of that eigenspace, which no two solvers share.  The k-medoids tail only sees row
 distances of the K selected vectors, which are invariant to both when the K-th and (K+1)-th eigenvalue are separated
