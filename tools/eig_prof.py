@@ -57,6 +57,8 @@ def main():
              ("knn 48x196 K49", laplacians(48, 196, 64, 0.25, 2.0, 10, 0, gen), 49),
              ("heat D768 48x196 K49", laplacians(48, 196, 768, 0.08, 2.0, 0, 0, gen), 49),
              ("planted 49x4 8x196 K49", laplacians(8, 196, 0, 0, 0, 0, 49, gen), 49),
+             ("knn 64x147 K49 (12 -> 4 frames)", laplacians(64, 147, 64, 0.25, 2.0, 10, 0, gen), 49),
+             ("knn 96x98 K49 (12 -> 6 frames)", laplacians(96, 98, 64, 0.25, 2.0, 10, 0, gen), 49),
              ("heat 16x64 K8", laplacians(16, 64, 32, 0.35, 2.0, 0, 0, gen), 8),
              ("heat 8x100 K25", laplacians(8, 100, 32, 0.35, 2.0, 0, 0, gen), 25),
              ("heat 4x37 K5", laplacians(4, 37, 16, 0.35, 2.0, 0, 0, gen), 5),
@@ -67,7 +69,7 @@ def main():
     import ctypes
     prof = torch.zeros(24, dtype=torch.int64, device="cuda")
     names = ["load", "tridiagonalise", "pack", "eigenvalues", "solve", "gram-schmidt", "back-transform", "store"]
-    for tag, Lm, K in cases[:1] + cases[4:5]:
+    for tag, Lm, K in cases[:1] + cases[6:7]:
         L.lib().cc_debug_set_eig_profile(ctypes.c_void_p(prof.data_ptr()))
         torch.ops.centerclip.spectral_embedding(Lm.cuda(), K, True)
         torch.cuda.synchronize()
