@@ -41,9 +41,14 @@ __device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702
 
 // debug hook (not part of the public ABI): per-workgroup phase timestamps (entry, prologue done, loop done, exit)
 __device__ long long* g_gemm_prof = nullptr;
+#ifdef CC_STAMP_WALL
+#define GEMM_CLOCK() wall_clock64()                       /* 100 MHz: a timeline in real time (dev builds) */
+#else
+#define GEMM_CLOCK() __builtin_readcyclecounter()
+#endif
 #define GEMM_STAMP(slot)                                                                                        \
     do {                                                                                                        \
-        if (prof && threadIdx.x == 0) prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)__builtin_readcyclecounter(); \
+        if (prof && threadIdx.x == 0) prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)GEMM_CLOCK(); \
     } while (0)
 
 template <int CTRL>
