@@ -115,6 +115,8 @@ int cc_launch_im2col3d(const cc_frames& frames, _Float16* A, int F, int T, int r
 // eig.hip: direct symmetric eigensolver for the K smallest eigenpairs (N <= 196, K <= 64, 2K <= N), see the file header
 bool cc_sym_eig_tridiag_supports(int N, int K);
 size_t cc_sym_eig_tridiag_ws_bytes(int P, int N);
+bool cc_sym_eig_tridiag_big_supports(int N, int K);              // 196 < N <= 640, K <= 128: the matrix in a global scratch
+size_t cc_sym_eig_tridiag_big_ws_bytes(int P, int N);
 int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int correct_sign, float* Q, int ldq, float* evals,
                               int* sweeps_out, void* ws, size_t ws_bytes, hipStream_t st);
 int cc_launch_text_embed(const TextEmbedArgs& e, hipStream_t st);

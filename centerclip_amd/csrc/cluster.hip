@@ -2344,7 +2344,9 @@ int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, 
 size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N) {
     if (P <= 0 || N <= 0) return 0;
     if (N <= 196) return cc_sym_eig_tridiag_ws_bytes(P, N);      // the direct solver's band scratch (eig.hip)
-    return N <= 201 ? 256 : cc_align_up((size_t)P * N * N * sizeof(float), 256);
+    const size_t jac = N <= 201 ? 256 : cc_align_up((size_t)P * N * N * sizeof(float), 256);
+    const size_t big = N <= 640 ? cc_sym_eig_tridiag_big_ws_bytes(P, N) : 0;     // matrix + fp64 vectors + bands in global memory
+    return jac > big ? jac : big;
 }
 
 // DEBUG hook (declared in no header, process-wide): 1 = always the Jacobi kernel, 0 = the direct solver where it applies.
@@ -2358,7 +2360,7 @@ int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int3
     if (N > 640) return CC_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ldq > K && hipMemsetAsync(Q, 0, (size_t)P * N * ldq * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
-    if (!g_force_jacobi && cc_sym_eig_tridiag_supports(N, K))    // tridiagonalisation + bisection + inverse iteration
+    if (!g_force_jacobi && (cc_sym_eig_tridiag_supports(N, K) || cc_sym_eig_tridiag_big_supports(N, K)))    // direct solver
         return cc_launch_sym_eig_tridiag(laplacian, P, N, K, correct_sign, Q, ldq, eigenvalues, sweeps_out, ws, ws_bytes, st);
     const bool in_lds = N <= 201;
     if (!in_lds && (!ws || ws_bytes < cc_spectral_embedding_workspace_bytes(P, N))) return CC_ERR_WORKSPACE;

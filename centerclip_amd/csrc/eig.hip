@@ -631,6 +631,336 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
 #undef TD_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same solver for matrices that do not fit in LDS (196 < N <= 640, K <= 128): the matrix lives in a global scratch
+// (L2 / MALL resident: 0.6 MB at N = 392), the fused pass streams the trailing block through the CU (float4 rows,
+// coalesced), the K vectors are fp64 rows of a second scratch (vector-major: a wave reads a vector contiguously),
+// Gram-Schmidt runs from memory (pivot vector in LDS, a wave per remaining vector), the back-transformation keeps the fp32
+// vectors in registers (G lanes per vector) and reads the reflector rows where the tridiagonalisation left them.
+// Phases, precisions and formulas are those of sym_eig_tridiag_kernel.
+__device__ __forceinline__ double td_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G, int MAXE, int MAXQ>          // G lanes per vector in the back-transformation, MAXE = ceil(N / G), MAXQ = ceil(N / 64)
+__global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const float* __restrict__ Lsym, float* __restrict__ fwork,
+                                                                         double* __restrict__ dwork, float* __restrict__ Q,
+                                                                         float* __restrict__ evals, int* __restrict__ sweeps_out,
+                                                                         int N, int K, int KP, int ldq, int correct_sign,
+                                                                         long long fstride, long long dstride) {
+    extern __shared__ __align__(16) unsigned char td_smem[];
+    const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int LD = (N + 3) & ~3;
+    float* A = fwork + (int64_t)p * fstride;                     // [N][LD]
+    double* Yv = dwork + (int64_t)p * dstride;                   // [K][LD] vectors
+    double* U0 = Yv + (int64_t)K * LD;                           // [N][KP] x 3 bands of U (1 / pivot first)
+    double* U1 = U0 + (int64_t)N * KP;
+    double* U2 = U1 + (int64_t)N * KP;
+    float* tau = reinterpret_cast<float*>(td_smem);              // [LD]
+    float* scl = tau + LD;                                       // [LD]
+    float* e = scl + LD;                                         // [LD]
+    float4* vwx = reinterpret_cast<float4*>(e + LD);             // [LD]; later de
+    float* part = reinterpret_cast<float*>(vwx + LD);            // [4][LD + 24]; later ds
+    double* lam = reinterpret_cast<double*>(part + 4 * (LD + 24));   // [128]
+    double* shf = lam + 128;                                     // [128]
+    double* qbuf = shf + 128;                                    // [LD] pivot vector of Gram-Schmidt
+    double* red = qbuf + LD;                                     // [16]
+    double2* de = reinterpret_cast<double2*>(vwx);
+    const int LDP = LD + 24;
+    const float* Lp = Lsym + (int64_t)p * N * N;
+
+    // ---- A: symmetrised copy ------------------------------------------------------------------------------------------
+    for (int idx = tid; idx < N * LD; idx += TD_THREADS) {
+        const int i = idx / LD, j = idx - i * LD;
+        A[idx] = j < N ? 0.5f * (Lp[(int64_t)i * N + j] + Lp[(int64_t)j * N + i]) : 0.f;
+    }
+    for (int j = tid; j < LD; j += TD_THREADS)
+        vwx[j] = make_float4(0.f, 0.f, (j >= 1 && j < N) ? 0.5f * (Lp[j] + Lp[(int64_t)j * N]) : 0.f, 0.f);
+    __syncthreads();
+
+    // ---- B: tridiagonalisation (see sym_eig_tridiag_kernel) --------------------------------------------------------------
+    const int rs = lane >> 4, qd = lane & 15;
+    const int qlast = (N - 1) >> 2;
+    float xv[MAXQ], vv[MAXQ];
+#pragma unroll
+    for (int t = 0; t < MAXQ; ++t) { xv[t] = 0.f; vv[t] = 0.f; }
+    float r_beta = 0.f, r_tk = 0.f, r_s = 0.f;
+    for (int k = 0; k <= N - 2; ++k) {
+        if (wave == 0 && k < N - 2) {
+            const int f = k + 1;
+            float sig = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) {
+                const int ii = lane + 64 * t;
+                const float x = vwx[min(f + ii, N - 1)].z;
+                xv[t] = f + ii < N ? x : 0.f;
+                sig = fmaf(xv[t], ii > 0 ? xv[t] : 0.f, sig);
+            }
+            sig = cc_wave_sum_fast(sig);
+            const float x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xv[0])));
+            r_beta = x0; r_tk = 0.f; r_s = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) vv[t] = 0.f;
+            if (sig != 0.f) {
+                const float nrm = sqrtf(fmaf(x0, x0, sig));
+                r_beta = x0 >= 0.f ? -nrm : nrm;
+                r_s = 1.f / (x0 - r_beta);
+                r_tk = 2.f / fmaf(r_s * r_s, sig, 1.f);
+#pragma unroll
+                for (int t = 0; t < MAXQ; ++t) vv[t] = (lane + 64 * t) == 0 ? 1.f : r_s * xv[t];
+            }
+        }
+        const int q0 = k >> 2;
+        const int nq = qlast - q0 + 1;
+        const int ncg = (nq + 15) >> 4;                          // 64-column groups of the block
+        int cq0, cstep, ch;
+        if (ncg >= 4) { cq0 = wave & 3; cstep = 4; ch = wave >> 2; }
+        else if (ncg == 3) { ch = (wave * 11) >> 5; cq0 = wave - 3 * ch; cstep = 3; }
+        else if (ncg == 2) { cq0 = wave & 1; cstep = 2; ch = wave >> 1; }
+        else { cq0 = 0; cstep = 1; ch = wave; }
+        const int rpc = (((N - k + 3) >> 2) + 3) & ~3;
+        if (ch < 4) {                                            // (wave-uniform)
+            const int jb = k + ch * rpc, je = min(jb + rpc, N);
+            for (int cq = cq0; cq < ncg; cq += cstep) {
+                const int q4 = q0 + (cq << 4) + qd;
+                const bool on = q4 <= qlast;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) {
+                    const float4 c0 = vwx[4 * q4], c1 = vwx[4 * q4 + 1], c2 = vwx[4 * q4 + 2], c3 = vwx[4 * q4 + 3];
+                    float* col = A + 4 * q4;
+#pragma unroll 2
+                    for (int j = jb + rs; j < je; j += 4) {
+                        float4 a = *reinterpret_cast<const float4*>(col + (int64_t)j * LD);
+                        const float4 o = vwx[j];
+                        {
+#pragma clang fp contract(off)
+                            a.x -= o.x * c0.y + o.y * c0.x;
+                            a.y -= o.x * c1.y + o.y * c1.x;
+                            a.z -= o.x * c2.y + o.y * c2.x;
+                            a.w -= o.x * c3.y + o.y * c3.x;
+                        }
+                        *reinterpret_cast<float4*>(col + (int64_t)j * LD) = a;
+                        acc.x = fmaf(a.x, o.z, acc.x);
+                        acc.y = fmaf(a.y, o.z, acc.y);
+                        acc.z = fmaf(a.z, o.z, acc.z);
+                        acc.w = fmaf(a.w, o.z, acc.w);
+                    }
+                }
+                acc.x = td_sum_rows(acc.x); acc.y = td_sum_rows(acc.y);
+                acc.z = td_sum_rows(acc.z); acc.w = td_sum_rows(acc.w);
+                if (on && rs == 0) *reinterpret_cast<float4*>(part + ch * LDP + (((cq << 4) + qd) << 2)) = acc;
+            }
+        }
+        __syncthreads();                                         // (also orders the global writes of the pass inside the CU)
+        if (k == N - 2) break;
+        if (wave == 0) {
+            const int f = k + 1;
+            const int cbase = q0 << 2;
+            float ww[MAXQ], cv[MAXQ];
+            float gam = 0.f;
+            const float ts = r_tk * r_s;
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) {
+                const int i = min(f + lane + 64 * t, N - 1), o = i - cbase;
+                const bool in = f + lane + 64 * t < N;
+                const float c = A[(int64_t)f * LD + i];
+                const float tt = (part[o] + part[LDP + o]) + (part[2 * LDP + o] + part[3 * LDP + o]);
+                cv[t] = in ? c : 0.f;
+                ww[t] = in ? ts * (tt - r_beta * c) : 0.f;
+                gam = fmaf(ww[t], vv[t], gam);
+            }
+            gam = cc_wave_sum_fast(gam);
+            const float hc = 0.5f * r_tk * gam;
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) ww[t] -= hc * vv[t];
+            const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ww[0])));
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) {
+                const int ii = lane + 64 * t, i = f + ii;
+                if (i < N) {
+                    vwx[i] = make_float4(vv[t], ww[t], ii == 0 ? 0.f : cv[t] - ww[t] - w0 * vv[t], 0.f);
+                    A[(int64_t)k * LD + i] = xv[t];              // the analytic x: the reflector tau belongs to
+                }
+            }
+            if (lane == 0) { vwx[k] = make_float4(0.f, 0.f, 0.f, 0.f); e[k] = r_beta; tau[k] = r_tk; scl[k] = r_s; }
+        }
+        __syncthreads();
+    }
+    {
+        double2 mine_de = make_double2(0.0, 0.0);
+        if (tid < N) {
+            const float ei = tid < N - 2 ? e[tid] : (tid == N - 2 ? A[(int64_t)(N - 2) * LD + N - 1] : 0.f);
+            mine_de = make_double2((double)A[(int64_t)tid * LD + tid], (double)ei);
+        }
+        __syncthreads();
+        if (tid < N) de[tid] = mine_de;                          // (N <= 640 < 1024: one element per thread)
+    }
+    __syncthreads();
+    double2* ds = reinterpret_cast<double2*>(part);
+    for (int i = tid; i < N + 24; i += TD_THREADS) {
+        const double2 t = i < N ? de[i] : make_double2(0.0, 0.0);
+        ds[i] = make_double2(t.x, fmax(t.y * t.y, 1e-280));
+    }
+    __syncthreads();
+
+    // ---- C: eigenvalues ---------------------------------------------------------------------------------------------------
+    double glo = 1.0e300, ghi = -1.0e300;
+    for (int i = lane; i < N; i += 64) {
+        const double r = (i > 0 ? fabs(de[i - 1].y) : 0.0) + fabs(de[i].y);
+        glo = fmin(glo, de[i].x - r);
+        ghi = fmax(ghi, de[i].x + r);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { glo = fmin(glo, __shfl_xor(glo, o, 64)); ghi = fmax(ghi, __shfl_xor(ghi, o, 64)); }
+    const double tnorm = fmax(fmax(fabs(glo), fabs(ghi)), 1e-300);
+    glo -= 4.0 * TD_EPS64 * tnorm * (double)N;
+    ghi += 4.0 * TD_EPS64 * tnorm * (double)N;
+    if (tid < 4 * K) {
+        const int kb = tid >> 2, gb = tid & 3;
+        double lo = glo, hi = ghi;
+        for (int it = 0; it < TD_SECTIONS; ++it) {
+            const double x = lo + (hi - lo) * ((double)(gb + 1) * 0.2);
+            const bool below = td_sturm(ds, N, x) <= kb;
+            double a = below ? x : lo, b = below ? -hi : -x;
+            a = fmax(a, td_dpp_f64<0xB1>(a)); a = fmax(a, td_dpp_f64<0x4E>(a));
+            b = fmax(b, td_dpp_f64<0xB1>(b)); b = fmax(b, td_dpp_f64<0x4E>(b));
+            lo = a; hi = -b;
+        }
+        if (gb == 0) lam[kb] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+
+    // ---- D: eigenvectors of T ------------------------------------------------------------------------------------------------
+    if (tid == 0) {
+        const double sep = 10.0 * TD_EPS64 * tnorm;
+        double prev = lam[0];
+        shf[0] = prev;
+        for (int q = 1; q < K; ++q) { prev = fmax(lam[q], prev + sep); shf[q] = prev; }
+    }
+    for (int idx = tid; idx < K * LD; idx += TD_THREADS) {
+        const int c = idx / LD, i = idx - c * LD;
+        Yv[idx] = i < N ? td_start_value((unsigned)i, (unsigned)c) : 0.0;
+    }
+    __syncthreads();
+    const double tiny = TD_EPS64 * tnorm;
+    if (tid < K) {                                               // (T - shift) x = y, lane = eigenvalue
+        const int c = tid;
+        double* yc = Yv + (int64_t)c * LD;
+        const double sh = shf[c];
+        double2 cur = de[0], nx = de[1];
+        double nr = yc[1];
+        double a = cur.x - sh, b = cur.y, cc = 0.0, r = yc[0];
+        for (int i = 0; i < N - 1; ++i) {
+            const int i2 = min(i + 2, N - 1);
+            const double2 nx2 = de[i2];
+            const double nr2 = yc[i2];
+            const double na = cur.y, nb = nx.x - sh, nc = nx.y;
+            const bool sw = fabs(na) > fabs(a);
+            double pa = sw ? na : a;
+            const double pb = sw ? nb : b, pc = sw ? nc : cc, pr = sw ? nr : r;
+            const double qa = sw ? a : na, qb = sw ? b : nb, qc = sw ? cc : nc, qr = sw ? r : nr;
+            if (fabs(pa) < tiny) pa = pa < 0.0 ? -tiny : tiny;
+            double ip = __builtin_amdgcn_rcp(pa);
+            ip = fma(fma(-pa, ip, 1.0), ip, ip);
+            ip = fma(fma(-pa, ip, 1.0), ip, ip);
+            const double ml = qa * ip;
+            U0[i * KP + c] = ip; U1[i * KP + c] = pb; U2[i * KP + c] = pc;
+            yc[i] = pr;
+            a = qb - ml * pb; b = qc - ml * pc; cc = 0.0; r = qr - ml * pr;
+            cur = nx; nx = nx2; nr = nr2;
+        }
+        if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;
+        double x1 = r / a, x2 = 0.0;
+        yc[N - 1] = x1;
+        for (int i = N - 2; i >= 0; --i) {
+            const double x = (yc[i] - U1[i * KP + c] * x1 - U2[i * KP + c] * x2) * U0[i * KP + c];
+            yc[i] = x;
+            x2 = x1; x1 = x;
+        }
+    }
+    __syncthreads();
+    for (int kk = 0; kk < K; ++kk) {                             // modified Gram-Schmidt from memory
+        double* yk = Yv + (int64_t)kk * LD;
+        const double v = tid < N ? yk[tid] : 0.0;
+        const double s = td_wave_sum(v * v);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        double n2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < TD_WAVES; ++w) n2 += red[w];
+        const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+        if (tid < N) { const double qv = v * inv; qbuf[tid] = qv; yk[tid] = qv; }
+        __syncthreads();
+        for (int k2 = kk + 1 + wave; k2 < K; k2 += TD_WAVES) {    // a wave per remaining vector
+            double* y2 = Yv + (int64_t)k2 * LD;
+            double yv[MAXQ];
+            double dsum = 0.0;
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) {
+                const int i = lane + 64 * t;
+                yv[t] = i < N ? y2[i] : 0.0;
+                dsum = fma(i < N ? qbuf[i] : 0.0, yv[t], dsum);
+            }
+            dsum = td_wave_sum(dsum);
+#pragma unroll
+            for (int t = 0; t < MAXQ; ++t) {
+                const int i = lane + 64 * t;
+                if (i < N) y2[i] = yv[t] - dsum * qbuf[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- E: back-transformation, fp32 vectors in registers (G lanes per vector) ------------------------------------------------
+    const int k = tid / G, g = tid - k * G;
+    const bool mine = k < K;
+    float z[MAXE];
+    if (mine) {
+#pragma unroll
+        for (int t = 0; t < MAXE; ++t) { const int i = g + G * t; z[t] = i < N ? (float)Yv[(int64_t)k * LD + i] : 0.f; }
+        for (int kr = N - 3; kr >= 0; --kr) {
+            const float tk = tau[kr];
+            if (tk == 0.f) continue;
+            const int f = kr + 1;
+            const float sc = scl[kr];
+            const float* row = A + (int64_t)kr * LD;
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAXE; ++t) {
+                if (G * t + G - 1 < f) continue;                 // (uniform: the reflector is zero there)
+                const int i = g + G * t;
+                const float v = (i > f && i < N) ? row[i] * sc : (i == f ? 1.f : 0.f);
+                s = fmaf(v, z[t], s);
+            }
+            s += cc_dpp_f32<0xB1>(s); s += cc_dpp_f32<0x4E>(s); s += cc_dpp_f32<0x141>(s);
+            if (G == 16) s += cc_dpp_f32<0x140>(s);
+            s *= tk;
+#pragma unroll
+            for (int t = 0; t < MAXE; ++t) {
+                if (G * t + G - 1 < f) continue;
+                const int i = g + G * t;
+                const float v = (i > f && i < N) ? row[i] * sc : (i == f ? 1.f : 0.f);    // (L1 hit)
+                z[t] -= s * v;
+            }
+        }
+        // ---- F
+        float sg = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXE; ++t) { const float u = z[t]; sg += (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (u * u); }
+        sg += cc_dpp_f32<0xB1>(sg); sg += cc_dpp_f32<0x4E>(sg); sg += cc_dpp_f32<0x141>(sg);
+        if (G == 16) sg += cc_dpp_f32<0x140>(sg);
+        const float flip = correct_sign ? (sg > 0.f ? 1.f : (sg < 0.f ? -1.f : 0.f)) : 1.f;
+        const int col = K - 1 - k;
+        float* Qp = Q + (int64_t)p * N * ldq;
+#pragma unroll
+        for (int t = 0; t < MAXE; ++t) { const int i = g + G * t; if (i < N) Qp[(int64_t)i * ldq + col] = z[t] * flip; }
+        if (g == 0 && evals) evals[(int64_t)p * K + col] = (float)lam[k];
+    }
+    if (tid == 0 && sweeps_out) sweeps_out[p] = 0;
+}
+
 // floats of the big region: the matrix, later the packed reflectors (fp32) + K vectors (fp64)
 size_t td_region_floats(int N, int K) {
     const size_t LD = (size_t)((N + 3) & ~3), KP = (size_t)(K | 1);
@@ -660,8 +990,46 @@ size_t cc_sym_eig_tridiag_ws_bytes(int P, int N) {               // three fp64 b
     return cc_align_up((size_t)P * 3 * N * 65 * sizeof(double), 256);
 }
 
+// ---- large N: per-problem scratch = matrix [N][LD] floats, then doubles: K vectors [LD] + 3 bands [N][KP]
+static size_t tdb_fstride(int N) { return (size_t)N * ((N + 3) & ~3); }
+static size_t tdb_dstride(int N, int K) { return (size_t)K * ((N + 3) & ~3) + 3 * (size_t)N * (K | 1); }
+static size_t tdb_smem_bytes(int N) {
+    const size_t LD = (size_t)((N + 3) & ~3);
+    return (3 * LD + 4 * LD + 4 * (LD + 24)) * sizeof(float) + (128 + 128 + LD + 16) * sizeof(double);
+}
+bool cc_sym_eig_tridiag_big_supports(int N, int K) { return N > 196 && N <= 640 && K >= 1 && K <= 128 && K <= N; }
+
+size_t cc_sym_eig_tridiag_big_ws_bytes(int P, int N) {           // (K <= 128)
+    return cc_align_up((size_t)P * tdb_fstride(N) * sizeof(float), 256) + cc_align_up((size_t)P * tdb_dstride(N, 128) * sizeof(double), 256);
+}
+
 int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int correct_sign, float* Q, int ldq, float* evals,
                               int* sweeps_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (cc_sym_eig_tridiag_big_supports(N, K)) {
+        if (!ws || ws_bytes < cc_sym_eig_tridiag_big_ws_bytes(P, N)) return CC_ERR_WORKSPACE;
+        float* fw = static_cast<float*>(ws);
+        double* dw = reinterpret_cast<double*>(static_cast<unsigned char*>(ws) + cc_align_up((size_t)P * tdb_fstride(N) * sizeof(float), 256));
+        const size_t smem = tdb_smem_bytes(N);
+        const int KP = K | 1;
+#define TDB_LAUNCH(G, MAXE, MAXQ)                                                                                       \
+    do {                                                                                                               \
+        auto kern = sym_eig_tridiag_big_kernel<G, MAXE, MAXQ>;                                                          \
+        hipLaunchKernelGGL(kern, dim3(P), dim3(TD_THREADS), smem, st, laplacian, fw, dw, Q, evals, sweeps_out, N, K, KP, ldq, \
+                           correct_sign, (long long)tdb_fstride(N), (long long)tdb_dstride(N, K));                     \
+    } while (0)
+        if (K <= 64) {
+            if (N <= 320) TDB_LAUNCH(16, 20, 5);
+            else if (N <= 448) TDB_LAUNCH(16, 28, 7);
+            else TDB_LAUNCH(16, 40, 10);
+        } else {
+            if (N <= 320) TDB_LAUNCH(8, 40, 5);
+            else if (N <= 448) TDB_LAUNCH(8, 56, 7);
+            else TDB_LAUNCH(8, 80, 10);
+        }
+#undef TDB_LAUNCH
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
     if (!cc_sym_eig_tridiag_supports(N, K)) return CC_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < cc_sym_eig_tridiag_ws_bytes(P, N)) return CC_ERR_WORKSPACE;
     const int KP = K | 1;
