@@ -649,11 +649,12 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
                                                                          double* __restrict__ dwork, float* __restrict__ Q,
                                                                          float* __restrict__ evals, int* __restrict__ sweeps_out,
                                                                          int N, int K, int KP, int ldq, int correct_sign,
-                                                                         long long fstride, long long dstride) {
+                                                                         long long fstride, long long dstride, long long* __restrict__ prof) {
     extern __shared__ __align__(16) unsigned char td_smem[];
     const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int LD = (N + 3) & ~3;
     float* A = fwork + (int64_t)p * fstride;                     // [N][LD]
+    float* Rf = A + (int64_t)N * ((N + 3) & ~3);                 // [N][LD] reflectors (raw x_k in row k, columns k+1..)
     double* Yv = dwork + (int64_t)p * dstride;                   // [K][LD] vectors
     double* U0 = Yv + (int64_t)K * LD;                           // [N][KP] x 3 bands of U (1 / pivot first)
     double* U1 = U0 + (int64_t)N * KP;
@@ -667,9 +668,11 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     double* shf = lam + 128;                                     // [128]
     double* qbuf = shf + 128;                                    // [LD] pivot vector of Gram-Schmidt
     double* red = qbuf + LD;                                     // [16]
+    float* cbuf = reinterpret_cast<float*>(red + 16);            // [LD] row k+1 of the step, as the pass produced it
     double2* de = reinterpret_cast<double2*>(vwx);
     const int LDP = LD + 24;
     const float* Lp = Lsym + (int64_t)p * N * N;
+    if (prof && p == 0 && tid == 0) prof[0] = (long long)wall_clock64();
 
     // ---- A: symmetrised copy ------------------------------------------------------------------------------------------
     for (int idx = tid; idx < N * LD; idx += TD_THREADS) {
@@ -680,8 +683,15 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
         vwx[j] = make_float4(0.f, 0.f, (j >= 1 && j < N) ? 0.5f * (Lp[j] + Lp[(int64_t)j * N]) : 0.f, 0.f);
     __syncthreads();
 
+    if (prof && p == 0 && tid == 0) prof[1] = (long long)wall_clock64();
     // ---- B: tridiagonalisation (see sym_eig_tridiag_kernel) --------------------------------------------------------------
-    const int rs = lane >> 4, qd = lane & 15;
+    // Ownership of the matrix is FIXED: row j belongs to row chunk (j >> 2) & 3 and row phase j & 3, column quad q to column
+    // group (q >> 4) & 3 and lane q & 15 - the same lane reads and writes an element in every step, so the global stores of a
+    // pass need not be visible to anybody else and the two barriers of a step only order LDS (s_waitcnt lgkmcnt(0) +
+    // s_barrier: stores stay in flight).  What other waves need of the fresh block goes through LDS: the partial sums and
+    // row k+1, which its owners copy into cbuf as they produce it.
+    const int qd = lane & 15, rph = lane >> 4;                   // column quad inside a group, row phase
+    const int ch = wave >> 2, cq0 = wave & 3;
     const int qlast = (N - 1) >> 2;
     float xv[MAXQ], vv[MAXQ];
 #pragma unroll
@@ -713,60 +723,64 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
             }
         }
         const int q0 = k >> 2;
-        const int nq = qlast - q0 + 1;
-        const int ncg = (nq + 15) >> 4;                          // 64-column groups of the block
-        int cq0, cstep, ch;
-        if (ncg >= 4) { cq0 = wave & 3; cstep = 4; ch = wave >> 2; }
-        else if (ncg == 3) { ch = (wave * 11) >> 5; cq0 = wave - 3 * ch; cstep = 3; }
-        else if (ncg == 2) { cq0 = wave & 1; cstep = 2; ch = wave >> 1; }
-        else { cq0 = 0; cstep = 1; ch = wave; }
-        const int rpc = (((N - k + 3) >> 2) + 3) & ~3;
-        if (ch < 4) {                                            // (wave-uniform)
-            const int jb = k + ch * rpc, je = min(jb + rpc, N);
-            for (int cq = cq0; cq < ncg; cq += cstep) {
-                const int q4 = q0 + (cq << 4) + qd;
-                const bool on = q4 <= qlast;
+        {
+            // my rows: j = 4 ch + rph (mod 16), j >= k
+            const int res = 4 * ch + rph;
+            const int jfirst = k + ((res - k) & 15);
+            for (int ag = (q0 >> 4) + ((cq0 - (q0 >> 4)) & 3); (ag << 4) <= qlast; ag += 4) {
+                const int q4 = (ag << 4) + qd;
+                const bool on = q4 >= q0 && q4 <= qlast;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (on) {
                     const float4 c0 = vwx[4 * q4], c1 = vwx[4 * q4 + 1], c2 = vwx[4 * q4 + 2], c3 = vwx[4 * q4 + 3];
                     float* col = A + 4 * q4;
-#pragma unroll 2
-                    for (int j = jb + rs; j < je; j += 4) {
-                        float4 a = *reinterpret_cast<const float4*>(col + (int64_t)j * LD);
-                        const float4 o = vwx[j];
-                        {
-#pragma clang fp contract(off)
-                            a.x -= o.x * c0.y + o.y * c0.x;
-                            a.y -= o.x * c1.y + o.y * c1.x;
-                            a.z -= o.x * c2.y + o.y * c2.x;
-                            a.w -= o.x * c3.y + o.y * c3.x;
+                    for (int j8 = jfirst; j8 < N; j8 += 128) {   // 8 rows in flight per lane
+                        float4 a[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = j8 + 16 * u;
+                            a[u] = j < N ? *reinterpret_cast<const float4*>(col + (int64_t)j * LD) : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
-                        *reinterpret_cast<float4*>(col + (int64_t)j * LD) = a;
-                        acc.x = fmaf(a.x, o.z, acc.x);
-                        acc.y = fmaf(a.y, o.z, acc.y);
-                        acc.z = fmaf(a.z, o.z, acc.z);
-                        acc.w = fmaf(a.w, o.z, acc.w);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = j8 + 16 * u;
+                            if (j < N) {
+                                const float4 o = vwx[j];
+                                {
+#pragma clang fp contract(off)
+                                    a[u].x -= o.x * c0.y + o.y * c0.x;
+                                    a[u].y -= o.x * c1.y + o.y * c1.x;
+                                    a[u].z -= o.x * c2.y + o.y * c2.x;
+                                    a[u].w -= o.x * c3.y + o.y * c3.x;
+                                }
+                                *reinterpret_cast<float4*>(col + (int64_t)j * LD) = a[u];
+                                if (j == k + 1) *reinterpret_cast<float4*>(cbuf + 4 * q4) = a[u];
+                                acc.x = fmaf(a[u].x, o.z, acc.x);
+                                acc.y = fmaf(a[u].y, o.z, acc.y);
+                                acc.z = fmaf(a[u].z, o.z, acc.z);
+                                acc.w = fmaf(a[u].w, o.z, acc.w);
+                            }
+                        }
                     }
                 }
                 acc.x = td_sum_rows(acc.x); acc.y = td_sum_rows(acc.y);
                 acc.z = td_sum_rows(acc.z); acc.w = td_sum_rows(acc.w);
-                if (on && rs == 0) *reinterpret_cast<float4*>(part + ch * LDP + (((cq << 4) + qd) << 2)) = acc;
+                if (on && rph == 0) *reinterpret_cast<float4*>(part + ch * LDP + 4 * q4) = acc;
             }
         }
-        __syncthreads();                                         // (also orders the global writes of the pass inside the CU)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (k == N - 2) break;
         if (wave == 0) {
             const int f = k + 1;
-            const int cbase = q0 << 2;
             float ww[MAXQ], cv[MAXQ];
             float gam = 0.f;
             const float ts = r_tk * r_s;
 #pragma unroll
             for (int t = 0; t < MAXQ; ++t) {
-                const int i = min(f + lane + 64 * t, N - 1), o = i - cbase;
+                const int i = min(f + lane + 64 * t, N - 1);
                 const bool in = f + lane + 64 * t < N;
-                const float c = A[(int64_t)f * LD + i];
-                const float tt = (part[o] + part[LDP + o]) + (part[2 * LDP + o] + part[3 * LDP + o]);
+                const float c = cbuf[i];
+                const float tt = (part[i] + part[LDP + i]) + (part[2 * LDP + i] + part[3 * LDP + i]);
                 cv[t] = in ? c : 0.f;
                 ww[t] = in ? ts * (tt - r_beta * c) : 0.f;
                 gam = fmaf(ww[t], vv[t], gam);
@@ -781,13 +795,15 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
                 const int ii = lane + 64 * t, i = f + ii;
                 if (i < N) {
                     vwx[i] = make_float4(vv[t], ww[t], ii == 0 ? 0.f : cv[t] - ww[t] - w0 * vv[t], 0.f);
-                    A[(int64_t)k * LD + i] = xv[t];              // the analytic x: the reflector tau belongs to
+                    Rf[(int64_t)k * LD + i] = xv[t];             // the analytic x (the reflector tau belongs to), in its own array:
+                                                                 // row k of the matrix has stores of its owners in flight
                 }
             }
             if (lane == 0) { vwx[k] = make_float4(0.f, 0.f, 0.f, 0.f); e[k] = r_beta; tau[k] = r_tk; scl[k] = r_s; }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    __syncthreads();                                             // the matrix is read by other lanes from here on
     {
         double2 mine_de = make_double2(0.0, 0.0);
         if (tid < N) {
@@ -805,6 +821,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     }
     __syncthreads();
 
+    if (prof && p == 0 && tid == 0) prof[2] = (long long)wall_clock64();
     // ---- C: eigenvalues ---------------------------------------------------------------------------------------------------
     double glo = 1.0e300, ghi = -1.0e300;
     for (int i = lane; i < N; i += 64) {
@@ -832,6 +849,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     }
     __syncthreads();
 
+    if (prof && p == 0 && tid == 0) prof[3] = (long long)wall_clock64();
     // ---- D: eigenvectors of T ------------------------------------------------------------------------------------------------
     if (tid == 0) {
         const double sep = 10.0 * TD_EPS64 * tnorm;
@@ -881,6 +899,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
         }
     }
     __syncthreads();
+    if (prof && p == 0 && tid == 0) prof[4] = (long long)wall_clock64();
     for (int kk = 0; kk < K; ++kk) {                             // modified Gram-Schmidt from memory
         double* yk = Yv + (int64_t)kk * LD;
         const double v = tid < N ? yk[tid] : 0.0;
@@ -913,6 +932,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
         __syncthreads();
     }
 
+    if (prof && p == 0 && tid == 0) prof[5] = (long long)wall_clock64();
     // ---- E: back-transformation, fp32 vectors in registers (G lanes per vector) ------------------------------------------------
     const int k = tid / G, g = tid - k * G;
     const bool mine = k < K;
@@ -920,31 +940,49 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     if (mine) {
 #pragma unroll
         for (int t = 0; t < MAXE; ++t) { const int i = g + G * t; z[t] = i < N ? (float)Yv[(int64_t)k * LD + i] : 0.f; }
-        for (int kr = N - 3; kr >= 0; --kr) {
-            const float tk = tau[kr];
-            if (tk == 0.f) continue;
+    }
+    {
+        // every reflector goes through LDS once (0 ... 0, 1, v ...), the next one is fetched while this one is applied
+        float* vb = part;                                        // 2 x [LD]
+        auto fetch = [&](int kr) -> float {
+            if (kr < 0 || tid >= LD) return 0.f;
             const int f = kr + 1;
-            const float sc = scl[kr];
-            const float* row = A + (int64_t)kr * LD;
-            float s = 0.f;
+            const float raw = (tid > f && tid < N) ? Rf[(int64_t)kr * LD + tid] * scl[kr] : 0.f;
+            return tid == f ? 1.f : raw;
+        };
+        float r1 = fetch(N - 3);
+        if (tid < LD) vb[((N - 3) & 1) * LD + tid] = r1;
+        r1 = fetch(N - 4);                                       // two rows ahead: the loads stay in flight across the barriers
+        __syncthreads();
+        for (int kr = N - 3; kr >= 0; --kr) {
+            const float r2 = fetch(kr - 2);
+            const float tk = tau[kr];
+            if (mine && tk != 0.f) {
+                const int f = kr + 1;
+                const float* v = vb + (kr & 1) * LD;
+                float s = 0.f;
 #pragma unroll
-            for (int t = 0; t < MAXE; ++t) {
-                if (G * t + G - 1 < f) continue;                 // (uniform: the reflector is zero there)
-                const int i = g + G * t;
-                const float v = (i > f && i < N) ? row[i] * sc : (i == f ? 1.f : 0.f);
-                s = fmaf(v, z[t], s);
-            }
-            s += cc_dpp_f32<0xB1>(s); s += cc_dpp_f32<0x4E>(s); s += cc_dpp_f32<0x141>(s);
-            if (G == 16) s += cc_dpp_f32<0x140>(s);
-            s *= tk;
+                for (int t = 0; t < MAXE; ++t) {
+                    if (G * t + G - 1 < f) continue;             // (uniform: the reflector is zero there)
+                    const int i = g + G * t;
+                    s = fmaf(i < LD ? v[i] : 0.f, z[t], s);
+                }
+                s += cc_dpp_f32<0xB1>(s); s += cc_dpp_f32<0x4E>(s); s += cc_dpp_f32<0x141>(s);
+                if (G == 16) s += cc_dpp_f32<0x140>(s);
+                s *= tk;
 #pragma unroll
-            for (int t = 0; t < MAXE; ++t) {
-                if (G * t + G - 1 < f) continue;
-                const int i = g + G * t;
-                const float v = (i > f && i < N) ? row[i] * sc : (i == f ? 1.f : 0.f);    // (L1 hit)
-                z[t] -= s * v;
+                for (int t = 0; t < MAXE; ++t) {
+                    if (G * t + G - 1 < f) continue;
+                    const int i = g + G * t;
+                    z[t] -= s * (i < LD ? v[i] : 0.f);
+                }
             }
+            if (kr > 0 && tid < LD) vb[((kr - 1) & 1) * LD + tid] = r1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            r1 = r2;
         }
+    }
+    if (mine) {
         // ---- F
         float sg = 0.f;
 #pragma unroll
@@ -959,6 +997,8 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
         if (g == 0 && evals) evals[(int64_t)p * K + col] = (float)lam[k];
     }
     if (tid == 0 && sweeps_out) sweeps_out[p] = 0;
+    __syncthreads();
+    if (prof && p == 0 && tid == 0) prof[6] = (long long)wall_clock64();
 }
 
 // floats of the big region: the matrix, later the packed reflectors (fp32) + K vectors (fp64)
@@ -991,11 +1031,11 @@ size_t cc_sym_eig_tridiag_ws_bytes(int P, int N) {               // three fp64 b
 }
 
 // ---- large N: per-problem scratch = matrix [N][LD] floats, then doubles: K vectors [LD] + 3 bands [N][KP]
-static size_t tdb_fstride(int N) { return (size_t)N * ((N + 3) & ~3); }
+static size_t tdb_fstride(int N) { return 2 * (size_t)N * ((N + 3) & ~3); }      // matrix + reflectors
 static size_t tdb_dstride(int N, int K) { return (size_t)K * ((N + 3) & ~3) + 3 * (size_t)N * (K | 1); }
 static size_t tdb_smem_bytes(int N) {
     const size_t LD = (size_t)((N + 3) & ~3);
-    return (3 * LD + 4 * LD + 4 * (LD + 24)) * sizeof(float) + (128 + 128 + LD + 16) * sizeof(double);
+    return (3 * LD + 4 * LD + 4 * (LD + 24) + LD) * sizeof(float) + (128 + 128 + LD + 16) * sizeof(double);
 }
 bool cc_sym_eig_tridiag_big_supports(int N, int K) { return N > 196 && N <= 640 && K >= 1 && K <= 128 && K <= N; }
 
@@ -1015,7 +1055,7 @@ int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int c
     do {                                                                                                               \
         auto kern = sym_eig_tridiag_big_kernel<G, MAXE, MAXQ>;                                                          \
         hipLaunchKernelGGL(kern, dim3(P), dim3(TD_THREADS), smem, st, laplacian, fw, dw, Q, evals, sweeps_out, N, K, KP, ldq, \
-                           correct_sign, (long long)tdb_fstride(N), (long long)tdb_dstride(N, K));                     \
+                           correct_sign, (long long)tdb_fstride(N), (long long)tdb_dstride(N, K), g_td_prof);                     \
     } while (0)
         if (K <= 64) {
             if (N <= 320) TDB_LAUNCH(16, 20, 5);

@@ -83,6 +83,15 @@ def main():
         st = prof.cpu().tolist()
         print(tag, "phases (us, workgroup 0):", ", ".join(f"{n} {(st[i + 1] - st[i]) / 100:.1f}" for i, n in enumerate(names)),
               f"| total {(st[8] - st[0]) / 100:.1f} | tridiagonalise, wave 0: pass {st[16] / 100:.1f}, wait {st[17] / 100:.1f}, scalar part {st[18] / 100:.1f}", flush=True)
+    for tag, Lm, K in [c for c in cases if c[1].shape[1] > 196][:2]:
+        L.lib().cc_debug_set_eig_profile(ctypes.c_void_p(prof.data_ptr()))
+        torch.ops.centerclip.spectral_embedding(Lm.cuda(), K, True)
+        torch.cuda.synchronize()
+        L.lib().cc_debug_set_eig_profile(ctypes.c_void_p(0))
+        st = prof.cpu().tolist()
+        nb = ["copy", "tridiagonalise", "eigenvalues", "solve", "gram-schmidt", "back-transform + store"]
+        print(tag, "phases (us, workgroup 0):", ", ".join(f"{n} {(st[i + 1] - st[i]) / 100:.0f}" for i, n in enumerate(nb)),
+              f"| total {(st[6] - st[0]) / 100:.0f}", flush=True)
     for tag, Lm, K in cases:
         for jac in (False, True):
             check(tag, Lm, K, jac)
