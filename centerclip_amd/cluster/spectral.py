@@ -4,8 +4,9 @@
     smallest eigenvalues  ->  batch_sign_flip_rasmus_bro  ->  row-normalise  ->  k-medoids on them
 
 The decomposition (the reference: the trailing K left singular vectors of a fp32 LAPACK SVD of L_sym) is
-cc_spectral_embedding_f32: for N <= 196 a direct solver (Householder tridiagonalisation, fp64 Sturm multi-section and
-inverse iteration for the K wanted pairs, back-transformation), else a batched one-sided Jacobi solver.  What "the same result" can mean for it: eigenpairs to working
+cc_spectral_embedding_f32: a direct solver (Householder tridiagonalisation, fp64 Sturm multi-section and inverse iteration
+for the K wanted pairs, back-transformation; the matrix in LDS for N <= 196, in a global scratch up to N = 640), with a
+batched one-sided Jacobi solver for the shapes outside its scope.  What "the same result" can mean for it: eigenpairs to working
 precision and the reference's singular values to 1e-5 - yes; the same *vectors* only up to sign and, where eigenvalues
 coincide to rounding, up to a rotation of that eigenspace, which no two solvers share.  The k-medoids tail only sees row
 distances of the K selected vectors, which are invariant to both when the K-th and (K+1)-th eigenvalue are separated

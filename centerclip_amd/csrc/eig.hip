@@ -25,7 +25,8 @@
 // what remains: residual |L q - lambda q| <= 4e-7, orthonormal to 1.3e-6, eigenvalues within 5e-7 of a float64 eigh over
 // heat-kernel / KNN / planted-partition Laplacians (coupling 0 ... 1e-3, identical blocks) at N = 196, K = 49.
 // Scope: the matrix in LDS next to 10 KB of vectors (N <= 196) and packed reflectors + K fp64 vectors in its place
-// afterwards (K = 49 at N = 196), K <= 64; other shapes keep the Jacobi kernel.
+// afterwards (K = 49 at N = 196), K <= 64; 196 < N <= 640 (K <= 128): sym_eig_tridiag_big_kernel below, the matrix in a global
+// scratch; what is left (K > 49 at N = 196, K > 128) keeps the Jacobi kernel.
 #include "cc_common.h"
 #include "cc_kernels.h"
 

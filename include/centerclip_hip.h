@@ -249,10 +249,10 @@ int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, 
  * The decomposition of batch_spectral_clustering (spectral.py:54-61): Q [P, N, ldq] (columns 0..K-1, the rest zeroed) = the
  * K eigenvectors of the symmetric positive semi-definite laplacian [P,N,N] with the smallest eigenvalues, in the reference's
  * column order (U[:, :, -K:] of torch.linalg.svd: eigenvalue descending), eigenvalues [P,K] optional, sweeps_out [P]
- * optional (Jacobi sweeps; 0 from the direct solver).  One workgroup per problem.  N <= 196 with the K vectors in LDS beside
- * the packed reflectors (K <= 49 at N = 196, K <= 64): direct solver - Householder tridiagonalisation (fp32), Sturm
- * multi-section and inverse iteration (fp64), back-transformation (eig.hip).  Other shapes up to N = 640: batched one-sided
- * Jacobi on 2I - L (the matrix in LDS for N <= 201, else in ws).
+ * optional (Jacobi sweeps; 0 from the direct solver).  One workgroup per problem.  Direct solver (eig.hip) - Householder
+ * tridiagonalisation (fp32), Sturm multi-section and inverse iteration (fp64), back-transformation: N <= 196 with the matrix
+ * and then the packed reflectors + K vectors in LDS (K <= 49 at N = 196, K <= 64), 196 < N <= 640 with K <= 128 from a global
+ * scratch in ws.  Remaining shapes up to N = 640: batched one-sided Jacobi on 2I - L.
  * correct_sign: batch_sign_flip_rasmus_bro (:110-137) applied (for a symmetric matrix it depends on the vector alone).
  * Parity: eigenpairs to fp32 working precision, the eigenvalues equal the reference's singular values to 1e-5; the vectors
  * equal the reference's up to sign and, where eigenvalues coincide to rounding, up to a rotation inside that eigenspace -
