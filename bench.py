@@ -302,8 +302,8 @@ def cluster_bench(c, device, iters=30):
 
 
 def spectral_cluster_bench(c, device):
-    """The same op with cluster_algo='spectral' (heat-kernel graph -> Laplacian -> batched Jacobi eigensolver -> k-medoids on
-    the embedding -> gather), one config's shape; eager launches between two events (the decomposition dominates: ms)."""
+    """The same op with cluster_algo='spectral' (heat-kernel graph -> Laplacian -> eigensolver, eig.hip -> k-medoids on the
+    embedding -> gather), one config's shape; eager launches between two events (the decomposition dominates: ms)."""
     from centerclip_amd.cluster import TokenClusterInter
     B, T, Tn, K, n = c["B"], c["T"], c["T_new"], c["K"], c["n"]
     x = torch.randn(B * T, 1 + n, 768, device=device) * 0.05
@@ -618,7 +618,7 @@ def main():
                     tc[name]["mtokens_per_s_all_ranks"] = round(float(tt), 2)
             extras["token_cluster"] = tc
             if world == 1:
-                extras["token_cluster_spectral"] = {"cfg2": spectral_cluster_bench(CLUSTER_SHAPES["cfg2"], device)}
+                extras["token_cluster_spectral"] = {name: spectral_cluster_bench(sh, device) for name, sh in CLUSTER_SHAPES.items()}
             extras["similarity_10k_x_1k"] = similarity_bench(device, world)
             if world > 1:
                 ms = event_time_ms(sink.gather, 50)
