@@ -645,6 +645,9 @@ __device__ __forceinline__ double td_wave_sum(double v) {
     return v;
 }
 
+#ifndef TDB_ROWS
+#define TDB_ROWS 8
+#endif
 template <int G, int MAXE, int MAXQ>          // G lanes per vector in the back-transformation, MAXE = ceil(N / G), MAXQ = ceil(N / 64)
 __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const float* __restrict__ Lsym, float* __restrict__ fwork,
                                                                          double* __restrict__ dwork, float* __restrict__ Q,
@@ -735,15 +738,15 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
                 if (on) {
                     const float4 c0 = vwx[4 * q4], c1 = vwx[4 * q4 + 1], c2 = vwx[4 * q4 + 2], c3 = vwx[4 * q4 + 3];
                     float* col = A + 4 * q4;
-                    for (int j8 = jfirst; j8 < N; j8 += 128) {   // 8 rows in flight per lane
-                        float4 a[8];
+                    for (int j8 = jfirst; j8 < N; j8 += 16 * TDB_ROWS) {   // TDB_ROWS rows in flight per lane
+                        float4 a[TDB_ROWS];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < TDB_ROWS; ++u) {
                             const int j = j8 + 16 * u;
                             a[u] = j < N ? *reinterpret_cast<const float4*>(col + (int64_t)j * LD) : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < TDB_ROWS; ++u) {
                             const int j = j8 + 16 * u;
                             if (j < N) {
                                 const float4 o = vwx[j];
