@@ -126,6 +126,27 @@ def test_eigensolver_tight_clusters_both_solvers(solver):
         L.lib().cc_debug_set_eig_jacobi(0)
 
 
+@pytest.mark.parametrize("P,N,K", [(3, 3, 1), (3, 3, 3), (2, 4, 2), (5, 33, 33), (2, 64, 64), (300, 40, 7), (2, 196, 1), (2, 197, 1),
+                                   (2, 200, 128), (3, 257, 64), (2, 321, 65), (1, 449, 3), (70, 210, 9)])
+def test_eigensolver_edge_shapes(P, N, K):
+    """Corners of the direct solver's dispatch (eig.hip): smallest sizes, K = N, K = 1, more problems than CUs, the first
+    sizes of the global-memory kernel and of each of its register layouts, 8 lanes per vector (K > 64); zero-padded Q columns."""
+    from centerclip_amd.cluster.spectral import spectral_laplacian
+    gen = torch.Generator().manual_seed(1000 * N + K)
+    X = (torch.randn(P, N, 12, generator=gen) * 0.6).to(DEV)
+    L = spectral_laplacian(X, sigma=2.0)
+    Q4, ev, _ = torch.ops.centerclip.spectral_embedding(L.contiguous(), K, True)
+    K4 = (K + 3) // 4 * 4
+    assert Q4.shape == (P, N, K4) and ev.shape == (P, K)
+    assert float(Q4[:, :, K:].abs().max()) == 0.0 if K4 > K else True
+    Qd, Ld, evd = Q4[:, :, :K].cpu().double(), L.cpu().double(), ev.cpu().double()
+    want = torch.flip(torch.linalg.eigvalsh(Ld)[:, :K], dims=[1])
+    assert float((evd - want).abs().max()) < 3e-6
+    assert float((Ld @ Qd - Qd * evd[:, None, :]).abs().max()) < 3e-6
+    assert float((Qd.transpose(1, 2) @ Qd - torch.eye(K, dtype=torch.float64)).abs().max()) < 4e-6
+    assert bool(((torch.sign(Qd) * Qd * Qd).sum(dim=1) > 0).all())
+
+
 def _module(cfg, agg):
     from centerclip_amd.cluster import TokenClusterInter
     return TokenClusterInter(algorithm="spectral", block_id=7, before_cluster_num=cfg["n"], cluster_num=cfg["K"],
