@@ -673,6 +673,22 @@ def main():
                                           "rows_computed": c["B"] * c["T_new"] + c["B"],
                                           "rows_all": c["B"] * c["T_new"] * (c["K"] + 1) + int(lens.sum()),
                                           "ms_per_step_all_rows": round(ms_all12, 3)}
+                # the same step at other evaluation batch sizes (the headline stays B = 16, BASELINE cfg 2): eval batches are
+                # independent, so batch_size_val is the user's to choose - the clustered blocks' 2,400-row GEMMs become 4,800 / 1,200
+                other = {}
+                for b2 in (8, 32):
+                    c2 = dict(c, B=b2)
+                    i2, m2, v2, vm2 = synthetic_batch(c2, device, seed=300 + b2)
+                    z2 = torch.zeros_like(i2)
+
+                    def step_b(i2=i2, m2=m2, v2=v2, vm2=vm2, z2=z2):
+                        o2 = model(i2, z2, m2, v2, vm2)
+                        return model.get_similarity_logits(o2["sequence_output"], o2["visual_output"], m2, vm2)[0]
+                    ms_b = graph_time_ms(step_b, launches=1, replays=20)
+                    other["B=%d" % b2] = {"ms_per_step": round(ms_b, 3), "clips_per_s": round(b2 / ms_b * 1e3, 1)}
+                    del i2, m2, v2, vm2, z2
+                model(ids, token_type, amask, video, vmask)           # back to the headline batch's workspace
+                res["other_batch_sizes"] = other
                 # N3: the same step fed with decoder-layout uint8 frames (normalisation fused into the patch gather)
                 u8 = torch.randint(0, 256, (c["B"], 1, c["T"], 224, 224, 3), dtype=torch.uint8, device=device)
                 ms_u8 = event_time_ms(lambda: model(ids, torch.zeros_like(ids), amask, u8, vmask), 10)
