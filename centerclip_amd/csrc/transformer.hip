@@ -323,7 +323,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
 //   per-wave 2 KB strip.  All global loads of a head (7 V + 8 K + 2 Q per lane) are issued up front.
 // Covers L = 50 (ViT-B/32 and every K = 49 clustered block) and the 32-token text tower.
 #define ATTW_KT 64
+// debug hook (declared in no header): per-workgroup real-time stamps of wave 0 (entry, operands staged, exit), 100 MHz
+__device__ long long* g_att_prof = nullptr;
+extern "C" void cc_debug_set_att_profile(long long* dev_buf) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_att_prof), &dev_buf, sizeof(dev_buf));
+}
+#define ATT_STAMP(slot)                                                                                              \
+    do {                                                                                                             \
+        if (aprof && threadIdx.x == 0 && blockIdx.x < 4096) aprof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)wall_clock64(); \
+    } while (0)
 __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float scale) {
+    long long* aprof = g_att_prof;
+    ATT_STAMP(0);
     __shared__ __attribute__((aligned(16))) _Float16 lds[4][ATT_D * ATTW_KT + 2 * 16 * (ATTW_KT + 8)];   // V^T + two P strips
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = blockIdx.x * 4 + wave;
@@ -384,6 +395,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    ATT_STAMP(1);
 
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -451,7 +463,9 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
         }
         __builtin_amdgcn_wave_barrier();
     }
+    ATT_STAMP(2);
 }
+#undef ATT_STAMP
 
 // ============================================================================ embeddings
 // conv1 as GEMM: A[f*n + (ph*g + pw)][c*p*p + kh*p + kw] = video[f][c][ph*p+kh][pw*p+kw]  (fp16)
