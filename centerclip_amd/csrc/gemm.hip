@@ -712,9 +712,10 @@ static int pick_tile(const GemmArgs& g, int epi) {
     if (n128 && mt128 * (g.N / 128) >= 300) return 1;
     if (n128 && mt64 * (g.N / 128) >= 400) return 3;
     if (mt128 * (g.N / 64) >= 400) return 2;
-    // long-K problems on the small tile: 128-deep k-steps (c_proj of the clustered blocks 25.5 -> 21.2 us alone,
-    // 2.158 vs 2.166 ms per step; the short-K out_proj loses with it)
-    return (g.K % 128 == 0 && g.K >= 2048) ? 8 : 4;
+    // the small tile with 128-deep k-steps: c_proj of the clustered blocks 25.5 -> 21.2 us alone, 2.158 vs 2.166 ms per step;
+    // since the round-3 loop (pinned phase-start wait) their out_proj (K = 768) gains too: 9.8 vs 10.7 us alone, 2.048-2.058
+    // vs 2.059-2.061 ms per step in 3 same-session A/B rounds
+    return (g.K % 128 == 0 && g.K >= 768) ? 8 : 4;
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
