@@ -22,12 +22,13 @@ def run(mode, dist, work, n=200):
     e0.record()
     for _ in range(n): one()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    bad = err.cpu().tolist(); err.zero_()
+    return e0.elapsed_time(e1) / n * 1e3, bad
 for work in (0, 20):
-    base = run(0, 8, work)
+    base, _ = run(0, 8, work)
     line = f"k-loop stand-in {work:2d}: no exchange {base:6.1f} us"
     for mode, name in ((1, "release / acquire fences"), (2, "vmcnt(0) + acquire")):
         for dist, where in ((8, "same XCD"), (1, "next XCD")):
-            t = run(mode, dist, work)
-            line += f" | {name}, {where}: {t:6.1f}"
-    print(line, "| give-ups, wrong sums:", err.cpu().tolist(), flush=True)
+            t, bad = run(mode, dist, work)
+            line += f" | {name}, {where}: {t:6.1f} (give-ups {bad[0]}, stale reads {bad[1]})"
+    print(line, flush=True)
