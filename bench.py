@@ -124,7 +124,8 @@ def graph_time_ms(fn, launches=20, replays=4):
 
 
 TILES = {1: (128, 128, 2, 2, 64), 2: (128, 64, 2, 2, 64), 3: (64, 128, 2, 2, 64), 4: (64, 64, 2, 2, 64),
-         5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128)}
+         5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128),
+         9: (256, 256, 2, 4, 64)}          # 9: split-K, two workgroups per tile (last template argument 2)
 
 
 def kernel_symbol(M, N, K, epi):
@@ -132,7 +133,7 @@ def kernel_symbol(M, N, K, epi):
     from centerclip_amd import _lib as L
     t = L.lib().cc_linear_tile_for(M, N, K, epi)
     bm, bn, wm, wn, bk = TILES[t]
-    return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
+    return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk, 2 if t == 9 else 1)
 
 
 def pmc_traffic(symbol):
@@ -145,8 +146,10 @@ def pmc_traffic(symbol):
         return None
     data = json.load(open(files[-1]))
     key = symbol.replace(" ", "")
+    # (profiles committed before the split-K template argument existed name the one-workgroup forms without it)
+    keys = (key, key[:-3] + ">") if key.endswith(",1>") else (key,)
     for name, v in data.items():
-        if key in name.replace(" ", ""):
+        if any(k in name.replace(" ", "") for k in keys):
             return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch_bytes": round(v["fetch_bytes_per_launch"]),
                     "write_bytes": round(v["write_bytes_per_launch"]),
                     "source": "committed profile profiles/%s (PMC pass of an earlier run, not measured here)" % os.path.basename(files[-1])}
@@ -179,7 +182,7 @@ def insitu_gemm_times(step, reps=6):
     for i in range(n):
         assert lib.cc_debug_gemm_timing_read(i, ctypes.byref(us), info) == 0
         bm, bn, wm, wn, epi, bk, m0, n0, k0, m1, n1, k1 = list(info)
-        sym = "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
+        sym = "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk & 0xffff, max(1, bk >> 16))
         e = out.setdefault(sym, dict(us=0.0, launches=0, flops=0.0, shapes={}))
         e["us"] += us.value
         e["launches"] += 1

@@ -75,6 +75,8 @@ def _declare(lib):
     lib.cc_spectral_workspace_bytes.argtypes = [i32, i32, i32]
     lib.cc_spectral_workspace_bytes.restype = sz
     lib.cc_spectral_embedding_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]
+    lib.cc_spectral_embedding_solver_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, sz, vp]
+    lib.cc_spectral_embedding_solver_f32.restype = c.c_int
     lib.cc_spectral_embedding_f32.restype = c.c_int
     lib.cc_spectral_laplacian_f32.restype = c.c_int
     lib.cc_svd_sign_flip_f32.restype = c.c_int

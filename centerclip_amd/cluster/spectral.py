@@ -57,10 +57,12 @@ def spectral_laplacian(X, sigma=2.5, mode='HeatKernel', spatial_temporal_graph=N
 
 
 @torch.no_grad()
-def spectral_embedding(L_sym, K, correct_sign=False):
-    """-> (Q [B,N,K] = the reference's U[:, :, -K:] up to sign / rotations inside degenerate eigenspaces, eigenvalues [B,K])."""
+def spectral_embedding(L_sym, K, correct_sign=False, solver="auto"):
+    """-> (Q [B,N,K] = the reference's U[:, :, -K:] up to sign / rotations inside degenerate eigenspaces, eigenvalues [B,K]).
+    solver: 'auto' (the direct solver wherever it applies) or 'jacobi' (the one-sided Jacobi kernel for every shape)."""
     L.require_device(L_sym)
-    Q, ev, _ = torch.ops.centerclip.spectral_embedding(L_sym.float().contiguous(), int(K), bool(correct_sign))
+    Q, ev, _ = torch.ops.centerclip.spectral_embedding(L_sym.float().contiguous(), int(K), bool(correct_sign),
+                                                       {"auto": 0, "jacobi": 1}[solver])
     return Q[:, :, :K], ev
 
 

@@ -49,7 +49,17 @@ struct GemmArgs {
     // any value >= n_valid (unaligned rows fall back to scalar stores).  The similarity GEMM of similarity.hip.
     float out_scale;
     int n_valid;
+    // Split-K workspace (host side only reads it from p[0]): CC_GEMM_SK_WS_BYTES of device memory whose first
+    // CC_GEMM_SK_FLAG_BYTES are zero before the first launch that uses it (every launch leaves them zero again).  Null:
+    // the dispatcher never picks a split-K form.
+    void* sk_ws;
 };
+
+// Split-K exchange area: [flags: 4096 ints][slots of 256 KB: one 256x256 fp32 partial tile, or two half tiles]
+#define CC_GEMM_SK_FLAG_BYTES (16 * 1024)
+#define CC_GEMM_SK_SLOT_BYTES (256 * 1024)
+#define CC_GEMM_SK_MAX_SLOTS 256
+#define CC_GEMM_SK_WS_BYTES ((size_t)CC_GEMM_SK_FLAG_BYTES + (size_t)CC_GEMM_SK_MAX_SLOTS * CC_GEMM_SK_SLOT_BYTES)
 
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
 // visual and the text tower: the small text problem rides in the tail round of the large one).
@@ -57,6 +67,9 @@ struct GemmPair {
     GemmArgs p[2];
     int tiles0;          // workgroups [0, tiles0) -> p[0], the rest -> p[1]
     int rider_prio;      // raise the wave priority of p[1]'s workgroups
+    int* sk_flags;       // split-K forms: the exchange area (see CC_GEMM_SK_WS_BYTES)
+    unsigned char* sk_slots;
+    int* sk_error;       // set to 1 when a bounded spin gave up (never in a healthy run)
 };
 
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st);
@@ -132,12 +145,13 @@ int cc_launch_head_project(const float* h, int row_mul, const int* row_idx, cons
 
 // cluster.hip: cc_token_gather_f32 / cc_token_cluster_variant_f32 with by-products for the next block's folded ln_1
 // (row_h16 [rows][W] fp16 copy of the dense output rows, row_stats [rows][2] their (sum, sum of squares))
+#define CC_INTERNAL __attribute__((visibility("hidden")))      /* shared between translation units, not exported */
 extern "C" {
-int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+CC_INTERNAL int cc_token_gather_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                          int32_t T_new, int32_t n, int32_t W, int32_t K, const int64_t* medoids, float* out,
                          int64_t out_tok_stride, int64_t out_frame_stride, _Float16* row_h16, float* row_stats,
                          float* row_shift, void* stream);
-int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
+CC_INTERNAL int cc_token_cluster_variant_rows(const float* x, int64_t in_tok_stride, int64_t in_frame_stride, int32_t B, int32_t T,
                                   int32_t T_new, int32_t n, int32_t W, int32_t K, int32_t metric, float norm_p,
                                   float threshold, int32_t iter_limit, int32_t split_size, int32_t pre_norm,
                                   const cc_cluster_variant* var, float* out, int64_t out_tok_stride,

@@ -467,12 +467,18 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 #define SEL_MAX_E 16   /* N <= 1023: ATen's row sum folds its accumulators once (pass 16) below 1024 terms */
 #define SEL_MAX_N 1023
 
-// debug hook (not part of the public ABI): per-problem phase timestamps of K2
+// development builds (-DCC_DEV_KNOBS) only: per-problem phase timestamps of K2
+#ifdef CC_DEV_KNOBS
 __device__ long long* g_sel_prof = nullptr;
+#define SEL_PROF_INIT() long long* prof = g_sel_prof
 #define SEL_STAMP(slot)                                                      \
     do {                                                                     \
         if (prof && tid == 0) prof[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
+#else
+#define SEL_PROF_INIT() constexpr long long* prof = nullptr        /* (the stamp code folds away) */
+#define SEL_STAMP(slot) do { } while (0)
+#endif
 
 // Position of token j in the order in which ATen's CPU row sum (SumKernel.cpp cascade_sum, 8-float vectors; the
 // arithmetic of fast_kmeans.py:82) consumes the N terms of a row.  The sum is a fixed tree:
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)p * N * N;
     const float* Dg = dist_in + base;
-    long long* prof = g_sel_prof;
+    SEL_PROF_INIT();
     SEL_STAMP(0);
 
     // ---- stage D: (d - chunk_max) - 1, then the diagonal - 1 (cluster_utils.py:35-41); 8 loads in flight
@@ -1589,9 +1595,11 @@ bool p_supported(int metric, float p) { return metric == CC_METRIC_COSINE || (p 
 
 extern "C" {
 
-int cc_debug_set_select_profile(long long* buf) {   // debug only; buf [P,16] int64 device memory or NULL
+#ifdef CC_DEV_KNOBS
+int cc_debug_set_select_profile(long long* buf) {   // development builds only; buf [P,16] int64 device memory or NULL
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), &buf, sizeof(buf)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
+#endif
 
 size_t cc_spectral_workspace_bytes(int32_t P, int32_t N, int32_t K) {
     if (P <= 0 || N <= 0 || K <= 0) return 0;
@@ -2349,14 +2357,12 @@ size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N) {
     return jac > big ? jac : big;
 }
 
-// DEBUG hook (declared in no header, process-wide): 1 = always the Jacobi kernel, 0 = the direct solver where it applies.
-static int g_force_jacobi = 0;
-void cc_debug_set_eig_jacobi(int on) { g_force_jacobi = on; }
-
-int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
-                              float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
-                              void* stream) {
+int cc_spectral_embedding_solver_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
+                                     float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, int32_t solver,
+                                     void* ws, size_t ws_bytes, void* stream) {
     if (!laplacian || !Q || P <= 0 || N <= 1 || K <= 0 || K > N || ldq < K) return CC_ERR_INVALID;
+    if (solver != CC_EIG_AUTO && solver != CC_EIG_JACOBI) return CC_ERR_INVALID;
+    const bool g_force_jacobi = solver == CC_EIG_JACOBI;
     if (N > 640) return CC_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ldq > K && hipMemsetAsync(Q, 0, (size_t)P * N * ldq * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
@@ -2392,6 +2398,13 @@ int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int3
 #undef EIG_LAUNCH
     CC_LAUNCH_CHECK();
     return CC_OK;
+}
+
+int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
+                              float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
+                              void* stream) {
+    return cc_spectral_embedding_solver_f32(laplacian, P, N, K, correct_sign, Q, ldq, eigenvalues, sweeps_out, CC_EIG_AUTO,
+                                            ws, ws_bytes, stream);
 }
 
 int cc_svd_sign_flip_f32(float* U, const float* S, const float* VT, int32_t P, int32_t M, int32_t K, int32_t N,

@@ -1022,8 +1022,10 @@ long long* g_td_prof = nullptr;
 
 }  // namespace
 
-// DEBUG hook (declared in no header, process-wide): wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries.
+// development builds (-DCC_DEV_KNOBS) only: wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries.
+#ifdef CC_DEV_KNOBS
 extern "C" void cc_debug_set_eig_profile(long long* dev_buf) { g_td_prof = dev_buf; }
+#endif
 
 bool cc_sym_eig_tridiag_supports(int N, int K) {
     if (N < 3 || N > 196 || K < 1 || K > 64 || K > N) return false;

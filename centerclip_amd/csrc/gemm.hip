@@ -39,30 +39,51 @@ __device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// debug hook (not part of the public ABI): per-workgroup phase timestamps (entry, prologue done, loop done, exit)
+// development builds (-DCC_DEV_KNOBS) only: per-workgroup phase timestamps (entry, prologue done, loop done, exit)
+#ifdef CC_DEV_KNOBS
 __device__ long long* g_gemm_prof = nullptr;
 #ifdef CC_STAMP_WALL
-#define GEMM_CLOCK() wall_clock64()                       /* 100 MHz: a timeline in real time (dev builds) */
+#define GEMM_CLOCK() wall_clock64()                       /* 100 MHz: a timeline in real time */
 #else
 #define GEMM_CLOCK() __builtin_readcyclecounter()
 #endif
+#define GEMM_PROF_INIT() long long* prof = g_gemm_prof
 #define GEMM_STAMP(slot)                                                                                        \
     do {                                                                                                        \
         if (prof && threadIdx.x == 0) prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)GEMM_CLOCK(); \
     } while (0)
+#else
+#define GEMM_PROF_INIT() do { } while (0)
+#define GEMM_STAMP(slot) do { } while (0)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {          // lane exchange inside a 16-lane DPP row (bit pattern)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
+// sc1 (write-through / L1-bypassing) 16-byte accesses for data handed from one workgroup to another inside a launch:
+// correct wherever the two workgroups run (the per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+}
+
+// SK = 2: split-K over two workgroups per output tile (the N = 768 residual GEMMs: 114 tiles of 256x256 would leave more
+// than half of the CUs idle, the 256x128 tile that fills them is 30 % slower per flop).  Workgroup ids b and b + 8 (same
+// XCD, dispatched back to back) form a pair: each runs one half of the k range over the whole tile, then they swap
+// halves of the accumulator - the fragment-row groups i = 2*ii + 1 go from k-half 0 to k-half 1 and the groups i = 2*ii
+// the other way, in accumulator layout (1 KB per fragment and wave: fully coalesced both ways), through sc1 stores /
+// loads and one flag per direction - and each finishes the epilogue of its 128 rows.  own + partner's is a two-term sum,
+// so the result does not depend on which of the two arrives first.
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
-    long long* prof = g_gemm_prof;
+    GEMM_PROF_INIT();
     GEMM_STAMP(0);
     const bool second = (int)blockIdx.x >= pr.tiles0;
     GemmArgs g = second ? pr.p[1] : pr.p[0];
     if (g.m_dev) g.M = *g.m_dev;                             // device-side row count (compacted captions): wave-uniform
+    static_assert(SK == 1 || (SK == 2 && EPI == EPI_F32_RESID_STATS && BM == 256 && BN == 256), "split-K form");
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -73,6 +94,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // tiles (tn fastest) so tiles sharing an A panel hit the same L2.
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = (int)blockIdx.x - (second ? pr.tiles0 : 0);
+    int khalf = 0, sk_pair = 0;
+    if constexpr (SK == 2) {                                 // ids 16u .. 16u+7: k-half 0 of tiles 8u .. 8u+7; 16u+8 .. 16u+15: k-half 1
+        khalf = (bid >> 3) & 1;
+        bid = ((bid >> 4) << 3) | (bid & 7);
+        if (bid >= nwg) return;                              // (the grid is rounded up to whole groups of 16)
+        sk_pair = (second ? (pr.tiles0 >> 1) : 0) + bid;
+    }
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -99,12 +127,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
     for (int q = 0; q < A_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8;
+        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        bsrc[q] = g.W + (int64_t)(col0 + r) * g.K + c * 8;
+        bsrc[q] = g.W + (int64_t)(col0 + r) * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
@@ -116,17 +144,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     };
 
     f32x4 acc[MI][NI];
+    // Residual epilogues: the accumulators START from the residual rows (h += a W^T + b is accumulated on top of h), read
+    // here in accumulator layout while the first stage is in flight - the epilogue then only stores (asynchronous), instead
+    // of every workgroup of the round fetching its fp32 tile at the same moment after its last MFMA.
+#ifdef CC_NO_RESID_ACC_INIT
+    constexpr bool ACC_INIT = false;
+#else
+    constexpr bool ACC_INIT = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) && SK == 1;
+#endif
+    if constexpr (!ACC_INIT) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK / SK);
     // The rider's tiles are the ones that spill into a second round when the carrier alone fills the slots (the
     // clustered blocks): served first by the CU's arbiters they free their slots sooner for the tiles still queued.
     const bool rider_first = second && pr.rider_prio;
     if (rider_first) __builtin_amdgcn_s_setprio(2);
     stage(0, 0);
+    if constexpr (ACC_INIT) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int m = min(row0 + wr * (BM / WM) + i * 16 + (lane & 15), g.M - 1);
+                const int n = col0 + wc * (BN / WN) + j * 16 + (lane >> 4) * 4;
+                acc[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + n);
+            }
+    }
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
     float row_mu = 0.f, row_rs = 1.f;
@@ -421,9 +469,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
             for (int r0 = 0; r0 < RH; r0 += RPI) {
                 const int m = row0 + wr * WTM + h0 + r0 + lr;
-                if (lane_on && m < g.M)
-                    *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) =
-                        *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
+                if (lane_on && m < g.M) {
+                    const h8 ov = *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
+#if defined(CC_F16OUT_POLICY) && CC_F16OUT_POLICY == 1          /* A/B builds: non-temporal / write-through stores of the fp16 outputs */
+                    __builtin_nontemporal_store(ov, reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc));
+#elif defined(CC_F16OUT_POLICY) && CC_F16OUT_POLICY == 2
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb),
+                                                           (int)(((int64_t)m * g.ldc + col0 + wc * WTN + lc) * 2), 0, 16);
+#else
+                    *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = ov;
+#endif
+                }
             }
             if (h0 + RH < WTM) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -455,7 +511,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     }
     const int er = lane / LPRF, ec = (lane % LPRF) * 4;           // this lane's row (within a pass) and column
     const int ncol = col0 + wc * WTN + ec;
-    auto out_row = [&](int i, int ps) { return row0 + wr * WTM + i * 16 + ps * RPP + er; };
+    // (split-K: register group i = 2*ii holds the fragment-row group 2*ii + khalf after the exchange below)
+    auto out_row = [&](int i, int ps) { return row0 + wr * WTM + (i + khalf) * 16 + ps * RPP + er; };
     // The fp32 residual rows come from HBM: they are fetched one fragment-row group ahead (issued before this
     // group's stores - a load behind a store to the same buffer cannot be hoisted by the compiler).
     float4 resv[2][PASSES];
@@ -466,10 +523,62 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             resv[slot][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + ncol);
         }
     };
-    if (RESID) fetch_residual(0, 0);
+    constexpr bool RESID_LOAD = RESID && !ACC_INIT;             // the residual is still to be fetched and added
+    if constexpr (SK == 2) {
+        // ---- swap accumulator halves with the partner workgroup (see the comment above the kernel)
+        constexpr int HALF_SLOT = CC_GEMM_SK_SLOT_BYTES / 2, FR = (MI / 2) * NI;     // 16 fragments of 1 KB per wave each way
+        const __amdgpu_buffer_rsrc_t wr_rs = sk_rsrc(pr.sk_slots + (size_t)(sk_pair * 2 + khalf) * HALF_SLOT);
+        const __amdgpu_buffer_rsrc_t rd_rs = sk_rsrc(pr.sk_slots + (size_t)(sk_pair * 2 + (khalf ^ 1)) * HALF_SLOT);
+        const int xoff = (wave * FR * 64 + lane) * 16;
+        if (khalf == 0) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if (RESID && i + 1 < MI) fetch_residual((i + 1) & 1, i + 1);
+            for (int ii = 0; ii < MI / 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[2 * ii + 1][j]), wr_rs,
+                                                           xoff + (ii * NI + j) * 1024, 0, 16);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < MI / 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[2 * ii][j]), wr_rs,
+                                                           xoff + (ii * NI + j) * 1024, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's half has left the CU ...
+        __syncthreads();                                           // ... and so has everybody else's
+        int* myflag = pr.sk_flags + sk_pair * 2 + khalf;
+        int* pflag = pr.sk_flags + sk_pair * 2 + (khalf ^ 1);
+        if (tid == 0) __hip_atomic_store(myflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (khalf) {                                              // own groups into the even register groups
+#pragma unroll
+            for (int ii = 0; ii < MI / 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[2 * ii][j] = acc[2 * ii + 1][j];
+        }
+        if (RESID_LOAD) fetch_residual(0, 0);                      // (in flight while the partner finishes)
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > 20000000ll) { *pr.sk_error = 1; break; }   // 0.2 s: never in a healthy run
+            }
+            __hip_atomic_store(pflag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zeros
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < MI / 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_rs, xoff + (ii * NI + j) * 1024, 0, 16));
+                acc[2 * ii][j] += o;
+            }
+    } else {
+        if (RESID_LOAD) fetch_residual(0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; i += SK) {
+        if (RESID_LOAD && i + SK < MI) fetch_residual(((i / SK) + 1) & 1, i + SK);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float4 bb = biasv[j];
@@ -483,13 +592,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             const int m = flane_on ? out_row(i, ps) : g.M;         // (idle lane slots of a 48-wide wave tile store nothing)
             float4 v = *reinterpret_cast<const float4*>(fstg + (ps * RPP + er) * LDF + (flane_on ? ec : 0));
             if (RESID) {
-                const float4 c = resv[i & 1][ps];
-                v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                if (RESID_LOAD) {
+                    const float4 c = resv[(i / SK) & 1][ps];
+                    v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                }
+#if defined(CC_RESID_STORE_POLICY) && CC_RESID_STORE_POLICY == 1        /* A/B builds: non-temporal / write-through residual stores */
+                if (m < g.M) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol));
+#elif defined(CC_RESID_STORE_POLICY) && CC_RESID_STORE_POLICY == 2
+                if (m < g.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), sk_rsrc(g.C), (int)(((int64_t)m * g.ldc + ncol) * 4), 0, 16);
+#else
                 if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
+#endif
                 if (STATS) {
                     // the consumer multiplies fp16(h - c_row): without the centring the rounding error of the copy scales
                     // with |mean| / sigma of the row (LayerNorm itself is shift invariant, so the consumer is unchanged)
-                    const float cr = centred ? rowsh[wr * WTM + i * 16 + ps * RPP + er] : 0.f;
+                    const float cr = centred ? rowsh[wr * WTM + (i + khalf) * 16 + ps * RPP + er] : 0.f;
                     const h4 o = {(_Float16)(v.x - cr), (_Float16)(v.y - cr), (_Float16)(v.z - cr), (_Float16)(v.w - cr)};
                     if (m < g.M) *reinterpret_cast<h4*>(g.c16 + (int64_t)m * g.ldc + ncol) = o;
                     if (centred && g.shift_out && tn == 0 && wc == 0 && (lane % LPRF) == 0 && m < g.M) g.shift_out[m] = cr;
@@ -534,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 }
             }
         }
-        if (i + 1 < MI) {                                         // the strip is rewritten by the next group
+        if (i + SK < MI) {                                        // the strip is rewritten by the next group
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
@@ -542,24 +659,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     GEMM_STAMP(3);
 }
 
-extern "C" {
-// arm: up to `cap` launches from now on are bracketed by events (previous records are dropped); cap <= 0 disarms
-int cc_debug_gemm_timing_begin(int cap);
-// disarm; -> number of launches recorded
-int cc_debug_gemm_timing_end(void);
-// launch i (the stream must have been synchronised): *us_out = stop - start of the dispatch in microseconds; + the launch's
-// 12-int record (see GemmTiming)
-int cc_debug_gemm_timing_read(int i, float* us_out, int* info12_out);
-}
-
-extern "C" int cc_debug_set_gemm_profile(long long* p) {   // debug only; p [workgroups, 4] int64 device memory or NULL
+#ifdef CC_DEV_KNOBS
+extern "C" int cc_debug_set_gemm_profile(long long* p) {   // development builds only; p [workgroups, 4] int64 device memory or NULL
     return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &p, sizeof(p)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
+#endif
 
 namespace {
 
-// Debug hook (cc_debug_gemm_timing_*, not part of the public ABI; process-wide, not thread-safe - a measurement aid for
-// bench.py): while armed, every launch of gemm_f16_kernel goes through hipExtLaunchKernelGGL with a start and a stop
+// Diagnostics (cc_debug_gemm_timing_*, declared in the diagnostics section of the public header; process-wide, not
+// thread-safe - a measurement aid for bench.py): while armed, every launch of gemm_f16_kernel goes through hipExtLaunchKernelGGL with a start and a stop
 // event, which receive the dispatch's own begin / end timestamps (what rocprofv3's kernel trace reads too) - so the
 // duration of a kernel symbol can be read IN SITU, inside the eagerly launched step between its real neighbours, instead
 // of from a stand-alone loop, and without the 2.5 - 5 us an event record of its own adds around a launch (measured: two
@@ -568,13 +677,13 @@ struct GemmTiming {
     bool armed = false;
     int count = 0, cap = 0;
     hipEvent_t* ev = nullptr;          // [2 * cap]: kernel start, kernel stop
-    int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK, M0, N0, K0, M1, N1, K1
+    int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK | SK << 16, M0, N0, K0, M1, N1, K1
 } g_timing;
 
-template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
-    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK>;
+    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK, SK>;
     if (smem > 64 * 1024) {
         static bool configured = false;      // per instantiation; benign race (idempotent call)
         if (!configured) {
@@ -587,7 +696,7 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     const int tid = (g_timing.armed && g_timing.count < g_timing.cap) ? g_timing.count++ : -1;
     if (tid >= 0) {
         const bool two = total > pr.tiles0;
-        const int rec[12] = {BM, BN, WM, WN, EPI, BK, pr.p[0].M, pr.p[0].N, pr.p[0].K,
+        const int rec[12] = {BM, BN, WM, WN, EPI, BK | (SK << 16), pr.p[0].M, pr.p[0].N, pr.p[0].K,
                              two ? pr.p[1].M : 0, two ? pr.p[1].N : 0, two ? pr.p[1].K : 0};
         memcpy(g_timing.info[tid], rec, sizeof(rec));
         hipExtLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), (unsigned)smem, st, g_timing.ev[2 * tid],
@@ -636,6 +745,54 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     }
 }
 
+// 256x256 tiles, two workgroups per tile (split-K, see the kernel): the residual epilogue only
+int launch_tile_sk2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
+    GemmPair pr{};
+    auto groups = [](const GemmArgs& g) { return (g.tiles_m * g.tiles_n + 7) / 8; };   // groups of 8 tiles = 16 workgroups
+    g0.tiles_m = (g0.M + 255) / 256;
+    g0.tiles_n = g0.N / 256;
+    pr.p[0] = g0;
+    pr.tiles0 = groups(g0) * 16;
+    int total = pr.tiles0;
+    if (g1) {
+        pr.p[1] = *g1;
+        pr.p[1].tiles_m = (g1->M + 255) / 256;
+        pr.p[1].tiles_n = g1->N / 256;
+        total += groups(pr.p[1]) * 16;
+    } else {
+        pr.p[1] = g0;
+    }
+    if (total / 2 > CC_GEMM_SK_MAX_SLOTS / 2 * 2 || !g0.sk_ws) return CC_ERR_INVALID;
+    pr.sk_flags = static_cast<int*>(g0.sk_ws);
+    pr.sk_error = pr.sk_flags + CC_GEMM_SK_FLAG_BYTES / 4 - 1;
+    pr.sk_slots = static_cast<unsigned char*>(g0.sk_ws) + CC_GEMM_SK_FLAG_BYTES;
+    return launch_one<256, 256, 2, 4, EPI_F32_RESID_STATS, GEMM_BK, 2>(pr, total, st);
+}
+
+// The split-K form pays when its grid is one nearly full round of workgroups that are all resident at once (the partners
+// wait for each other) - the N = 768 residual GEMMs of the full-size blocks.
+static int g_num_cus = 0;
+bool sk2_applies(const GemmArgs& g0, const GemmArgs* g1) {
+#ifndef CC_SPLITK_AUTO
+    // Measured (profiles/r04_splitk.txt): slower than the one-workgroup 256x128 tile on the shapes it was built for (out_proj
+    // 33.6 vs 25.4 us, c_proj 60.6 vs 55.8 us) - these launches are bound by the fp32 residual stream of their epilogue, which
+    // the exchange doubles.  The form stays selectable (tile 9) and tested; the dispatcher does not pick it.
+    return false;
+#endif
+    if (!g0.sk_ws || g0.row_step || g0.row_map) return false;
+    auto ok = [](const GemmArgs& g) { return (g.N % 256) == 0 && (g.K % 128) == 0; };
+    if (!ok(g0) || (g1 && !ok(*g1))) return false;
+    auto wgs = [](const GemmArgs& g) { return ((((g.M + 255) / 256) * (g.N / 256) + 7) / 8) * 16; };
+    const int total = wgs(g0) + (g1 ? wgs(*g1) : 0);
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        const bool have = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
+        g_num_cus = have ? prop.multiProcessorCount : 256;         // (no device: the host-side queries answer for an MI355X)
+    }
+    return total <= g_num_cus && total <= CC_GEMM_SK_MAX_SLOTS && total * 4 >= g_num_cus * 3;
+}
+
 // tiles whose wave tile is 48 columns wide exist for the fp16-output epilogues and the plain fp32 one
 template <int BM, int BN, int WM, int WN>
 int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
@@ -680,8 +837,8 @@ static bool gemm_shape_ok(const GemmArgs& g) {
 static bool epi_is_f16(int epi) {
     return epi == EPI_F16 || epi == EPI_F16_GELU || epi == EPI_F16_LN || epi == EPI_F16_GELU_LN;
 }
-static int tile_bn(int tile) { return tile == 5 ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
-static int tile_bk(int tile) { return tile == 8 ? 128 : GEMM_BK; }
+static int tile_bn(int tile) { return (tile == 5 || tile == 9 || tile == 10) ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
+static int tile_bk(int tile) { return (tile == 8 || tile == 9) ? 128 : GEMM_BK; }     // (9: two k-halves of whole 64-deep steps)
 
 static int pick_tile(const GemmArgs& g, int epi) {
     // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
@@ -719,11 +876,13 @@ static int pick_tile(const GemmArgs& g, int epi) {
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
-// 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0)
+// 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0); 9 = 256x256 split-K (two
+// workgroups per tile, residual epilogue, needs the exchange scratch); 10 = 128x256 (8 waves)
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
     if (tile == 0) {
         tile = pick_tile(g0, epi);
+        if (epi == EPI_F32_RESID_STATS && sk2_applies(g0, g1)) tile = 9;
 #ifdef CC_DEV_KNOBS
         // tuning aid (development builds only, -DCC_DEV_KNOBS): CC_TILE_E<epi>_<S|B>[_K<k>]=<tile> overrides the choice for
         // small (M < 5000) / big problems; the environment is scanned once
@@ -736,23 +895,24 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             char name[32];
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
-            if (ov && ov[0] >= '1' && ov[0] <= '8') tile = ov[0] - '0';
+            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10) tile = atoi(ov);
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c_K%d", epi, g0.M < 5000 ? 'S' : 'B', g0.K);   // one shape only
             ov = getenv(name);
-            if (ov && ov[0] >= '1' && ov[0] <= '8') tile = ov[0] - '0';
+            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10) tile = atoi(ov);
         }
 #endif
-        if (g1) {                                  // the rider must be divisible by the carrier's BN
+        if (g1 && tile != 9) {                     // the rider must be divisible by the carrier's BN
             if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7 || tile == 6)) ? 1 : 4;
             if (g1->K % tile_bk(tile)) tile = 4;
         }
     }
     if (tile == 7 && !epi_is_f16(epi) && epi != EPI_F32) return CC_ERR_INVALID;
+    if (tile == 9 && (epi != EPI_F32_RESID_STATS || !g0.sk_ws)) return CC_ERR_INVALID;
     if ((g0.K % tile_bk(tile)) || (g1 && (g1->K % tile_bk(tile)))) return CC_ERR_INVALID;
     const int bn = tile_bn(tile);
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
     if (slots_out) {
-        const int wn = (tile == 5) ? 4 : 2;
+        const int wn = (tile == 5 || tile == 9 || tile == 10) ? 4 : 2;
         slots_out[0] = g0.N / bn * wn;
         slots_out[1] = g1 ? g1->N / bn * wn : 0;
         if (slots_out[0] > CC_LN_MAX_SLOTS || slots_out[1] > CC_LN_MAX_SLOTS) return CC_ERR_UNSUPPORTED;
@@ -766,6 +926,8 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         case 6: return launch_tile<256, 128, 4, 2>(g0, g1, epi, st);
         case 7: return launch_tile_f16<256, 192, 2, 4>(g0, g1, epi, st);
         case 8: return launch_tile<64, 64, 2, 2, 128>(g0, g1, epi, st);
+        case 9: return launch_tile_sk2(g0, g1, st);
+        case 10: return launch_tile<128, 256, 2, 4>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
 }
@@ -1027,37 +1189,56 @@ int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, c
 
 /* Host-side query: the tile the dispatcher picks for a stand-alone launch of this shape and epilogue (CC_EPI_* or the
  * internal ids 5 = LN-folded f16, 6 = LN-folded f16 + QuickGELU, 7 = residual + statistics): 1 = 128x128, 2 = 128x64,
- * 3 = 64x128, 4 = 64x64 (4 waves), 5 = 256x256, 7 = 256x192 (8 waves), 8 = 64x64 with 128-deep k-steps; <= 0: unsupported.
+ * 3 = 64x128, 4 = 64x64 (4 waves), 5 = 256x256, 7 = 256x192 (8 waves), 8 = 64x64 with 128-deep k-steps, 9 = 256x256 split-K
+ * (two workgroups per tile; the answer for the residual epilogue called WITH the split-K scratch); <= 0: unsupported.
  * (bench.py names the kernel instantiation a shape runs on with it.) */
 int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K;
     if (!gemm_shape_ok(g) || epilogue < 0 || epilogue > EPI_F32_RESID_STATS) return CC_ERR_INVALID;
+    g.sk_ws = &g;                                    // (any non-null value: only tested) - the answer for a call with the scratch
+    if (epilogue == EPI_F32_RESID_STATS && sk2_applies(g, nullptr)) return 9;
     return pick_tile(g, epilogue);
 }
 
 /* Host-side query: the number of partial-sum slots per row cc_linear_resid_stats_f16 writes for this shape and tile
- * (0 = auto), i.e. (N / tile columns) x (wave columns of the tile); <= 0: the shape / tile is not supported. */
-int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile) {
+ * (0 = auto), i.e. (N / tile columns) x (wave columns of the tile); <= 0: the shape / tile is not supported.
+ * with_ws != 0: the answer for cc_linear_resid_stats_ws_f16 called with a split-K workspace. */
+int cc_linear_resid_stats_slots_ws(int32_t M, int32_t N, int32_t K, int32_t tile, int32_t with_ws) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K;
     if (!gemm_shape_ok(g)) return CC_ERR_INVALID;
-    if (tile == 0) tile = pick_tile(g, EPI_F32_RESID_STATS);
-    if (tile < 1 || tile > 8 || tile == 7 || (K % tile_bk(tile)) || (N % tile_bn(tile))) return CC_ERR_INVALID;
-    const int slots = N / tile_bn(tile) * ((tile == 5) ? 4 : 2);
+    if (tile == 0) {
+        tile = pick_tile(g, EPI_F32_RESID_STATS);
+        g.sk_ws = with_ws ? &g : nullptr;            // (any non-null value: only tested)
+        if (sk2_applies(g, nullptr)) tile = 9;
+    }
+    if (tile < 1 || tile > 10 || tile == 7 || (K % tile_bk(tile)) || (N % tile_bn(tile)) || (tile == 9 && !with_ws)) return CC_ERR_INVALID;
+    const int slots = N / tile_bn(tile) * ((tile == 5 || tile == 9 || tile == 10) ? 4 : 2);
     return slots > CC_LN_MAX_SLOTS ? CC_ERR_UNSUPPORTED : slots;
 }
+int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile) {
+    return cc_linear_resid_stats_slots_ws(M, N, K, tile, 0);
+}
+
+/* Scratch of the split-K forms of the residual Linear (tile 9: two workgroups per 256x256 tile that swap accumulator
+ * halves).  Its first cc_linear_splitk_flag_bytes() bytes must be zero before the first call that uses it; every call
+ * leaves them zero.  One workspace serves any number of calls on ONE stream (calls on different streams need their own). */
+size_t cc_linear_splitk_workspace_bytes(void) { return CC_GEMM_SK_WS_BYTES; }
+size_t cc_linear_splitk_flag_bytes(void) { return CC_GEMM_SK_FLAG_BYTES; }
 
 /* Residual Linear that also emits what the next folded LayerNorm needs: h (fp32, in place) += a W^T + b;
  * h16 = fp16(h - c_row); stats_out [M][*slots_out][2] = per-tile partial (sum, sum of squares) of the fp16 rows;
  * c_row = shift_in[m] + mean of the previous centred copy (stats_in [M][slots_in][2]), written to shift_out [M]
- * (stats_in NULL: c_row = 0). */
-int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
-                              float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
-                              int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
-                              void* stream) {
+ * (stats_in NULL: c_row = 0).  ws (optional): cc_linear_splitk_workspace_bytes() - with it tile 0 may pick, and tile 9
+ * selects, the split-K form. */
+int cc_linear_resid_stats_ws_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
+                                 float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
+                                 int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
+                                 void* ws, size_t ws_bytes, void* stream) {
     if (!a_f16 || !w_f16 || !h || !h16_out || !stats_out || !slots_out) return CC_ERR_INVALID;
     if (stats_in && (slots_in <= 0 || slots_in > CC_LN_MAX_SLOTS || !shift_out)) return CC_ERR_INVALID;
+    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
     GemmArgs g{};
     g.A = static_cast<const _Float16*>(a_f16);
     g.W = static_cast<const _Float16*>(w_f16);
@@ -1067,10 +1248,19 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
     g.c16 = static_cast<_Float16*>(h16_out);
     g.stats_out = stats_out;
     g.shift_in = shift_in; g.shift_stats = stats_in; g.shift_slots = slots_in; g.shift_out = shift_out;
+    g.sk_ws = ws;
     int slots[2] = {0, 0};
     const int rc = cc_gemm_dispatch2(g, nullptr, EPI_F32_RESID_STATS, tile, static_cast<hipStream_t>(stream), slots);
     *slots_out = slots[0];
     return rc;
+}
+
+int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
+                              float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
+                              int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
+                              void* stream) {
+    return cc_linear_resid_stats_ws_f16(a_f16, w_f16, bias, h, h16_out, stats_out, slots_out, shift_in, stats_in, slots_in,
+                                        shift_out, M, N, K, tile, nullptr, 0, stream);
 }
 
 int cc_debug_gemm_timing_begin(int cap) {

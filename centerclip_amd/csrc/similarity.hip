@@ -470,6 +470,55 @@ extern "C" int cc_rank_counts_f32(const float* sim, int32_t rows, int32_t cols, 
     return CC_OK;
 }
 
+// ---------------------------------------------------------------------------- multi-sentence video -> text maxima
+// tensor_video_to_text_sim (utils/metrics.py:68-76): for every (group of sentences, video) the best similarity of the
+// group's sentences; NaN entries (fully masked clips) count as -inf.  out [n_groups, cols] must hold -inf beforehand
+// (group_max_fill_kernel); a thread walks one column over a chunk of rows, keeps the running maximum while the group id
+// repeats (sentences of one video are neighbours) and publishes it with an ordered atomic on a group change - so rows of
+// one group may also be spread over chunks, or over the row blocks of several ranks.
+__global__ void group_max_fill_kernel(float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -INFINITY;
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {      // (finite or -inf values; initial -inf)
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+constexpr int GMAX_ROWS = 64;       // rows per chunk
+__global__ __launch_bounds__(256) void group_max_rows_kernel(const float* __restrict__ sim, int rows, int cols,
+                                                             int64_t row_stride, const int* __restrict__ group,
+                                                             int n_groups, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * GMAX_ROWS, r1 = min(rows, r0 + GMAX_ROWS);
+    if (c >= cols) return;
+    int gcur = -1;
+    float m = -INFINITY;
+    for (int r = r0; r < r1; ++r) {
+        const int g = group[r];
+        if (g != gcur) {
+            if (gcur >= 0 && gcur < n_groups) atomic_max_f32(out + (int64_t)gcur * cols + c, m);
+            gcur = g;
+            m = -INFINITY;
+        }
+        const float v = sim[(int64_t)r * row_stride + c];
+        m = (v == v && v > m) ? v : m;
+    }
+    if (gcur >= 0 && gcur < n_groups) atomic_max_f32(out + (int64_t)gcur * cols + c, m);
+}
+
+extern "C" int cc_group_max_rows_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, const int32_t* group,
+                                     int32_t n_groups, float* out, void* stream) {
+    if (!out || n_groups <= 0 || cols <= 0 || rows < 0 || (rows > 0 && (!sim || !group))) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)n_groups * cols;
+    hipLaunchKernelGGL(group_max_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n);
+    if (rows > 0)
+        hipLaunchKernelGGL(group_max_rows_kernel, dim3((cols + 255) / 256, (rows + GMAX_ROWS - 1) / GMAX_ROWS), dim3(256), 0, st,
+                           sim, rows, cols, row_stride, group, n_groups, out);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 // ============================================================================ N4 (forward part): contrastive loss
 // CrossEn.forward (modules/losses.py:8-18): logpt = log_softmax(sim, -1); loss = mean(-diag(logpt)), and the symmetric
 // form CLIP4Clip.forward builds from it (modules/clip4clip.py:250-253): (CrossEn(sim) + CrossEn(sim^T)) / 2.

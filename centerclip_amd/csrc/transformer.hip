@@ -323,17 +323,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
 //   per-wave 2 KB strip.  All global loads of a head (7 V + 8 K + 2 Q per lane) are issued up front.
 // Covers L = 50 (ViT-B/32 and every K = 49 clustered block) and the 32-token text tower.
 #define ATTW_KT 64
-// debug hook (declared in no header): per-workgroup real-time stamps of wave 0 (entry, operands staged, exit), 100 MHz
+// development builds (-DCC_DEV_KNOBS) only: per-workgroup real-time stamps of wave 0 (entry, operands staged, exit), 100 MHz
+#ifdef CC_DEV_KNOBS
 __device__ long long* g_att_prof = nullptr;
 extern "C" void cc_debug_set_att_profile(long long* dev_buf) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_att_prof), &dev_buf, sizeof(dev_buf));
 }
+#define ATT_PROF_INIT() long long* aprof = g_att_prof
 #define ATT_STAMP(slot)                                                                                              \
     do {                                                                                                             \
         if (aprof && threadIdx.x == 0 && blockIdx.x < 4096) aprof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)wall_clock64(); \
     } while (0)
+#else
+#define ATT_PROF_INIT() do { } while (0)
+#define ATT_STAMP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float scale) {
-    long long* aprof = g_att_prof;
+    ATT_PROF_INIT();
     ATT_STAMP(0);
     __shared__ __attribute__((aligned(16))) _Float16 lds[4][ATT_D * ATTW_KT + 2 * 16 * (ATTW_KT + 8)];   // V^T + two P strips
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

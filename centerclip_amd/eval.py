@@ -48,6 +48,10 @@ class HipBackend:
     def counts_ref_columns(sim, ref_vals):
         return torch.ops.centerclip.rank_counts_ref(sim, ref_vals.contiguous(), True)
 
+    @staticmethod
+    def group_max(sim, groups, n_groups):
+        return torch.ops.centerclip.group_max_rows(sim.contiguous(), groups.to(torch.int32).contiguous(), int(n_groups))
+
 
 class _Cache:
     """Features of the items this process encoded, with their positions in the dataset."""
@@ -259,10 +263,7 @@ def _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world,
     else:
         tv = multi_sentence_metrics_from_counts(counts_tv, np.isfinite(truth_all))
         # ---- video -> text: best sentence of every group per video (utils/metrics.py:68-76), then ranks of the diagonal
-        best = torch.full((n_video, n_video), float("-inf"), device=device)              # [group, video]
-        if nloc:
-            clean = torch.where(block != block, torch.full_like(block, float("-inf")), block)
-            best.scatter_reduce_(0, gt_cols.view(-1, 1).expand(-1, n_video), clean, "amax", include_self=True)
+        best = be.group_max(block if nloc else block.new_zeros((0, n_video)), gt_cols, n_video)      # [group, video]
         if world > 1:
             ccdist.all_reduce_(best, "max")
         vt = metrics_from_counts(be.counts_cols(best.t().contiguous(), torch.arange(n_video, dtype=torch.int32, device=device))[:, :2])

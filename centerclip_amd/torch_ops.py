@@ -168,6 +168,22 @@ def _(h16, w_ln, c1, c2, stats, slots, gelu, eps, tile):
     return h16.new_empty((h16.shape[0], w_ln.shape[0]))
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_ws(t):
+    """Split-K exchange area of the residual Linear, one per (device, stream): zeroed once (every call leaves its flags
+    zero), never freed (a captured graph keeps the address)."""
+    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        nbytes = int(L.lib().cc_linear_splitk_workspace_bytes())
+        ws = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
+        ws[:int(L.lib().cc_linear_splitk_flag_bytes())].zero_()
+        _SPLITK_WS[key] = ws
+    return ws
+
+
 @custom_op(NS + "::linear_resid_stats_f16", mutates_args=("h", "h16", "stats", "shift_out"), device_types="cuda")
 def linear_resid_stats_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], h: torch.Tensor,
                            h16: torch.Tensor, stats: torch.Tensor, shift_in: Optional[torch.Tensor],
@@ -177,9 +193,11 @@ def linear_resid_stats_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torc
     M, K = a.shape
     N = w.shape[0]
     slots = ctypes.c_int32(0)
-    L.check(L.lib().cc_linear_resid_stats_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(h), L.ptr(h16), L.ptr(stats),
-                                              ctypes.byref(slots), L.ptr(shift_in), L.ptr(stats_in), int(slots_in),
-                                              L.ptr(shift_out), M, N, K, tile, _st(a)), "cc_linear_resid_stats_f16")
+    ws = _splitk_ws(a)
+    L.check(L.lib().cc_linear_resid_stats_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(h), L.ptr(h16), L.ptr(stats),
+                                                 ctypes.byref(slots), L.ptr(shift_in), L.ptr(stats_in), int(slots_in),
+                                                 L.ptr(shift_out), M, N, K, tile, L.ptr(ws), ws.numel(), _st(a)),
+            "cc_linear_resid_stats_ws_f16")
 
 
 @linear_resid_stats_f16.register_fake
@@ -188,10 +206,11 @@ def _(a, w, bias, h, h16, stats, shift_in, stats_in, slots_in, shift_out, tile):
 
 
 def resid_stats_slots(M, N, K, tile=0):
-    """Partial-sum slots per row cc_linear_resid_stats_f16 writes for this shape (a host-side query of the tile choice)."""
-    n = L.lib().cc_linear_resid_stats_slots(int(M), int(N), int(K), int(tile))
+    """Partial-sum slots per row the residual Linear writes for this shape (a host-side query of the tile choice; the op
+    always passes the split-K scratch)."""
+    n = L.lib().cc_linear_resid_stats_slots_ws(int(M), int(N), int(K), int(tile), 1)
     if n <= 0:
-        raise L.CenterClipHipError("cc_linear_resid_stats_slots(%d, %d, %d, %d): unsupported shape / tile" % (M, N, K, tile))
+        raise L.CenterClipHipError("cc_linear_resid_stats_slots_ws(%d, %d, %d, %d): unsupported shape / tile" % (M, N, K, tile))
     return n
 
 
@@ -579,10 +598,10 @@ def _(x, frame_major, T, T_new, sigma, mode, knn_k, mutual, graph):
 
 
 @custom_op(NS + "::spectral_embedding", mutates_args=(), device_types="cuda")
-def spectral_embedding(laplacian: torch.Tensor, K: int, correct_sign: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """The decomposition of batch_spectral_clustering (spectral.py:54-61, cc_spectral_embedding_f32): laplacian [P,N,N] ->
-    (Q [P,N,K4] with K4 = K rounded up to 4 and zero padding columns - the k-medoids kernels read 16-byte pieces -,
-    eigenvalues [P,K] in the reference's order, sweeps [P])."""
+def spectral_embedding(laplacian: torch.Tensor, K: int, correct_sign: bool, solver: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The decomposition of batch_spectral_clustering (spectral.py:54-61, cc_spectral_embedding_solver_f32): laplacian [P,N,N]
+    -> (Q [P,N,K4] with K4 = K rounded up to 4 and zero padding columns - the k-medoids kernels read 16-byte pieces -,
+    eigenvalues [P,K] in the reference's order, sweeps [P]).  solver: 0 = CC_EIG_AUTO, 1 = CC_EIG_JACOBI."""
     P, N, _ = laplacian.shape
     K4 = (K + 3) // 4 * 4
     Q = _e(P, N, K4, like=laplacian, dtype=torch.float32)
@@ -590,13 +609,14 @@ def spectral_embedding(laplacian: torch.Tensor, K: int, correct_sign: bool) -> T
     sw = _e(P, like=laplacian, dtype=torch.int32)
     lib = L.lib()
     ws = L.workspace(lib.cc_spectral_embedding_workspace_bytes(P, N), laplacian.device)
-    L.check(lib.cc_spectral_embedding_f32(L.ptr(laplacian), P, N, int(K), int(correct_sign), L.ptr(Q), K4, L.ptr(ev), L.ptr(sw),
-                                          L.ptr(ws), ws.numel(), _st(laplacian)), "cc_spectral_embedding_f32")
+    L.check(lib.cc_spectral_embedding_solver_f32(L.ptr(laplacian), P, N, int(K), int(correct_sign), L.ptr(Q), K4, L.ptr(ev),
+                                                 L.ptr(sw), int(solver), L.ptr(ws), ws.numel(), _st(laplacian)),
+            "cc_spectral_embedding_solver_f32")
     return Q, ev, sw
 
 
 @spectral_embedding.register_fake
-def _(laplacian, K, correct_sign):
+def _(laplacian, K, correct_sign, solver=0):
     P, N, _ = laplacian.shape
     return (laplacian.new_empty((P, N, (K + 3) // 4 * 4)), laplacian.new_empty((P, K)),
             laplacian.new_empty((P,), dtype=torch.int32))
@@ -876,6 +896,23 @@ def _(sim, ref_vals, transpose):
     return sim.new_empty((sim.shape[1] if transpose else sim.shape[0], 2), dtype=torch.int32)
 
 
+@custom_op(NS + "::group_max_rows", mutates_args=(), device_types="cuda")
+def group_max_rows(sim: torch.Tensor, group: torch.Tensor, n_groups: int) -> torch.Tensor:
+    """[n_groups, cols] maxima of sim's rows per group id (int32 [rows]), NaN ignored, -inf for groups without a row:
+    tensor_video_to_text_sim (utils/metrics.py:68-76)."""
+    rows, cols = sim.shape
+    out = _e(int(n_groups), cols, like=sim, dtype=torch.float32)
+    L.check(L.lib().cc_group_max_rows_f32(L.ptr(sim) if rows else None, rows, cols, sim.stride(0) if rows else cols,
+                                          L.ptr(group) if rows else None, int(n_groups), L.ptr(out), _st(sim)),
+            "cc_group_max_rows_f32")
+    return out
+
+
+@group_max_rows.register_fake
+def _(sim, group, n_groups):
+    return sim.new_empty((n_groups, sim.shape[1]))
+
+
 @custom_op(NS + "::contrastive_loss", mutates_args=(), device_types="cuda")
 def contrastive_loss(sim: torch.Tensor) -> torch.Tensor:
     """CrossEn(sim), CrossEn(sim.T) and their mean (modules/losses.py:8-18, clip4clip.py:250-253) -> [3] fp32."""
@@ -897,7 +934,7 @@ OPS = ("contrastive_loss", "contrastive_loss_grad", "spectral_laplacian", "spect
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",
-       "rank_counts_cols", "rank_counts_ref")
+       "rank_counts_cols", "rank_counts_ref", "group_max_rows")
 
 
 def logit_multiplier(logit_scale):

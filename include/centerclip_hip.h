@@ -265,6 +265,14 @@ size_t cc_spectral_workspace_bytes(int32_t P, int32_t N, int32_t K);
 int cc_spectral_embedding_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
                               float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, void* ws, size_t ws_bytes,
                               void* stream);
+/* The same with the solver named: CC_EIG_AUTO = the direct solver wherever it applies (cc_spectral_embedding_f32),
+ * CC_EIG_JACOBI = the one-sided Jacobi kernel for every shape (what shapes outside the direct solver's scope run; the
+ * tests hold both against float64). */
+#define CC_EIG_AUTO   0
+#define CC_EIG_JACOBI 1
+int cc_spectral_embedding_solver_f32(const float* laplacian, int32_t P, int32_t N, int32_t K, int32_t correct_sign,
+                                     float* Q, int32_t ldq, float* eigenvalues, int32_t* sweeps_out, int32_t solver,
+                                     void* ws, size_t ws_bytes, void* stream);
 int cc_svd_sign_flip_f32(float* U, const float* S, const float* VT, int32_t P, int32_t M, int32_t K, int32_t N,
                          void* stream);
 
@@ -333,6 +341,19 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
                               void* h16_out, float* stats_out, int32_t* slots_out, const float* shift_in,
                               const float* stats_in, int32_t slots_in, float* shift_out,
                               int32_t M, int32_t N, int32_t K, int32_t tile, void* stream);
+/* The same with a split-K scratch (tile 9, or tile 0 when the shape calls for it: the N = 768 residual Linears of the
+ * full-size blocks, modules/clip.py:207-211,240,251, run as two workgroups per 256x256 tile that swap accumulator halves).
+ * ws: cc_linear_splitk_workspace_bytes(); its first cc_linear_splitk_flag_bytes() bytes must be ZERO before the first
+ * call that uses it and every call leaves them zero; one workspace per stream.  ws NULL = cc_linear_resid_stats_f16.
+ * cc_linear_resid_stats_slots_ws: the slots query for a call with (with_ws != 0) / without the scratch. */
+size_t cc_linear_splitk_workspace_bytes(void);
+size_t cc_linear_splitk_flag_bytes(void);
+int cc_linear_resid_stats_slots_ws(int32_t M, int32_t N, int32_t K, int32_t tile, int32_t with_ws);
+int cc_linear_resid_stats_ws_f16(const void* a_f16, const void* w_f16, const float* bias, float* h,
+                                 void* h16_out, float* stats_out, int32_t* slots_out, const float* shift_in,
+                                 const float* stats_in, int32_t slots_in, float* shift_out,
+                                 int32_t M, int32_t N, int32_t K, int32_t tile, void* ws, size_t ws_bytes,
+                                 void* stream);
 
 /* Multi-head self-attention core of nn.MultiheadAttention (modules/clip.py:220-226):
  * qkv [nseq*L, 3W] fp16 (row = seq*L + token; q | k | v, heads = contiguous 64-wide slices),
@@ -577,6 +598,29 @@ int cc_rank_counts_cols_f32(const float* sim, int32_t rows, int32_t cols, int64_
  * broadcast ground-truth values (swap the strides to walk columns) and the per-rank counts are summed. */
 int cc_rank_counts_ref_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride,
                            const float* ref_vals, int32_t* counts, void* stream);
+
+/* tensor_video_to_text_sim (utils/metrics.py:68-76) on the device: out [n_groups, cols] = for every group g and column
+ * (video) v the maximum of sim[r, v] over the rows (sentences) r with group[r] == g, NaN entries ignored, -inf where a
+ * group has no row here (a rank's row block of the clip-sharded evaluation: the per-rank results are combined with a MAX
+ * all-reduce).  group [rows] int32 in [0, n_groups); rows = 0 only fills out with -inf. */
+int cc_group_max_rows_f32(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, const int32_t* group,
+                          int32_t n_groups, float* out, void* stream);
+
+/* ==========================================================================================
+ * Diagnostics (not on the product path; process-wide state, not thread-safe).
+ * While armed, every launch of the tiled GEMM kernel is issued with a start / stop event pair that receives the dispatch's
+ * own begin / end timestamps (what rocprofv3 --kernel-trace reads), so a kernel symbol can be timed IN SITU, inside an
+ * eagerly enqueued step between its real neighbours.  bench.py's `roofline` uses it.  Never arm during graph capture.
+ *   cc_debug_gemm_timing_begin(cap)  arm for up to `cap` launches (earlier records are dropped); cap <= 0 disarms + frees
+ *   cc_debug_gemm_timing_end()       disarm; -> number of launches recorded
+ *   cc_debug_gemm_timing_read(i, us_out, info12_out)   (after synchronising the stream) duration of launch i in
+ *        microseconds + its record: BM, BN, WM, WN, epilogue id, BK | split << 16, then M, N, K of the carrier and of the
+ *        rider problem (zeros without a rider).
+ * The per-workgroup stamp hooks (cc_debug_set_*_profile) exist only in development builds (-DCC_DEV_KNOBS).
+ * ========================================================================================== */
+int cc_debug_gemm_timing_begin(int cap);
+int cc_debug_gemm_timing_end(void);
+int cc_debug_gemm_timing_read(int i, float* us_out, int* info12_out);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,19 @@ def test_library_exports_every_declared_symbol(libpath):
     assert lib.cc_status_string(-1) == b"invalid argument"
 
 
+def test_library_exports_nothing_the_header_does_not_declare(libpath):
+    """Every cc_* symbol the shipped library exports is declared in include/centerclip_hip.h: no undeclared entry points,
+    no debug hooks with process-wide state outside the header's diagnostics section (development builds add theirs with
+    -DCC_DEV_KNOBS)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("cc_")
+                       and ln.split()[-2] in ("T", "t", "W")})
+    assert exported, "nm found no cc_ exports"
+    undeclared = [s for s in exported if s not in set(declared_symbols())]
+    assert not undeclared, "exported but not declared in the header: %s" % undeclared
+
+
 def test_workspace_query_and_argument_validation_need_no_gpu(libpath):
     from centerclip_amd import _lib as L
     lib = L.lib()

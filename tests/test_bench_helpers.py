@@ -16,7 +16,7 @@ def _bench():
 
 def test_pmc_traffic_resolves_for_the_profiled_gemms():
     b = _bench()
-    for kernel, algorithmic in (("gemm_f16_kernel<256, 256, 2, 4, 6, 64>", 78.4e6), ("gemm_f16_kernel<256, 128, 4, 2, 7, 64>", 113e6)):
+    for kernel, algorithmic in (("gemm_f16_kernel<256, 256, 2, 4, 6, 64, 1>", 78.4e6), ("gemm_f16_kernel<256, 128, 4, 2, 7, 64, 1>", 113e6)):
         tr = b.pmc_traffic(kernel)
         assert tr is not None, kernel
         assert abs(tr["hbm_bytes_per_launch"] - (tr["fetch_bytes"] + tr["write_bytes"])) <= 2          # (each rounded)
@@ -26,10 +26,10 @@ def test_pmc_traffic_resolves_for_the_profiled_gemms():
 
 def test_kernel_symbol_names_the_instantiation_the_dispatcher_picks():
     b = _bench()
-    assert b.kernel_symbol(9600, 3072, 768, 6) == "gemm_f16_kernel<256, 256, 2, 4, 6, 64>"      # c_fc
-    assert b.kernel_symbol(9600, 2304, 768, 5) == "gemm_f16_kernel<256, 192, 2, 4, 5, 64>"      # in_proj
-    assert b.kernel_symbol(2400, 768, 3072, 7) == "gemm_f16_kernel<64, 64, 2, 2, 7, 128>"       # c_proj, clustered blocks
-    assert b.kernel_symbol(9600, 768, 3072, 7) == "gemm_f16_kernel<256, 128, 4, 2, 7, 64>"      # c_proj: one round of 228 tiles
+    assert b.kernel_symbol(9600, 3072, 768, 6) == "gemm_f16_kernel<256, 256, 2, 4, 6, 64, 1>"      # c_fc
+    assert b.kernel_symbol(9600, 2304, 768, 5) == "gemm_f16_kernel<256, 192, 2, 4, 5, 64, 1>"      # in_proj
+    assert b.kernel_symbol(2400, 768, 3072, 7) == "gemm_f16_kernel<64, 64, 2, 2, 7, 128, 1>"       # c_proj, clustered blocks
+    assert b.kernel_symbol(9600, 768, 3072, 7) == "gemm_f16_kernel<256, 128, 4, 2, 7, 64, 1>"      # c_proj: one round of 228 tiles
 
 
 def test_cluster_pmc_traffic_resolves():

@@ -179,6 +179,14 @@ class _TorchBackend:
     def counts_ref_columns(sim, ref):
         return torch.stack([(sim > ref[None, :]).sum(0), (sim == ref[None, :]).sum(0)], 1).to(torch.int32)
 
+    @staticmethod
+    def group_max(sim, groups, n_groups):
+        best = torch.full((n_groups, sim.shape[1]), float("-inf"))
+        if sim.shape[0]:
+            clean = torch.where(sim != sim, torch.full_like(sim, float("-inf")), sim)
+            best.scatter_reduce_(0, groups.long().view(-1, 1).expand(-1, sim.shape[1]), clean, "amax", include_self=True)
+        return best
+
 
 class _TableModel(torch.nn.Module):
     """Stands in for CLIP4Clip: features are looked up from the inputs (ids carry a row number, 'frames' are features)."""

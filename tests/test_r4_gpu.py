@@ -1,0 +1,64 @@
+"""Round-4 GPU tests: the split-K form of the residual Linear (two workgroups per 256x256 tile swapping accumulator
+halves inside one launch) against float64 and against the single-workgroup tile."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(9600, 768, 768), (9600, 768, 3072), (9479, 768, 3072), (8200, 512, 2048), (300, 256, 128)])
+def test_splitk_residual_linear(M, N, K):
+    """tile 9 (split-K, modules/clip.py:207-211,240,251: out_proj / c_proj with the residual add) == float64 to the rounding
+    of the fp16 operands, bit-identical from call to call, statistics / shifts as the one-workgroup tile writes them."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=gen).half()
+    w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
+    b = torch.randn(N, generator=gen) * 0.1
+    h0 = torch.randn(M, N, generator=gen) * 2 + 0.3
+    prev = torch.randn(M, N, generator=gen) + 5.0                 # the rows one sublayer ago (supplies the row shift)
+    href = h0.double() + a.double() @ w.double().t() + b.double()
+    _, st_in, sh_in = ops.row_stats(prev.to(DEV))
+    outs = []
+    for tile in (9, 9, 9, 6 if N % 128 == 0 else 4):
+        h = h0.to(DEV).clone()
+        h16, stats, slots, sh_out = ops.linear_resid_stats_f16(a.to(DEV), w.to(DEV), b.to(DEV), h, tile=tile, shift_in=sh_in,
+                                                               stats_in=st_in.view(M, 1, 2))
+        torch.cuda.synchronize()
+        assert relerr(h.cpu(), href) < 2e-4
+        centre = sh_out.double().cpu()[:, None]
+        assert torch.equal(h16, (h - sh_out[:, None]).half())
+        s = stats.sum(1).double().cpu()
+        np.testing.assert_allclose(s[:, 0].numpy(), h16.double().sum(-1).cpu().numpy(), rtol=1e-5, atol=2e-3)
+        np.testing.assert_allclose(s[:, 1].numpy(), (h16.double() ** 2).sum(-1).cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(centre[:, 0].numpy(), prev.double().mean(-1).numpy(), rtol=0, atol=5e-3)
+        outs.append((h.clone(), h16.clone(), stats.clone(), slots))
+    assert outs[0][3] == N // 256 * 4
+    for o in outs[1:3]:                                            # identical bits on every call
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    assert relerr(outs[0][0].cpu(), outs[3][0].cpu()) < 1e-5      # the other tile: another summation order only
+
+
+def test_splitk_flags_left_clean():
+    """The flag area of the exchange scratch is all zeros after split-K calls (the next launch relies on it)."""
+    from centerclip_amd import ops, torch_ops as T, _lib as L
+    assert T.resid_stats_slots(9600, 768, 3072, 9) == 12 and T.resid_stats_slots(9600, 768, 768, 9) == 12
+    assert T.resid_stats_slots(9600, 768, 3072) != 12      # (measured slower: not picked automatically)
+    M, N, K = 9600, 768, 768
+    a = torch.randn(M, K, device=DEV).half()
+    w = (torch.randn(N, K, device=DEV) * K ** -0.5).half()
+    h = torch.zeros(M, N, device=DEV)
+    for _ in range(3):
+        ops.linear_resid_stats_f16(a, w, None, h, tile=9)
+    torch.cuda.synchronize()
+    ws = T._splitk_ws(a)
+    nflag = int(L.lib().cc_linear_splitk_flag_bytes())
+    assert int(ws[:nflag].view(torch.int32).abs().sum()) == 0
+    assert relerr(h.cpu(), 3 * (a.double() @ w.double().t()).cpu()) < 2e-4

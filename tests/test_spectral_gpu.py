@@ -100,7 +100,7 @@ def test_eigensolver_shapes(N, K):
 @pytest.mark.parametrize("solver", ["direct", "jacobi"])
 def test_eigensolver_tight_clusters_both_solvers(solver):
     """Planted partitions, eigenvalue 0 of multiplicity K up to the coupling: the direct solver (eig.hip: fp64 shifts, the
-    analytic reflector) reaches the fp32 floor, the Jacobi kernel - forced through its debug hook, it is what shapes outside
+    analytic reflector) reaches the fp32 floor, the Jacobi kernel - selected through the solver argument, it is what shapes outside
     the direct solver's scope run - its documented bounds.  Shapes cover the three register layouts of the LDS kernel, the
     global-memory kernel (N > 196) and the fallback (K too large for the LDS layout at N = 196)."""
     from centerclip_amd import _lib as L
@@ -108,22 +108,18 @@ def test_eigensolver_tight_clusters_both_solvers(solver):
     from oracle import probe_tridiag as pt
     rng = np.random.default_rng(7)
     cases = [(196, 49, 1e-6), (196, 49, 0.0), (96, 24, 1e-8), (48, 12, 1e-4), (196, 64, 1e-6), (200, 50, 1e-6), (392, 98, 1e-6)]
-    L.lib().cc_debug_set_eig_jacobi(1 if solver == "jacobi" else 0)
-    try:
-        for N, K, leak in cases:
-            parts = 49 if (N, K) == (196, 64) else K
-            Lm = np.stack([pt.planted(rng, N, parts, leak, perm) for perm in (False, True)])
-            Q, ev = spectral_embedding(dev(Lm), K, correct_sign=True)
-            Qd, Ld, evd = Q.cpu().double(), torch.from_numpy(Lm).double(), ev.cpu().double()
-            res = float((Ld @ Qd - Qd * evd[:, None, :]).abs().max())
-            orth = float((Qd.transpose(1, 2) @ Qd - torch.eye(K, dtype=torch.float64)).abs().max())
-            everr = float((evd - torch.linalg.eigvalsh(Ld)[:, :K].flip(-1)).abs().max())
-            direct = solver == "direct" and not (N == 196 and K > 49)                  # (that shape: the Jacobi kernel)
-            assert res < (3e-6 if direct else 2e-5), (N, K, leak, res)
-            assert orth < (3e-6 if direct else 1e-5), (N, K, leak, orth)
-            assert everr < (2e-6 if direct else 3e-4), (N, K, leak, everr)       # (one-sided Jacobi: |mu| of nearly equal rows)
-    finally:
-        L.lib().cc_debug_set_eig_jacobi(0)
+    for N, K, leak in cases:
+        parts = 49 if (N, K) == (196, 64) else K
+        Lm = np.stack([pt.planted(rng, N, parts, leak, perm) for perm in (False, True)])
+        Q, ev = spectral_embedding(dev(Lm), K, correct_sign=True, solver="jacobi" if solver == "jacobi" else "auto")
+        Qd, Ld, evd = Q.cpu().double(), torch.from_numpy(Lm).double(), ev.cpu().double()
+        res = float((Ld @ Qd - Qd * evd[:, None, :]).abs().max())
+        orth = float((Qd.transpose(1, 2) @ Qd - torch.eye(K, dtype=torch.float64)).abs().max())
+        everr = float((evd - torch.linalg.eigvalsh(Ld)[:, :K].flip(-1)).abs().max())
+        direct = solver == "direct" and not (N == 196 and K > 49)                  # (that shape: the Jacobi kernel)
+        assert res < (3e-6 if direct else 2e-5), (N, K, leak, res)
+        assert orth < (3e-6 if direct else 1e-5), (N, K, leak, orth)
+        assert everr < (2e-6 if direct else 3e-4), (N, K, leak, everr)       # (one-sided Jacobi: |mu| of nearly equal rows)
 
 
 @pytest.mark.parametrize("P,N,K", [(3, 3, 1), (3, 3, 3), (2, 4, 2), (5, 33, 33), (2, 64, 64), (300, 40, 7), (2, 196, 1), (2, 197, 1),

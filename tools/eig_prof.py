@@ -32,9 +32,9 @@ def laplacians(P, N, D, scale, sigma, knn, planted, gen):
 
 
 def check(tag, Lm, K, jacobi):
-    L.lib().cc_debug_set_eig_jacobi(1 if jacobi else 0)
+    sv = 1 if jacobi else 0                      # CC_EIG_JACOBI / CC_EIG_AUTO
     Ld = Lm.cuda()
-    Q, ev, sw = torch.ops.centerclip.spectral_embedding(Ld, K, True)
+    Q, ev, sw = torch.ops.centerclip.spectral_embedding(Ld, K, True, sv)
     torch.cuda.synchronize()
     Qd = Q[:, :, :K].double().cpu(); evd = ev.double().cpu(); L64 = Lm.double()
     ref = torch.linalg.eigvalsh(L64)[:, :K].flip(-1)
@@ -42,14 +42,13 @@ def check(tag, Lm, K, jacobi):
     orth = float((Qd.transpose(1, 2) @ Qd - torch.eye(K, dtype=torch.float64)).abs().max())
     everr = float((evd - ref).abs().max())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(1): torch.ops.centerclip.spectral_embedding(Ld, K, True)
+    for _ in range(1): torch.ops.centerclip.spectral_embedding(Ld, K, True, sv)
     e0.record()
     reps = 20 if Lm.shape[1] <= 200 else 3
-    for _ in range(reps): torch.ops.centerclip.spectral_embedding(Ld, K, True)
+    for _ in range(reps): torch.ops.centerclip.spectral_embedding(Ld, K, True, sv)
     e1.record(); torch.cuda.synchronize()
     print(f"{tag:34s} {'jacobi' if jacobi else 'direct':7s} residual {res:.2e} orth {orth:.2e} eigenvalue err {everr:.2e} "
           f"finite {bool(torch.isfinite(Q).all())}  {e0.elapsed_time(e1) / reps * 1e3:8.1f} us / call", flush=True)
-    L.lib().cc_debug_set_eig_jacobi(0)
 
 
 def main():

@@ -11,7 +11,7 @@ for M, N, K in [(9600, 768, 768), (9600, 768, 3072), (2400, 768, 768), (2400, 76
     h16 = torch.empty(M, N, device=dev, dtype=torch.float16); st = torch.empty(M * 64, device=dev)
     _, st_in, sh_in = ops.row_stats(torch.randn(M, N, device=dev)); sh_out = torch.empty(M, device=dev)
     line = "%5d x %4d x %4d" % (M, N, K)
-    for t in (0, 1, 2, 3, 4, 6, 8):
+    for t in (0, 1, 4, 6, 8, 9, 10):
         try:
             fn = lambda: ops.linear_resid_stats_f16(a, w, b, h, tile=t, h16=h16, stats=st, shift_in=sh_in, stats_in=st_in.view(M, 1, 2), shift_out=sh_out)
             ms = bench.graph_time_ms(fn, launches=20, replays=3)
