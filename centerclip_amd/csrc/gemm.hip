@@ -17,6 +17,7 @@
 #include "cc_kernels.h"
 #include <hip/hip_ext.h>
 #include <cstring>
+#include <type_traits>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,14 @@ __device__ long long* g_gemm_prof = nullptr;
 #define GEMM_PROF_INIT() do { } while (0)
 #define GEMM_STAMP(slot) do { } while (0)
 #endif
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {         // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {          // lane exchange inside a 16-lane DPP row (bit pattern)
@@ -144,20 +153,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     };
 
     f32x4 acc[MI][NI];
-    // Residual epilogues: the accumulators START from the residual rows (h += a W^T + b is accumulated on top of h), read
-    // here in accumulator layout while the first stage is in flight - the epilogue then only stores (asynchronous), instead
-    // of every workgroup of the round fetching its fp32 tile at the same moment after its last MFMA.
-#ifdef CC_NO_RESID_ACC_INIT
-    constexpr bool ACC_INIT = false;
+    // Residual epilogues: the fp32 residual tile (h += a W^T + b) is fetched into registers DURING the main loop, in
+    // accumulator layout, two fragments (the two 64-byte halves of 16 rows' cache lines) behind the LDS-DMA loads of each of
+    // the first k-steps.  Fetched after the loop - or in front of it, as the start value of the accumulators - it is one
+    // burst of every workgroup of the round at the same moment (9600 x 768: 29.5 MB, 4.3 us at the HBM / MALL rate with the
+    // matrix cores idle; measured with per-workgroup stamps, profiles/r04_gemm_timeline.txt).  In-order return makes a
+    // load wait for nothing but the stage issued just before it.
+#ifdef CC_NO_RESID_PREFETCH
+    constexpr bool RESID_PF = false;
 #else
-    constexpr bool ACC_INIT = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) && SK == 1;
+    // (not for the 256x256 tile: its 128 accumulator registers leave no room for 128 more)
+    constexpr bool RESID_PF = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) && SK == 1 && !(BM == 256 && BN == 256);
 #endif
-    if constexpr (!ACC_INIT) {
+    // (the k-steps that carry a piece are peeled off the loop at compile time: selected by a run-time test of the step
+    // index the register array turns into a scratch array with a computed offset)
+    constexpr int RPF_FRAGS = MI * NI, RPF_PER_STEP = (RPF_FRAGS % 4 == 0) ? 4 : RPF_FRAGS, RPF_STEPS = RPF_FRAGS / RPF_PER_STEP;
+    f32x4 resid[RESID_PF ? MI : 1][RESID_PF ? NI : 1];
+    auto resid_fetch_step = [&](auto ic) {                    // piece ic (a std::integral_constant) of RPF_STEPS
+        if constexpr (RESID_PF) {
+            constexpr int c = decltype(ic)::value;
+            static_for<RPF_PER_STEP>([&](auto uc) {
+                constexpr int f = c * RPF_PER_STEP + decltype(uc)::value, i = f / NI, j = f % NI;
+                const int m = min(row0 + wr * (BM / WM) + i * 16 + (lane & 15), g.M - 1);
+                const int n = col0 + wc * (BN / WN) + j * 16 + (lane >> 4) * 4;
+                resid[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + n);
+            });
+        }
+    };
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = __builtin_amdgcn_readfirstlane(g.K / BK / SK);
     // The rider's tiles are the ones that spill into a second round when the carrier alone fills the slots (the
@@ -165,15 +191,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const bool rider_first = second && pr.rider_prio;
     if (rider_first) __builtin_amdgcn_s_setprio(2);
     stage(0, 0);
-    if constexpr (ACC_INIT) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int m = min(row0 + wr * (BM / WM) + i * 16 + (lane & 15), g.M - 1);
-                const int n = col0 + wc * (BN / WN) + j * 16 + (lane >> 4) * 4;
-                acc[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + n);
-            }
+    const bool resid_spread = nk >= RPF_STEPS + 2;             // short K: everything in front of the loop
+    if constexpr (RESID_PF) {
+        if (!resid_spread) static_for<RPF_STEPS>([&](auto ic) { resid_fetch_step(ic); });
     }
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
@@ -301,7 +321,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
             __syncthreads();
         };
-        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        int kt = 0;
+        if constexpr (RESID_PF) {
+            if (resid_spread) {
+                static_for<RPF_STEPS>([&](auto ic) { step(decltype(ic)::value & 1, decltype(ic)::value, true); resid_fetch_step(ic); });
+                kt = RPF_STEPS;
+            }
+        }
+        for (; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
         fetch_epilogue_operands();
         step((nk - 1) & 1, nk - 1, false);
     } else if (HALF_SHIFTED) {
@@ -355,6 +382,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
         };
         int kt = 0;
+        if constexpr (RESID_PF) {
+            if (resid_spread) {
+                static_for<RPF_STEPS>([&](auto ic) {
+                    constexpr int c = decltype(ic)::value;
+                    phase1(c & 1);
+                    __syncthreads();
+                    phase2(c & 1, c, true);
+                    resid_fetch_step(ic);
+                });
+                kt = RPF_STEPS;
+            }
+        }
         for (; kt + 2 < nk; ++kt) {                           // steady state: a stage to load in every step
             phase1(kt & 1);
             __syncthreads();
@@ -404,7 +443,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
             __syncthreads();
         };
-        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        int kt = 0;
+        if constexpr (RESID_PF) {
+            if (resid_spread) {
+                static_for<RPF_STEPS>([&](auto ic) { step(decltype(ic)::value & 1, decltype(ic)::value, true); resid_fetch_step(ic); });
+                kt = RPF_STEPS;
+            }
+        }
+        for (; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
         fetch_epilogue_operands();
         step((nk - 1) & 1, nk - 1, false);
     }
@@ -523,7 +569,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             resv[slot][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + ncol);
         }
     };
-    constexpr bool RESID_LOAD = RESID && !ACC_INIT;             // the residual is still to be fetched and added
+    constexpr bool RESID_LOAD = RESID && !RESID_PF;             // the residual is still to be fetched (split-K form)
     if constexpr (SK == 2) {
         // ---- swap accumulator halves with the partner workgroup (see the comment above the kernel)
         constexpr int HALF_SLOT = CC_GEMM_SK_SLOT_BYTES / 2, FR = (MI / 2) * NI;     // 16 fragments of 1 KB per wave each way
@@ -582,8 +628,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float4 bb = biasv[j];
-            *reinterpret_cast<float4*>(fstg + l15 * LDF + j * 16 + lg * 4) =
-                make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+            float4 sv = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+            if constexpr (RESID_PF) {                              // (a W^T + b) + h, the order of the fetch-in-the-epilogue form
+                const f32x4 c = resid[RESID_PF ? i : 0][RESID_PF ? j : 0];
+                sv.x += c[0]; sv.y += c[1]; sv.z += c[2]; sv.w += c[3];
+            }
+            *reinterpret_cast<float4*>(fstg + l15 * LDF + j * 16 + lg * 4) = sv;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the strip is private to this wave
         __builtin_amdgcn_wave_barrier();

@@ -130,7 +130,20 @@ SPECTRAL_CASES = {
     "planted_heat": dict(seed=61, B=2, T=4, T_new=2, n=16, W=32, K=4, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
     "planted_knn_spg": dict(seed=62, B=2, T=6, T_new=2, n=16, W=32, K=6, sigma=2.0, graph="KNN", knn_k=0, spg=1, sep=6.0),
     "planted_k5_odd": dict(seed=63, B=3, T=3, T_new=1, n=25, W=32, K=5, sigma=2.0, graph="HeatKernel", knn_k=0, sep=5.0),
+    # the real layouts (round 4): ViT-B/32 12 -> 3 frames (N = 196, K = 49: the LDS eigensolver at its largest shape),
+    # 64 -> 8 frames (N = 392: the global-memory eigensolver; heat kernel, and KNN graph + spatial-temporal mask), ViT-B/16 12 -> 4 frames with
+    # K = 100 (N = 588, groups of 5 and 6 tokens), full width
+    "planted_196_k49": dict(seed=64, B=2, T=4, T_new=1, n=49, W=768, K=49, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
+    "planted_392_k49": dict(seed=65, B=1, T=16, T_new=2, n=49, W=768, K=49, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
+    # (with the spatial-temporal mask a group has to be connected under it: K = 56 makes the groups the rows of the 7 x 7 grid)
+    "planted_392_k56_knn": dict(seed=67, B=1, T=8, T_new=1, n=49, W=768, K=56, sigma=2.0, graph="KNN", knn_k=0, spg=1, sep=6.0),
+    "planted_588_k100": dict(seed=66, B=1, T=3, T_new=1, n=196, W=768, K=100, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
 }
+
+
+def planted_group(j, N, K):
+    """Planted group of token j of a segment: contiguous runs of floor / ceil(N / K) tokens (N / K when it divides)."""
+    return (j * K) // N
 
 
 def planted_tokens(cfg):
@@ -140,7 +153,6 @@ def planted_tokens(cfg):
     B, T, Tn, n, W, K = (cfg[k] for k in ("B", "T", "T_new", "n", "W", "K"))
     fd = T // Tn
     N = fd * n
-    assert N % K == 0
     x = np.zeros((1 + n, B * T, W), dtype=np.float32)
     x[0] = fullmant(cfg["seed"] + 1, (B * T, W))
     for b in range(B):
@@ -153,7 +165,7 @@ def planted_tokens(cfg):
                 for i in range(n):
                     j = f * n + i
                     noise = (rng.integers(-64, 65, size=W).astype(np.float32) * np.float32(0.05 / 64.0))
-                    x[1 + i, b * T + s_ * fd + f] = centres[j // (N // K)] + noise
+                    x[1 + i, b * T + s_ * fd + f] = centres[planted_group(j, N, K)] + noise
     return x
 
 

@@ -105,7 +105,7 @@ def test_spectral_planted_partitions_oracle_reproduces_reference():
     same assignment as the reference module, every medoid in its own planted group, and the module output for both
     aggregations."""
     from oracle import cluster_oracle as co
-    from oracle.recipes import SPECTRAL_CASES, planted_tokens
+    from oracle.recipes import SPECTRAL_CASES, planted_tokens, planted_group
     for tag, cfg in SPECTRAL_CASES.items():
         x = torch.from_numpy(planted_tokens(cfg))
         T, Tn, n, K = cfg["T"], cfg["T_new"], cfg["n"], cfg["K"]
@@ -116,9 +116,9 @@ def test_spectral_planted_partitions_oracle_reproduces_reference():
         asg, med = co.literal_spectral_clustering(tokens, K, cfg["graph"], knn_k, "euclidean", 1e-6, 100, 2.0, True, 16,
                                                   cfg["sigma"], graph)
         N = fd * n
-        planted = (torch.arange(N) // (N // K)).expand(tokens.shape[0], N)
+        planted = planted_group(torch.arange(N), N, K).expand(tokens.shape[0], N)
         assert torch.equal(asg, planted) and np.array_equal(SPG[f"{tag}_mean_assign"].astype(np.int64), planted.numpy())
-        assert torch.equal(med // (N // K), torch.arange(K).expand_as(med))
+        assert torch.equal(planted_group(med, N, K), torch.arange(K).expand_as(med))
         for name, agg in (("none", None), ("mean", "mean")):
             ref_asg = torch.from_numpy(SPG[f"{tag}_{name}_assign"].astype(np.int64))
             ref_med = torch.from_numpy(SPG[f"{tag}_{name}_medoids"].astype(np.int64))

@@ -50,7 +50,6 @@ def test_splitk_flags_left_clean():
     """The flag area of the exchange scratch is all zeros after split-K calls (the next launch relies on it)."""
     from centerclip_amd import ops, torch_ops as T, _lib as L
     assert T.resid_stats_slots(9600, 768, 3072, 9) == 12 and T.resid_stats_slots(9600, 768, 768, 9) == 12
-    assert T.resid_stats_slots(9600, 768, 3072) != 12      # (measured slower: not picked automatically)
     M, N, K = 9600, 768, 768
     a = torch.randn(M, K, device=DEV).half()
     w = (torch.randn(N, K, device=DEV) * K ** -0.5).half()

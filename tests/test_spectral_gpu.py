@@ -20,7 +20,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cluster_oracle as co                                 # noqa: E402
-from oracle.recipes import SPECTRAL_CASES, planted_tokens               # noqa: E402
+from oracle.recipes import SPECTRAL_CASES, planted_tokens, planted_group               # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -171,9 +171,9 @@ def test_spectral_module_on_planted_partitions(sg, tag):
     y, _ = mod(x)
     med = mod.last_medoids.cpu()
     assert med.shape == sg[f"{tag}_none_medoids"].shape
-    assert torch.equal(med // (N // K), torch.arange(K).expand_as(med))
+    assert torch.equal(planted_group(med, N, K), torch.arange(K).expand_as(med))
     ref_med = torch.from_numpy(sg[f"{tag}_none_medoids"].astype(np.int64))
-    assert torch.equal(ref_med // (N // K), torch.arange(K).expand_as(ref_med))
+    assert torch.equal(planted_group(ref_med, N, K), torch.arange(K).expand_as(ref_med))
     # the output is the gather of exactly those tokens + the CLS means
     want = co.literal_token_cluster_variant(x.cpu(), T, Tn, K, "kmediods++", None, medoids=med,
                                             assign=torch.zeros(med.shape[0], N, dtype=torch.long))

@@ -7,8 +7,8 @@ import torch
 from centerclip_amd import ops, _lib as L
 lib = L.lib()
 lib.cc_debug_set_gemm_profile.argtypes = [ctypes.c_void_p]
-shapes = [(9600, 3072, 768, "f16", 5), (5376, 3072, 768, "f16", 5), (9600, 3072, 768, "f16_gelu", 5), (9600, 768, 3072, "f32_resid", 0),
-          (9600, 2304, 768, "f16", 0), (9600, 768, 768, "f32_resid", 0)]
+shapes = [(9600, 768, 768, "f32_resid", 6), (9600, 768, 3072, "f32_resid", 6), (9600, 768, 3072, "f32_resid", 10),
+          (2400, 768, 768, "f32_resid", 8), (2400, 768, 3072, "f32_resid", 8)]
 for M, N, K, epi, tile in shapes:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
     b = torch.randn(N, device="cuda")
