@@ -49,6 +49,7 @@ CFG2 = dict(name="cfg2 MSR-VTT-shaped: ViT-B/32 224^2, 12 frames -> 3 segments @
             B=16, T=12, T_new=3, K=49, cluster_block=7, words=32, patch=32, res=224, width=768, layers=12)
 # cluster-op shapes of the other BASELINE.json configs: reported as µs/call + Mtokens/s
 CLUSTER_SHAPES = {"cfg2": dict(B=16, T=12, T_new=3, n=49, K=49, split=16),
+                  "cfg3 MSVD-shaped (per GPU)": dict(B=64, T=12, T_new=4, n=49, K=49, split=16),      # P = 256 problems: fills the chip
                   "cfg4 ActivityNet-shaped (per GPU)": dict(B=8, T=64, T_new=8, n=49, K=49, split=16),
                   "cfg5 ViT-B/16": dict(B=16, T=12, T_new=4, n=196, K=100, split=4)}
 
@@ -156,12 +157,14 @@ def pmc_traffic(symbol):
     return None
 
 
-def insitu_gemm_times(step, reps=6):
+def insitu_gemm_times(step, reps=6, rider_rows=None, rider_rows_launched=None):
     """Duration of every gemm_f16_kernel launch INSIDE the step, measured live with HIP events on the launch stream: the
     library launches each of them with a start / stop event pair (hipExtLaunchKernelGGL, cc_debug_gemm_timing_*: the events
     receive the dispatch's begin / end timestamps; the whole step is enqueued by one C call, far faster than the GPU drains
     it, so the launches run back to back between their real neighbours as in the captured graph).  -> {symbol: dict(us, launches_per_step, flops_per_step, shapes)}; flops count
-    both problems of a paired launch (ViT carrier + text rider)."""
+    both problems of a paired launch (ViT carrier + text rider); the rider is counted with the rows it COMPUTES
+    (`rider_rows`: the compacted captions, read from the device by its tiles) where the launch is sized for
+    `rider_rows_launched` (captions x words)."""
     import ctypes
     from centerclip_amd import _lib as L
     lib = L.lib()
@@ -186,8 +189,9 @@ def insitu_gemm_times(step, reps=6):
         e = out.setdefault(sym, dict(us=0.0, launches=0, flops=0.0, shapes={}))
         e["us"] += us.value
         e["launches"] += 1
-        e["flops"] += 2.0 * m0 * n0 * k0 + 2.0 * m1 * n1 * k1
-        key = "%dx%dx%d%s" % (m0, n0, k0, " + rider %dx%dx%d" % (m1, n1, k1) if m1 else "")
+        m1c = rider_rows if (rider_rows is not None and m1 == rider_rows_launched) else m1
+        e["flops"] += 2.0 * m0 * n0 * k0 + 2.0 * m1c * n1 * k1
+        key = "%dx%dx%d%s" % (m0, n0, k0, " + rider %dx%dx%d%s" % (m1, n1, k1, " (%d rows computed)" % m1c if m1c != m1 else "") if m1 else "")
         sh = e["shapes"].setdefault(key, [0, 0.0])
         sh[0] += 1
         sh[1] += us.value
@@ -611,6 +615,14 @@ def main():
     elapsed = statistics.median(windows)
 
     extras = {}
+    if world > 1:                        # always reported at N > 1: how many ranks RCCL carried and what the exchange step cost
+        with torch.no_grad():
+            ms = event_time_ms(sink.gather, 50)
+        tt = torch.tensor([ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        extras["feature_all_gather"] = dict(bytes_per_rank=sink.rec, bytes_gathered=sink.bytes_per_gather,
+                                            us_per_call=round(float(tt) * 1e3, 1), backend=dist.get_backend(),
+                                            ranks=dist.get_world_size(), collectives_per_step=1)
     if not a.no_extras:
         with torch.no_grad():
             tc = {name: cluster_bench(s, device, iters=30 if name == "cfg2" else 10) for name, s in CLUSTER_SHAPES.items()}
@@ -623,19 +635,13 @@ def main():
             if world == 1:
                 extras["token_cluster_spectral"] = {name: spectral_cluster_bench(sh, device) for name, sh in CLUSTER_SHAPES.items()}
             extras["similarity_10k_x_1k"] = similarity_bench(device, world)
-            if world > 1:
-                ms = event_time_ms(sink.gather, 50)
-                tt = torch.tensor([ms], device=device, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                extras["feature_all_gather"] = dict(bytes_per_rank=sink.rec, bytes_gathered=sink.bytes_per_gather,
-                                                    us_per_call=round(float(tt) * 1e3, 1),
-                                                    backend=dist.get_backend(), collectives_per_step=1)
-
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         clips = c["B"] * world * a.steps
         res = {"metric": "clips/sec (ViT-B/32, 12f)", "value": round(clips / elapsed, 2), "unit": "clips/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+               "n_gpus": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+               "ranks_in_communicator": (dist.get_world_size() if world > 1 else 1),
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 MFMA operands, fp32 accumulate/residual/LN/softmax; cluster + similarity fp32",
                "data": "synthetic (N(0,1) frames, random token ids, random-init weights with CLIP init statistics rounded through fp16)",
                "timing": {"windows": len(windows), "steps_per_window": a.steps, "statistic": "median window (max over ranks per window)",
@@ -655,7 +661,9 @@ def main():
                                                                                   res["token_cluster"]["cfg2"]["mtokens_per_s"])
         if world == 1 and not a.no_extras:
             with torch.no_grad():
-                roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device, insitu_gemm_times(step1))
+                rows_text = int((ids.argmax(dim=-1) + 1).sum())
+                roof, rows, gemm_us, gemm_flops = gemm_roofline(c, device, insitu_gemm_times(step1, rider_rows=rows_text,
+                                                                                              rider_rows_launched=int(ids.numel())))
                 res["roofline"] = roof
                 res["gemm_breakdown"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
                 res["gemm_time_share_of_step"] = round(gemm_us / (ms_per_step * 1e3), 3)

@@ -221,6 +221,12 @@ class TokenClusterInter(torch.nn.Module):
             keep.append(self.cls_multiplier.detach().to(device).float().reshape(-1).contiguous())
             var.cls_multiplier = keep[-1].data_ptr()
         if self.algorithm == 'sparse_sampling':
+            if self.training:
+                # the reference draws fresh random ids per segment in training mode (cluster_utils.py:150-162); the fused
+                # encoder caches this struct per model, so it would silently keep the eval-mode centre ids: refuse instead
+                # (the module / block-level forwards draw the ids per call, see _run)
+                raise NotImplementedError("cluster_algo='sparse_sampling' in training mode inside the fused encoder: "
+                                          "use the module / block-level forwards (random ids per call)")
             keep.append(self._sparse_ids(N, device))
             var.fixed_ids = keep[-1].data_ptr()
         if self.algorithm == 'spectral':

@@ -17,7 +17,6 @@
 #include "cc_kernels.h"
 #include <hip/hip_ext.h>
 #include <cstring>
-#include <type_traits>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -57,14 +56,6 @@ __device__ long long* g_gemm_prof = nullptr;
 #define GEMM_PROF_INIT() do { } while (0)
 #define GEMM_STAMP(slot) do { } while (0)
 #endif
-
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {         // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {          // lane exchange inside a 16-lane DPP row (bit pattern)
@@ -153,33 +144,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     };
 
     f32x4 acc[MI][NI];
-    // Residual epilogues: the fp32 residual tile (h += a W^T + b) is fetched into registers DURING the main loop, in
-    // accumulator layout, two fragments (the two 64-byte halves of 16 rows' cache lines) behind the LDS-DMA loads of each of
-    // the first k-steps.  Fetched after the loop - or in front of it, as the start value of the accumulators - it is one
-    // burst of every workgroup of the round at the same moment (9600 x 768: 29.5 MB, 4.3 us at the HBM / MALL rate with the
-    // matrix cores idle; measured with per-workgroup stamps, profiles/r04_gemm_timeline.txt).  In-order return makes a
-    // load wait for nothing but the stage issued just before it.
-#ifdef CC_NO_RESID_PREFETCH
-    constexpr bool RESID_PF = false;
-#else
-    // (not for the 256x256 tile: its 128 accumulator registers leave no room for 128 more)
-    constexpr bool RESID_PF = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS) && SK == 1 && !(BM == 256 && BN == 256);
-#endif
-    // (the k-steps that carry a piece are peeled off the loop at compile time: selected by a run-time test of the step
-    // index the register array turns into a scratch array with a computed offset)
-    constexpr int RPF_FRAGS = MI * NI, RPF_PER_STEP = (RPF_FRAGS % 4 == 0) ? 4 : RPF_FRAGS, RPF_STEPS = RPF_FRAGS / RPF_PER_STEP;
-    f32x4 resid[RESID_PF ? MI : 1][RESID_PF ? NI : 1];
-    auto resid_fetch_step = [&](auto ic) {                    // piece ic (a std::integral_constant) of RPF_STEPS
-        if constexpr (RESID_PF) {
-            constexpr int c = decltype(ic)::value;
-            static_for<RPF_PER_STEP>([&](auto uc) {
-                constexpr int f = c * RPF_PER_STEP + decltype(uc)::value, i = f / NI, j = f % NI;
-                const int m = min(row0 + wr * (BM / WM) + i * 16 + (lane & 15), g.M - 1);
-                const int n = col0 + wc * (BN / WN) + j * 16 + (lane >> 4) * 4;
-                resid[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + n);
-            });
-        }
-    };
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -191,10 +155,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const bool rider_first = second && pr.rider_prio;
     if (rider_first) __builtin_amdgcn_s_setprio(2);
     stage(0, 0);
-    const bool resid_spread = nk >= RPF_STEPS + 2;             // short K: everything in front of the loop
-    if constexpr (RESID_PF) {
-        if (!resid_spread) static_for<RPF_STEPS>([&](auto ic) { resid_fetch_step(ic); });
-    }
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
     float row_mu = 0.f, row_rs = 1.f;
@@ -321,14 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
             __syncthreads();
         };
-        int kt = 0;
-        if constexpr (RESID_PF) {
-            if (resid_spread) {
-                static_for<RPF_STEPS>([&](auto ic) { step(decltype(ic)::value & 1, decltype(ic)::value, true); resid_fetch_step(ic); });
-                kt = RPF_STEPS;
-            }
-        }
-        for (; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
         fetch_epilogue_operands();
         step((nk - 1) & 1, nk - 1, false);
     } else if (HALF_SHIFTED) {
@@ -382,18 +335,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
         };
         int kt = 0;
-        if constexpr (RESID_PF) {
-            if (resid_spread) {
-                static_for<RPF_STEPS>([&](auto ic) {
-                    constexpr int c = decltype(ic)::value;
-                    phase1(c & 1);
-                    __syncthreads();
-                    phase2(c & 1, c, true);
-                    resid_fetch_step(ic);
-                });
-                kt = RPF_STEPS;
-            }
-        }
         for (; kt + 2 < nk; ++kt) {                           // steady state: a stage to load in every step
             phase1(kt & 1);
             __syncthreads();
@@ -443,14 +384,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
             __syncthreads();
         };
-        int kt = 0;
-        if constexpr (RESID_PF) {
-            if (resid_spread) {
-                static_for<RPF_STEPS>([&](auto ic) { step(decltype(ic)::value & 1, decltype(ic)::value, true); resid_fetch_step(ic); });
-                kt = RPF_STEPS;
-            }
-        }
-        for (; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
+        for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
         fetch_epilogue_operands();
         step((nk - 1) & 1, nk - 1, false);
     }
@@ -569,7 +503,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             resv[slot][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + ncol);
         }
     };
-    constexpr bool RESID_LOAD = RESID && !RESID_PF;             // the residual is still to be fetched (split-K form)
+    // Where the fp32 residual tile is fetched was measured four ways (profiles/r04_gemm_timeline.txt; 9600 x 768 x 768,
+    // 256x128 tile: prologue / loop / epilogue per workgroup): here, one fragment-row group ahead of its use: 1.8 / 11.1 /
+    // 6.4 us; as the start value of the accumulators: 6.1 / 11.1 / 2.1; two fragments behind each of the first k-steps'
+    // LDS-DMA loads: 1.8 / 15.9 / 2.3 (loads return in order, so every step's wait for its stage also waits for the
+    // HBM-latency loads issued before it); added into the accumulators at one k-step, the workgroups dealt over four such
+    // steps: 3.3 / 14.8 / 2.2 and results that depend on the tile and the grid.  The 128 KB cost a workgroup ~4 us wherever
+    // they stand (16 half-used cache lines per instruction in any register-layout form; whole rows through the LDS strip
+    // here) - the fetch stays in the epilogue, where the sum order is the same for every tile.
+    constexpr bool RESID_LOAD = RESID;
     if constexpr (SK == 2) {
         // ---- swap accumulator halves with the partner workgroup (see the comment above the kernel)
         constexpr int HALF_SLOT = CC_GEMM_SK_SLOT_BYTES / 2, FR = (MI / 2) * NI;     // 16 fragments of 1 KB per wave each way
@@ -629,10 +571,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         for (int j = 0; j < NI; ++j) {
             const float4 bb = biasv[j];
             float4 sv = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
-            if constexpr (RESID_PF) {                              // (a W^T + b) + h, the order of the fetch-in-the-epilogue form
-                const f32x4 c = resid[RESID_PF ? i : 0][RESID_PF ? j : 0];
-                sv.x += c[0]; sv.y += c[1]; sv.z += c[2]; sv.w += c[3];
-            }
             *reinterpret_cast<float4*>(fstg + l15 * LDF + j * 16 + lg * 4) = sv;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the strip is private to this wave
@@ -646,13 +584,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     const float4 c = resv[(i / SK) & 1][ps];
                     v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
                 }
-#if defined(CC_RESID_STORE_POLICY) && CC_RESID_STORE_POLICY == 1        /* A/B builds: non-temporal / write-through residual stores */
-                if (m < g.M) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol));
-#elif defined(CC_RESID_STORE_POLICY) && CC_RESID_STORE_POLICY == 2
-                if (m < g.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), sk_rsrc(g.C), (int)(((int64_t)m * g.ldc + ncol) * 4), 0, 16);
+                // write-through (sc1): the rows leave the XCD's L2 while the launch runs instead of in the write-back at its
+                // end (nobody re-reads them from this L2: the consumer is another launch); step 2.000 -> 1.990 ms in 3 A/B rounds
+#ifdef CC_PLAIN_RESID_STORES
+                constexpr bool wt_ok = false;
 #else
-                if (m < g.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
+                const bool wt_ok = (int64_t)g.M * g.ldc < (int64_t)0x1fffffff;     // (the buffer form takes a 32-bit byte offset)
 #endif
+                if (m < g.M) {
+                    if (wt_ok)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), sk_rsrc(g.C),
+                                                               (int)(((int64_t)m * g.ldc + ncol) * 4), 0, 16);
+                    else
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
+                }
                 if (STATS) {
                     // the consumer multiplies fp16(h - c_row): without the centring the rounding error of the copy scales
                     // with |mean| / sigma of the row (LayerNorm itself is shift invariant, so the consumer is unchanged)

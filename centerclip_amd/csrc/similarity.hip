@@ -8,8 +8,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // rows [R, E] -> rows / |row|   (one wave per row)
-// Split form of a normalised value for the fp16 matrix cores: hi = fp16(2^10 x), lo = fp16(2^10 x - hi) - both in fp16's
-// normal range, 2^10 x = hi + lo to 22 bits.  A row is written as THREE planes side by side, [3E] halfs per row:
+// Split form of a normalised value for the fp16 matrix cores: hi = fp16(2^10 x), lo = fp16(2^10 x - hi), 2^10 x = hi + lo
+// to 22 bits.  For the components that carry a unit row (|x| >= 2^-14: hi normal) lo is at most 2^-11 |hi| and becomes a
+// SUBNORMAL fp16 number for |x| below ~2^-3: the scheme relies on v_mfma_f32_16x16x32_f16 multiplying fp16 denormals
+// exactly (it does on gfx950, whatever the wave's denormal mode; tests/test_r4_gpu.py::test_similarity_tiny_components
+// holds a row dominated by tiny components against float64 - flushed lo parts would show as 2^-11 relative errors).  A row is written as THREE planes side by side, [3E] halfs per row:
 //   text  side (A'):  [ hi | hi | lo ]        video side (B'):  [ hi | lo | hi ]
 // so that  A' . B'^T = hi.hi + hi.lo + lo.hi  is ONE fp16 GEMM with K = 3E on the main GEMM pipeline (gemm.hip), scaled
 // back by the exact factor 2^-20 in its epilogue; the dropped lo.lo term is 2^-22 relative (fp32 rounding level).
@@ -331,6 +334,10 @@ static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int
     const int tile = sim_tile(Bt, Bv, &bn);
     g.M = Bt; g.N = (Bv + bn - 1) / bn * bn; g.K = 3 * E; g.ldc = ldl;
     g.n_valid = Bv;
+    // the tiles read video rows up to the padded count: their products are dropped (n_valid), but they are read - zeros
+    // instead of whatever the workspace held (uninitialised reads under sanitizers, NaN patterns through the matrix cores)
+    if (g.N > Bv && hipMemsetAsync(vb.hi + (size_t)Bv * 3 * E, 0, (size_t)(g.N - Bv) * 3 * E * sizeof(_Float16), st) != hipSuccess)
+        return CC_ERR_HIP;
     g.out_scale = mult * 9.5367431640625e-07f;                // 2^-20: undo the two 2^10 operand scalings (exact)
     return cc_gemm_dispatch(g, EPI_F32, tile, st);
 }

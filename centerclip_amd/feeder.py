@@ -34,6 +34,10 @@ class DeviceFeeder:
         with torch.cuda.stream(self.copy_stream):
             if self._used[k]:
                 self.copy_stream.wait_event(self.free[k])
+            else:
+                # a freshly allocated slot may be memory the caching allocator took back from the compute stream with that
+                # stream's last kernels on it still queued: the first copy into it waits for what is enqueued there
+                self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             for d, h in zip(self.slots[k], host_batch):
                 d.copy_(h, non_blocking=True)                        # asynchronous only from pinned memory
             self.ready[k].record(self.copy_stream)

@@ -49,8 +49,9 @@ class _ContrastiveLoss(torch.autograd.Function):
         loss3, d_text, d_vis, d_ls = torch.ops.centerclip.contrastive_loss_grad(text, vis, mask, float(scale_value))
         ctx.save_for_backward(d_text, d_vis, d_ls)
         ctx.shapes = (sequence_output.shape, visual_output.shape, sequence_output.dtype, visual_output.dtype)
-        ctx.mark_non_differentiable(loss3[0], loss3[1])
-        return loss3[2], loss3[0], loss3[1]
+        l_tv, l_vt, loss = loss3[0], loss3[1], loss3[2]          # bind the views once: the marks below apply to THESE objects
+        ctx.mark_non_differentiable(l_tv, l_vt)
+        return loss, l_tv, l_vt
 
     @staticmethod
     def backward(ctx, g, _g1, _g2):

@@ -26,12 +26,21 @@ def _import_reference():
     sys.modules["botocore.exceptions"].ClientError = Exception
     sys.modules["ftfy"].fix_text = lambda s: s
     sys.dont_write_bytecode = True
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
-    import modules.clip as rclip
-    import modules.clip4clip as rc4c
-    import modules.cluster.cluster as rcc
-    import utils.metrics as rmetrics
+    # the repository root first and /root/reference/modules not at all while importing: the cluster generators put that
+    # directory on sys.path (they import `cluster.*` top-level), where `utils` would resolve to modules/utils.py instead of
+    # the utils/ package (`python oracle/gen_golden.py all` died here)
+    mods_dir = os.path.join(REF, "modules")
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [p_ for p_ in sys.path if p_ not in (REF, mods_dir)]
+    if "utils" in sys.modules and not hasattr(sys.modules["utils"], "__path__"):
+        del sys.modules["utils"]
+    try:
+        import modules.clip as rclip
+        import modules.clip4clip as rc4c
+        import modules.cluster.cluster as rcc
+        import utils.metrics as rmetrics
+    finally:
+        sys.path[:] = saved
     return rclip, rc4c, rcc, rmetrics
 
 

@@ -61,3 +61,28 @@ def test_splitk_flags_left_clean():
     nflag = int(L.lib().cc_linear_splitk_flag_bytes())
     assert int(ws[:nflag].view(torch.int32).abs().sum()) == 0
     assert relerr(h.cpu(), 3 * (a.double() @ w.double().t()).cpu()) < 2e-4
+
+
+def test_similarity_tiny_components():
+    """The split-fp16 similarity GEMM on rows whose mass sits in ONE component while all others are tiny (their lo parts,
+    and for the smallest also the hi parts, are subnormal fp16 numbers): logits vs float64 <= 5e-5, i.e. nothing is flushed
+    (modules/clip4clip.py:357-366 computes this product in fp32)."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    Bt, Bv, E = 300, 260, 512
+    t = torch.randn(Bt, E, generator=gen) * 1e-4
+    v = torch.randn(Bv, E, generator=gen) * 1e-4
+    t[torch.arange(Bt), torch.randint(0, E, (Bt,), generator=gen)] = 1.0
+    v[torch.arange(Bv), torch.randint(0, E, (Bv,), generator=gen)] = 1.0
+    t[:, :8] *= 1e-3                                               # a few components around 1e-7: hi subnormal too
+    tn, vn = ops.normalize_rows(t.to(DEV)), ops.normalize_rows(v.to(DEV))
+    got = ops.scaled_dot_nt(tn, vn, 1.0).double().cpu()
+    want = (t.double() / t.double().norm(dim=-1, keepdim=True)) @ (v.double() / v.double().norm(dim=-1, keepdim=True)).t()
+    assert float((got - want).abs().max()) <= 5e-5
+    # the GEMM alone, on the fp32 rows it was given: a flushed lo part of a 1e-4 component beside a unit component is an
+    # absolute error of 5e-8 in an entry of size 1e-4; the split scheme itself stays below 1e-10 there
+    exact = tn.double().cpu() @ vn.double().cpu().t()
+    small = exact.abs() < 1e-3
+    assert int(small.sum()) > 1000
+    assert float((got - exact).abs()[small].max()) <= 5e-9
+    assert float((got - exact).abs().max()) <= 5e-7
