@@ -126,13 +126,16 @@ def graph_time_ms(fn, launches=20, replays=4):
 
 TILES = {1: (128, 128, 2, 2, 64), 2: (128, 64, 2, 2, 64), 3: (64, 128, 2, 2, 64), 4: (64, 64, 2, 2, 64),
          5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128),
-         9: (256, 256, 2, 4, 64)}          # 9: split-K, two workgroups per tile (last template argument 2)
+         9: (256, 256, 2, 4, 64),          # 9: split-K, two workgroups per tile (last template argument 2)
+         10: (128, 256, 2, 4, 64), 11: (256, 256, 2, 4, 64)}     # 11: the persistent form, its own kernel (gemm_persist_kernel<epi>)
 
 
 def kernel_symbol(M, N, K, epi):
     """Name of the gemm_f16_kernel instantiation a stand-alone launch of this shape runs on (as rocprofv3 prints it)."""
     from centerclip_amd import _lib as L
     t = L.lib().cc_linear_tile_for(M, N, K, epi)
+    if t == 11:
+        return "gemm_persist_kernel<%d>" % epi
     bm, bn, wm, wn, bk = TILES[t]
     return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk, 2 if t == 9 else 1)
 
@@ -185,7 +188,8 @@ def insitu_gemm_times(step, reps=6, rider_rows=None, rider_rows_launched=None):
     for i in range(n):
         assert lib.cc_debug_gemm_timing_read(i, ctypes.byref(us), info) == 0
         bm, bn, wm, wn, epi, bk, m0, n0, k0, m1, n1, k1 = list(info)
-        sym = "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk & 0xffff, max(1, bk >> 16))
+        sym = ("gemm_persist_kernel<%d>" % epi if (bk >> 16) == 3 else
+               "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk & 0xffff, max(1, bk >> 16)))
         e = out.setdefault(sym, dict(us=0.0, launches=0, flops=0.0, shapes={}))
         e["us"] += us.value
         e["launches"] += 1

@@ -54,6 +54,10 @@ def declare(lib):
     lib.cc_row_stats_f16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.cc_linear_ln_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp]
     lib.cc_linear_resid_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), vp, vp, i32, vp, i32, i32, i32, i32, vp]
+    lib.cc_linear_ws_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]
+    lib.cc_linear_ws_f16.restype = c.c_int
+    lib.cc_linear_ln_ws_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
+    lib.cc_linear_ln_ws_f16.restype = c.c_int
     lib.cc_linear_tile_for.argtypes = [i32, i32, i32, i32]
     lib.cc_linear_tile_for.restype = c.c_int
     lib.cc_linear_resid_stats_slots.argtypes = [i32, i32, i32, i32]

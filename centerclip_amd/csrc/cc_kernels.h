@@ -78,6 +78,12 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
 // The same product for a FEW selected rows (GemmArgs::row_step / row_map; epilogues EPI_F16_GELU_LN, EPI_F32_RESID and
 // EPI_F32_RESID_STATS; N % 32 == 0, K % 32 == 0; with statistics N <= 32 * CC_LN_MAX_SLOTS): latency-bound, so the K
 // range is split over the 8 waves of a workgroup and the grid has one workgroup per 32 output columns.
+// gemm_persist.hip: the persistent 256x256 form (one workgroup per CU walking a range of the launch's k-steps; tiles cut
+// between two workgroups are summed through the exchange scratch g0.sk_ws).  fp16-output epilogues.
+bool cc_gemm_persist_applies(const GemmArgs& g0, const GemmArgs* g1, int epi);
+int cc_gemm_persist_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st);
+// diagnostics (cc_debug_gemm_timing_*): while armed, -> true and a start / stop event pair for this launch
+bool cc_gemm_timing_claim(const int rec12[12], hipEvent_t* start, hipEvent_t* stop);
 bool cc_gemm_rows_ok(int N, int K, int epi);
 int cc_gemm_rows_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st, int* slots_out = nullptr);
 

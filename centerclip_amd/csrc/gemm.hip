@@ -675,6 +675,17 @@ struct GemmTiming {
     int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK | SK << 16, M0, N0, K0, M1, N1, K1
 } g_timing;
 
+}  // namespace
+bool cc_gemm_timing_claim(const int rec12[12], hipEvent_t* start, hipEvent_t* stop) {
+    if (!(g_timing.armed && g_timing.count < g_timing.cap)) return false;
+    const int tid = g_timing.count++;
+    memcpy(g_timing.info[tid], rec12, sizeof(int) * 12);
+    *start = g_timing.ev[2 * tid];
+    *stop = g_timing.ev[2 * tid + 1];
+    return true;
+}
+namespace {
+
 template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
@@ -872,9 +883,14 @@ static int pick_tile(const GemmArgs& g, int epi) {
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
 // 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0); 9 = 256x256 split-K (two
-// workgroups per tile, residual epilogue, needs the exchange scratch); 10 = 128x256 (8 waves)
+// workgroups per tile, residual epilogue, needs the exchange scratch); 10 = 128x256 (8 waves); 11 = 256x256 persistent
+// (gemm_persist.hip: fp16-output epilogues, needs the exchange scratch and at least one tile per CU)
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
+    if (tile == 11) {                              // the persistent 256x256 form: selectable, never picked (measured slower)
+        if (!cc_gemm_persist_applies(g0, g1, epi)) return CC_ERR_INVALID;
+        return cc_gemm_persist_dispatch2(g0, g1, epi, st);
+    }
     if (tile == 0) {
         tile = pick_tile(g0, epi);
         if (epi == EPI_F32_RESID_STATS && sk2_applies(g0, g1)) tile = 9;
@@ -1153,17 +1169,23 @@ int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_
 
 extern "C" {
 
-int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
-                  int32_t ldc, int32_t epilogue, int32_t tile, void* stream) {
+int cc_linear_ws_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
+                     int32_t ldc, int32_t epilogue, int32_t tile, void* ws, size_t ws_bytes, void* stream) {
     if (!a_f16 || !w_f16 || !c) return CC_ERR_INVALID;
     if (epilogue == EPI_F32_PATCH) return CC_ERR_INVALID;
+    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
     GemmArgs g{};
     g.A = static_cast<const _Float16*>(a_f16);
     g.W = static_cast<const _Float16*>(w_f16);
     g.bias = bias;
     g.C = c;
     g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+    g.sk_ws = ws;
     return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
+}
+int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
+                  int32_t ldc, int32_t epilogue, int32_t tile, void* stream) {
+    return cc_linear_ws_f16(a_f16, w_f16, bias, c, M, N, K, ldc, epilogue, tile, nullptr, 0, stream);
 }
 
 /* LayerNorm-folded Linear: y = LN(h) W^T + b evaluated as rstd (h16 Wln^T - mu c1) + c2 (see cc_fold_layernorm_linear_f32).
@@ -1171,8 +1193,15 @@ int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void*
 int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
                      int32_t slots, float eps, void* out_f16, int32_t M, int32_t N, int32_t K, int32_t gelu,
                      int32_t tile, void* stream) {
+    return cc_linear_ln_ws_f16(h_f16, w_ln_f16, c1, c2, stats, slots, eps, out_f16, M, N, K, gelu, tile, nullptr, 0, stream);
+}
+int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
+                        int32_t slots, float eps, void* out_f16, int32_t M, int32_t N, int32_t K, int32_t gelu,
+                        int32_t tile, void* ws, size_t ws_bytes, void* stream) {
     if (!h_f16 || !w_ln_f16 || !c1 || !c2 || !stats || !out_f16 || slots <= 0 || slots > CC_LN_MAX_SLOTS) return CC_ERR_INVALID;
+    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
     GemmArgs g{};
+    g.sk_ws = ws;
     g.A = static_cast<const _Float16*>(h_f16);
     g.W = static_cast<const _Float16*>(w_ln_f16);
     g.bias = c2;

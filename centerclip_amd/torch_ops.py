@@ -58,13 +58,30 @@ def _e(*shape, like, dtype):
 
 
 # ------------------------------------------------------------------------------------------ Linear / LN / attention
+_SPLITK_WS = {}
+
+
+def _splitk_ws(t):
+    """Split-K exchange area of the residual Linear, one per (device, stream): zeroed once (every call leaves its flags
+    zero), never freed (a captured graph keeps the address)."""
+    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        nbytes = int(L.lib().cc_linear_splitk_workspace_bytes())
+        ws = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
+        ws[:int(L.lib().cc_linear_splitk_flag_bytes())].zero_()
+        _SPLITK_WS[key] = ws
+    return ws
+
+
 @custom_op(NS + "::linear_f16", mutates_args=(), device_types="cuda")
 def linear_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: str, tile: int) -> torch.Tensor:
     M, K = a.shape
     N = w.shape[0]
     out = _e(M, N, like=a, dtype=torch.float16 if epilogue.startswith("f16") else torch.float32)
-    L.check(L.lib().cc_linear_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, N, EPI[epilogue], tile, _st(a)),
-            "cc_linear_f16")
+    ws = _splitk_ws(a)
+    L.check(L.lib().cc_linear_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, N, EPI[epilogue], tile, L.ptr(ws),
+                                     ws.numel(), _st(a)), "cc_linear_ws_f16")
     return out
 
 
@@ -78,8 +95,9 @@ def linear_f16_out(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    tile: int) -> None:
     """epilogue 'f32_resid': out += a w^T + b in place; the other epilogues overwrite ``out`` (row stride honoured)."""
     M, K = a.shape
-    L.check(L.lib().cc_linear_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], K, out.stride(0),
-                                  EPI[epilogue], tile, _st(a)), "cc_linear_f16")
+    ws = _splitk_ws(a)
+    L.check(L.lib().cc_linear_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], K, out.stride(0),
+                                     EPI[epilogue], tile, L.ptr(ws), ws.numel(), _st(a)), "cc_linear_ws_f16")
 
 
 @linear_f16_out.register_fake
@@ -158,30 +176,16 @@ def linear_ln_f16(h16: torch.Tensor, w_ln: torch.Tensor, c1: torch.Tensor, c2: t
     M, K = h16.shape
     N = w_ln.shape[0]
     out = _e(M, N, like=h16, dtype=torch.float16)
-    L.check(L.lib().cc_linear_ln_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
-                                     L.ptr(out), M, N, K, int(gelu), tile, _st(h16)), "cc_linear_ln_f16")
+    ws = _splitk_ws(h16)
+    L.check(L.lib().cc_linear_ln_ws_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
+                                        L.ptr(out), M, N, K, int(gelu), tile, L.ptr(ws), ws.numel(), _st(h16)),
+            "cc_linear_ln_ws_f16")
     return out
 
 
 @linear_ln_f16.register_fake
 def _(h16, w_ln, c1, c2, stats, slots, gelu, eps, tile):
     return h16.new_empty((h16.shape[0], w_ln.shape[0]))
-
-
-_SPLITK_WS = {}
-
-
-def _splitk_ws(t):
-    """Split-K exchange area of the residual Linear, one per (device, stream): zeroed once (every call leaves its flags
-    zero), never freed (a captured graph keeps the address)."""
-    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
-    ws = _SPLITK_WS.get(key)
-    if ws is None:
-        nbytes = int(L.lib().cc_linear_splitk_workspace_bytes())
-        ws = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
-        ws[:int(L.lib().cc_linear_splitk_flag_bytes())].zero_()
-        _SPLITK_WS[key] = ws
-    return ws
 
 
 @custom_op(NS + "::linear_resid_stats_f16", mutates_args=("h", "h16", "stats", "shift_out"), device_types="cuda")

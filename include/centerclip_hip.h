@@ -307,6 +307,13 @@ int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_
 int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
                   int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
                   void* stream);
+/* The same with the exchange scratch of the split forms (cc_linear_splitk_workspace_bytes(), flag bytes zero, one per
+ * stream): with it tile 0 may pick, and tile 11 selects, the persistent 256x256 form for the fp16-output epilogues - one
+ * workgroup per CU walking an equal share of the launch's k-steps, a tile cut between two workgroups summed through the
+ * scratch (N % 256 == 0, at least one tile per CU).  ws NULL = cc_linear_f16. */
+int cc_linear_ws_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
+                     int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* LayerNorm over the last dim (fp32 statistics, eps as given) - modules/clip.py:183-189.
  * Row r is read at in + r*in_stride and written at out + r*out_stride (elements); out is fp16
@@ -332,7 +339,11 @@ int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, float* shi
 int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
                      const float* stats, int32_t slots, float eps, void* out_f16,
                      int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* stream);
-/* host-side query: the tile (1-8, see cc_linear_f16) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
+int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
+                        const float* stats, int32_t slots, float eps, void* out_f16,
+                        int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* ws, size_t ws_bytes,
+                        void* stream);       /* (with the exchange scratch, see cc_linear_ws_f16) */
+/* host-side query: the tile (1-11, see cc_linear_f16 / cc_linear_ws_f16; the answer for a call WITH the exchange scratch) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
  * LN-folded f16 without / with QuickGELU, 7 = residual + statistics); <= 0: unsupported */
 int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue);
 /* host-side query: slots per row cc_linear_resid_stats_f16 will write for this shape (tile 0 = auto); <= 0: unsupported */

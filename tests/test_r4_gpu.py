@@ -86,3 +86,49 @@ def test_similarity_tiny_components():
     assert int(small.sum()) > 1000
     assert float((got - exact).abs()[small].max()) <= 5e-9
     assert float((got - exact).abs().max()) <= 5e-7
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(9600, 3072, 768, True), (9600, 2304, 768, False), (9479, 2304, 768, False),
+                                        (19200, 3072, 768, True), (20000, 1024, 512, False)])
+def test_persistent_gemm_matches_the_tiled_kernel(M, N, K, gelu):
+    """tile 11 (gemm_persist.hip: one workgroup per CU over an equal share of the launch's k-steps; modules/clip.py:207-211,
+    220-226 with the folded LayerNorm) against float64 and against the 256x256 tile: bit-identical (also in the tiles cut
+    between two workgroups), identical bits from call to call; flags of the exchange scratch left at zero."""
+    from centerclip_amd import ops, torch_ops as T, _lib as L
+    gen = torch.Generator().manual_seed(M + N)
+    h = torch.randn(M, K, generator=gen) * 2 + 0.3
+    gamma, beta = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.2
+    w = torch.randn(N, K, generator=gen) * K ** -0.5
+    b = torch.randn(N, generator=gen) * 0.1
+    pre = F.layer_norm(h.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    want = pre * torch.sigmoid(1.702 * pre) if gelu else pre
+    h16, st1, _ = ops.row_stats(h.to(DEV))
+    wf, c1, c2 = ops.fold_layernorm_linear(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV))
+    y5 = ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=gelu, tile=5)
+    ys = [ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=gelu, tile=11) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert relerr(ys[0].float().cpu(), want) < 3e-3
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    # a cut tile's head is handed over and its tail continues from it: every element is the same left-to-right sum over k
+    assert torch.equal(ys[0], y5)
+    assert torch.equal(ops.linear_ln_f16(h16, wf, c1, c2, st1, 1, gelu=gelu, tile=0), y5)      # (the dispatcher's own choice)
+    ws = T._splitk_ws(h16)
+    assert int(ws[:int(L.lib().cc_linear_splitk_flag_bytes())].view(torch.int32).abs().sum()) == 0
+
+
+def test_persistent_gemm_plain_epilogues_and_row_stride():
+    """The plain fp16 epilogues through the persistent form, and an output row stride wider than N."""
+    from centerclip_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    M, N, K = 9600, 3072, 768
+    a = torch.randn(M, K, generator=gen).half()
+    w = (torch.randn(N, K, generator=gen) * K ** -0.5).half()
+    b = torch.randn(N, generator=gen)
+    ref = a.double() @ w.double().t() + b.double()
+    for epi in ("f16", "f16_gelu"):
+        y = ops.linear_f16(a.to(DEV), w.to(DEV), b.to(DEV), epi, tile=11)
+        want = ref * torch.sigmoid(1.702 * ref) if epi == "f16_gelu" else ref
+        assert relerr(y.float().cpu(), want) < 2e-3
+    out = torch.zeros(M, N + 64, device=DEV, dtype=torch.float16)
+    ops.linear_f16(a.to(DEV), w.to(DEV), b.to(DEV), "f16", out=out[:, :N], tile=11)
+    assert relerr(out[:, :N].float().cpu(), ref) < 2e-3 and float(out[:, N:].abs().max()) == 0.0
