@@ -347,14 +347,26 @@ def similarity_bench(device, world=1):
     """pairwise-similarities/s: 10k texts x 1k videos (3 segments each): pooling / normalising into split fp16 planes + ONE
     fp16 MFMA GEMM over the K-concatenated planes (3 products per algorithmic multiply-add).  world > 1:
     rows sharded over ranks (dist.sharded_similarity with the HIP kernel), time = max over ranks."""
-    from centerclip_amd import ops, dist as ccdist
+    from centerclip_amd import ops, dist as ccdist, torch_ops as T_
     Nt, Nv, Tn, E = 10000, 1000, 3, 512
     g = torch.Generator().manual_seed(11)
     t = torch.randn(Nt, E, generator=g).to(device)
     v = torch.randn(Nv, Tn, E, generator=g).to(device)
     m = torch.ones(Nv, Tn, dtype=torch.long, device=device)
+    parts = None
     if world == 1:
         ms = event_time_ms(lambda: ops.loose_similarity(t, v, m, 1.0), 20)
+        # the evaluation loop's form: operand planes written when the batches are encoded, the matrix = the GEMM alone
+        tp = torch.ops.centerclip.normalize_rows_planes(t, False)
+        vp = torch.zeros(T_.padded_video_rows(Nv), 3 * E, device=device, dtype=torch.float16)
+        vp[:Nv] = torch.ops.centerclip.video_pool_normalize_planes(v, m)
+        ms_gemm = graph_time_ms(lambda: torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, 2.718281828), launches=10, replays=3)
+        ms_prep = graph_time_ms(lambda: (torch.ops.centerclip.normalize_rows_planes(t, False),
+                                         torch.ops.centerclip.video_pool_normalize_planes(v, m)), launches=10, replays=3)
+        parts = dict(gemm_from_cached_planes_us=round(ms_gemm * 1e3, 1), plane_writing_us=round(ms_prep * 1e3, 1),
+                     note="eval_epoch writes the planes batch by batch with the encoders' outputs; its final matrix costs the GEMM",
+                     pairs_per_s_gemm_alone=round(Nt * Nv / ms_gemm * 1e3, 0),
+                     gemm_issued_f16_mfma_frac=round(3 * 2.0 * Nt * Nv * E / ms_gemm / 1e9 / MFMA_F16_PEAK_TFLOPS, 4))
     else:
         t0, t1 = ccdist.shard_rows(Nt)
         v0, v1 = ccdist.shard_rows(Nv)
@@ -374,7 +386,8 @@ def similarity_bench(device, world=1):
                 frac_of_f16_mfma_peak=round(3 * flops / ms / 1e9 / MFMA_F16_PEAK_TFLOPS / world, 4),
                 algorithmic_bytes=int((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4),
                 frac_of_hbm_peak=round(((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4) / ms / 1e6 / HBM_PEAK_GBS / world, 4),
-                sharding="rows over %d ranks, videos all-gathered (%.1f MB)" % (world, Nv * E * 4 / 1e6) if world > 1 else "single GPU")
+                sharding="rows over %d ranks, videos all-gathered (%.1f MB)" % (world, Nv * E * 4 / 1e6) if world > 1 else "single GPU",
+                parts=parts)
 
 
 def pcie_inclusive_bench(model, c, device, steps=150):

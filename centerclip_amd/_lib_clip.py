@@ -116,6 +116,16 @@ def declare(lib):
     lib.cc_clip_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, c.POINTER(TextModel), vp, i32, i32, vp, vp, sz, vp]
     lib.cc_clip_encode.restype = c.c_int
     lib.cc_similarity_workspace_bytes.restype = sz
+    lib.cc_similarity_plane_row_bytes.argtypes = [i32]
+    lib.cc_similarity_plane_row_bytes.restype = sz
+    lib.cc_similarity_padded_rows.argtypes = [i32]
+    lib.cc_similarity_padded_rows.restype = i32
+    lib.cc_normalize_rows_planes_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    lib.cc_normalize_rows_planes_f32.restype = c.c_int
+    lib.cc_video_pool_normalize_planes_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.cc_video_pool_normalize_planes_f32.restype = c.c_int
+    lib.cc_scaled_dot_planes_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, i32, vp]
+    lib.cc_scaled_dot_planes_f32.restype = c.c_int
     lib.cc_similarity_workspace_bytes.argtypes = [i32, i32, i32]
     lib.cc_video_pool_normalize_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.cc_loose_similarity_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, sz, vp]

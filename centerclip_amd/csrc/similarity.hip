@@ -325,7 +325,7 @@ static void sim_planes(void* ws, int Bt, int Bv, int E, SplitOut& ta, SplitOut& 
 }
 
 static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int Bv, int E, float mult, float* logits,
-                             int ldl, hipStream_t st) {
+                             int ldl, hipStream_t st, bool zero_pad = true) {
     GemmArgs g{};
     g.A = ta.hi;
     g.W = vb.hi;
@@ -336,7 +336,7 @@ static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int
     g.n_valid = Bv;
     // the tiles read video rows up to the padded count: their products are dropped (n_valid), but they are read - zeros
     // instead of whatever the workspace held (uninitialised reads under sanitizers, NaN patterns through the matrix cores)
-    if (g.N > Bv && hipMemsetAsync(vb.hi + (size_t)Bv * 3 * E, 0, (size_t)(g.N - Bv) * 3 * E * sizeof(_Float16), st) != hipSuccess)
+    if (zero_pad && g.N > Bv && hipMemsetAsync(vb.hi + (size_t)Bv * 3 * E, 0, (size_t)(g.N - Bv) * 3 * E * sizeof(_Float16), st) != hipSuccess)
         return CC_ERR_HIP;
     g.out_scale = mult * 9.5367431640625e-07f;                // 2^-20: undo the two 2^10 operand scalings (exact)
     return cc_gemm_dispatch(g, EPI_F32, tile, st);
@@ -355,6 +355,40 @@ int cc_scaled_dot_nt_f32(const float* a, const float* b, int32_t Bt, int32_t Bv,
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((nb + 2047) / 2048 < 4096 ? (nb + 2047) / 2048 : 4096)), dim3(256), 0, st, b, vb, nb);
     CC_LAUNCH_CHECK();
     return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, st);
+}
+
+/* ---- the similarity operands as the producers' by-product (eval: S3).  The text / video features of a batch are written
+ * as split-fp16 planes when the batch is encoded; the Nt x Nv matrix at the end of the epoch is then the GEMM alone.
+ * A plane row is 3E halfs: text side [hi | hi | lo], video side [hi | lo | hi] (see the top of this file). */
+size_t cc_similarity_plane_row_bytes(int32_t E) { return E > 0 ? (size_t)E * 6 : 0; }
+/* rows of a video-side plane buffer the GEMM reads for Bv videos (whole tiles): allocate and ZERO this many */
+int32_t cc_similarity_padded_rows(int32_t Bv) { return Bv > 0 ? (int32_t)sim_rows_pad(Bv) : 0; }
+
+int cc_normalize_rows_planes_f32(const float* in, float* out, void* planes, int32_t video_side, int32_t R, int32_t E,
+                                 void* stream) {
+    if (!in || !planes || R <= 0 || E <= 0 || (E & 63)) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       SplitOut{static_cast<_Float16*>(planes), E, video_side ? 1 : 0}, R, E);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_video_pool_normalize_planes_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
+                                       float* pooled, void* planes, void* stream) {
+    if (!planes || (E & 63)) return CC_ERR_INVALID;
+    const VidAddr ad{Bv > 0 ? Bv : 1, 0, 0, Tn, 1};
+    return video_pool_launch(visual, video_mask, ad, Bv, Tn, E, pooled, SplitOut{static_cast<_Float16*>(planes), E, 1}, stream);
+}
+
+int cc_scaled_dot_planes_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
+                             int32_t video_rows, int32_t E, float mult, float* logits, int32_t ldl, void* stream) {
+    if (!text_planes || !video_planes || !logits || Bt <= 0 || Bv <= 0 || E <= 0 || (E & 63) || ldl < Bv) return CC_ERR_INVALID;
+    int bn = 256;
+    (void)sim_tile(Bt, Bv, &bn);
+    if (video_rows < (Bv + bn - 1) / bn * bn) return CC_ERR_WORKSPACE;       // the tiles read whole multiples of their width
+    const SplitOut ta{const_cast<_Float16*>(static_cast<const _Float16*>(text_planes)), E, 0};
+    const SplitOut vb{const_cast<_Float16*>(static_cast<const _Float16*>(video_planes)), E, 1};
+    return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, static_cast<hipStream_t>(stream), false);
 }
 
 int cc_loose_similarity_grouped_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t group,

@@ -40,6 +40,25 @@ class HipBackend:
     pool_normalize = staticmethod(ops.video_pool_normalize)
     dot_nt = staticmethod(ops.scaled_dot_nt)
 
+    # The operands of the final matrix as by-products of encoding a batch (split-fp16 planes, [rows, 3E] fp16): what the
+    # epoch's last step multiplies is then ONE GEMM launch.  A backend's "operand rows" are opaque to the loop: it only
+    # concatenates, scatters and (sharded) all-gathers them.
+    @staticmethod
+    def text_operand(feats):
+        return torch.ops.centerclip.normalize_rows_planes(feats.float().contiguous(), False)
+
+    @staticmethod
+    def video_operand(visual_output, mask):
+        if visual_output.dim() == 2:                               # pooled + normalised already (pre_visual_pooling)
+            return torch.ops.centerclip.normalize_rows_planes(visual_output.float().contiguous(), True)
+        return torch.ops.centerclip.video_pool_normalize_planes(visual_output.float().contiguous(), mask.to(torch.long).contiguous())
+
+    video_operand_rows = staticmethod(T.padded_video_rows)          # rows to allocate (zeroed) for n videos
+
+    @staticmethod
+    def dot_operands(text_op, video_op, n_video, mult):
+        return torch.ops.centerclip.scaled_dot_planes(text_op.contiguous(), video_op, int(n_video), float(mult))
+
     @staticmethod
     def counts_cols(sim, gt_cols):
         return torch.ops.centerclip.rank_counts_cols(sim.contiguous(), gt_cols)
@@ -72,26 +91,28 @@ class _Cache:
         return torch.cat(parts, 0) if parts else torch.zeros((0, width), device=device, dtype=dtype)
 
 
-def _pooled_rows(core, visual_output, video_mask, be):
-    """[b, T', E] per-segment features + the loader's mask -> [b, E] pooled + normalised (clip4clip.py:305-316,357-360);
-    [b, E] inputs (eval with pre_visual_pooling) are already that."""
+def _video_operand(core, visual_output, video_mask, be):
+    """[b, T', E] per-segment features + the loader's mask (or [b, E] pooled rows) -> the video-side operand rows of the
+    final matrix (clip4clip.py:305-316,357-360 folded into their production)."""
     if visual_output.dim() == 2:
-        return visual_output
+        return be.video_operand(visual_output, None)
     vm = video_mask.view(-1, video_mask.shape[-1])
     if vm.shape[1] != visual_output.shape[1]:
         vm = core.get_video_mask_after_cluster(vm)
-    return be.pool_normalize(visual_output.contiguous(), vm.contiguous())
+    return be.video_operand(visual_output.contiguous(), vm.contiguous())
 
 
 def _similarity_matrix(model, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list,
                        backend=HipBackend):
     """-> device tensor [Nt, Nv] from the cached per-batch lists (this process' cache only; no collective)."""
     core = model.module if hasattr(model, 'module') else model
-    text = torch.cat([s.reshape(s.shape[0], -1) for s in batch_sequence_output_list], 0)
-    pooled = torch.cat([_pooled_rows(core, v, masks[0], backend)
-                        for v, masks in zip(batch_visual_output_list, batch_list_v)], 0)
+    text = torch.cat([backend.text_operand(s.reshape(s.shape[0], -1)) for s in batch_sequence_output_list], 0)
+    vids = torch.cat([_video_operand(core, v, masks[0], backend) for v, masks in zip(batch_visual_output_list, batch_list_v)], 0)
+    n_video = vids.shape[0]
+    video_all = torch.zeros(max(n_video, backend.video_operand_rows(n_video)), vids.shape[1], device=vids.device, dtype=vids.dtype)
+    video_all[:n_video] = vids
     mult = T.logit_multiplier(core._logit_scale_value())
-    return backend.dot_nt(backend.normalize_rows(text), pooled, mult)
+    return backend.dot_operands(text, video_all, n_video, mult)
 
 
 def _run_on_single_gpu(model, batch_list_t, batch_list_v, batch_sequence_output_list, batch_visual_output_list,
@@ -175,14 +196,15 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
             input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
             if not multi:
                 out = model(input_ids, segment_ids, input_mask, video, video_mask)
-                cache.add_text(out['sequence_output'], pos)
-                cache.add_video(_pooled_rows(core, out['visual_output'], video_mask, be), pos)
+                cache.add_text(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1)), pos)
+                cache.add_video(_video_operand(core, out['visual_output'], video_mask, be), pos)
                 continue
-            cache.add_text(model(input_ids, segment_ids, input_mask)['sequence_output'], pos)
+            seq = model(input_ids, segment_ids, input_mask)['sequence_output']
+            cache.add_text(be.text_operand(seq.reshape(seq.shape[0], -1)), pos)
             rows = [i for i, p in enumerate(pos.tolist()) if p in video_of_last]      # items that carry their clip's video
             if rows:
                 vout = model(video=video[rows, ...], video_mask=video_mask[rows, ...])['visual_output']
-                cache.add_video(_pooled_rows(core, vout, video_mask[rows, ...], be),
+                cache.add_video(_video_operand(core, vout, video_mask[rows, ...], be),
                                 torch.as_tensor([video_of_last[int(pos[i])] for i in rows], dtype=torch.long))
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -212,7 +234,10 @@ def _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world,
     the block is the whole matrix and no collective runs.  -> (tv_metrics, vt_metrics, (Nt, Nv))."""
     text_pos = torch.cat(cache.text_pos) if cache.text_pos else torch.zeros(0, dtype=torch.long)
     video_pos = torch.cat(cache.video_pos) if cache.video_pos else torch.zeros(0, dtype=torch.long)
-    E = (cache.text[0] if cache.text else cache.video[0]).shape[-1] if (cache.text or cache.video) else 0
+    # the cached rows are the backend's operand rows of the final product (HIP: split-fp16 planes, [rows, 3E] fp16)
+    parts = cache.text + cache.video
+    E = parts[0].shape[-1] if parts else 0
+    dtype = parts[0].dtype if parts else torch.float32
     if world > 1:                                       # ranks must agree on the geometry before any payload moves
         sizes = ccdist.all_gather_ints([n_text, n_video, E, len(text_pos), len(video_pos)], device)
         if len({tuple(s[:2]) for s in sizes}) != 1:
@@ -221,15 +246,14 @@ def _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world,
         if sum(s[3] for s in sizes) != n_text or sum(s[4] for s in sizes) != n_video:
             raise RuntimeError("eval_epoch(shard=True): the ranks' shards do not add up to the dataset (%s) - every rank "
                                "must iterate the same unsharded loader or a DistributedSampler(shuffle=False)" % (sizes,))
-    text = _Cache._cat(cache.text, E, device, torch.float32)
-    local_video = _Cache._cat(cache.video, E, device, torch.float32)
-    # ---- exchange step: all pooled video rows, in dataset order
+    text = _Cache._cat(cache.text, E, device, dtype)
+    local_video = _Cache._cat(cache.video, E, device, dtype)
+    # ---- exchange step: the video operand rows of every rank, in dataset order (zero rows pad up to whole GEMM tiles)
+    video_all = torch.zeros(max(n_video, be.video_operand_rows(n_video)), E, device=device, dtype=dtype)
     if world > 1:
         rows, pos = ccdist.gather_varlen(local_video, video_pos.to(device))
-        video_all = torch.empty(n_video, E, device=device, dtype=torch.float32)
         video_all[pos] = rows
     else:
-        video_all = torch.empty_like(local_video)
         video_all[video_pos.to(device)] = local_video
     text_pos = text_pos.to(device)
     if last_sentence is None:
@@ -239,7 +263,7 @@ def _sharded_metrics(core, cache, n_text, n_video, last_sentence, device, world,
         gt_cols = torch.searchsorted(bounds, text_pos)
     mult = T.logit_multiplier(core._logit_scale_value())
     nloc = text.shape[0]
-    block = be.dot_nt(be.normalize_rows(text), video_all, mult) if nloc else torch.zeros(0, n_video, device=device)
+    block = be.dot_operands(text, video_all, n_video, mult) if nloc else torch.zeros(0, n_video, device=device)
     # ---- text -> video: rank of the ground-truth column in every local row
     c3 = be.counts_cols(block, gt_cols.to(torch.int32)) if nloc else torch.zeros(0, 3, dtype=torch.int32, device=device)
     truth = block.gather(1, gt_cols.view(-1, 1)).squeeze(1) if nloc else torch.zeros(0, device=device)

@@ -799,6 +799,60 @@ def _(x):
     return torch.empty_like(x)
 
 
+@custom_op(NS + "::normalize_rows_planes", mutates_args=(), device_types="cuda")
+def normalize_rows_planes(x: torch.Tensor, video_side: bool) -> torch.Tensor:
+    """rows / |row| written as the split-fp16 planes the similarity GEMM multiplies: [R, 3E] fp16 (text side [hi|hi|lo],
+    video side [hi|lo|hi]) - the operand of scaled_dot_planes, produced when a batch is encoded."""
+    R, E = x.shape
+    planes = _e(R, 3 * E, like=x, dtype=torch.float16)
+    L.check(L.lib().cc_normalize_rows_planes_f32(L.ptr(x), None, L.ptr(planes), int(video_side), R, E, _st(x)),
+            "cc_normalize_rows_planes_f32")
+    return planes
+
+
+@normalize_rows_planes.register_fake
+def _(x, video_side):
+    return x.new_empty((x.shape[0], 3 * x.shape[1]), dtype=torch.float16)
+
+
+@custom_op(NS + "::video_pool_normalize_planes", mutates_args=(), device_types="cuda")
+def video_pool_normalize_planes(visual: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """_mean_pooling_for_similarity_visual + the final normalisation (clip4clip.py:305-316,357-360) -> video-side planes
+    [Bv, 3E] fp16."""
+    Bv, Tn, E = visual.shape
+    planes = _e(Bv, 3 * E, like=visual, dtype=torch.float16)
+    L.check(L.lib().cc_video_pool_normalize_planes_f32(L.ptr(visual), L.ptr(mask), Bv, Tn, E, None, L.ptr(planes), _st(visual)),
+            "cc_video_pool_normalize_planes_f32")
+    return planes
+
+
+@video_pool_normalize_planes.register_fake
+def _(visual, mask):
+    return visual.new_empty((visual.shape[0], 3 * visual.shape[2]), dtype=torch.float16)
+
+
+@custom_op(NS + "::scaled_dot_planes", mutates_args=(), device_types="cuda")
+def scaled_dot_planes(text_planes: torch.Tensor, video_planes: torch.Tensor, n_video: int, mult: float) -> torch.Tensor:
+    """[Bt, n_video] = mult * text . video^T from the planes: the GEMM launch alone.  video_planes holds at least
+    padded_video_rows(n_video) rows, zeros behind n_video."""
+    Bt, E3 = text_planes.shape
+    out = _e(Bt, int(n_video), like=text_planes, dtype=torch.float32)
+    L.check(L.lib().cc_scaled_dot_planes_f32(L.ptr(text_planes), L.ptr(video_planes), Bt, int(n_video), video_planes.shape[0],
+                                             E3 // 3, float(mult), L.ptr(out), int(n_video), _st(text_planes)),
+            "cc_scaled_dot_planes_f32")
+    return out
+
+
+@scaled_dot_planes.register_fake
+def _(text_planes, video_planes, n_video, mult):
+    return text_planes.new_empty((text_planes.shape[0], n_video), dtype=torch.float32)
+
+
+def padded_video_rows(n_video):
+    """Rows a video-side plane buffer needs for n_video videos (whole GEMM tiles; the rows behind n_video must be zero)."""
+    return int(L.lib().cc_similarity_padded_rows(int(n_video)))
+
+
 @custom_op(NS + "::scaled_dot_nt", mutates_args=(), device_types="cuda")
 def scaled_dot_nt(a: torch.Tensor, b: torch.Tensor, mult: float) -> torch.Tensor:
     Bt, E = a.shape
@@ -938,7 +992,8 @@ OPS = ("contrastive_loss", "contrastive_loss_grad", "spectral_laplacian", "spect
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",
-       "rank_counts_cols", "rank_counts_ref", "group_max_rows")
+       "rank_counts_cols", "rank_counts_ref", "group_max_rows", "normalize_rows_planes", "video_pool_normalize_planes",
+       "scaled_dot_planes")
 
 
 def logit_multiplier(logit_scale):

@@ -533,6 +533,24 @@ int cc_clip_encode_frames(const cc_vit_model* vm, const cc_frames* frames, int32
  * visual [Bv, Tn, E] fp32, video_mask [Bv, Tn] int64 (as the reference passes it), text [Bt, E].
  * pooled_out (optional) [Bv, E] receives v_bar.  ws: (Bv + Bt) * E floats. */
 size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E);
+
+/* The operands of the similarity GEMM as a by-product of their producers (the evaluation loop, main.py:381-534: features
+ * are cached batch by batch and multiplied once at the end).  A plane row = 3E fp16 values, cc_similarity_plane_row_bytes(E):
+ *   cc_normalize_rows_planes_f32        rows / |row| (clip4clip.py:361-362) -> planes [R, 3E] (video_side 0: the text operand,
+ *                                       1: rows that are pooled video features already) and, optionally, fp32 `out`
+ *   cc_video_pool_normalize_planes_f32  clip4clip.py:305-316,357-360 -> video-side planes [Bv, 3E] (+ fp32 `pooled`, optional)
+ *   cc_scaled_dot_planes_f32            logits [Bt, Bv] = mult * text . video^T from the planes: ONE GEMM launch, nothing else.
+ *                                       The video plane buffer must hold video_rows >= cc_similarity_padded_rows(Bv) rows with
+ *                                       the rows behind Bv ZERO (the tiles read whole multiples of their width).
+ * E % 64 == 0.  Same values as cc_scaled_dot_nt_f32 on the normalised rows. */
+size_t cc_similarity_plane_row_bytes(int32_t E);
+int32_t cc_similarity_padded_rows(int32_t Bv);
+int cc_normalize_rows_planes_f32(const float* in, float* out, void* planes, int32_t video_side, int32_t R, int32_t E,
+                                 void* stream);
+int cc_video_pool_normalize_planes_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn, int32_t E,
+                                       float* pooled, void* planes, void* stream);
+int cc_scaled_dot_planes_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
+                             int32_t video_rows, int32_t E, float mult, float* logits, int32_t ldl, void* stream);
 int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn,
                                 int32_t E, float* pooled, void* stream);
 int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask,

@@ -169,6 +169,24 @@ class _TorchBackend:
     def dot_nt(a, b, mult):
         return mult * a @ b.t()
 
+    # operand rows of the final product: the stand-in keeps plain normalised fp32 rows
+    @classmethod
+    def text_operand(cls, feats):
+        return cls.normalize_rows(feats.float())
+
+    @classmethod
+    def video_operand(cls, visual_output, mask):
+        return cls.normalize_rows(visual_output.float()) if visual_output.dim() == 2 else cls.pool_normalize(visual_output.float(), mask)
+
+    @staticmethod
+    def video_operand_rows(n):
+        return n + 3                                              # (exercises the zero padding rows)
+
+    @classmethod
+    def dot_operands(cls, text_op, video_op, n_video, mult):
+        assert float(video_op[n_video:].abs().sum()) == 0.0
+        return cls.dot_nt(text_op, video_op[:n_video], mult)
+
     @staticmethod
     def counts_cols(sim, gt):
         d = sim.gather(1, gt.long().view(-1, 1))

@@ -132,3 +132,26 @@ def test_persistent_gemm_plain_epilogues_and_row_stride():
     out = torch.zeros(M, N + 64, device=DEV, dtype=torch.float16)
     ops.linear_f16(a.to(DEV), w.to(DEV), b.to(DEV), "f16", out=out[:, :N], tile=11)
     assert relerr(out[:, :N].float().cpu(), ref) < 2e-3 and float(out[:, N:].abs().max()) == 0.0
+
+
+def test_similarity_from_cached_operand_planes():
+    """The evaluation loop's form of the matrix (main.py:502-534): operand planes written per batch with the features, ONE
+    GEMM at the end == cc_loose_similarity on the same features bit for bit, ragged sizes, masks with zeros; and
+    eval._similarity_matrix (S3) through it == the all-at-once op."""
+    from centerclip_amd import ops, torch_ops as T, eval as ev
+    gen = torch.Generator().manual_seed(3)
+    Nt, Nv, Tn, E = 1203, 517, 3, 512
+    t = torch.randn(Nt, E, generator=gen).to(DEV)
+    v = torch.randn(Nv, Tn, E, generator=gen).to(DEV)
+    m = (torch.rand(Nv, Tn, generator=gen) > 0.2).long().to(DEV)
+    m[:, 0] = 1
+    want = ops.loose_similarity(t, v, m, 1.0)
+    tp = torch.cat([torch.ops.centerclip.normalize_rows_planes(t[i:i + 100].contiguous(), False) for i in range(0, Nt, 100)])
+    vp = torch.zeros(T.padded_video_rows(Nv), 3 * E, device=DEV, dtype=torch.float16)
+    vp[:Nv] = torch.cat([torch.ops.centerclip.video_pool_normalize_planes(v[i:i + 64].contiguous(), m[i:i + 64].contiguous())
+                         for i in range(0, Nv, 64)])
+    got = torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, float(np.float32(np.exp(np.float32(1.0)))))
+    # (the same planes, the same GEMM: equal up to the last bit of the scale factor exp(logit_scale) the two entries form)
+    assert float(((got - want).abs() / want.abs().clamp_min(1e-6)).max()) <= 2.5e-7
+    with pytest.raises(RuntimeError):                              # too few (zeroed) padding rows
+        torch.ops.centerclip.scaled_dot_planes(tp, vp[:Nv].contiguous(), Nv, 1.0)
