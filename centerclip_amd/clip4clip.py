@@ -16,7 +16,7 @@ from . import ops
 from . import torch_ops as T
 from .clip import build_clip_model, load_clip_state_dict, zero_scalar
 from . import dist as ccdist
-from .dist import AllGather, all_gather
+from .dist import AllGather, PackedAllGather, all_gather
 from .losses import contrastive_loss
 
 
@@ -116,9 +116,8 @@ class CLIP4Clip(nn.Module):
             # gradient in one kernel chain); the towers have no backward here, so the gradient edge ends at
             # sequence_output / visual_output (detached leaves unless the caller made them require grad).
             seq, vis, vmask = sequence_output.contiguous(), visual_output.contiguous(), video_mask.contiguous()
-            if ccdist.world_size() > 1:
-                seq, vis = AllGather.apply(seq), AllGather.apply(vis)
-                vmask = all_gather(vmask)
+            if ccdist.world_size() > 1:              # ONE collective for the three tensors, gradient slices of the own shard back
+                vis, vmask, seq = PackedAllGather.apply(vis, vmask, seq)
             sim_loss, _, _ = contrastive_loss(seq, vis, vmask, self.clip.logit_scale, self._logit_scale_value())
             output_dict['loss'] = sim_loss + cluster_loss
             output_dict['cluster_loss'] = cluster_loss

@@ -6,6 +6,8 @@
   messages are <= 2 MB (latency-bound over xGMI), so fewer, larger collectives.  Values as in the reference; the
   reference also splices the INPUT tensor back into its rank's slot (utils.py:56) so that autograd reaches the local
   shard - all_gather() returns plain gathered bytes (no autograd edge); use AllGather.apply for the differentiable form.
+* PackedAllGather: the differentiable form for SEVERAL tensors in one collective (the training branch's exchange).
+* GradientBuckets: data-parallel gradient averaging as bucketed reduce-scatter + all-gather (main.py:124,321).
 * PackedFeatures: the same exchange with NO packing step at all - the encoders write their features straight into a
   preallocated record (visual | text | mask), one all_gather_into_tensor moves the records, and the similarity kernel
   reads the gathered records in place (cc_loose_similarity_grouped_f32).
@@ -66,6 +68,101 @@ class AllGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None
+
+
+class PackedAllGather(torch.autograd.Function):
+    """The training branch's exchange (modules/utils.py:25-64 applied to visual_output, video_mask and sequence_output at
+    modules/clip4clip.py:351-355: three all-gathers + a barrier) as ONE collective: the tensors - any dtypes, any
+    trailing shapes - travel in one packed byte buffer (all_gather above); backward hands every floating-point input the
+    gradient slice of its own shard (utils.py:38-44), integer inputs (the mask) get none.
+
+        vis_all, mask_all, seq_all = PackedAllGather.apply(visual_output, video_mask, sequence_output)
+    """
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.rank = rank()
+        ctx.rows = [t.shape[0] for t in tensors]
+        ctx.diff = [t.is_floating_point() for t in tensors]
+        outs = all_gather(*tensors)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        ctx.mark_non_differentiable(*[o for o, d in zip(outs, ctx.diff) if not d])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for g, b, d in zip(grads, ctx.rows, ctx.diff):
+            out.append(g[b * ctx.rank: b * (ctx.rank + 1)] if (d and g is not None) else None)
+        return tuple(out)
+
+
+class GradientBuckets:
+    """The gradient exchange of data-parallel training (main.py:124 wraps the model in DistributedDataParallel; its
+    all-reduce averages the gradients over the ranks after scaler.scale(loss).backward(), main.py:321) as bucketed
+    reduce-scatter + all-gather over RCCL:
+
+    * the parameters' gradients are packed into flat fp32 buckets of ~`bucket_bytes` (in reverse registration order: the
+      order in which backward produces them), each padded to a multiple of the world size;
+    * per bucket ONE reduce_scatter_tensor (every rank receives the sum of its 1/G slice) and ONE all_gather_into_tensor of
+      the averaged slices.  On a node whose GPUs are joined by point-to-point xGMI links both halves move (G-1)/G of the
+      bucket per rank spread over all 7 links at once - the direct pattern - instead of a ring's G-1 dependent hops; bucket
+      size is the knob that keeps each transfer above the link's latency-bound regime (25 MB default: 3.1 MB per peer at
+      G = 8).  The two halves of consecutive buckets can overlap (async_op) - reduce() issues every bucket's reduce-scatter
+      before waiting for the first.
+    * the averaged gradients are scattered back into .grad (views of the flat buckets after the first call: no copies).
+
+    Values: the mean over ranks of every gradient, as DistributedDataParallel produces (its bucket order differs, so sums
+    may differ in the last bit; asserted against an all-reduce mean in tests/test_dist_cpu.py)."""
+
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world_size()
+        order = list(reversed(self.params))
+        self.buckets = []                       # (flat buffer, [(param, offset, numel)])
+        cur, cur_n = [], 0
+        cap = max(1, bucket_bytes // 4)
+        for p in order:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(self._make(cur, cur_n))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(self._make(cur, cur_n))
+
+    def _make(self, plist, n):
+        pad = -(-n // self.world) * self.world
+        flat = torch.zeros(pad, dtype=torch.float32, device=plist[0].device)
+        slots, off = [], 0
+        for p in plist:
+            slots.append((p, off, p.numel()))
+            off += p.numel()
+        return flat, slots
+
+    def reduce(self):
+        """Average .grad of every parameter over the ranks (in place).  Parameters without a gradient count as zeros."""
+        for flat, slots in self.buckets:
+            for p, off, n in slots:
+                dst = flat[off:off + n]
+                if p.grad is None:
+                    dst.zero_()
+                elif p.grad.data_ptr() != dst.data_ptr():
+                    dst.copy_(p.grad.reshape(-1))
+        if self.world > 1:
+            works, shards = [], []
+            for flat, _ in self.buckets:
+                shard = torch.empty(flat.numel() // self.world, dtype=flat.dtype, device=flat.device)
+                works.append(dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True))
+                shards.append(shard)
+            for (flat, _), w, shard in zip(self.buckets, works, shards):
+                w.wait()
+                shard.div_(self.world)
+                dist.all_gather_into_tensor(flat, shard)
+        for flat, slots in self.buckets:
+            for p, off, n in slots:
+                p.grad = flat[off:off + n].view_as(p)
+        return self
 
 
 class PackedFeatures:

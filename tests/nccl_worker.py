@@ -5,6 +5,8 @@ one process per GPU, backend nccl (= RCCL).  Checks, against data every rank can
   * dist.sharded_similarity with the HIP NT GEMM == the single-rank matrix
   * eval.eval_epoch(shard=True) (clip-sharded evaluation loop, HIP kernels + the collectives) == the single-process
     eval_epoch on rank 0, single- and multi-sentence protocols
+  * dist.PackedAllGather (one collective, own-shard gradient slices) and dist.GradientBuckets (reduce-scatter + all-gather
+    gradient averaging) against per-tensor references
 ``--share-gpu``: every rank uses cuda:0 and the collectives run over gloo (a 1-GPU box can still drive world 2 through the
 HIP-backed loop).  Prints NCCL_WORKER_OK world=<n> on rank 0."""
 import os
@@ -105,6 +107,28 @@ def main():
     full = gather_rows(block, Nt)
     assert torch.equal(full, ops.scaled_dot_nt(t, v, 2.0)), "sharded similarity"
     sharded_eval_leg(rank, world, dev)
+    # the training branch's exchange as one collective with the gradient slices back (N4), and the bucketed gradient
+    # averaging (reduce-scatter + all-gather) against an all-reduce mean
+    from centerclip_amd.dist import PackedAllGather, GradientBuckets
+    xv = vis.view(B, Tn, E).to(dev).clone().requires_grad_(True)
+    xs = seq.view(B, 1, E).to(dev).clone().requires_grad_(True)
+    pv, pm, ps = PackedAllGather.apply(xv, mask.to(dev), xs)
+    assert torch.equal(pv.detach(), allv) and torch.equal(pm, allm) and torch.equal(ps.detach().squeeze(1), alls)
+    wv = torch.arange(world * B, device=dev, dtype=torch.float32)[:, None, None]
+    ((pv * wv).sum() + (ps * wv).sum() * 2).backward()
+    own = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
+    assert torch.equal(xv.grad[:, 0, 0], own) and torch.equal(xs.grad[:, 0, 0], 2 * own)
+    params = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in ((768, 768), (3072,), (5, 7), (1,))]
+    gb = GradientBuckets(params, bucket_bytes=1 << 20)
+    gg = torch.Generator().manual_seed(500 + rank)
+    want_g = []
+    for p_ in params:
+        p_.grad = torch.randn(p_.shape, generator=gg).to(dev)
+        t_ = p_.grad.clone()
+        dist.all_reduce(t_)
+        want_g.append(t_ / world)
+    gb.reduce()
+    assert all(torch.allclose(p_.grad, w_, rtol=0, atol=1e-5) for p_, w_ in zip(params, want_g)), "gradient buckets"
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

@@ -131,6 +131,70 @@ def case_allgather_autograd(rank, world):
     return bool(torch.equal(y.detach(), want) and torch.equal(x.grad[:, 0], torch.arange(2 * rank, 2 * rank + 2, dtype=torch.float32)))
 
 
+def case_packed_allgather_autograd(rank, world):
+    """PackedAllGather (the training branch's exchange, modules/utils.py:25-64 at clip4clip.py:351-355 as ONE collective):
+    forward == three AllGather.apply / all_gather calls, backward == their gradients (own-shard slices), exactly."""
+    from centerclip_amd.dist import AllGather, PackedAllGather, all_gather
+    vis0, mask, seq0 = _features(rank)
+    w = [torch.randn(world * 3, 2, 8, generator=torch.Generator().manual_seed(5)),
+         torch.randn(world * 3, 1, 8, generator=torch.Generator().manual_seed(6))]
+    out = []
+    for packed in (True, False):
+        vis, seq = vis0.clone().requires_grad_(True), seq0.clone().requires_grad_(True)
+        if packed:
+            gv, gm, gs = PackedAllGather.apply(vis, mask, seq)
+        else:
+            gv, gs, gm = AllGather.apply(vis), AllGather.apply(seq), all_gather(mask)
+        loss = (gv * w[0] * gm[:, :, None].float()).sum() + (gs * w[1]).pow(2).sum()
+        loss.backward()
+        out.append((gv.detach(), gm, gs.detach(), vis.grad, seq.grad, gm.requires_grad))
+    a, b = out
+    return bool(all(torch.equal(x, y) for x, y in zip(a[:5], b[:5])) and not a[5])
+
+
+def case_gradient_buckets(rank, world):
+    """GradientBuckets (main.py:124,321: DDP's gradient averaging as bucketed reduce-scatter + all-gather): every .grad ==
+    the mean over the ranks (an all_reduce per tensor), several buckets, a parameter without gradient, sizes that do not
+    divide by the world size; a second call reuses the flat buckets."""
+    from centerclip_amd.dist import GradientBuckets
+    torch.manual_seed(3)
+    shapes = [(7, 5), (13,), (64, 33), (1,), (3, 3, 3), (129,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    gb = GradientBuckets(params + [frozen], bucket_bytes=4096)          # -> several buckets
+    ok = len(gb.buckets) > 2
+    for step in range(2):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        local = [torch.randn(s, generator=g) for s in shapes]
+        for i, (p, gr) in enumerate(zip(params, local)):
+            p.grad = None if (i == 3 and rank == 0) else gr.clone()       # one rank has no gradient for one parameter
+        want = []
+        for i, gr in enumerate(local):
+            t = torch.zeros_like(gr) if (i == 3 and rank == 0) else gr.clone()
+            dist.all_reduce(t)
+            want.append(t / world)
+        gb.reduce()
+        ok = ok and all(torch.allclose(p.grad, w_, rtol=0, atol=1e-6) for p, w_ in zip(params, want))
+        ok = ok and frozen.grad is None
+    return bool(ok)
+
+
+def test_packed_allgather_autograd_world2():
+    assert all(_run("case_packed_allgather_autograd").values())
+
+
+def test_gradient_buckets_world2():
+    assert all(_run("case_gradient_buckets").values())
+
+
+def test_gradient_buckets_single_process_keeps_gradients():
+    from centerclip_amd.dist import GradientBuckets
+    p = torch.nn.Parameter(torch.zeros(5))
+    p.grad = torch.arange(5.0)
+    GradientBuckets([p]).reduce()
+    assert torch.equal(p.grad, torch.arange(5.0))
+
+
 def test_packed_features_world2():
     assert all(_run("case_packed_features").values())
 
