@@ -155,3 +155,19 @@ def test_similarity_from_cached_operand_planes():
     assert float(((got - want).abs() / want.abs().clamp_min(1e-6)).max()) <= 2.5e-7
     with pytest.raises(RuntimeError):                              # too few (zeroed) padding rows
         torch.ops.centerclip.scaled_dot_planes(tp, vp[:Nv].contiguous(), Nv, 1.0)
+
+
+def test_p1_lattice_vit_b16_shipped_shape():
+    """Parity level P1 at the shape the shipped ViT-B/16 configurations run (scripts/activitynet.sh:104-122, lsmdc.sh:71-73:
+    4 frames x 196 tokens per segment -> N = 784, K = 160, W = 768, split_size 4): two chunks, the second ragged; the
+    reference's indices (tests/golden/r4_golden.npz, oracle/gen_golden_r4.py) bit for bit."""
+    import os
+    from centerclip_amd import cluster as cl
+    from oracle.recipes import lattice
+    g4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r4_golden.npz"))
+    seed, P, N, W, K, split, iters = [int(v) for v in g4["p1m_b16_cfg"]]
+    X = torch.from_numpy(lattice(seed, (P, N, W))).to(DEV)
+    a, m = cl.batch_fast_kmedoids_with_split(X, K, distance="euclidean", threshold=1e-6, iter_limit=iters,
+                                             id_sort=True, norm_p=2.0, split_size=split, pre_norm=False)
+    assert np.array_equal(m.cpu().numpy(), g4["p1m_b16_medoids"].astype(np.int64))
+    assert np.array_equal(a.cpu().numpy(), g4["p1m_b16_assign"].astype(np.int64))
