@@ -1,0 +1,363 @@
+// N4, first slice of training: the backward pieces of ONE ResidualAttentionBlock (modules/clip.py:228-253; the reference
+// obtains them from torch.autograd inside main.py:321 scaler.scale(loss).backward()).  The contractions (dgrad / wgrad of
+// the four Linear layers) run on the forward GEMM kernel with swapped operand roles (centerclip_amd/train.py); this file
+// holds what is not a GEMM:
+//   layernorm_backward      dx = rstd (g - mean(g) - xhat mean(g xhat)),  g = dy gamma;  dgamma = sum dy xhat, dbeta = sum dy
+//   quick_gelu_backward     d/dx [x sigmoid(1.702 x)] = s + 1.702 x s (1 - s)
+//   attention_backward      dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8   (L <= 64)
+//   column_sums             bias gradients
+//   absmax / cast_scaled / unscale   gradients travel through the fp16 matrix cores with a per-tensor power-of-two scale
+//                           chosen on the device (no host synchronisation), removed again from the fp32 product
+// fp32 arithmetic throughout; every reduction has a fixed order (no atomics on floats): identical bits on every run.
+#include "cc_kernels.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int LNB_ROWS = 32;        // rows per workgroup (4 waves x 8 rows)
+
+// One wave per row; lane l owns columns l*4 + t*256 (t < 4: W <= 1024).  Per-workgroup partial sums of dgamma / dbeta go
+// to part [blocks][2][W]; lnb_reduce_kernel adds them in block order.
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                                 const float* __restrict__ dres, float* __restrict__ dx,
+                                                                 float* __restrict__ part, int rows, int W, float eps) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dg[4], db[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dg[t] = db[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
+        if (row >= rows) break;                                   // (wave-uniform)
+        const float* src = x + (int64_t)row * x_stride;
+        float4 v[4], g[4];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            v[t] = w < W ? *reinterpret_cast<const float4*>(src + w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+        }
+        const float mean = cc_wave_sum_fast(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            if (w < W) {
+                v[t].x -= mean; v[t].y -= mean; v[t].z -= mean; v[t].w -= mean;
+                q += (v[t].x * v[t].x + v[t].y * v[t].y) + (v[t].z * v[t].z + v[t].w * v[t].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(cc_wave_sum_fast(q) / (float)W + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            g[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w < W) {
+                v[t].x *= rstd; v[t].y *= rstd; v[t].z *= rstd; v[t].w *= rstd;          // xhat
+                const float4 d = *reinterpret_cast<const float4*>(dy + (int64_t)row * W + w);
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + w);
+                g[t] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                sg += (g[t].x + g[t].y) + (g[t].z + g[t].w);
+                sgx += (g[t].x * v[t].x + g[t].y * v[t].y) + (g[t].z * v[t].z + g[t].w * v[t].w);
+                dg[t].x += d.x * v[t].x; dg[t].y += d.y * v[t].y; dg[t].z += d.z * v[t].z; dg[t].w += d.w * v[t].w;
+                db[t].x += d.x; db[t].y += d.y; db[t].z += d.z; db[t].w += d.w;
+            }
+        }
+        const float c1 = cc_wave_sum_fast(sg) / (float)W, c2 = cc_wave_sum_fast(sgx) / (float)W;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = lane * 4 + t * 256;
+            if (w < W) {
+                float4 o = make_float4(rstd * (g[t].x - c1 - v[t].x * c2), rstd * (g[t].y - c1 - v[t].y * c2),
+                                       rstd * (g[t].z - c1 - v[t].z * c2), rstd * (g[t].w - c1 - v[t].w * c2));
+                if (dres) {
+                    const float4 r = *reinterpret_cast<const float4*>(dres + (int64_t)row * W + w);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *reinterpret_cast<float4*>(dx + (int64_t)row * W + w) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w = lane * 4 + t * 256;
+        *reinterpret_cast<float4*>(&red[0][wave][w]) = dg[t];
+        *reinterpret_cast<float4*>(&red[1][wave][w]) = db[t];
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * W + w] = ((red[0][0][w] + red[0][1][w]) + red[0][2][w]) + red[0][3][w];
+        part[((int64_t)blockIdx.x * 2 + 1) * W + w] = ((red[1][0][w] + red[1][1][w]) + red[1][2][w]) + red[1][3][w];
+    }
+}
+
+__global__ __launch_bounds__(256) void lnb_reduce_kernel(const float* __restrict__ part, int blocks, int W,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < blocks; ++i) {
+        a += part[((int64_t)i * 2 + 0) * W + w];
+        b += part[((int64_t)i * 2 + 1) * W + w];
+    }
+    dgamma[w] = a;
+    dbeta[w] = b;
+}
+
+__global__ __launch_bounds__(256) void quick_gelu_backward_kernel(const _Float16* __restrict__ u_pre, const float* __restrict__ du,
+                                                                  float* __restrict__ out, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        const h4 x = *reinterpret_cast<const h4*>(u_pre + i);
+        const float4 d = *reinterpret_cast<const float4*>(du + i);
+        float o[4];
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xv = (float)x[e];
+            const float s = 1.0f / (1.0f + expf(-1.702f * xv));
+            o[e] = dd[e] * (s + 1.702f * xv * s * (1.0f - s));
+        }
+        *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// u = QuickGELU(u_pre) on fp16 (the training forward keeps the pre-activation for the backward pass)
+__global__ __launch_bounds__(256) void quick_gelu_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        const h4 x = *reinterpret_cast<const h4*>(in + i);
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xv = (float)x[e];
+            o[e] = (_Float16)(xv / (1.0f + expf(-1.702f * xv)));
+        }
+        *reinterpret_cast<h4*>(out + i) = o;
+    }
+}
+
+// column sums of [rows, cols] fp32: per-workgroup partials over row chunks in a fixed order, then one reduce
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void column_partial_kernel(const float* __restrict__ in, int rows, int cols,
+                                                             float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += in[(int64_t)r * cols + c];
+    part[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restrict__ part, int chunks, int cols,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < chunks; ++i) s += part[(int64_t)i * cols + c];
+    out[c] = s;
+}
+
+// Attention backward, one workgroup per (sequence, head), head_dim 64, L <= 64.  q, k, v rows of qkv [nseq*L, 3W] fp16
+// (row = seq*L + token; heads are 64-wide slices), d_out [nseq*L, W] fp32 -> d_qkv [nseq*L, 3W] fp32.  Everything of a
+// head lives in LDS as fp32; thread (i, c) loops are plain dot products in index order.
+constexpr int AB_L = 64, AB_D = 64;
+constexpr int AB_SMEM = (4 * AB_L * (AB_D + 1) + 2 * AB_L * (AB_L + 1)) * 4;
+__global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ d_out,
+                                                                 float* __restrict__ d_qkv, int L, int heads, int W, int causal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];          // AB_SMEM bytes (> the 64 KB static limit)
+    float (*Q)[AB_D + 1] = reinterpret_cast<float (*)[AB_D + 1]>(ab_smem);
+    float (*K)[AB_D + 1] = Q + AB_L;
+    float (*V)[AB_D + 1] = K + AB_L;
+    float (*dO)[AB_D + 1] = V + AB_L;
+    float (*P)[AB_L + 1] = reinterpret_cast<float (*)[AB_L + 1]>(dO + AB_L);
+    float (*dS)[AB_L + 1] = P + AB_L;
+    const int seq = blockIdx.x / heads, head = blockIdx.x % heads, tid = threadIdx.x;
+    const int64_t row0 = (int64_t)seq * L;
+    for (int idx = tid; idx < L * AB_D; idx += 256) {
+        const int t = idx / AB_D, d = idx % AB_D;
+        const _Float16* r = qkv + (row0 + t) * 3 * W + head * AB_D + d;
+        Q[t][d] = (float)r[0];
+        K[t][d] = (float)r[W];
+        V[t][d] = (float)r[2 * W];
+        dO[t][d] = d_out[(row0 + t) * W + head * AB_D + d];
+    }
+    __syncthreads();
+    // S = Q K^T / 8 (+ causal mask), P = softmax rows
+    for (int idx = tid; idx < L * L; idx += 256) {
+        const int i = idx / L, j = idx % L;
+        float s = 0.f;
+        for (int d = 0; d < AB_D; ++d) s = fmaf(Q[i][d], K[j][d], s);
+        P[i][j] = (causal && j > i) ? -INFINITY : s * 0.125f;
+    }
+    __syncthreads();
+    if (tid < L) {
+        float mx = -INFINITY;
+        for (int j = 0; j < L; ++j) mx = fmaxf(mx, P[tid][j]);
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) { const float e = expf(P[tid][j] - mx); P[tid][j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < L; ++j) P[tid][j] *= inv;
+    }
+    __syncthreads();
+    // dP = dO V^T ; dS = P (dP - sum_j dP P)
+    for (int idx = tid; idx < L * L; idx += 256) {
+        const int i = idx / L, j = idx % L;
+        float s = 0.f;
+        for (int d = 0; d < AB_D; ++d) s = fmaf(dO[i][d], V[j][d], s);
+        dS[i][j] = s;
+    }
+    __syncthreads();
+    if (tid < L) {
+        float dot = 0.f;
+        for (int j = 0; j < L; ++j) dot = fmaf(dS[tid][j], P[tid][j], dot);
+        for (int j = 0; j < L; ++j) dS[tid][j] = P[tid][j] * (dS[tid][j] - dot);
+    }
+    __syncthreads();
+    // dV = P^T dO ; dQ = dS K / 8 ; dK = dS^T Q / 8
+    for (int idx = tid; idx < L * AB_D; idx += 256) {
+        const int t = idx / AB_D, d = idx % AB_D;
+        float dv = 0.f, dq = 0.f, dk = 0.f;
+        for (int j = 0; j < L; ++j) {
+            dv = fmaf(P[j][t], dO[j][d], dv);
+            dq = fmaf(dS[t][j], K[j][d], dq);
+            dk = fmaf(dS[j][t], Q[j][d], dk);
+        }
+        float* o = d_qkv + (row0 + t) * 3 * W + head * AB_D + d;
+        o[0] = dq * 0.125f;
+        o[W] = dk * 0.125f;
+        o[2 * W] = dv;
+    }
+}
+
+// ---- fp32 gradients through the fp16 matrix cores: |x| max -> scale = 2^k with scale * max in [8192, 16384) -> fp16 copy
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ in, int64_t n, unsigned* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(in[i]));
+    m = cc_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // (non-negative floats order as their bits)
+}
+__global__ __launch_bounds__(256) void cast_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int64_t n,
+                                                          const float* __restrict__ amax, float* __restrict__ scale_out) {
+    const float a = *amax;
+    // 2^k: exact to apply and to remove
+    const float scale = (a > 0.f && isfinite(a)) ? exp2f(floorf(log2f(16384.0f / a))) : 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(in + i);
+            const h4 o = {(_Float16)(v.x * scale), (_Float16)(v.y * scale), (_Float16)(v.z * scale), (_Float16)(v.w * scale)};
+            *reinterpret_cast<h4*>(out + i) = o;
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = (_Float16)(in[j] * scale);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void unscale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ sa,
+                                                      const float* __restrict__ sb) {
+    const float inv = 1.0f / ((*sa) * (sb ? *sb : 1.0f));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= inv;
+}
+
+inline unsigned grid_for(int64_t n, int per_block) {
+    const int64_t b = (n + per_block - 1) / per_block;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W) {
+    if (rows <= 0 || W <= 0) return 0;
+    return (size_t)((rows + LNB_ROWS - 1) / LNB_ROWS) * 2 * W * sizeof(float);
+}
+
+int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gamma, const float* dy, const float* dres,
+                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < cc_layernorm_backward_workspace_bytes(rows, W)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blocks = (rows + LNB_ROWS - 1) / LNB_ROWS;
+    hipLaunchKernelGGL(layernorm_backward_kernel, dim3(blocks), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
+                       static_cast<float*>(ws), rows, W, eps);
+    hipLaunchKernelGGL(lnb_reduce_kernel, dim3((W + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), blocks, W,
+                       dgamma, dbeta);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, void* stream) {
+    if (!u_pre_f16 || !du || !du_pre || n <= 0 || (n & 3)) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(quick_gelu_backward_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(u_pre_f16), du, du_pre, n);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_quick_gelu_f16(const void* in_f16, void* out_f16, int64_t n, void* stream) {
+    if (!in_f16 || !out_f16 || n <= 0 || (n & 3)) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(quick_gelu_f16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(in_f16), static_cast<_Float16*>(out_f16), n);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * cols * sizeof(float);
+}
+
+int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < cc_column_sums_workspace_bytes(rows, cols)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int chunks = (rows + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(column_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, st, in, rows, cols,
+                       static_cast<float*>(ws));
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), chunks,
+                       cols, out);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L, int32_t heads,
+                              int32_t W, int32_t causal, void* stream) {
+    if (!qkv_f16 || !d_out || !d_qkv || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * AB_D) return CC_ERR_INVALID;
+    if (L > AB_L) return CC_ERR_UNSUPPORTED;
+    static bool configured = false;              // benign race (idempotent call)
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_backward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, AB_SMEM) != hipSuccess)
+            return CC_ERR_HIP;
+        configured = true;
+    }
+    hipLaunchKernelGGL(attention_backward_kernel, dim3(nseq * heads), dim3(256), AB_SMEM, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(qkv_f16), d_out, d_qkv, L, heads, W, causal);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream) {
+    if (!in || !out_f16 || !amax_scratch || !scale_out || n <= 0) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, st, in, n, reinterpret_cast<unsigned*>(amax_scratch));
+    hipLaunchKernelGGL(cast_scaled_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, in, static_cast<_Float16*>(out_f16), n,
+                       amax_scratch, scale_out);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale_b, void* stream) {
+    if (!x || !scale_a || n <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(unscale_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, scale_a,
+                       scale_b);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+}  // extern "C"

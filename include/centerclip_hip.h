@@ -636,6 +636,35 @@ int cc_group_max_rows_f32(const float* sim, int32_t rows, int32_t cols, int64_t 
                           int32_t n_groups, float* out, void* stream);
 
 /* ==========================================================================================
+ * N4, first slice of training: the backward of one ResidualAttentionBlock (modules/clip.py:228-253; the reference gets
+ * it from torch.autograd in main.py:321).  The dgrad / wgrad contractions run on cc_linear_f16 with swapped operand roles
+ * (centerclip_amd/train.py); these entry points are the pieces that are not a GEMM.  fp32 arithmetic, fixed summation
+ * orders (identical bits on every run).
+ *   cc_layernorm_backward_f32   x [rows, W] (row stride x_stride), dy [rows, W] -> dx [rows, W] = dres (optional, the
+ *                               residual branch's gradient) + LayerNorm backward; dgamma, dbeta [W].  W % 4 == 0, W <= 1024.
+ *   cc_quick_gelu_backward_f16  du_pre = du * d/dx [x sigmoid(1.702 x)] at x = u_pre (fp16, the c_fc output before the
+ *                               activation, clip.py:192-194); n % 4 == 0
+ *   cc_attention_backward_f16   qkv [nseq*L, 3W] fp16 (as cc_attention_f16), d_out [nseq*L, W] fp32 -> d_qkv [nseq*L, 3W] fp32
+ *                               (softmax(q k^T / 8 + mask) v per 64-wide head); L <= 64
+ *   cc_column_sums_f32          out [cols] = column sums of in [rows, cols] (bias gradients)
+ *   cc_cast_scaled_f16          fp32 -> fp16 with a power-of-two scale chosen on the device from the tensor's largest
+ *                               magnitude (scale * max in [8192, 16384)); *scale_out (device) receives it; amax_scratch: one
+ *                               device float.  cc_unscale_f32 divides an fp32 product by one or two such scales.
+ * ========================================================================================== */
+size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W);
+int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gamma, const float* dy, const float* dres,
+                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, void* ws,
+                              size_t ws_bytes, void* stream);
+int cc_quick_gelu_f16(const void* in_f16, void* out_f16, int64_t n, void* stream);     /* QuickGELU on fp16 (training forward) */
+int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, void* stream);
+int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L,
+                              int32_t heads, int32_t W, int32_t causal, void* stream);
+size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
+int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
+int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);
+int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale_b, void* stream);
+
+/* ==========================================================================================
  * Diagnostics (not on the product path; process-wide state, not thread-safe).
  * While armed, every launch of the tiled GEMM kernel is issued with a start / stop event pair that receives the dispatch's
  * own begin / end timestamps (what rocprofv3 --kernel-trace reads), so a kernel symbol can be timed IN SITU, inside an

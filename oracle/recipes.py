@@ -332,3 +332,34 @@ def conv3d_patch_weight(seed, shape):
 
 PATCH3D_SEED = 901        # linear_patch='3d' fixture (p3d_* of r3_golden.npz)
 MINOR_SEED = 911          # mean_residual / training-mode sparse_sampling fixtures (mr_*, ss_train_*)
+
+
+# N4: backward of one ResidualAttentionBlock (modules/clip.py:196-253).  x [L, N, W] LND, dz the gradient fed into the output
+BLOCK_GRAD_CASES = {
+    "bg_visual": dict(seed=91, L=50, N=6, W=128, heads=2, causal=False),
+    "bg_text": dict(seed=92, L=12, N=5, W=128, heads=2, causal=True),
+}
+
+
+def block_grad_inputs(cfg):
+    """-> (x [L,N,W], dz [L,N,W], state dict of the block under the reference's parameter names), fp32; weights rounded
+    through fp16 (as convert_weights yields) so that the fp16 operands of the HIP path carry exactly these values."""
+    rng = np.random.default_rng(cfg["seed"])
+    L, N, W = cfg["L"], cfg["N"], cfg["W"]
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x = rng.standard_normal((L, N, W)).astype(np.float32) * 1.5 + 0.2
+    dz = rng.standard_normal((L, N, W)).astype(np.float32) * 0.01
+    sd = {
+        "attn.in_proj_weight": f16(rng.standard_normal((3 * W, W)) * W ** -0.5),
+        "attn.in_proj_bias": f16(rng.standard_normal(3 * W) * 0.1),
+        "attn.out_proj.weight": f16(rng.standard_normal((W, W)) * W ** -0.5),
+        "attn.out_proj.bias": f16(rng.standard_normal(W) * 0.1),
+        "ln_1.weight": f16(1.0 + 0.2 * rng.standard_normal(W)), "ln_1.bias": f16(0.1 * rng.standard_normal(W)),
+        "mlp.c_fc.weight": f16(rng.standard_normal((4 * W, W)) * W ** -0.5),
+        "mlp.c_fc.bias": f16(rng.standard_normal(4 * W) * 0.1),
+        "mlp.c_proj.weight": f16(rng.standard_normal((W, 4 * W)) * (4 * W) ** -0.5),
+        "mlp.c_proj.bias": f16(rng.standard_normal(W) * 0.1),
+        "ln_2.weight": f16(1.0 + 0.2 * rng.standard_normal(W)), "ln_2.bias": f16(0.1 * rng.standard_normal(W)),
+    }
+    sd = {k: v.astype(np.float32) for k, v in sd.items()}
+    return x, dz, sd

@@ -314,10 +314,10 @@ def test_eval_epoch_against_the_reference(g2, g3, name):
     loader.dataset = Namespace(**attrs)
     seen = {}
 
-    class Spy(ev.HipBackend):                                # the loop's NT GEMM, recorded
+    class Spy(ev.HipBackend):                                # the loop's one GEMM over the cached operand planes, recorded
         @staticmethod
-        def dot_nt(a, b, mult):
-            seen["sim"] = ev.HipBackend.dot_nt(a, b, mult)
+        def dot_operands(t_op, v_op, n_video, mult):
+            seen["sim"] = ev.HipBackend.dot_operands(t_op, v_op, n_video, mult)
             return seen["sim"]
     r1, t_inf, info = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy)
     ref = g3[f"ev_{name}_sim"]
@@ -331,7 +331,7 @@ def test_eval_epoch_against_the_reference(g2, g3, name):
     assert list(info) == [str(s) for s in g3[f"ev_{name}_info"]]
     # N1 alone, exactly: the reference's matrix through the device metric kernels -> the reference's strings
     class Given(ev.HipBackend):
-        dot_nt = staticmethod(lambda a, b, mult: torch.from_numpy(ref).to(DEV))
+        dot_operands = staticmethod(lambda t_op, v_op, n_video, mult: torch.from_numpy(ref).to(DEV))
     r1b, _, info_b = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Given)
     assert list(info_b) == [str(s) for s in g3[f"ev_{name}_info"]] and abs(r1b - float(g3[f"ev_{name}_r1"])) < 1e-4
 
