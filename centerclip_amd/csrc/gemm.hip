@@ -451,14 +451,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 const int m = row0 + wr * WTM + h0 + r0 + lr;
                 if (lane_on && m < g.M) {
                     const h8 ov = *reinterpret_cast<const h8*>(stg + (r0 + lr) * LDO + lc);
-#if defined(CC_F16OUT_POLICY) && CC_F16OUT_POLICY == 1          /* A/B builds: non-temporal / write-through stores of the fp16 outputs */
-                    __builtin_nontemporal_store(ov, reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc));
-#elif defined(CC_F16OUT_POLICY) && CC_F16OUT_POLICY == 2
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb),
-                                                           (int)(((int64_t)m * g.ldc + col0 + wc * WTN + lc) * 2), 0, 16);
+                    // The c_fc output (59 MB at the bench shape, the largest tensor of a block) is written through (sc1): it
+                    // leaves the XCD's L2 while the launch runs instead of in the write-back at its end, and nobody re-reads
+                    // it from this L2.  Measured per launch in situ (profiles/r04_store_policy.txt): c_fc 57.9 -> 55.6 us; the
+                    // same policy on the in_proj output costs that launch 3.5 us, so it is keyed on the epilogue.
+#ifdef CC_PLAIN_F16_STORES
+                    constexpr bool wt_out = false;
 #else
-                    *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = ov;
+                    const bool wt_out = GELU && (int64_t)g.M * g.ldc < (int64_t)0x3fffffff;   // (32-bit byte offset of the buffer form)
 #endif
+                    if (wt_out)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb),
+                                                               (int)(((int64_t)m * g.ldc + col0 + wc * WTN + lc) * 2), 0, 16);
+                    else
+                        *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = ov;
                 }
             }
             if (h0 + RH < WTM) {

@@ -3,7 +3,7 @@
 #   PMC HBM-traffic and MFMA-utilisation passes (each counter group in its own run, counters + kernel trace only),
 #   then the bench line (with extras + cpu baseline; it reads the fresh traffic file) and the rocprofv3 kernel
 #   stats of the same bench command.  Results land in gpurun_out/profiles/ - copy them into profiles/.
-r=${1:-r03}
+r=${1:-r04}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles
 bash tools/pmc.sh $r python tools/kernels_for_pmc.py > gpurun_out/profiles/pmc.log 2>&1
