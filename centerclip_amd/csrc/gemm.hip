@@ -26,6 +26,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define GEMM_BK 64
+// LDS stage buffers of a tile: three where they fit (the 8-wave 256x128 / 128x256 tiles: 3 x 48 KB) - the LDS-DMA loads of
+// a stage are then issued TWO k-steps before its barrier instead of one, which is what an operand that comes from HBM
+// rather than the Infinity Cache needs (a launch inside the step reads what the launch before it has just written: c_proj
+// 55 us with its A operand left in the MALL by the previous launch of a loop, 65-75 us with it cold, tools/cold_operands.py).
+#ifdef CC_TWO_STAGES
+#define GEMM_NST(BM, BN, WAVES, BK) 2
+#else
+#define GEMM_NST(BM, BN, WAVES, BK) (((WAVES) == 8 && (BK) == 64 && 3 * ((BM) + (BN)) * (BK) * 2 <= 160 * 1024) ? 3 : 2)
+#endif
 
 __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -87,8 +96,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int NST = GEMM_NST(BM, BN, WM * WN, BK);
     constexpr int CH = BK / 8;                               // 16-byte chunks per staged row (8 or 16)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * (A_BYTES + B_BYTES)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NST * (A_BYTES + B_BYTES)
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
     // tiles (tn fastest) so tiles sharing an A panel hit the same L2.
@@ -284,6 +294,62 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         for (int kt = 0; kt + 1 < nk; ++kt) step(kt & 1, kt, true);
         fetch_epilogue_operands();
         step((nk - 1) & 1, nk - 1, false);
+    } else if constexpr (HALF_SHIFTED && NST == 3) {
+        // The half-shifted loop over THREE stage buffers: stage kt + 3 is issued behind the barrier of step kt, which only
+        // waits for stage kt + 1 - a counted s_waitcnt (the loads of stage kt + 2 stay in flight across it) and a raw
+        // s_barrier: __syncthreads() would drain every LDS-DMA load in flight.  No other vector-memory operation is issued
+        // between the prologue and the last step, so the count is exact.
+        constexpr int NLOAD = A_LOADS + B_LOADS, LPG = (NLOAD + MI - 1) / MI, BPG = (NI + MI - 1) / MI;
+        h8 a0[MI], b0[NI], a1[MI], b1[NI];
+        if (nk > 1) stage(1, 1);
+        if (nk > 2) stage(2, 2);
+        read_frags(0, 0, a0, b0);
+        auto phase1 = [&](int buf) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                mma_row(i, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < BPG; ++q)
+                    if (i * BPG + q < NI) read_b(buf, 1, i * BPG + q, b1);
+                read_a(buf, 1, i, a1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto phase2 = [&](int buf, int nxt, int kt, bool with_stage) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (with_stage) {
+#pragma unroll
+                    for (int q = 0; q < LPG; ++q)
+                        if (i * LPG + q < NLOAD) stage_piece(buf, kt + 3, i * LPG + q);
+                }
+                mma_row(i, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < BPG; ++q)
+                    if (i * BPG + q < NI) read_b(nxt, 0, i * BPG + q, b0);
+                read_a(nxt, 0, i, a0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int cur = 0;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            phase1(cur);
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");   // stage kt + 1 landed, kt + 2 in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // ... for every wave; buffer `cur` fully read
+            phase2(cur, nxt, kt, kt + 3 < nk);
+            cur = nxt;
+        }
+        read_frags(cur, 1, a1, b1);
+        mma(a0, b0);
+        __syncthreads();                                          // every wave is done with the staging buffers
+        fetch_epilogue_operands();
+        mma(a1, b1);
     } else if (HALF_SHIFTED) {
         // Every MFMA phase is written as MI groups of one fragment row (NI MFMAs), and the other work of the phase -
         // the fragment reads of the next k-half and, after the barrier, the LDS-DMA loads of the stage after next - is
@@ -400,7 +466,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         // 128-byte row segments (8 lanes x 16 B) instead of 16 rows x 32 B per instruction.
         constexpr int LDO = WTN + 8;                          // halfs per staged row (144-byte rows for WTN = 64)
         constexpr int STATS_BYTES = FOLD_LN ? BM * 8 : 0;     // (mu, rstd) per tile row, at the start of smem
-        constexpr int RH_MAX = (2 * (A_BYTES + B_BYTES) - STATS_BYTES) / (NWAVES * LDO * 2);
+        constexpr int RH_MAX = (NST * (A_BYTES + B_BYTES) - STATS_BYTES) / (NWAVES * LDO * 2);
         constexpr int RH = (RH_MAX >= WTM) ? WTM : (RH_MAX >= 64 ? 64 : (RH_MAX >= 32 ? 32 : 16));
         static_assert(WTM % RH == 0 && RH % 16 == 0, "epilogue staging geometry");
         float2* rowst = reinterpret_cast<float2*>(smem);
@@ -694,7 +760,7 @@ namespace {
 
 template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
-    constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
+    constexpr size_t smem = (size_t)GEMM_NST(BM, BN, WM * WN, BK) * (size_t)(BM + BN) * BK * 2;
     auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK, SK>;
     if (smem > 64 * 1024) {
         static bool configured = false;      // per instantiation; benign race (idempotent call)
@@ -874,7 +940,14 @@ static int pick_tile(const GemmArgs& g, int epi) {
     // residual epilogue at N = 768: the 256x128 tile (8 waves, one workgroup per CU) when its grid is one nearly full
     // round of the 256 CUs - half the A-panel re-reads of the 128x128 tile (stand-alone c_proj 55.5 vs 58.7 us = 816
     // TFLOP/s, out_proj 24.9 vs 26.2; on the step 2.124 vs 2.128 ms over 3 same-session A/B rounds)
-    if (epi == EPI_F32_RESID_STATS && n128) {
+    // (round 4: the same tile for the patch embedding - its A operand, the im2col matrix, is 58 MB the launch before has just
+    // written, and the 256x128 tile runs on three stage buffers)
+#ifdef CC_PATCH_TILE1
+    const bool patch6 = false;
+#else
+    const bool patch6 = epi == EPI_F32_PATCH;
+#endif
+    if ((epi == EPI_F32_RESID_STATS || patch6) && n128) {
         const long t6 = (long)((g.M + 255) / 256) * (g.N / 128);
         if (t6 >= 200 && t6 <= 256) return 6;
     }
