@@ -133,6 +133,8 @@ TILES = {1: (128, 128, 2, 2, 64), 2: (128, 64, 2, 2, 64), 3: (64, 128, 2, 2, 64)
 def kernel_symbol(M, N, K, epi):
     """Name of the gemm_f16_kernel instantiation a stand-alone launch of this shape runs on (as rocprofv3 prints it)."""
     from centerclip_amd import _lib as L
+    if epi == 8:                                 # in_proj + attention in one launch: always the 256x192 tile
+        return "gemm_f16_kernel<256, 192, 2, 4, 8, 64, 1>"
     t = L.lib().cc_linear_tile_for(M, N, K, epi)
     if t == 11:
         return "gemm_persist_kernel<%d>" % epi
@@ -220,9 +222,10 @@ def gemm_roofline(c, device, insitu=None):
     n0, n1 = c["cluster_block"] - 1, 13 - c["cluster_block"]
     # (name, M, N, K, epilogue id, calls per step)
     shapes = [("patch_embed", B * T * 49, W, 3 * 32 * 32, 3, 1),
-              ("in_proj", M0, 3 * W, W, 5, n0), ("out_proj", M0, W, W, 7, n0),
+              ("in_proj+attention" if L0 <= 56 else "in_proj", M0, 3 * W, W, 8 if L0 <= 56 else 5, n0), ("out_proj", M0, W, W, 7, n0),
               ("c_fc", M0, 4 * W, W, 6, n0), ("c_proj", M0, W, 4 * W, 7, n0),
-              ("in_proj@clustered", M1, 3 * W, W, 5, n1), ("out_proj@clustered", M1, W, W, 7, n1 - 1),
+              ("in_proj+attention@clustered" if L1 <= 56 else "in_proj@clustered", M1, 3 * W, W, 8 if L1 <= 56 else 5, n1),
+              ("out_proj@clustered", M1, W, W, 7, n1 - 1),
               ("c_fc@clustered", M1, 4 * W, W, 6, n1 - 1), ("c_proj@clustered", M1, W, 4 * W, 7, n1 - 1)]
     # (block 12 runs out_proj / c_fc / c_proj on the B * T_new CLS rows only - gemm_rows_kernel, 0.06 GFLOP, not listed)
     rows = []
@@ -230,13 +233,18 @@ def gemm_roofline(c, device, insitu=None):
         a = torch.randn(M, K, device=device).half()
         w = (torch.randn(N, K, device=device) * K ** -0.5).half()
         bias = torch.randn(N, device=device)
-        if epi in (5, 6):                        # LayerNorm-folded consumer epilogue, statistics in 12 slots
+        if epi in (5, 6, 8):                     # LayerNorm-folded consumer epilogue, statistics in 12 slots
             hres = torch.randn(M, K, device=device)
             h16, _, _ = ops.row_stats(hres)
             stats = torch.randn(M, 12, 2, device=device).abs()
             wf, c1, c2 = ops.fold_layernorm_linear(w.float(), bias, torch.ones(K, device=device), torch.zeros(K, device=device))
-            fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, g=(epi == 6):
-                  ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=g))
+            if epi == 8:                         # ... with the attention of the tile's frames behind it (L0 / L1 tokens per frame)
+                Ltok = L1 if name.endswith("@clustered") else L0
+                fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, nseq=M // Ltok, Ltok=Ltok:
+                      ops.inproj_attention_f16(h16, wf, c1, c2, stats, 12, nseq, Ltok, K // 64))
+            else:
+                fn = (lambda h16=h16, wf=wf, c1=c1, c2=c2, stats=stats, g=(epi == 6):
+                      ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=g))
         elif epi == 7:                           # residual epilogue that also emits centred fp16 rows + partial sums
             hres = torch.zeros(M, N, device=device)
             h16b = torch.empty(M, N, device=device, dtype=torch.float16)

@@ -58,6 +58,8 @@ def declare(lib):
     lib.cc_linear_ws_f16.restype = c.c_int
     lib.cc_linear_ln_ws_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.cc_linear_ln_ws_f16.restype = c.c_int
+    lib.cc_inproj_attention_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.cc_inproj_attention_f16.restype = c.c_int
     lib.cc_linear_tile_for.argtypes = [i32, i32, i32, i32]
     lib.cc_linear_tile_for.restype = c.c_int
     lib.cc_linear_resid_stats_slots.argtypes = [i32, i32, i32, i32]

@@ -7,7 +7,10 @@
 // with the row statistics (mu, rstd) reduced from per-tile partial sums the producing epilogue wrote.
 // EPI_F32_RESID_STATS: residual add that also emits the fp16 copy of the new rows and those partial sums.
 enum { EPI_F16 = 0, EPI_F16_GELU = 1, EPI_F32_RESID = 2, EPI_F32_PATCH = 3, EPI_F32 = 4,
-       EPI_F16_LN = 5, EPI_F16_GELU_LN = 6, EPI_F32_RESID_STATS = 7 };
+       EPI_F16_LN = 5, EPI_F16_GELU_LN = 6, EPI_F32_RESID_STATS = 7,
+       // in_proj with the LayerNorm folded AND the attention of its sequences in the epilogue (cc_gemm_attn_dispatch2 only):
+       // the q, k, v rows of a tile never leave the CU - C is the attention output [M, W] fp16
+       EPI_ATTN_LN = 8 };
 #define CC_LN_MAX_SLOTS 32
 
 struct GemmArgs {
@@ -53,6 +56,12 @@ struct GemmArgs {
     // CC_GEMM_SK_FLAG_BYTES are zero before the first launch that uses it (every launch leaves them zero again).  Null:
     // the dispatcher never picks a split-K form.
     void* sk_ws;
+    // EPI_ATTN_LN (cc_gemm_attn_dispatch2): N = 3W, W = heads * 64; a tile is att_spt whole sequences (rows) x one head
+    // (its 64 q, 64 k and 64 v columns); sequence s = att_L tokens at row s * att_L, or - compacted captions -
+    // att_seq_len[s] tokens at row att_seq_off[s] (att_L is then the upper bound)
+    int att_L, att_nseq, att_spt, att_causal;
+    const int* att_seq_off;
+    const int* att_seq_len;
 };
 
 // Split-K exchange area: [flags: 4096 ints][slots of 256 KB: one 256x256 fp32 partial tile, or two half tiles]
@@ -127,6 +136,11 @@ struct AttArgs {
     const int* seq_len;
 };
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
+// in_proj (LayerNorm folded) + attention in one launch (gemm.hip, EPI_ATTN_LN): g.A = centred fp16 rows, g.W / bias / ln_* as
+// for EPI_F16_LN, g.C = attention output [M, W] fp16; the att_* fields describe the sequences.  applies(): head width 64,
+// att_L <= 64 and the folded form available - otherwise the caller runs the two launches.
+bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1);
+int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st);
 
 int cc_launch_im2col(const cc_frames& frames, _Float16* A, int F, int res, int p, hipStream_t st);
 int cc_launch_im2col3d(const cc_frames& frames, _Float16* A, int F, int T, int res, int p, hipStream_t st);   // linear_patch '3d'

@@ -162,7 +162,10 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         if (sl) { sl[0] = a[0]; sl[1] = b[0]; }
         return r;
     };
-    // ---- q,k,v = in_proj(ln_1(x))   [LayerNorm folded]
+    // ---- q,k,v = in_proj(ln_1(x))   [LayerNorm folded]  and  attn = softmax(q k^T / 8) v
+    // One launch where the sequences fit a row tile (L <= 56: the ViT-B/32 frames, every clustered block, the captions): a
+    // workgroup owns whole sequences x one head and keeps their q, k, v in LDS (EPI_ATTN_LN); otherwise in_proj writes qkv
+    // and the attention kernel reads it back.
     {
         GemmArgs g0 = base(c0, M0, c0->h16, w0->in_proj_ln_weight_f16, w0->in_proj_ln_c2, c0->qkv, 3 * Wa, Wa);
         g0.ln_stats = c0->st0; g0.ln_slots = c0->slots0; g0.ln_c1 = w0->in_proj_ln_c1;
@@ -171,15 +174,25 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
             g1 = base(c1, M1, c1->h16, w1->in_proj_ln_weight_f16, w1->in_proj_ln_c2, c1->qkv, 3 * Wb, Wb);
             g1.ln_stats = c1->st0; g1.ln_slots = c1->slots0; g1.ln_c1 = w1->in_proj_ln_c1;
         }
-        rc = dispatch(g0, g1, EPI_F16_LN, 1, nullptr);
-        if (rc) return rc;
-    }
-    {
-        AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal, 0, 0, c0->seq_off, c0->seq_len};
-        AttArgs a1{};
-        if (c1) a1 = AttArgs{c1->qkv, c1->att, c1->nseq, c1->L, c1->heads, c1->W, c1->causal, 0, 0, c1->seq_off, c1->seq_len};
-        rc = cc_launch_attention2(a0, c1 ? &a1 : nullptr, st);
-        if (rc) return rc;
+        auto fused = [](GemmArgs g, const BlockCtx* c) {
+            g.C = c->att; g.ldc = c->W;
+            g.att_L = c->L; g.att_nseq = c->nseq; g.att_causal = c->causal; g.att_seq_off = c->seq_off; g.att_seq_len = c->seq_len;
+            return g;
+        };
+        GemmArgs f0 = fused(g0, c0), f1{};
+        if (c1) f1 = fused(g1, c1);
+        if (!(unpair & 1) && c0->heads * 64 == Wa && (!c1 || c1->heads * 64 == Wb) && cc_gemm_attn_applies(f0, c1 ? &f1 : nullptr)) {
+            rc = cc_gemm_attn_dispatch2(f0, c1 ? &f1 : nullptr, st);
+            if (rc) return rc;
+        } else {
+            rc = dispatch(g0, g1, EPI_F16_LN, 1, nullptr);
+            if (rc) return rc;
+            AttArgs a0{c0->qkv, c0->att, c0->nseq, c0->L, c0->heads, c0->W, c0->causal, 0, 0, c0->seq_off, c0->seq_len};
+            AttArgs a1{};
+            if (c1) a1 = AttArgs{c1->qkv, c1->att, c1->nseq, c1->L, c1->heads, c1->W, c1->causal, 0, 0, c1->seq_off, c1->seq_len};
+            rc = cc_launch_attention2(a0, c1 ? &a1 : nullptr, st);
+            if (rc) return rc;
+        }
     }
     // ---- x = x + out_proj(attn)   [+ fp16 copy and row statistics for ln_2]
     {

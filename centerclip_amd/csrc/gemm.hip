@@ -36,6 +36,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GEMM_NST(BM, BN, WAVES, BK) (((WAVES) == 8 && (BK) == 64 && 3 * ((BM) + (BN)) * (BK) * 2 <= 160 * 1024) ? 3 : 2)
 #endif
 
+// EPI_ATTN_LN epilogue LDS map (bytes): row statistics [256] x 8 | Q [256][72] | K [256][72] | V^T [64][328] (5 slots of 64
+// keys or 8 of 32) | P strips 8 x [16][72] | sequence table
+#define ATTN_QS 72
+#define ATTN_VS 328
+#define ATTN_Q_OFF 2048
+#define ATTN_TAB_OFF (ATTN_Q_OFF + 2 * 256 * ATTN_QS * 2 + 64 * ATTN_VS * 2 + 8 * 16 * ATTN_QS * 2)
+#define ATTN_SMEM (ATTN_TAB_OFF + 64)
+
 __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -64,6 +72,14 @@ __device__ long long* g_gemm_prof = nullptr;
 #else
 #define GEMM_PROF_INIT() do { } while (0)
 #define GEMM_STAMP(slot) do { } while (0)
+#endif
+
+#ifdef CC_DEV_KNOBS
+// dev builds: the q | k | v values of the in_proj + attention form, written back as the two-launch form lays them out [M, 3W]
+__device__ _Float16* g_attn_dump = nullptr;
+extern "C" void cc_debug_set_attn_dump(_Float16* dev_buf) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dump), &dev_buf, sizeof(dev_buf));
+}
 #endif
 
 template <int CTRL>
@@ -124,7 +140,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int gsz = min(g.tiles_m - first_m, GROUP_M);
     const int in_group = bid - group * per_group;
     const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-    const int row0 = tm * BM, col0 = tn * BN;
+    // (EPI_ATTN_LN: a row tile is att_spt whole sequences, a column tile the q | k | v columns of head tn)
+    constexpr bool ATTN = (EPI == EPI_ATTN_LN);
+    static_assert(!ATTN || (BM == 256 && BN == 192 && WM == 2 && WN == 4 && BK == 64 && SK == 1), "in_proj + attention form");
+    const int att_s0 = ATTN ? tm * g.att_spt : 0;
+    const int row0 = ATTN ? (g.att_seq_off ? g.att_seq_off[att_s0] : att_s0 * g.att_L) : tm * BM, col0 = tn * BN;
     if (row0 >= g.M) return;                                 // (only with m_dev: the grid was sized for the upper bound)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +162,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        bsrc[q] = g.W + (int64_t)(col0 + r) * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
+        const int wrow = ATTN ? (r >> 6) * (g.N / 3) + tn * 64 + (r & 63) : col0 + r;
+        bsrc[q] = g.W + (int64_t)wrow * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // folded LayerNorm: thread r < BM reduces the producer's partial sums of tile row r right away (fixed
     // slot order, 8 loads in flight) - the L2 latency hides under the main loop; result parked in 2 registers.
     float row_mu = 0.f, row_rs = 1.f;
-    if ((EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN) && tid < BM) {
+    if ((EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN || ATTN) && tid < BM) {
         const int m = min(row0 + tid, g.M - 1);
         const float2* ps = reinterpret_cast<const float2*>(g.ln_stats) + (int64_t)m * g.ln_slots;
         float sum = 0.f, sq = 0.f;
@@ -204,12 +225,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // Per-column epilogue operands (bias, LN-fold column sums) are fetched into registers while the last k-step's
     // MFMAs run: issued from inside the epilogue, behind its stores, every fragment would pay its own L2 round trip.
     constexpr bool RESID = (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_STATS);
-    constexpr bool LNFOLD = (EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
+    constexpr bool LNFOLD = (EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN || ATTN);
     float4 biasv[NI], c1v[LNFOLD ? NI : 1];
     auto fetch_epilogue_operands = [&]() {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = col0 + wc * (BN / WN) + j * 16 + lg * 4;
+            const int lc = wc * (BN / WN) + j * 16 + lg * 4;
+            const int n = ATTN ? (lc >> 6) * (g.N / 3) + tn * 64 + (lc & 63) : col0 + lc;
             biasv[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (LNFOLD) c1v[j] = *reinterpret_cast<const float4*>(g.ln_c1 + n);
         }
@@ -461,6 +483,176 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     constexpr bool OUT_F16 = (EPI == EPI_F16 || EPI == EPI_F16_GELU || EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
     constexpr bool FOLD_LN = (EPI == EPI_F16_LN || EPI == EPI_F16_GELU_LN);
     constexpr bool GELU = (EPI == EPI_F16_GELU || EPI == EPI_F16_GELU_LN);
+    if constexpr (ATTN) {
+        // ---- in_proj + attention.  The tile's q, k, v (fp16, the very values the two-launch form writes to HBM) go to LDS:
+        // Q and K row-major [tile row][64 d] (both are the d-contiguous MFMA operands of S^T = K Q^T), V transposed
+        // [64 d][sequence slot of 32 / 64 keys] (the key-contiguous operand of O^T = V^T P^T).  Then the (sequence, 16-query
+        // tile) items of the tile are dealt over the 8 waves; each is the arithmetic of attention_wave_kernel (transformer.hip)
+        // in the same order, so the two forms agree bit for bit.  q, k, v never reach HBM: 2 x 44 MB less traffic per block
+        // at the bench shape, and one launch boundary less.
+        constexpr int QS = ATTN_QS, VS = ATTN_VS, PS = ATTN_QS;
+        float2* rowst = reinterpret_cast<float2*>(smem);
+        _Float16* Qs = reinterpret_cast<_Float16*>(smem + ATTN_Q_OFF);
+        _Float16* Ks = Qs + 256 * QS;
+        _Float16* Vt = Ks + 256 * QS;
+        _Float16* Pw = Vt + 64 * VS + wave * (16 * PS);
+        int* stab = reinterpret_cast<int*>(smem + ATTN_TAB_OFF);   // [j]: first tile row of sequence j, [8 + j]: its length
+        const int nst = min(g.att_spt, g.att_nseq - att_s0);
+        const int slot = g.att_L > 32 ? 64 : 32, nkb = slot >> 5, nkt = slot >> 4;
+        if (tid < BM) rowst[tid] = make_float2(row_mu, row_rs);
+        if (tid < 8) {
+            const bool have = tid < nst;
+            stab[tid] = !have ? (1 << 20) : (g.att_seq_off ? g.att_seq_off[att_s0 + tid] - row0 : tid * g.att_L);
+            stab[8 + tid] = !have ? 0 : (g.att_seq_len ? g.att_seq_len[att_s0 + tid] : g.att_L);
+        }
+        __syncthreads();
+        int offv[8], lenv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { offv[j] = stab[j]; lenv[j] = stab[8 + j]; }
+        {   // keys [len, slot) of every sequence's V slot are multiplied by P = 0: they must be finite
+            const int d = tid & 63, sq = tid >> 6;
+            if (sq < nst)
+                for (int key = stab[8 + sq]; key < slot; ++key) Vt[d * VS + sq * slot + key] = (_Float16)0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = wr * WTM + i * 16 + l15;
+            const float2 t2 = rowst[r];
+            int sq = 0, off = 0, len = lenv[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j)
+                if (r >= offv[j]) { sq = j; off = offv[j]; len = lenv[j]; }
+            const int key = r - off;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                f32x4 v = acc[i][j];
+                {   // (statement for statement the fold of the fp16-output epilogue below: the same contractions, the same bits)
+                    const float mu = t2.x, rs = t2.y;
+                    const float4 c1 = c1v[j];
+                    v[0] = rs * (v[0] - mu * c1.x); v[1] = rs * (v[1] - mu * c1.y);
+                    v[2] = rs * (v[2] - mu * c1.z); v[3] = rs * (v[3] - mu * c1.w);
+                }
+                {
+                    const float4 bb = biasv[j];
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                const int cb = wc * WTN + j * 16;                  // wave-uniform: 16 columns never straddle q | k | v
+                const int cc = (cb & 63) + lg * 4;
+                if (cb < 64) *reinterpret_cast<h4*>(Qs + r * QS + cc) = o;
+                else if (cb < 128) *reinterpret_cast<h4*>(Ks + r * QS + cc) = o;
+                else if (key < len) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Vt[(cc + e) * VS + sq * slot + key] = o[e];
+                }
+            }
+        }
+        __syncthreads();
+#ifdef CC_DEV_KNOBS
+        if (g_attn_dump) {
+            const int Wd = g.N / 3;
+            for (int idx = tid; idx < 256 * 64; idx += THREADS) {
+                const int r = idx >> 6, d = idx & 63;
+                int sq = 0, off = 0, len = lenv[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+                    if (r >= offv[j]) { sq = j; off = offv[j]; len = lenv[j]; }
+                if (r - off < len) {
+                    _Float16* o = g_attn_dump + (int64_t)(row0 + r) * g.N + tn * 64 + d;
+                    o[0] = Qs[r * QS + d]; o[Wd] = Ks[r * QS + d]; o[2 * Wd] = Vt[d * VS + sq * slot + (r - off)];
+                }
+            }
+        }
+#endif
+        const int qtmax = (g.att_L + 15) >> 4;
+        const bool CAUSAL = g.att_causal != 0;
+        _Float16* Cb = reinterpret_cast<_Float16*>(g.C);
+        for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qtmax; it += NWAVES) {
+            const int sq = it / qtmax, qt = it - sq * qtmax;       // wave-uniform
+            const int off = stab[sq], L = stab[8 + sq];
+            if (qt * 16 >= L) continue;
+            const int q = qt * 16 + l15;
+            h8 qf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                qf[ks] = *reinterpret_cast<const h8*>(Qs + (off + min(q, L - 1)) * QS + (ks * 4 + lg) * 8);
+            f32x4 sc[4];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) break;                              // wave-uniform
+                const int kr = off + min(kt * 16 + l15, L - 1);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const h8 kf = *reinterpret_cast<const h8*>(Ks + kr * QS + (ks * 4 + lg) * 8);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kt * 16 + lg * 4 + e;
+                    const bool ok = key < L && (!CAUSAL || key <= q);
+                    a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+                    mx = fmaxf(mx, a[e]);
+                }
+                sc[kt] = a;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pexp = (sc[kt][e] > -1.0e38f) ? __expf(sc[kt][e] - mx) : 0.f;
+                    sc[kt][e] = pexp;
+                    sum += pexp;
+                }
+            }
+            sum += __shfl_xor(sum, 16, CC_WAVE);
+            sum += __shfl_xor(sum, 32, CC_WAVE);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) break;
+                // (the product is rounded to fp32 and then to fp16, as in attention_wave_kernel: left alone, the compiler folds
+                // multiply and conversion into one v_fma_mixlo_f16 here - a single rounding, 1 ulp off in ~1e-5 of the entries)
+                float p0 = sc[kt][0] * inv, p1 = sc[kt][1] * inv, p2 = sc[kt][2] * inv, p3 = sc[kt][3] * inv;
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                const h4 ph = {(_Float16)p0, (_Float16)p1, (_Float16)p2, (_Float16)p3};
+                *reinterpret_cast<h4*>(Pw + l15 * PS + kt * 16 + lg * 4) = ph;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb >= nkb) break;
+                const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * PS + kb * 32 + lg * 8);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const h8 vf = *reinterpret_cast<const h8*>(Vt + (dt * 16 + l15) * VS + sq * slot + (kb * 4 + lg) * 8);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+            if (q < L) {
+                _Float16* dst = Cb + (int64_t)(row0 + off + q) * g.ldc + tn * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                    *reinterpret_cast<h4*>(dst + dt * 16 + lg * 4) = oh;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        GEMM_STAMP(3);
+        return;
+    }
     if (OUT_F16) {
         // fp16 outputs go through LDS (the staging buffers are free now) so that a wave stores whole
         // 128-byte row segments (8 lanes x 16 B) instead of 16 rows x 32 B per instruction.
@@ -550,7 +742,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     constexpr int LPRF_ACT = WTN / 4;                             // lanes that carry a row, 16 B each (16, 12 or 8)
     constexpr int LPRF = LPRF_ACT <= 8 ? 8 : 16;                  // lane slots per row (48-wide wave tiles: 12 of 16)
     constexpr int RPP = 64 / LPRF, PASSES = 16 / RPP;             // rows per access, accesses per 16-row group
-    static_assert(OUT_F16 || LPRF_ACT == 16 || LPRF_ACT == 8 || (LPRF_ACT == 12 && EPI == EPI_F32), "fp32 epilogue geometry");
+    static_assert(ATTN || OUT_F16 || LPRF_ACT == 16 || LPRF_ACT == 8 || (LPRF_ACT == 12 && EPI == EPI_F32), "fp32 epilogue geometry");
     const bool flane_on = (LPRF == LPRF_ACT) || (lane % LPRF) < LPRF_ACT;
     static_assert(NWAVES * 16 * LDF * 4 <= 2 * (A_BYTES + B_BYTES), "fp32 epilogue strip fits the staging buffers");
     float* fstg = reinterpret_cast<float*>(smem) + wave * (16 * LDF);
@@ -760,7 +952,8 @@ namespace {
 
 template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
-    constexpr size_t smem = (size_t)GEMM_NST(BM, BN, WM * WN, BK) * (size_t)(BM + BN) * BK * 2;
+    constexpr size_t smem_loop = (size_t)GEMM_NST(BM, BN, WM * WN, BK) * (size_t)(BM + BN) * BK * 2;
+    constexpr size_t smem = (EPI == EPI_ATTN_LN && smem_loop < ATTN_SMEM) ? (size_t)ATTN_SMEM : smem_loop;
     auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK, SK>;
     if (smem > 64 * 1024) {
         static bool configured = false;      // per instantiation; benign race (idempotent call)
@@ -1020,6 +1213,44 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         case 10: return launch_tile<128, 256, 2, 4>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ in_proj + attention
+// One launch for q, k, v = in_proj(ln_1(x)) and softmax(q k^T / 8) v: a workgroup owns att_spt whole sequences x one head (256
+// tile rows x its 192 weight rows), so the tile's q, k, v stay in LDS (EPI_ATTN_LN above).  Sequences per tile: as many as fit
+// 256 rows and the V^T slots (5 of 64 keys, or 8 of 32 keys).
+static bool attn_problem_ok(const GemmArgs& g) {
+    return g.att_L > 0 && g.att_L <= 56 && g.att_nseq > 0 && g.N == 3 * g.K && (g.K % 64) == 0 && g.ldc == g.K && g.ln_stats &&
+           g.ln_c1 && g.bias && !g.row_step && !g.row_map;
+}
+bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1) {
+#ifdef CC_NO_FUSED_ATTENTION
+    return false;
+#endif
+    return attn_problem_ok(g0) && (!g1 || attn_problem_ok(*g1));
+}
+int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
+    if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1)) || !cc_gemm_attn_applies(g0, g1)) return CC_ERR_INVALID;
+    auto shape = [](GemmArgs& g) {
+        const int by_rows = 256 / g.att_L, by_slots = g.att_L > 32 ? 5 : 8;
+        g.att_spt = by_rows < by_slots ? by_rows : by_slots;
+        g.tiles_m = (g.att_nseq + g.att_spt - 1) / g.att_spt;
+        g.tiles_n = g.K / 64;
+    };
+    GemmPair pr{};
+    shape(g0);
+    pr.p[0] = g0;
+    pr.tiles0 = g0.tiles_m * g0.tiles_n;
+    int total = pr.tiles0;
+    if (g1) {
+        pr.p[1] = *g1;
+        shape(pr.p[1]);
+        total += pr.p[1].tiles_m * pr.p[1].tiles_n;
+        pr.rider_prio = g0.M < 5000;
+    } else {
+        pr.p[1] = g0;
+    }
+    return launch_one<256, 192, 2, 4, EPI_ATTN_LN>(pr, total, st);
 }
 
 // ------------------------------------------------------------------------------------------------ selected rows
@@ -1288,6 +1519,32 @@ int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1
     g.M = M; g.N = N; g.K = K; g.ldc = N;
     g.ln_stats = stats; g.ln_slots = slots; g.ln_c1 = c1; g.ln_eps = eps;
     return cc_gemm_dispatch(g, gelu ? EPI_F16_GELU_LN : EPI_F16_LN, tile, static_cast<hipStream_t>(stream));
+}
+
+/* in_proj with the LayerNorm folded + multi-head attention in ONE launch (modules/clip.py:210-214: ln_1 -> nn.MultiheadAttention's
+ * in_proj and scaled-dot-product core): att[M, W] fp16 = softmax(q k^T / 8 [+ causal mask]) v per (sequence, head), with
+ * q | k | v = LN(h) Wqkv^T + b evaluated as in cc_linear_ln_f16 (w_ln_f16 [3W, W], c1 / c2 [3W], stats [M][slots][2]).
+ * nseq sequences of L tokens (row = s * L + t), or - seq_off / seq_len non-null - seq_len[s] <= L tokens from row seq_off[s]
+ * (packed back to back); m_dev (may be null): device-side count of valid rows.  W = heads * 64, L <= 56.  The q, k, v rows of a
+ * tile stay in LDS; results are bit-identical to cc_linear_ln_f16 followed by cc_attention_f16.
+ * CC_ERR_UNSUPPORTED when the shape is outside the fused form (the caller then runs the two launches). */
+int cc_inproj_attention_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
+                            int32_t slots, float eps, void* att_f16, int32_t nseq, int32_t L, int32_t heads, int32_t causal,
+                            const int32_t* seq_off, const int32_t* seq_len, const int32_t* m_dev, void* stream) {
+    if (!h_f16 || !w_ln_f16 || !c1 || !c2 || !stats || !att_f16 || slots <= 0 || slots > CC_LN_MAX_SLOTS || nseq <= 0 || L <= 0 ||
+        heads <= 0 || (seq_off == nullptr) != (seq_len == nullptr))
+        return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(h_f16);
+    g.W = static_cast<const _Float16*>(w_ln_f16);
+    g.bias = c2;
+    g.C = att_f16;
+    g.M = nseq * L; g.K = heads * 64; g.N = 3 * g.K; g.ldc = g.K;
+    g.ln_stats = stats; g.ln_slots = slots; g.ln_c1 = c1; g.ln_eps = eps;
+    g.m_dev = m_dev;
+    g.att_L = L; g.att_nseq = nseq; g.att_causal = causal; g.att_seq_off = seq_off; g.att_seq_len = seq_len;
+    if (!cc_gemm_attn_applies(g, nullptr)) return CC_ERR_UNSUPPORTED;
+    return cc_gemm_attn_dispatch2(g, nullptr, static_cast<hipStream_t>(stream));
 }
 
 /* Host-side query: the tile the dispatcher picks for a stand-alone launch of this shape and epilogue (CC_EPI_* or the

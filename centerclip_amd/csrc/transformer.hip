@@ -440,8 +440,10 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            h4 ph = {(_Float16)(s[kt][0] * inv), (_Float16)(s[kt][1] * inv), (_Float16)(s[kt][2] * inv),
-                     (_Float16)(s[kt][3] * inv)};
+            // two roundings (fp32 product, then fp16), pinned: the in_proj + attention form of gemm.hip computes the same bits
+            float p0 = s[kt][0] * inv, p1 = s[kt][1] * inv, p2 = s[kt][2] * inv, p3 = s[kt][3] * inv;
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            h4 ph = {(_Float16)p0, (_Float16)p1, (_Float16)p2, (_Float16)p3};
             *reinterpret_cast<h4*>(Pq + l15 * PS + kt * 16 + lg * 4) = ph;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -108,6 +108,15 @@ def linear_ln_f16(h16, w_ln, c1, c2, stats, slots, gelu=False, eps=1e-5, out=Non
     return y
 
 
+def inproj_attention_f16(h16, w_ln, c1, c2, stats, slots, nseq, L_tok, heads, causal=False, eps=1e-5, seq_off=None, seq_len=None):
+    """LayerNorm-folded in_proj + multi-head attention in ONE launch (clip.py:210-214) on frame-major rows (row = s * L_tok + t,
+    or seq_len[s] tokens from row seq_off[s]); q, k, v stay in LDS.  -> att [nseq * L_tok, W] fp16, bit-identical to
+    linear_ln_f16 followed by attention_f16.  W = heads * 64, L_tok <= 56."""
+    L.require_device(h16, w_ln)
+    return _ops.inproj_attention_f16(h16, w_ln, c1, c2, stats, int(slots), float(eps), int(nseq), int(L_tok), int(heads),
+                                     bool(causal), seq_off, seq_len)
+
+
 def linear_resid_stats_f16(a, w, bias, h, tile=0, h16=None, stats=None, shift_in=None, stats_in=None, shift_out=None):
     """h += a @ w.T + bias in place; returns (h16, stats [M, slots, 2], slots, shift_out).  h16 = fp16(h - c_row) with
     c_row = shift_in + mean of the previous centred copy (stats_in [M, slots_in, 2]); without stats_in c_row = 0.

@@ -188,6 +188,24 @@ def _(h16, w_ln, c1, c2, stats, slots, gelu, eps, tile):
     return h16.new_empty((h16.shape[0], w_ln.shape[0]))
 
 
+@custom_op(NS + "::inproj_attention_f16", mutates_args=(), device_types="cuda")
+def inproj_attention_f16(h16: torch.Tensor, w_ln: torch.Tensor, c1: torch.Tensor, c2: torch.Tensor, stats: torch.Tensor,
+                         slots: int, eps: float, nseq: int, L_tok: int, heads: int, causal: bool,
+                         seq_off: Optional[torch.Tensor], seq_len: Optional[torch.Tensor]) -> torch.Tensor:
+    """LN-folded in_proj + attention in one launch (frame-major rows); -> att [nseq * L_tok, W] fp16."""
+    M, W = h16.shape
+    out = torch.zeros(M, W, device=h16.device, dtype=torch.float16) if seq_off is not None else _e(M, W, like=h16, dtype=torch.float16)
+    L.check(L.lib().cc_inproj_attention_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
+                                            L.ptr(out), nseq, L_tok, heads, int(causal), L.ptr(seq_off), L.ptr(seq_len), None,
+                                            _st(h16)), "cc_inproj_attention_f16")
+    return out
+
+
+@inproj_attention_f16.register_fake
+def _(h16, w_ln, c1, c2, stats, slots, eps, nseq, L_tok, heads, causal, seq_off, seq_len):
+    return h16.new_empty(h16.shape)
+
+
 @custom_op(NS + "::linear_resid_stats_f16", mutates_args=("h", "h16", "stats", "shift_out"), device_types="cuda")
 def linear_resid_stats_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], h: torch.Tensor,
                            h16: torch.Tensor, stats: torch.Tensor, shift_in: Optional[torch.Tensor],
@@ -988,7 +1006,7 @@ def _(sim):
 
 
 OPS = ("contrastive_loss", "contrastive_loss_grad", "spectral_laplacian", "spectral_graph_laplacian", "spectral_embedding", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
-       "linear_ln_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward", "token_apply_selection",
+       "linear_ln_f16", "inproj_attention_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward", "token_apply_selection",
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",
        "loose_similarity", "video_pool_normalize", "normalize_rows", "scaled_dot_nt", "scaled_dot_nt_out", "rank_counts",

@@ -343,6 +343,16 @@ int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1
                         const float* stats, int32_t slots, float eps, void* out_f16,
                         int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* ws, size_t ws_bytes,
                         void* stream);       /* (with the exchange scratch, see cc_linear_ws_f16) */
+/* in_proj with the LayerNorm folded + the multi-head attention core in ONE launch (modules/clip.py:210-214, the ln_1 ->
+ * nn.MultiheadAttention path of ResidualAttentionBlock.attention): att [M, W] fp16 = softmax(q k^T / 8 [causal]) v per
+ * (sequence, head) with q | k | v = LN(h) Wqkv^T + b evaluated as in cc_linear_ln_f16 (w_ln_f16 [3W, W], c1 / c2 [3W], stats
+ * [M][slots][2]).  A workgroup owns whole sequences x one head and keeps their q, k, v in LDS - they never reach HBM.  Rows:
+ * nseq sequences of L tokens (row = s * L + t), or - seq_off / seq_len both non-null (device arrays) - seq_len[s] <= L tokens
+ * from row seq_off[s], packed back to back; m_dev (device, may be null) = count of valid rows.  W = heads * 64, L <= 56.
+ * Bit-identical to cc_linear_ln_f16 followed by cc_attention_f16.  CC_ERR_UNSUPPORTED outside that shape range. */
+int cc_inproj_attention_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
+                            int32_t slots, float eps, void* att_f16, int32_t nseq, int32_t L, int32_t heads, int32_t causal,
+                            const int32_t* seq_off, const int32_t* seq_len, const int32_t* m_dev, void* stream);
 /* host-side query: the tile (1-11, see cc_linear_f16 / cc_linear_ws_f16; the answer for a call WITH the exchange scratch) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
  * LN-folded f16 without / with QuickGELU, 7 = residual + statistics); <= 0: unsupported */
 int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue);

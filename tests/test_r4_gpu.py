@@ -208,3 +208,59 @@ def test_block_backward_against_reference_autograd(tag):
     assert torch.equal(xa.grad, dx)
     for k, p_ in blk.named_parameters():
         assert p_.grad is not None and torch.equal(p_.grad.reshape(-1), grads[k].reshape(-1)), k
+
+
+# ----------------------------------------------------------------------------- in_proj + attention in one launch
+def _inproj_inputs(M, W, seed):
+    from centerclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(M, W, generator=g) * 1.5 + 0.3).cuda()
+    w = (torch.randn(3 * W, W, generator=g) * 0.04).cuda()
+    b = (torch.randn(3 * W, generator=g) * 0.1).cuda()
+    gamma = (1.0 + 0.1 * torch.randn(W, generator=g)).cuda()
+    beta = (0.1 * torch.randn(W, generator=g)).cuda()
+    h16, st, _ = ops.row_stats(x)
+    wf, c1, c2 = ops.fold_layernorm_linear(w, b, gamma, beta)
+    return h16, st, wf, c1, c2
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", [(192, 50, 12, False), (48, 50, 12, False), (16, 32, 8, True), (7, 50, 12, False),
+                                                  (3, 17, 2, True), (11, 33, 4, False), (5, 56, 2, True), (40, 9, 3, False)])
+def test_inproj_attention_one_launch_is_bit_identical(nseq, L, heads, causal):
+    """cc_inproj_attention_f16 (q, k, v kept in LDS) against cc_linear_ln_f16 + cc_attention_f16 on the same rows."""
+    from centerclip_amd import ops
+    W = heads * 64
+    h16, st, wf, c1, c2 = _inproj_inputs(nseq * L, W, 100 + nseq)
+    qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1)
+    want = ops.attention_f16(qkv, nseq, L, heads, causal=causal)
+    got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, nseq, L, heads, causal=causal)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # ... and both against the plain fp32 formula of modules/clip.py:210-214 on the fp16 q, k, v
+    q, k, v = (t.view(nseq, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().split(W, dim=1))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=s.device).triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(nseq * L, W)
+    assert relerr(got.float(), ref) < 2e-3
+
+
+def test_inproj_attention_packed_captions():
+    """Variable-length sequences packed back to back (the compacted captions of the text tower): every caption must equal
+    the two-launch result of that caption alone."""
+    from centerclip_amd import ops
+    heads, W, L = 8, 512, 32
+    lens = [32, 5, 17, 1, 32, 20, 9, 31, 16, 2, 27, 13, 8, 32, 3, 19, 11]          # 17 captions: 3 row tiles of 8
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    Mv = int(sum(lens))
+    h16, st, wf, c1, c2 = _inproj_inputs(len(lens) * L, W, 7)
+    seq_off = torch.from_numpy(off).cuda()
+    seq_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, len(lens), L, heads, causal=True, seq_off=seq_off, seq_len=seq_len)
+    torch.cuda.synchronize()
+    for s, (o, n) in enumerate(zip(off, lens)):
+        qkv = ops.linear_ln_f16(h16[o:o + n].contiguous(), wf, c1, c2, st[o:o + n].contiguous(), 1)
+        want = ops.attention_f16(qkv, 1, n, heads, causal=True)
+        assert torch.equal(got[o:o + n], want), (s, n)
+    assert not got[Mv:].any()                                                        # rows behind the packed captions: untouched

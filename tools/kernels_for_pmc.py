@@ -17,6 +17,9 @@ for name, N, K in [("c_fc", 3072, 768), ("in_proj", 2304, 768)]:
     out = torch.empty(M, N, device="cuda", dtype=torch.float16)
     for _ in range(5):
         ops.linear_ln_f16(h16, wf, c1, c2, stats, 12, gelu=(name == "c_fc"), out=out)
+    if name == "in_proj":                       # the form the encoders run: the frames' attention in the same launch
+        for _ in range(5):
+            ops.inproj_attention_f16(h16, wf, c1, c2, stats, 12, M // 50, 50, K // 64)
     torch.cuda.synchronize()
 a = torch.randn(M, 3072, device="cuda").half(); w = (torch.randn(768, 3072, device="cuda") * 3072 ** -0.5).half()
 b = torch.randn(768, device="cuda"); hres = torch.zeros(M, 768, device="cuda")
