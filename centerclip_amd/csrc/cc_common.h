@@ -28,6 +28,29 @@ __device__ __forceinline__ unsigned cc_float_to_ordered_uint(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// x combined with the value 16 (32) lanes away, without the LDS crossbar: v_permlane16_swap / v_permlane32_swap (gfx950)
+// exchange DPP rows between two copies of the register - afterwards the two registers hold, in every lane, this lane's value
+// and its partner's.  The same two operands as `x op __shfl_xor(x, 16)`, so max and (commutative) add give the same bits as
+// the ds_bpermute form; a dependent LDS round trip (~100 cycles) becomes two VALU instructions.
+__device__ __forceinline__ void cc_lane_xor16_pair(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void cc_lane_xor32_pair(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float cc_rows_max(float x) {          // max over the 4 lanes l15 + 16 * {0, 1, 2, 3}
+    float a, b;
+    cc_lane_xor16_pair(x, a, b); x = fmaxf(a, b);
+    cc_lane_xor32_pair(x, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float cc_rows_sum(float x) {          // (x[l] + x[l ^ 16]) + the same of the other half
+    float a, b;
+    cc_lane_xor16_pair(x, a, b); x = a + b;
+    cc_lane_xor32_pair(x, a, b); return a + b;
+}
+
 __device__ __forceinline__ float cc_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CC_WAVE);

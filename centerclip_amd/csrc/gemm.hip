@@ -37,12 +37,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 // EPI_ATTN_LN epilogue LDS map (bytes): row statistics [256] x 8 | Q [256][72] | K [256][72] | V^T [64][328] (5 slots of 64
-// keys or 8 of 32) | P strips 8 x [16][72] | sequence table
+// keys or 8 of 32) | P strips 8 x [16][72] | sequence table [16] | V^T column of every tile row [256]
 #define ATTN_QS 72
 #define ATTN_VS 328
 #define ATTN_Q_OFF 2048
 #define ATTN_TAB_OFF (ATTN_Q_OFF + 2 * 256 * ATTN_QS * 2 + 64 * ATTN_VS * 2 + 8 * 16 * ATTN_QS * 2)
-#define ATTN_SMEM (ATTN_TAB_OFF + 64)
+#define ATTN_SMEM (ATTN_TAB_OFF + 64 + 1024)
 
 __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        const int wrow = ATTN ? (r >> 6) * (g.N / 3) + tn * 64 + (r & 63) : col0 + r;
+        // (ATTN: wave column wc multiplies the d-slice [16 wc, 16 wc + 16) of q, of k and of v: LDS row 48 wc + 16 sec + dd)
+        const int wrow = ATTN ? ((r % 48) >> 4) * (g.N / 3) + tn * 64 + (r / 48) * 16 + (r & 15) : col0 + r;
         bsrc[q] = g.W + (int64_t)wrow * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
     }
     auto stage = [&](int buf, int kt) {
@@ -204,6 +205,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         const float var = fmaxf(sq / (float)g.K - row_mu * row_mu, 0.f);
         row_rs = 1.0f / sqrtf(var + g.ln_eps);
     }
+    // ATTN: thread r also finds where tile row r lands in the V^T tile (sequence slot * slot width + token), -1 = no sequence
+    int att_vcol = -1;
+    if (ATTN && tid < BM) {
+        const int nst = min(g.att_spt, g.att_nseq - att_s0), slotw = g.att_L > 32 ? 64 : 32;
+        if (!g.att_seq_off) {
+            const int sq = tid / g.att_L;
+            if (sq < nst) att_vcol = sq * slotw + (tid - sq * g.att_L);
+        } else {
+            for (int j = 0; j < nst; ++j) {
+                const int off = g.att_seq_off[att_s0 + j] - row0, len = g.att_seq_len[att_s0 + j];
+                if (tid >= off && tid < off + len) att_vcol = j * slotw + (tid - off);
+            }
+        }
+    }
     // residual epilogue with row centring: c_row = the row's mean one sublayer ago (the shift the previous producer used
     // + the mean of the centred copy it wrote), reduced here the same way; parked in row_mu until the epilogue
     if (EPI == EPI_F32_RESID_STATS && g.shift_stats && tid < BM) {
@@ -230,8 +245,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     auto fetch_epilogue_operands = [&]() {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int lc = wc * (BN / WN) + j * 16 + lg * 4;
-            const int n = ATTN ? (lc >> 6) * (g.N / 3) + tn * 64 + (lc & 63) : col0 + lc;
+            if (ATTN && j == 2) {                       // the V fragment is accumulated transposed: one column (d) per lane
+                const int n = 2 * (g.N / 3) + tn * 64 + wc * 16 + l15;
+                biasv[j] = make_float4(g.bias[n], 0.f, 0.f, 0.f);
+                c1v[LNFOLD ? j : 0] = make_float4(g.ln_c1[n], 0.f, 0.f, 0.f);
+                continue;
+            }
+            const int n = ATTN ? j * (g.N / 3) + tn * 64 + wc * 16 + lg * 4 : col0 + wc * (BN / WN) + j * 16 + lg * 4;
             biasv[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (LNFOLD) c1v[j] = *reinterpret_cast<const float4*>(g.ln_c1 + n);
         }
@@ -263,8 +283,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) {
+                // (ATTN: the V fragment with the operands swapped - a lane then holds 4 consecutive tile rows (keys) of one d,
+                // the layout of the V^T tile the attention reads)
+                if (ATTN && j == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
     };
     auto read_a = [&](int buf, int ks, int i, h8 (&af)[MI]) {
         const unsigned char* la = smem + buf * (A_BYTES + B_BYTES);
@@ -284,7 +308,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     };
     auto mma_row = [&](int i, const h8 (&af)[MI], const h8 (&bf)[NI]) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) {
+            if (ATTN && j == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
     };
     // Measured (tools/gemm_phases.py, cycles per k-step): the half-shifted order wins where one workgroup owns the
     // CU (256x256: 3413 -> 2961) and for the 64x64 tile (1114 -> 953); with two 128-wide workgroups per CU the
@@ -499,69 +526,97 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         int* stab = reinterpret_cast<int*>(smem + ATTN_TAB_OFF);   // [j]: first tile row of sequence j, [8 + j]: its length
         const int nst = min(g.att_spt, g.att_nseq - att_s0);
         const int slot = g.att_L > 32 ? 64 : 32, nkb = slot >> 5, nkt = slot >> 4;
-        if (tid < BM) rowst[tid] = make_float2(row_mu, row_rs);
+        // dev builds: -DCC_ATTN_STAMP_AT=n moves the third timeline stamp to point n of this epilogue, taken by thread
+        // CC_ATTN_STAMP_TID (default 0; 448 = the first lane of a wave that writes V)
+#if defined(CC_DEV_KNOBS) && defined(CC_ATTN_STAMP_AT)
+#ifndef CC_ATTN_STAMP_TID
+#define CC_ATTN_STAMP_TID 0
+#endif
+#define ATTN_STAMP_AT(n)                                                                                          \
+    do {                                                                                                          \
+        if ((n) == CC_ATTN_STAMP_AT && prof && threadIdx.x == CC_ATTN_STAMP_TID)                                  \
+            prof[(int64_t)blockIdx.x * 4 + 2] = (long long)GEMM_CLOCK();                                          \
+    } while (0)
+#else
+#define ATTN_STAMP_AT(n) do { } while (0)
+#endif
+        int* vcolS = stab + 16;                                    // [256]: V^T column of tile row r (prologue), -1 = none
+        if (tid < BM) { rowst[tid] = make_float2(row_mu, row_rs); vcolS[tid] = att_vcol; }
         if (tid < 8) {
             const bool have = tid < nst;
             stab[tid] = !have ? (1 << 20) : (g.att_seq_off ? g.att_seq_off[att_s0 + tid] - row0 : tid * g.att_L);
             stab[8 + tid] = !have ? 0 : (g.att_seq_len ? g.att_seq_len[att_s0 + tid] : g.att_L);
         }
         __syncthreads();
-        int offv[8], lenv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { offv[j] = stab[j]; lenv[j] = stab[8 + j]; }
+        ATTN_STAMP_AT(1);
         {   // keys [len, slot) of every sequence's V slot are multiplied by P = 0: they must be finite
             const int d = tid & 63, sq = tid >> 6;
             if (sq < nst)
                 for (int key = stab[8 + sq]; key < slot; ++key) Vt[d * VS + sq * slot + key] = (_Float16)0.f;
         }
+        // Wave column wc holds the d-slice [16 wc, 16 wc + 16) of q (fragment 0), k (1) and v (2, transposed: a lane has rows
+        // lg*4 .. +3 of column d = 16 wc + l15).  Rows (2a, 2a + 1) belong to one sequence when the sequences are uniform and
+        // of even length: V^T then takes 4-byte writes (two keys of one d).
+        const bool pairs = !g.att_seq_off && (g.att_L & 1) == 0;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = wr * WTM + i * 16 + l15;
-            const float2 t2 = rowst[r];
-            int sq = 0, off = 0, len = lenv[0];
+            {
+                const float2 t2 = rowst[r];
+                const float mu = t2.x, rs = t2.y;
 #pragma unroll
-            for (int j = 1; j < 8; ++j)
-                if (r >= offv[j]) { sq = j; off = offv[j]; len = lenv[j]; }
-            const int key = r - off;
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 v = acc[i][j];
+                    {   // (statement for statement the fold of the fp16-output epilogue below: the same contractions, the same bits)
+                        const float4 c1 = c1v[j];
+                        v[0] = rs * (v[0] - mu * c1.x); v[1] = rs * (v[1] - mu * c1.y);
+                        v[2] = rs * (v[2] - mu * c1.z); v[3] = rs * (v[3] - mu * c1.w);
+                    }
+                    {
+                        const float4 bb = biasv[j];
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    h4 o;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                f32x4 v = acc[i][j];
-                {   // (statement for statement the fold of the fp16-output epilogue below: the same contractions, the same bits)
-                    const float mu = t2.x, rs = t2.y;
-                    const float4 c1 = c1v[j];
-                    v[0] = rs * (v[0] - mu * c1.x); v[1] = rs * (v[1] - mu * c1.y);
-                    v[2] = rs * (v[2] - mu * c1.z); v[3] = rs * (v[3] - mu * c1.w);
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<h4*>((j == 0 ? Qs : Ks) + r * QS + wc * 16 + lg * 4) = o;
                 }
-                {
-                    const float4 bb = biasv[j];
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                h4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                const int cb = wc * WTN + j * 16;                  // wave-uniform: 16 columns never straddle q | k | v
-                const int cc = (cb & 63) + lg * 4;
-                if (cb < 64) *reinterpret_cast<h4*>(Qs + r * QS + cc) = o;
-                else if (cb < 128) *reinterpret_cast<h4*>(Ks + r * QS + cc) = o;
-                else if (key < len) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Vt[(cc + e) * VS + sq * slot + key] = o[e];
+            }
+            {
+                const int m0 = wr * WTM + i * 16 + lg * 4;         // this lane's 4 rows of the V fragment
+                const float4 sa = *reinterpret_cast<const float4*>(rowst + m0), sb = *reinterpret_cast<const float4*>(rowst + m0 + 2);
+                const int4 vc = *reinterpret_cast<const int4*>(vcolS + m0);
+                const float c1 = c1v[2].x, bb = biasv[2].x;
+                const f32x4 v = acc[i][2];
+                // (two fused multiply-adds per value, as the compiler contracts the statements above)
+                const _Float16 h0 = (_Float16)__builtin_fmaf(sa.y, __builtin_fmaf(-sa.x, c1, v[0]), bb);
+                const _Float16 h1 = (_Float16)__builtin_fmaf(sa.w, __builtin_fmaf(-sa.z, c1, v[1]), bb);
+                const _Float16 h2 = (_Float16)__builtin_fmaf(sb.y, __builtin_fmaf(-sb.x, c1, v[2]), bb);
+                const _Float16 h3 = (_Float16)__builtin_fmaf(sb.w, __builtin_fmaf(-sb.z, c1, v[3]), bb);
+                _Float16* vrow = Vt + (wc * 16 + l15) * VS;
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                if (pairs) {
+                    if (vc.x >= 0) *reinterpret_cast<h2v*>(vrow + vc.x) = h2v{h0, h1};
+                    if (vc.z >= 0) *reinterpret_cast<h2v*>(vrow + vc.z) = h2v{h2, h3};
+                } else {
+                    if (vc.x >= 0) vrow[vc.x] = h0;
+                    if (vc.y >= 0) vrow[vc.y] = h1;
+                    if (vc.z >= 0) vrow[vc.z] = h2;
+                    if (vc.w >= 0) vrow[vc.w] = h3;
                 }
             }
         }
+        ATTN_STAMP_AT(2);
         __syncthreads();
+        ATTN_STAMP_AT(3);
 #ifdef CC_DEV_KNOBS
         if (g_attn_dump) {
             const int Wd = g.N / 3;
             for (int idx = tid; idx < 256 * 64; idx += THREADS) {
-                const int r = idx >> 6, d = idx & 63;
-                int sq = 0, off = 0, len = lenv[0];
-#pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (r >= offv[j]) { sq = j; off = offv[j]; len = lenv[j]; }
-                if (r - off < len) {
+                const int r = idx >> 6, d = idx & 63, vc = vcolS[r];
+                if (vc >= 0) {
                     _Float16* o = g_attn_dump + (int64_t)(row0 + r) * g.N + tn * 64 + d;
-                    o[0] = Qs[r * QS + d]; o[Wd] = Ks[r * QS + d]; o[2 * Wd] = Vt[d * VS + sq * slot + (r - off)];
+                    o[0] = Qs[r * QS + d]; o[Wd] = Ks[r * QS + d]; o[2 * Wd] = Vt[d * VS + vc];
                 }
             }
         }
@@ -590,30 +645,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     const h8 kf = *reinterpret_cast<const h8*>(Ks + kr * QS + (ks * 4 + lg) * 8);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
                 }
+                if (kt * 16 + 15 < L && (!CAUSAL || kt < qt)) {     // wave-uniform: no key of this tile is masked
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kt * 16 + lg * 4 + e;
-                    const bool ok = key < L && (!CAUSAL || key <= q);
-                    a[e] = ok ? a[e] * 0.125f : -3.0e38f;
-                    mx = fmaxf(mx, a[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = a[e] * 0.125f;
+                        mx = fmaxf(mx, a[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt * 16 + lg * 4 + e;
+                        const bool ok = key < L && (!CAUSAL || key <= q);
+                        a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+                        mx = fmaxf(mx, a[e]);
+                    }
                 }
                 sc[kt] = a;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+            mx = cc_rows_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 if (kt >= nkt) break;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pexp = (sc[kt][e] > -1.0e38f) ? __expf(sc[kt][e] - mx) : 0.f;
+                    const float pexp = __expf(sc[kt][e] - mx);    // (a masked key: exp2 of -4e38 or -inf = 0 exactly)
                     sc[kt][e] = pexp;
                     sum += pexp;
                 }
             }
-            sum += __shfl_xor(sum, 16, CC_WAVE);
-            sum += __shfl_xor(sum, 32, CC_WAVE);
+            sum = cc_rows_sum(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {

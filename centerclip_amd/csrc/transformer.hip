@@ -263,8 +263,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
                 s[kt] = a;
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+        mx = cc_rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < ATT_MAX_KT / 16; ++kt) {
@@ -277,8 +276,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttPair pr, float scale)
                 }
             }
         }
-        sum += __shfl_xor(sum, 16, CC_WAVE);
-        sum += __shfl_xor(sum, 32, CC_WAVE);
+        sum = cc_rows_sum(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int kt = 0; kt < ATT_MAX_KT / 16; ++kt) {
@@ -424,8 +422,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
             }
             s[kt] = a;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, CC_WAVE));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, CC_WAVE));
+        mx = cc_rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -435,8 +432,7 @@ __global__ __launch_bounds__(256) void attention_wave_kernel(AttPair pr, float s
                 s[kt][e] = pexp;
                 sum += pexp;
             }
-        sum += __shfl_xor(sum, 16, CC_WAVE);
-        sum += __shfl_xor(sum, 32, CC_WAVE);
+        sum = cc_rows_sum(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
