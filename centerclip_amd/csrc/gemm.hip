@@ -17,6 +17,7 @@
 #include "cc_kernels.h"
 #include <hip/hip_ext.h>
 #include <cstring>
+#include <type_traits>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         _Float16* Pw = Vt + 64 * VS + wave * (16 * PS);
         int* stab = reinterpret_cast<int*>(smem + ATTN_TAB_OFF);   // [j]: first tile row of sequence j, [8 + j]: its length
         const int nst = min(g.att_spt, g.att_nseq - att_s0);
-        const int slot = g.att_L > 32 ? 64 : 32, nkb = slot >> 5, nkt = slot >> 4;
+        const int slot = g.att_L > 32 ? 64 : 32;
         // dev builds: -DCC_ATTN_STAMP_AT=n moves the third timeline stamp to point n of this epilogue, taken by thread
         // CC_ATTN_STAMP_TID (default 0; 448 = the first lane of a wave that writes V)
 #if defined(CC_DEV_KNOBS) && defined(CC_ATTN_STAMP_AT)
@@ -624,93 +625,106 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         const int qtmax = (g.att_L + 15) >> 4;
         const bool CAUSAL = g.att_causal != 0;
         _Float16* Cb = reinterpret_cast<_Float16*>(g.C);
-        for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qtmax; it += NWAVES) {
-            const int sq = it / qtmax, qt = it - sq * qtmax;       // wave-uniform
-            const int off = stab[sq], L = stab[8 + sq];
-            if (qt * 16 >= L) continue;
-            const int q = qt * 16 + l15;
-            h8 qf[2];
+        // One item = (sequence, 16-query tile).  Straight-line per item: every LDS operand (Q, K, V^T fragments) is requested
+        // up front, then the S MFMAs, the softmax, P through the wave's strip, the PV MFMAs - with the key-tile count a
+        // template constant the compiler schedules the waits instead of paying a full LDS round trip per key tile.
+        auto run_items = [&](auto nkt_c) {
+            constexpr int NKT = decltype(nkt_c)::value, NKB = NKT / 2, SLOT = NKT * 16;
+            for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qtmax; it += NWAVES) {
+                const int sq = it / qtmax, qt = it - sq * qtmax;   // wave-uniform
+                const int off = stab[sq], L = stab[8 + sq];
+                if (qt * 16 >= L) continue;
+                const int q = qt * 16 + l15;
+                h8 qf[2], kf[NKT][2], vf[NKB][4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                qf[ks] = *reinterpret_cast<const h8*>(Qs + (off + min(q, L - 1)) * QS + (ks * 4 + lg) * 8);
-            f32x4 sc[4];
-            float mx = -3.0e38f;
+                for (int ks = 0; ks < 2; ++ks)
+                    qf[ks] = *reinterpret_cast<const h8*>(Qs + (off + min(q, L - 1)) * QS + (ks * 4 + lg) * 8);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt >= nkt) break;                              // wave-uniform
-                const int kr = off + min(kt * 16 + l15, L - 1);
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const int kr = off + min(kt * 16 + l15, L - 1);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const h8 kf = *reinterpret_cast<const h8*>(Ks + kr * QS + (ks * 4 + lg) * 8);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *reinterpret_cast<const h8*>(Ks + kr * QS + (ks * 4 + lg) * 8);
                 }
-                if (kt * 16 + 15 < L && (!CAUSAL || kt < qt)) {     // wave-uniform: no key of this tile is masked
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        vf[kb][dt] = *reinterpret_cast<const h8*>(Vt + (dt * 16 + l15) * VS + sq * SLOT + (kb * 4 + lg) * 8);
+                f32x4 sc[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[ks], a, 0, 0, 0);
+                    sc[kt] = a;
+                }
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    f32x4 a = sc[kt];
+                    if (kt * 16 + 15 < L && (!CAUSAL || kt < qt)) { // wave-uniform: no key of this tile is masked
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = a[e] * 0.125f;
+                            mx = fmaxf(mx, a[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt * 16 + lg * 4 + e;
+                            const bool ok = key < L && (!CAUSAL || key <= q);
+                            a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+                            mx = fmaxf(mx, a[e]);
+                        }
+                    }
+                    sc[kt] = a;
+                }
+                mx = cc_rows_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        a[e] = a[e] * 0.125f;
-                        mx = fmaxf(mx, a[e]);
+                        const float pexp = __expf(sc[kt][e] - mx);   // (a masked key: exp2 of -4e38 or -inf = 0 exactly)
+                        sc[kt][e] = pexp;
+                        sum += pexp;
                     }
-                } else {
+                sum = cc_rows_sum(sum);
+                const float inv = 1.0f / sum;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = kt * 16 + lg * 4 + e;
-                        const bool ok = key < L && (!CAUSAL || key <= q);
-                        a[e] = ok ? a[e] * 0.125f : -3.0e38f;
-                        mx = fmaxf(mx, a[e]);
+                for (int kt = 0; kt < NKT; ++kt) {
+                    // (the product is rounded to fp32 and then to fp16, as in attention_wave_kernel: left alone, the compiler
+                    // folds multiply and conversion into one v_fma_mixlo_f16 here - a single rounding, 1 ulp off in ~1e-5 of
+                    // the entries)
+                    float p0 = sc[kt][0] * inv, p1 = sc[kt][1] * inv, p2 = sc[kt][2] * inv, p3 = sc[kt][3] * inv;
+                    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                    const h4 ph = {(_Float16)p0, (_Float16)p1, (_Float16)p2, (_Float16)p3};
+                    *reinterpret_cast<h4*>(Pw + l15 * PS + kt * 16 + lg * 4) = ph;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * PS + kb * 32 + lg * 8);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kb][dt], pf, o[dt], 0, 0, 0);
+                }
+                if (q < L) {
+                    _Float16* dst = Cb + (int64_t)(row0 + off + q) * g.ldc + tn * 64;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                        *reinterpret_cast<h4*>(dst + dt * 16 + lg * 4) = oh;
                     }
                 }
-                sc[kt] = a;
+                __builtin_amdgcn_wave_barrier();
             }
-            mx = cc_rows_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt >= nkt) break;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pexp = __expf(sc[kt][e] - mx);    // (a masked key: exp2 of -4e38 or -inf = 0 exactly)
-                    sc[kt][e] = pexp;
-                    sum += pexp;
-                }
-            }
-            sum = cc_rows_sum(sum);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt >= nkt) break;
-                // (the product is rounded to fp32 and then to fp16, as in attention_wave_kernel: left alone, the compiler folds
-                // multiply and conversion into one v_fma_mixlo_f16 here - a single rounding, 1 ulp off in ~1e-5 of the entries)
-                float p0 = sc[kt][0] * inv, p1 = sc[kt][1] * inv, p2 = sc[kt][2] * inv, p3 = sc[kt][3] * inv;
-                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
-                const h4 ph = {(_Float16)p0, (_Float16)p1, (_Float16)p2, (_Float16)p3};
-                *reinterpret_cast<h4*>(Pw + l15 * PS + kt * 16 + lg * 4) = ph;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            f32x4 o[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb >= nkb) break;
-                const h8 pf = *reinterpret_cast<const h8*>(Pw + l15 * PS + kb * 32 + lg * 8);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const h8 vf = *reinterpret_cast<const h8*>(Vt + (dt * 16 + l15) * VS + sq * slot + (kb * 4 + lg) * 8);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
-                }
-            }
-            if (q < L) {
-                _Float16* dst = Cb + (int64_t)(row0 + off + q) * g.ldc + tn * 64;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
-                    *reinterpret_cast<h4*>(dst + dt * 16 + lg * 4) = oh;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        };
+        if (slot == 64) run_items(std::integral_constant<int, 4>{});
+        else run_items(std::integral_constant<int, 2>{});
         GEMM_STAMP(3);
         return;
     }
