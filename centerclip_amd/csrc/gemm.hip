@@ -319,6 +319,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // plain order is faster (1832 vs 2033; re-measured in round 3 with the pinned phase-start wait: 1,468-1,572 vs 1,560-1,705)
     // - the co-resident workgroup already fills the LDS-latency gap.
         constexpr bool HALF_SHIFTED = (NWAVES == 8) || (BM == 64 && BN == 64);
+    // residual rows requested from inside the three-stage loop (see there); the epilogue's row-major geometry
+#ifdef CC_NO_RESID_PREFETCH
+    constexpr bool RES_PREFETCH = false;
+#else
+    constexpr bool RES_PREFETCH = RESID && NST == 3 && SK == 1 && HALF_SHIFTED && BK == GEMM_BK;
+#endif
+    constexpr int PF_LPRF = ((BN / WN) / 4 <= 8) ? 8 : 16, PF_RPP = 64 / PF_LPRF, PF_PASSES = 16 / PF_RPP;
+    f32x4 resall[RES_PREFETCH ? MI : 1][RES_PREFETCH ? PF_PASSES : 1];
+    constexpr bool res_have = RES_PREFETCH;
     if constexpr (BK > GEMM_BK) {
         // Deep k-step (BK = 128, the 64x64 tile only): the small tile is bound by the latency of the LDS-DMA round trip,
         // one per k-step and workgroup (~900 cycles for 8 MFMAs per wave at BK = 64) - twice the bytes per stage halves
@@ -354,6 +363,49 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         if (nk > 1) stage(1, 1);
         if (nk > 2) stage(2, 2);
         read_frags(0, 0, a0, b0);
+        // Residual epilogues: the tile's fp32 residual rows (128 KB per workgroup, 29.5 MB per launch from HBM - 4.3 us at the
+        // HBM rate when every workgroup of the one round asks at the same moment, with every matrix core idle) are requested
+        // from inside the loop, into registers in the epilogue's row-major layout: PF_G groups of PF_R 16-byte loads per lane,
+        // one group behind the stage loads of each of the steps nk-10 .. nk-3.  Vector-memory operations return in order,
+        // so a wait for stage kt + 1 also waits for everything issued before it - but not for what was issued after: the
+        // waits of the last steps count the younger residual groups (the two of the steps kt-2 and kt-1) as allowed-
+        // outstanding, and every group has two k-steps to arrive before anything waits for it.  Those steps are peeled
+        // (tail_step<T>) so that the counts and the registers of a group are compile-time constants.
+        // Measured (profiles/r04_resid_prefetch.txt): out_proj per workgroup 1.9 / 12.0 / 6.9 us (prologue / loop / epilogue)
+        // -> 2.0 / 14.4 / 3.2, the launch alone 23.2 -> 19.9 us; the step 1.849 -> 1.823 ms in three same-session A/B rounds
+        // (all 16 loads behind the last stage instead: 1.840).
+        constexpr int PF_G = 8, PF_R = RES_PREFETCH ? MI * PF_PASSES / PF_G : 0;
+        static_assert(!RES_PREFETCH || (MI * PF_PASSES == PF_G * PF_R && PF_PASSES % PF_R == 0), "residual groups");
+        // (buffer loads: one per-lane byte offset for all groups, the group's row offset in an SGPR, rows behind M read as 0)
+        __amdgpu_buffer_rsrc_t res_rsrc;
+        int res_voff = 0;
+        if constexpr (RES_PREFETCH) {
+            const int64_t first = (int64_t)(row0 + wr * (BM / WM)) * g.ldc;            // first element of this wave's rows
+            const int64_t left = ((int64_t)g.M * g.ldc - first) * 4;                    // bytes from there to the end of C
+            res_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(g.C) + first, 0,
+                                                         (int)(left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left)), 0x00020000);
+            res_voff = ((lane / PF_LPRF) * g.ldc + col0 + wc * (BN / WN) + (lane % PF_LPRF) * 4) * 4;
+        }
+        auto prefetch_group = [&](auto grp_c) {
+            if constexpr (RES_PREFETCH) {
+                constexpr int GRP = decltype(grp_c)::value;
+#pragma unroll
+                for (int u = 0; u < PF_R; ++u) {
+                    constexpr int GPI = PF_PASSES / PF_R;             // groups per fragment row
+                    const int i = GRP / GPI, ps = (GRP % GPI) * PF_R + u;
+                    resall[i][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  res_rsrc, res_voff, (i * 16 + ps * PF_RPP) * g.ldc * 4, 0));
+                }
+            }
+        };
+        auto prefetch_all = [&]() {
+            prefetch_group(std::integral_constant<int, 0>{}); prefetch_group(std::integral_constant<int, 1>{});
+            prefetch_group(std::integral_constant<int, 2>{}); prefetch_group(std::integral_constant<int, 3>{});
+            prefetch_group(std::integral_constant<int, 4>{}); prefetch_group(std::integral_constant<int, 5>{});
+            prefetch_group(std::integral_constant<int, 6>{}); prefetch_group(std::integral_constant<int, 7>{});
+        };
+        const bool res_spread = RES_PREFETCH && nk >= PF_G + 2;   // (shorter K: requested before the loop - its waits then
+        if (RES_PREFETCH && !res_spread) prefetch_all();          //  merely wait longer than they have to)
         auto phase1 = [&](int buf) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +438,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             }
         };
         int cur = 0;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
+        auto plain_step = [&](int kt) {
             const int nxt = cur == 2 ? 0 : cur + 1;
             phase1(cur);
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");   // stage kt + 1 landed, kt + 2 in flight
@@ -394,10 +446,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             __builtin_amdgcn_s_barrier();                         // ... for every wave; buffer `cur` fully read
             phase2(cur, nxt, kt, kt + 3 < nk);
             cur = nxt;
+        };
+        auto tail_step = [&](auto t_c) {                          // step kt = nk - 10 + T of the last PF_G + 1 steps
+            constexpr int T = decltype(t_c)::value;
+            const int kt = nk - (PF_G + 2) + T, nxt = cur == 2 ? 0 : cur + 1;
+            phase1(cur);
+            constexpr int younger = ((T - 2 >= 0 && T - 2 < PF_G) ? 1 : 0) + ((T - 1 >= 0 && T - 1 < PF_G) ? 1 : 0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((T < PF_G ? NLOAD : 0) + younger * PF_R) : "memory");
+            __builtin_amdgcn_s_barrier();
+            phase2(cur, nxt, kt, T + 1 < PF_G);
+            if constexpr (T < PF_G) prefetch_group(std::integral_constant<int, (T < PF_G ? T : 0)>{});
+            cur = nxt;
+        };
+        if (res_spread) {
+            for (int kt = 0; kt < nk - (PF_G + 2); ++kt) plain_step(kt);
+            tail_step(std::integral_constant<int, 0>{}); tail_step(std::integral_constant<int, 1>{});
+            tail_step(std::integral_constant<int, 2>{}); tail_step(std::integral_constant<int, 3>{});
+            tail_step(std::integral_constant<int, 4>{}); tail_step(std::integral_constant<int, 5>{});
+            tail_step(std::integral_constant<int, 6>{}); tail_step(std::integral_constant<int, 7>{});
+            tail_step(std::integral_constant<int, 8>{});
+        } else {
+            for (int kt = 0; kt + 1 < nk; ++kt) plain_step(kt);
         }
         read_frags(cur, 1, a1, b1);
         mma(a0, b0);
-        __syncthreads();                                          // every wave is done with the staging buffers
+        if constexpr (RES_PREFETCH) {                             // (__syncthreads() would drain the residual loads)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();                                      // every wave is done with the staging buffers
+        }
         fetch_epilogue_operands();
         mma(a1, b1);
     } else if (HALF_SHIFTED) {
@@ -901,11 +979,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 acc[2 * ii][j] += o;
             }
     } else {
-        if (RESID_LOAD) fetch_residual(0, 0);
+        if (RESID_LOAD && !res_have) fetch_residual(0, 0);
     }
+    static_assert(!RES_PREFETCH || (PF_LPRF == LPRF && PF_RPP == RPP && PF_PASSES == PASSES), "prefetch geometry = epilogue geometry");
 #pragma unroll
     for (int i = 0; i < MI; i += SK) {
-        if (RESID_LOAD && i + SK < MI) fetch_residual(((i / SK) + 1) & 1, i + SK);
+        if (RESID_LOAD && !res_have && i + SK < MI) fetch_residual(((i / SK) + 1) & 1, i + SK);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float4 bb = biasv[j];
@@ -920,7 +999,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
             float4 v = *reinterpret_cast<const float4*>(fstg + (ps * RPP + er) * LDF + (flane_on ? ec : 0));
             if (RESID) {
                 if (RESID_LOAD) {
-                    const float4 c = resv[(i / SK) & 1][ps];
+                    float4 c;
+                    if constexpr (RES_PREFETCH) { const f32x4 t = resall[i][ps]; c = make_float4(t[0], t[1], t[2], t[3]); }
+                    else c = resv[(i / SK) & 1][ps];
                     v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
                 }
                 // write-through (sc1): the rows leave the XCD's L2 while the launch runs instead of in the write-back at its

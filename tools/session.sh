@@ -1,8 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 o=gpurun_out
-tag=${1:-r4q}
-timeout 600 python -m pytest tests/test_r4_gpu.py -x -q -k "inproj" > $o/${tag}_tests_new.txt 2>&1; tail -15 $o/${tag}_tests_new.txt
-timeout 900 python -m pytest tests/test_clip_gpu.py tests/test_r3_gpu.py -x -q > $o/${tag}_tests.txt 2>&1; tail -5 $o/${tag}_tests.txt
-bash tools/ab.sh nofuse fuse 3 > $o/${tag}_ab.txt 2>&1; cat $o/${tag}_ab.txt | paste - - - - - -
-bash tools/insitu.sh ${tag}_fuse $PWD/ab/lib_fuse.so > /dev/null 2>&1; head -14 $o/insitu_${tag}_fuse.txt
+tag=${1:-r4u}
+timeout 900 python -m pytest tests/test_clip_gpu.py tests/test_r2_gpu.py tests/test_r3_gpu.py tests/test_r4_gpu.py -x -q > $o/${tag}_tests.txt 2>&1; tail -3 $o/${tag}_tests.txt
+for i in 1 2 3; do for v in nopf pf pf2; do echo -n "$v "; CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; done; done | paste - - - - - - - - -
+for v in wallnopf wall; do echo $v; CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python tools/gemm_timeline.py 2>&1 | head -2; done
