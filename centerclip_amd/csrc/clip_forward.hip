@@ -319,10 +319,16 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         const int g = vm->resolution / vm->patch, n = g * g, F = B * T;
         W = vm->width;
         tokens = n;
-        // the split-K GEMMs hand accumulator halves over through v.sk: flags start from zero (each launch leaves them zero;
-        // this keeps a caller's uninitialised workspace, or an aborted earlier run, from being read as "partner ready")
+        // The split-K GEMM forms hand accumulator halves over through v.sk and need its flags zero (each launch leaves them
+        // zero; a caller's uninitialised workspace must not read as "partner ready").  The dispatcher picks those forms only
+        // in a -DCC_SPLITK_AUTO build (measured slower) - every other build leaves the towers without the
+        // scratch (the forms cannot be chosen) and saves the 4.5 us fill launch per encode.
+#ifdef CC_SPLITK_AUTO
         if (hipMemsetAsync(v.sk, 0, CC_GEMM_SK_FLAG_BYTES, st) != hipSuccess) return CC_ERR_HIP;
         cv.sk = v.sk;
+#else
+        cv.sk = nullptr;
+#endif
         // patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
         const bool patch3d = vm->conv2_weight_f16 != nullptr;      // linear_patch '3d' (clip.py:306-317)
         rc = patch3d ? cc_launch_im2col3d(*video, v.im2col, F, T, vm->resolution, vm->patch, st)
