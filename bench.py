@@ -51,7 +51,9 @@ CFG2 = dict(name="cfg2 MSR-VTT-shaped: ViT-B/32 224^2, 12 frames -> 3 segments @
 CLUSTER_SHAPES = {"cfg2": dict(B=16, T=12, T_new=3, n=49, K=49, split=16),
                   "cfg3 MSVD-shaped (per GPU)": dict(B=64, T=12, T_new=4, n=49, K=49, split=16),      # P = 256 problems: fills the chip
                   "cfg4 ActivityNet-shaped (per GPU)": dict(B=8, T=64, T_new=8, n=49, K=49, split=16),
-                  "cfg5 ViT-B/16": dict(B=16, T=12, T_new=4, n=196, K=100, split=4)}
+                  "cfg5 ViT-B/16": dict(B=16, T=12, T_new=4, n=196, K=100, split=4),
+                  # scripts/activitynet.sh:104-122 (ViT-B/16, 60 -> 15 frames, K = 160, batch 4 per GPU): N = 784
+                  "cfg6 ViT-B/16 ActivityNet (per GPU)": dict(B=4, T=60, T_new=15, n=196, K=160, split=4)}
 
 
 def task_config(c):

@@ -5,7 +5,7 @@
 
 The decomposition (the reference: the trailing K left singular vectors of a fp32 LAPACK SVD of L_sym) is
 cc_spectral_embedding_f32: a direct solver (Householder tridiagonalisation, fp64 Sturm multi-section and inverse iteration
-for the K wanted pairs, back-transformation; the matrix in LDS for N <= 196, in a global scratch up to N = 640), with a
+for the K wanted pairs, back-transformation; the matrix in LDS for N <= 196, in a global scratch up to N = 832, K = 192), with a
 batched one-sided Jacobi solver for the shapes outside its scope.  What "the same result" can mean for it: eigenpairs to working
 precision and the reference's singular values to 1e-5 - yes; the same *vectors* only up to sign and, where eigenvalues
 coincide to rounding, up to a rotation of that eigenspace, which no two solvers share.  The k-medoids tail only sees row

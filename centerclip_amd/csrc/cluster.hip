@@ -2353,7 +2353,7 @@ size_t cc_spectral_embedding_workspace_bytes(int32_t P, int32_t N) {
     if (P <= 0 || N <= 0) return 0;
     if (N <= 196) return cc_sym_eig_tridiag_ws_bytes(P, N);      // the direct solver's band scratch (eig.hip)
     const size_t jac = N <= 201 ? 256 : cc_align_up((size_t)P * N * N * sizeof(float), 256);
-    const size_t big = N <= 640 ? cc_sym_eig_tridiag_big_ws_bytes(P, N) : 0;     // matrix + fp64 vectors + bands in global memory
+    const size_t big = N <= 832 ? cc_sym_eig_tridiag_big_ws_bytes(P, N) : 0;     // matrix + fp64 vectors + bands in global memory
     return jac > big ? jac : big;
 }
 
@@ -2363,7 +2363,9 @@ int cc_spectral_embedding_solver_f32(const float* laplacian, int32_t P, int32_t 
     if (!laplacian || !Q || P <= 0 || N <= 1 || K <= 0 || K > N || ldq < K) return CC_ERR_INVALID;
     if (solver != CC_EIG_AUTO && solver != CC_EIG_JACOBI) return CC_ERR_INVALID;
     const bool g_force_jacobi = solver == CC_EIG_JACOBI;
-    if (N > 640) return CC_ERR_UNSUPPORTED;
+    // (the Jacobi kernel stops at N = 640; 640 < N <= 832 - ViT-B/16 with four frames per segment, N = 784, K = 160 - exists
+    // in the direct solver only)
+    if (N > 640 && (g_force_jacobi || !cc_sym_eig_tridiag_big_supports(N, K))) return CC_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ldq > K && hipMemsetAsync(Q, 0, (size_t)P * N * ldq * sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
     if (!g_force_jacobi && (cc_sym_eig_tridiag_supports(N, K) || cc_sym_eig_tridiag_big_supports(N, K)))    // direct solver

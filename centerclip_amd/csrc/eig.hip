@@ -25,7 +25,7 @@
 // what remains: residual |L q - lambda q| <= 4e-7, orthonormal to 1.3e-6, eigenvalues within 5e-7 of a float64 eigh over
 // heat-kernel / KNN / planted-partition Laplacians (coupling 0 ... 1e-3, identical blocks) at N = 196, K = 49.
 // Scope: the matrix in LDS next to 10 KB of vectors (N <= 196) and packed reflectors + K fp64 vectors in its place
-// afterwards (K = 49 at N = 196), K <= 64; 196 < N <= 640 (K <= 128): sym_eig_tridiag_big_kernel below, the matrix in a global
+// afterwards (K = 49 at N = 196), K <= 64; 196 < N <= 832 (K <= 192): sym_eig_tridiag_big_kernel below, the matrix in a global
 // scratch; what is left (K > 49 at N = 196, K > 128) keeps the Jacobi kernel.
 #include "cc_common.h"
 #include "cc_kernels.h"
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same solver for matrices that do not fit in LDS (196 < N <= 640, K <= 128): the matrix lives in a global scratch
+// The same solver for matrices that do not fit in LDS (196 < N <= 832, K <= 192): the matrix lives in a global scratch
 // (L2 / MALL resident: 0.6 MB at N = 392), the fused pass streams the trailing block through the CU (float4 rows,
 // coalesced), the K vectors are fp64 rows of a second scratch (vector-major: a wave reads a vector contiguously),
 // Gram-Schmidt runs from memory (pivot vector in LDS, a wave per remaining vector), the back-transformation keeps the fp32
@@ -648,7 +648,10 @@ __device__ __forceinline__ double td_wave_sum(double v) {
 #ifndef TDB_ROWS
 #define TDB_ROWS 8
 #endif
-template <int G, int MAXE, int MAXQ>          // G lanes per vector in the back-transformation, MAXE = ceil(N / G), MAXQ = ceil(N / 64)
+#define TDB_MAXK 192                          // vectors per problem (ViT-B/16 ships K = 160 at N = 784, scripts/activitynet.sh:104-122)
+#define TDB_MAXN 832
+// MULTI: more vectors than TD_THREADS / G - the back-transformation runs in passes (N > 640 or K > 128)
+template <int G, int MAXE, int MAXQ, bool MULTI = false>   // G lanes per vector in the back-transformation, MAXE = ceil(N / G), MAXQ = ceil(N / 64)
 __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const float* __restrict__ Lsym, float* __restrict__ fwork,
                                                                          double* __restrict__ dwork, float* __restrict__ Q,
                                                                          float* __restrict__ evals, int* __restrict__ sweeps_out,
@@ -668,9 +671,9 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     float* e = scl + LD;                                         // [LD]
     float4* vwx = reinterpret_cast<float4*>(e + LD);             // [LD]; later de
     float* part = reinterpret_cast<float*>(vwx + LD);            // [4][LD + 24]; later ds
-    double* lam = reinterpret_cast<double*>(part + 4 * (LD + 24));   // [128]
-    double* shf = lam + 128;                                     // [128]
-    double* qbuf = shf + 128;                                    // [LD] pivot vector of Gram-Schmidt
+    double* lam = reinterpret_cast<double*>(part + 4 * (LD + 24));   // [TDB_MAXK]
+    double* shf = lam + TDB_MAXK;                                // [TDB_MAXK]
+    double* qbuf = shf + TDB_MAXK;                               // [LD] pivot vector of Gram-Schmidt
     double* red = qbuf + LD;                                     // [16]
     float* cbuf = reinterpret_cast<float*>(red + 16);            // [LD] row k+1 of the step, as the pass produced it
     double2* de = reinterpret_cast<double2*>(vwx);
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
             mine_de = make_double2((double)A[(int64_t)tid * LD + tid], (double)ei);
         }
         __syncthreads();
-        if (tid < N) de[tid] = mine_de;                          // (N <= 640 < 1024: one element per thread)
+        if (tid < N) de[tid] = mine_de;                          // (N <= 832 < 1024: one element per thread)
     }
     __syncthreads();
     double2* ds = reinterpret_cast<double2*>(part);
@@ -937,8 +940,10 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
     }
 
     if (prof && p == 0 && tid == 0) prof[5] = (long long)wall_clock64();
-    // ---- E: back-transformation, fp32 vectors in registers (G lanes per vector) ------------------------------------------------
-    const int k = tid / G, g = tid - k * G;
+    // ---- E: back-transformation, fp32 vectors in registers (G lanes per vector), TD_THREADS / G vectors per pass over the
+    // reflectors (K = 160 at N = 784: three passes of 64 vectors - the vectors of a pass stay in registers for its whole sweep)
+    auto back_pass = [&](int kpass) {
+    const int k = kpass + tid / G, g = tid % G;
     const bool mine = k < K;
     float z[MAXE];
     if (mine) {
@@ -1000,6 +1005,15 @@ __global__ __launch_bounds__(TD_THREADS) void sym_eig_tridiag_big_kernel(const f
         for (int t = 0; t < MAXE; ++t) { const int i = g + G * t; if (i < N) Qp[(int64_t)i * ldq + col] = z[t] * flip; }
         if (g == 0 && evals) evals[(int64_t)p * K + col] = (float)lam[k];
     }
+    };
+    if constexpr (MULTI) {
+        for (int kpass = 0; kpass < K; kpass += TD_THREADS / G) {
+            back_pass(kpass);
+            __syncthreads();                                     // the reflector strip is refilled by the next pass
+        }
+    } else {
+        back_pass(0);
+    }
     if (tid == 0 && sweeps_out) sweeps_out[p] = 0;
     __syncthreads();
     if (prof && p == 0 && tid == 0) prof[6] = (long long)wall_clock64();
@@ -1041,12 +1055,13 @@ static size_t tdb_fstride(int N) { return 2 * (size_t)N * ((N + 3) & ~3); }     
 static size_t tdb_dstride(int N, int K) { return (size_t)K * ((N + 3) & ~3) + 3 * (size_t)N * (K | 1); }
 static size_t tdb_smem_bytes(int N) {
     const size_t LD = (size_t)((N + 3) & ~3);
-    return (3 * LD + 4 * LD + 4 * (LD + 24) + LD) * sizeof(float) + (128 + 128 + LD + 16) * sizeof(double);
+    return (3 * LD + 4 * LD + 4 * (LD + 24) + LD) * sizeof(float) + (2 * TDB_MAXK + LD + 16) * sizeof(double);
 }
-bool cc_sym_eig_tridiag_big_supports(int N, int K) { return N > 196 && N <= 640 && K >= 1 && K <= 128 && K <= N; }
+bool cc_sym_eig_tridiag_big_supports(int N, int K) { return N > 196 && N <= TDB_MAXN && K >= 1 && K <= TDB_MAXK && K <= N; }
 
-size_t cc_sym_eig_tridiag_big_ws_bytes(int P, int N) {           // (K <= 128)
-    return cc_align_up((size_t)P * tdb_fstride(N) * sizeof(float), 256) + cc_align_up((size_t)P * tdb_dstride(N, 128) * sizeof(double), 256);
+size_t cc_sym_eig_tridiag_big_ws_bytes(int P, int N) {           // (sized for K = TDB_MAXK)
+    return cc_align_up((size_t)P * tdb_fstride(N) * sizeof(float), 256) +
+           cc_align_up((size_t)P * tdb_dstride(N, TDB_MAXK) * sizeof(double), 256);
 }
 
 int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int correct_sign, float* Q, int ldq, float* evals,
@@ -1057,20 +1072,25 @@ int cc_launch_sym_eig_tridiag(const float* laplacian, int P, int N, int K, int c
         double* dw = reinterpret_cast<double*>(static_cast<unsigned char*>(ws) + cc_align_up((size_t)P * tdb_fstride(N) * sizeof(float), 256));
         const size_t smem = tdb_smem_bytes(N);
         const int KP = K | 1;
-#define TDB_LAUNCH(G, MAXE, MAXQ)                                                                                       \
+#define TDB_LAUNCH(G, MAXE, MAXQ, MULTI)                                                                                \
     do {                                                                                                               \
-        auto kern = sym_eig_tridiag_big_kernel<G, MAXE, MAXQ>;                                                          \
+        auto kern = sym_eig_tridiag_big_kernel<G, MAXE, MAXQ, MULTI>;                                                   \
         hipLaunchKernelGGL(kern, dim3(P), dim3(TD_THREADS), smem, st, laplacian, fw, dw, Q, evals, sweeps_out, N, K, KP, ldq, \
                            correct_sign, (long long)tdb_fstride(N), (long long)tdb_dstride(N, K), g_td_prof);                     \
     } while (0)
-        if (K <= 64) {
-            if (N <= 320) TDB_LAUNCH(16, 20, 5);
-            else if (N <= 448) TDB_LAUNCH(16, 28, 7);
-            else TDB_LAUNCH(16, 40, 10);
+        if (N > 640 || K > 128) {                   // passes of 64 vectors (98 registers per vector at G = 8, N = 784 would not fit)
+            if (N <= 320) TDB_LAUNCH(16, 20, 5, true);
+            else if (N <= 448) TDB_LAUNCH(16, 28, 7, true);
+            else if (N <= 640) TDB_LAUNCH(16, 40, 10, true);
+            else TDB_LAUNCH(16, 52, 13, true);
+        } else if (K <= 64) {
+            if (N <= 320) TDB_LAUNCH(16, 20, 5, false);
+            else if (N <= 448) TDB_LAUNCH(16, 28, 7, false);
+            else TDB_LAUNCH(16, 40, 10, false);
         } else {
-            if (N <= 320) TDB_LAUNCH(8, 40, 5);
-            else if (N <= 448) TDB_LAUNCH(8, 56, 7);
-            else TDB_LAUNCH(8, 80, 10);
+            if (N <= 320) TDB_LAUNCH(8, 40, 5, false);
+            else if (N <= 448) TDB_LAUNCH(8, 56, 7, false);
+            else TDB_LAUNCH(8, 80, 10, false);
         }
 #undef TDB_LAUNCH
         CC_LAUNCH_CHECK();

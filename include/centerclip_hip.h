@@ -251,8 +251,9 @@ int cc_spectral_graph_laplacian_f32(const float* x, const cc_token_layout* lay, 
  * column order (U[:, :, -K:] of torch.linalg.svd: eigenvalue descending), eigenvalues [P,K] optional, sweeps_out [P]
  * optional (Jacobi sweeps; 0 from the direct solver).  One workgroup per problem.  Direct solver (eig.hip) - Householder
  * tridiagonalisation (fp32), Sturm multi-section and inverse iteration (fp64), back-transformation: N <= 196 with the matrix
- * and then the packed reflectors + K vectors in LDS (K <= 49 at N = 196, K <= 64), 196 < N <= 640 with K <= 128 from a global
- * scratch in ws.  Remaining shapes up to N = 640: batched one-sided Jacobi on 2I - L.
+ * and then the packed reflectors + K vectors in LDS (K <= 49 at N = 196, K <= 64), 196 < N <= 832 with K <= 192 from a global
+ * scratch in ws (ViT-B/16 ships N = 784, K = 160, scripts/activitynet.sh:104-122).  Remaining shapes up to N = 640: batched
+ * one-sided Jacobi on 2I - L.
  * correct_sign: batch_sign_flip_rasmus_bro (:110-137) applied (for a symmetric matrix it depends on the vector alone).
  * Parity: eigenpairs to fp32 working precision, the eigenvalues equal the reference's singular values to 1e-5; the vectors
  * equal the reference's up to sign and, where eigenvalues coincide to rounding, up to a rotation inside that eigenspace -

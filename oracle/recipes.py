@@ -138,6 +138,9 @@ SPECTRAL_CASES = {
     # (with the spatial-temporal mask a group has to be connected under it: K = 56 makes the groups the rows of the 7 x 7 grid)
     "planted_392_k56_knn": dict(seed=67, B=1, T=8, T_new=1, n=49, W=768, K=56, sigma=2.0, graph="KNN", knn_k=0, spg=1, sep=6.0),
     "planted_588_k100": dict(seed=66, B=1, T=3, T_new=1, n=196, W=768, K=100, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
+    # ViT-B/16 60 -> 15 frames with K = 160 (scripts/activitynet.sh:104-122): N = 784, groups of 4 and 5 tokens - more vectors
+    # than one back-transformation pass of the direct eigensolver holds
+    "planted_784_k160": dict(seed=68, B=1, T=4, T_new=1, n=196, W=768, K=160, sigma=2.0, graph="HeatKernel", knn_k=0, sep=6.0),
 }
 
 

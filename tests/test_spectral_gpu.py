@@ -79,11 +79,12 @@ def test_eigensolver_against_the_reference_svd(r2):
 
 
 @pytest.mark.parametrize("N,K", [(2, 1), (5, 2), (65, 7), (98, 49), (130, 10), (147, 49), (196, 49), (197, 5), (230, 12), (392, 49),
-                                 (588, 100), (640, 128)])
+                                 (588, 100), (640, 128), (300, 150), (640, 160), (784, 160), (832, 192)])
 def test_eigensolver_shapes(N, K):
     """Odd / tiny / multi-register / LDS-resident / global-memory problem sizes - among them the reference's own spectral
-    settings, 12 -> 6 / 4 / 3 frames of 49 tokens with K = 49 (scripts/lsmdc.sh:128-152): eigenpairs of a random graph Laplacian
-    against float64 eigh (values; vectors through the residual)."""
+    settings, 12 -> 6 / 4 / 3 frames of 49 tokens with K = 49 (scripts/lsmdc.sh:128-152) and ViT-B/16's four frames of 196 tokens
+    with K = 160 (scripts/activitynet.sh:104-122; more vectors than one back-transformation pass holds): eigenpairs of a random
+    graph Laplacian against float64 eigh (values; vectors through the residual)."""
     from centerclip_amd.cluster.spectral import spectral_laplacian, spectral_embedding
     gen = torch.Generator().manual_seed(N)
     X = (torch.randn(2, N, 16, generator=gen) * 0.7).to(DEV)

@@ -1,5 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-o=gpurun_out
-for i in 1 2 3; do for v in base stg stgwt; do echo -n "$v "; CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; done; done | paste - - - - - - - - -
-for v in stg stgwt; do CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so timeout 300 python -m pytest tests/test_r4_gpu.py -x -q -k inproj 2>&1 | tail -1; done
+timeout 900 python -m pytest tests/test_spectral_gpu.py tests/test_cluster_gpu.py -x -q 2>&1 | tail -3
+python - <<'PY'
+import torch, bench, json
+dev = torch.device("cuda:0")
+for name in ("cfg5 ViT-B/16", "cfg6 ViT-B/16 ActivityNet (per GPU)"):
+    sh = bench.CLUSTER_SHAPES[name]
+    print(name, json.dumps(bench.cluster_bench(sh, dev, iters=10)), flush=True)
+    print(name, "spectral", json.dumps(bench.spectral_cluster_bench(sh, dev)), flush=True)
+PY
