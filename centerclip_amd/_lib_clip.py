@@ -136,6 +136,10 @@ def declare(lib):
     lib.cc_cast_scaled_f16.restype = c.c_int
     lib.cc_unscale_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.cc_unscale_f32.restype = c.c_int
+    lib.cc_bertadam_workspace_bytes.argtypes = []
+    lib.cc_bertadam_workspace_bytes.restype = sz
+    lib.cc_bertadam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, sz, vp]
+    lib.cc_bertadam_step_f32.restype = c.c_int
     lib.cc_similarity_plane_row_bytes.argtypes = [i32]
     lib.cc_similarity_plane_row_bytes.restype = sz
     lib.cc_similarity_padded_rows.argtypes = [i32]

@@ -94,7 +94,14 @@ class CLIP4Clip(nn.Module):
             video_mask = video_mask.view(-1, video_mask.shape[-1])
             if self.cluster_inter or self.deep_cluster:
                 video_mask = self.get_video_mask_after_cluster(video_mask)
-        if input_ids is not None and video is not None:
+        if self.training and torch.is_grad_enabled() and input_ids is not None and video is not None:
+            # training (main.py:311): the towers with their backward (centerclip_amd.train), gradients reach every parameter
+            from . import train as cctrain
+            vfeat, cluster_loss = cctrain.encode_image_train(self.clip, video, video_frame)
+            tfeat = cctrain.encode_text_train(self.clip, input_ids)
+            sequence_output = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
+            visual_output = vfeat.view(video_mask.size(0), -1, vfeat.size(-1))
+        elif input_ids is not None and video is not None:
             # both towers in one enqueue: the text tower's blocks share their launches with the ViT's
             vfeat, tfeat = self.clip.encode_pair(video, input_ids, video_frame=video_frame)
             sequence_output = tfeat.view(input_ids.size(0), -1, tfeat.size(-1))
@@ -113,8 +120,7 @@ class CLIP4Clip(nn.Module):
         if self.training:
             # the reference's training branch (clip4clip.py:245-262): features of all ranks -> logits -> symmetric CrossEn.
             # The loss is differentiable with respect to the features and logit_scale (losses.contrastive_loss: forward and
-            # gradient in one kernel chain); the towers have no backward here, so the gradient edge ends at
-            # sequence_output / visual_output (detached leaves unless the caller made them require grad).
+            # gradient in one kernel chain); the features come from the differentiable towers above.
             seq, vis, vmask = sequence_output.contiguous(), visual_output.contiguous(), video_mask.contiguous()
             if ccdist.world_size() > 1:              # ONE collective for the three tensors, gradient slices of the own shard back
                 vis, vmask, seq = PackedAllGather.apply(vis, vmask, seq)

@@ -268,6 +268,49 @@ inline unsigned grid_for(int64_t n, int per_block) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------- BertAdam
+// utils/optimization.py:100-170, one parameter tensor per call: per-tensor gradient clipping (clip_grad_norm_(p, max_grad_norm):
+// g *= max / (||g|| + 1e-6) when that factor is < 1 - the gradient tensor is rescaled in place as the reference does), moments,
+// update = m / (sqrt(v) + e) [+ weight_decay * p], p -= lr_scheduled * update.  Two launches: the sum of squares (a fixed
+// grid, double atomics would make it order dependent: per-block partials reduced in block order by the second kernel), then
+// the elementwise step.  No bias correction - this is the BERT variant.
+constexpr int BA_BLOCKS = 64;
+__global__ __launch_bounds__(256) void bertadam_norm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void bertadam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, int64_t n, const double* __restrict__ partial,
+                                                             int nblocks, float lr, float b1, float b2, float eps, float wd,
+                                                             float max_norm) {
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        double tot = 0.0;
+        for (int b = 0; b < nblocks; ++b) tot += partial[b];
+        const float c = max_norm / ((float)sqrt(tot) + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] * b1 + (1.f - b1) * gi;
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float upd = mi / (sqrtf(vi) + eps);
+        const float pi = p[i];
+        if (wd > 0.f) upd += wd * pi;
+        g[i] = gi; m[i] = mi; v[i] = vi;
+        p[i] = pi - lr * upd;
+    }
+}
+
 extern "C" {
 
 size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W) {
@@ -356,6 +399,25 @@ int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale
     if (!x || !scale_a || n <= 0) return CC_ERR_INVALID;
     hipLaunchKernelGGL(unscale_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, scale_a,
                        scale_b);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+size_t cc_bertadam_workspace_bytes(void) { return BA_BLOCKS * sizeof(double); }
+
+/* One BertAdam step on one parameter tensor (utils/optimization.py:100-170; all tensors fp32, n elements): grad is clipped in
+ * place to max_grad_norm (<= 0: no clipping), next_m / next_v updated, param -= lr_scheduled * (m / (sqrt(v) + e) + wd * param).
+ * lr_scheduled = lr * schedule(step / t_total, warmup) is the caller's (host arithmetic, centerclip_amd.train.BertAdam). */
+int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v, int64_t n, float lr_scheduled, float b1,
+                         float b2, float e, float weight_decay, float max_grad_norm, void* ws, size_t ws_bytes, void* stream) {
+    if (!param || !grad || !next_m || !next_v || n <= 0) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < cc_bertadam_workspace_bytes()) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* partial = static_cast<double*>(ws);
+    const int nb = (int)((n + 255) / 256 < BA_BLOCKS ? (n + 255) / 256 : BA_BLOCKS);
+    if (max_grad_norm > 0.f) hipLaunchKernelGGL(bertadam_norm_kernel, dim3(nb), dim3(256), 0, st, grad, n, partial);
+    hipLaunchKernelGGL(bertadam_step_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, param, grad, next_m, next_v, n, partial, nb,
+                       lr_scheduled, b1, b2, e, weight_decay, max_grad_norm);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -16,10 +16,12 @@
 * ``ResidualAttentionBlockFunction`` wires both into torch.autograd (d/dx and the 12 parameter gradients), so a block can sit
   in a graph that ends in losses.contrastive_loss; dist.GradientBuckets then averages the gradients over the ranks.
 
-What is NOT here (and therefore not claimed): the backward of the fused encoders (patch embedding, ln_pre, the heads, the
-block with a token-cluster module inside - its own backward exists, cc_token_cluster_backward_f32), mixed-precision master
-weights / BertAdam, and any tuning - this is the correctness slice the review asked for, checked against torch.autograd on
-the reference block (tests/test_r4_gpu.py, fixture tests/golden/r4_golden.npz) to 1e-3 of each tensor's largest entry.
+Round 4, later: the towers themselves (encode_image_train / encode_text_train below: patch embedding, ln_pre, the blocks with
+a token-cluster module in front, the heads), BertAdam (utils/optimization.py) on cc_bertadam_step_f32 and train_epoch
+(main.py:291-378) - CLIP4Clip.forward in training mode runs on them, so a training step reaches every parameter.  What is NOT
+here: linear_patch='3d' and mean_residual in training, fp16 GradScaler semantics (the master weights are fp32 and the HIP
+backward scales per tensor on the device), and any tuning - per-op launches from Python, checked against torch.autograd on the
+reference model (tests/test_r4_gpu.py, fixture tests/golden/r4_golden.npz) to 2e-3 of each tensor's largest entry.
 Transposed fp16 copies (W^T, dY^T, X^T) are made with torch (data movement at the edge of the C ABI).
 """
 import torch
@@ -165,3 +167,253 @@ def block_apply(block, x_lnd):
     """Differentiable block forward: ``z = block_apply(block, x); loss(z).backward()`` fills x.grad and block.*.grad."""
     named = dict(block.named_parameters())
     return ResidualAttentionBlockFunction.apply(block, x_lnd, *[named[k] for k in _PARAM_ORDER])
+
+
+# ================================================================================================ the towers, differentiable
+# What main.py:291-378 (train_epoch) needs from the model: CLIP4Clip.forward in training mode with gradients reaching every
+# parameter.  The towers below are the reference's forward (modules/clip.py:320-345 visual, :471-496 text) composed of the HIP
+# forward / backward pieces: patch embedding and the projection heads as GEMMs (LinearFunction: dgrad / wgrad on the forward
+# kernel), LayerNorms (LayerNormFunction), the blocks (ResidualAttentionBlockFunction), the token-cluster module (its own
+# autograd, cluster/cluster.py).  What stays torch glue: reshapes / permutes / concatenation, the broadcast adds of the class
+# and positional embeddings, the embedding-table gather with its scatter-add gradient, the EOT row gather.
+
+class LinearFunction(torch.autograd.Function):
+    """y [M, N] fp32 = x [M, K] @ w[N, K]^T (+ b): fp16 MFMA operands, fp32 accumulate; gradients as _grad_linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x16 = x.detach().to(torch.float16).contiguous()
+        ctx.save_for_backward(x16, w)
+        ctx.has_bias = b is not None
+        ctx.need_dx = x.requires_grad
+        return ops.linear_f16(x16, w.detach().to(torch.float16).contiguous(), None if b is None else b.detach().float().contiguous(),
+                              "f32")
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w = ctx.saved_tensors
+        dx, dw, db = _grad_linear(dy.contiguous().float(), x16, w.detach().to(torch.float16).t().contiguous())
+        return (dx if ctx.need_dx else None), dw.to(w.dtype), (db if ctx.has_bias else None)
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """LayerNorm over the last dim of x [rows, W] fp32 (modules/clip.py:183-189), backward = cc_layernorm_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.detach().float().contiguous()
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return ops.layernorm(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = _ln_backward(x, gamma.detach().float().contiguous(), dy.contiguous().float(), None, ctx.eps)
+        return dx, dg.to(gamma.dtype), db.to(gamma.dtype), None
+
+
+def _layernorm(ln, x2d):
+    return LayerNormFunction.apply(x2d, ln.weight, ln.bias, ln.eps)
+
+
+def _blocks(transformer, x_lnd):
+    """The resblocks on LND activations; a block's token-cluster module runs in front of it (clip.py:236-242)."""
+    for blk in transformer.resblocks:
+        if blk.tokencluster_inter is not None:
+            if getattr(blk.tokencluster_inter, "mean_residual", False):
+                raise NotImplementedError("training towers: mean_residual is not built")
+            x_lnd, _ = blk.tokencluster_inter(x_lnd)
+            x_lnd = _plain(blk, x_lnd)
+        else:
+            x_lnd = block_apply(blk, x_lnd)
+    return x_lnd
+
+
+class _NoCluster:
+    """A view of a block without its cluster module (block_forward_train refuses blocks that carry one: here the module has
+    already run)."""
+
+    def __init__(self, blk):
+        self._blk = blk
+        self.tokencluster_inter = None
+
+    def __getattr__(self, name):
+        return getattr(self._blk, name)
+
+
+def _plain(blk, x_lnd):
+    view = _NoCluster(blk)
+    named = dict(blk.named_parameters())
+    return ResidualAttentionBlockFunction.apply(view, x_lnd, *[named[k] for k in _PARAM_ORDER])
+
+
+def encode_image_train(clip, video, video_frame):
+    """CLIP.encode_image (modules/clip.py:460-469 with VisualTransformer.forward :320-345, linear_patch '2d') with gradients:
+    video [F, 3, H, W] fp32 -> (features [F', embed_dim], cluster_loss)."""
+    vis = clip.visual
+    if vis.linear_patch != '2d':
+        raise NotImplementedError("training towers: linear_patch='3d' is not built")
+    L.require_device(video)
+    F, p, W = video.shape[0], vis.patch_size, vis.width
+    g = vis.input_resolution // p
+    # conv1 (kernel = stride = p, no bias) as a GEMM over the patch rows (c, kh, kw) - a reshape of the frames, no gather
+    a = video.float().view(F, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(F * g * g, 3 * p * p)
+    x = LinearFunction.apply(a, vis.conv1.weight.view(W, -1), None).view(F, g * g, W)
+    cls = vis.class_embedding.to(x.dtype) + torch.zeros(F, 1, W, dtype=x.dtype, device=x.device)
+    x = torch.cat([cls, x], dim=1) + vis.positional_embedding.to(x.dtype)
+    x = _layernorm(vis.ln_pre, x.reshape(F * (g * g + 1), W)).view(F, g * g + 1, W)
+    x = _blocks(vis.transformer, x.permute(1, 0, 2).contiguous()).permute(1, 0, 2)          # NLD -> LND -> NLD
+    cls_rows = x[:, 0, :].contiguous()                        # ln_post(x) @ proj, of which encode_image keeps the CLS row
+    feats = LinearFunction.apply(_layernorm(vis.ln_post, cls_rows), vis.proj.t(), None)
+    return feats, torch.zeros((), device=video.device)
+
+
+def encode_text_train(clip, ids):
+    """CLIP.encode_text (modules/clip.py:471-496) with gradients: ids [B, n_ctx] -> [B, embed_dim]."""
+    L.require_device(ids)
+    B, n_ctx = ids.shape
+    W = clip.transformer.width
+    x = clip.token_embedding(ids).float() + clip.positional_embedding[:n_ctx].float()
+    x = _blocks(clip.transformer, x.permute(1, 0, 2).contiguous()).permute(1, 0, 2).contiguous()
+    eot = x[torch.arange(B, device=x.device), ids.argmax(dim=-1)]                             # the EOT token has the largest id
+    return LinearFunction.apply(_layernorm(clip.ln_final, eot.contiguous()), clip.text_projection.t(), None)
+
+
+# ================================================================================================ BertAdam
+def warmup_cosine(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    import math
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    return x / warmup if x < warmup else 1.0
+
+
+def warmup_linear(x, warmup=0.002):
+    return x / warmup if x < warmup else max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {'warmup_cosine': warmup_cosine, 'warmup_constant': warmup_constant, 'warmup_linear': warmup_linear}
+
+
+class BertAdam(torch.optim.Optimizer):
+    """utils/optimization.py:55-170 (the optimizer main.py:161-167 builds): same constructor, same state names
+    ('step', 'next_m', 'next_v'), same per-tensor clipping / decoupled weight decay / schedule; the tensor arithmetic of a
+    step is one cc_bertadam_step_f32 call per parameter (no host synchronisation)."""
+
+    def __init__(self, params, lr, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        super().__init__(params, dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                                      weight_decay=weight_decay, max_grad_norm=max_grad_norm))
+
+    @staticmethod
+    def _lr(group, step):
+        if group['t_total'] != -1:
+            return group['lr'] * SCHEDULES[group['schedule']](step / group['t_total'], group['warmup'])
+        return group['lr']
+
+    def get_lr(self):
+        lr = []
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    return [0]
+                lr.append(self._lr(group, state['step']))
+        return lr
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = L.lib()
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("BertAdam (HIP): fp32 contiguous parameters (the master weights)")
+                L.require_device(p)
+                grad = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else None
+                if grad is None:
+                    p.grad = p.grad.float().contiguous()
+                    grad = p.grad
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['next_m'] = torch.zeros_like(p)
+                    state['next_v'] = torch.zeros_like(p)
+                ws = L.workspace(lib.cc_bertadam_workspace_bytes(), p.device)
+                _check(lib.cc_bertadam_step_f32(L.ptr(p), L.ptr(grad), L.ptr(state['next_m']), L.ptr(state['next_v']), p.numel(),
+                                                float(self._lr(group, state['step'])), float(group['b1']), float(group['b2']),
+                                                float(group['e']), float(group['weight_decay']), float(group['max_grad_norm']),
+                                                L.ptr(ws), ws.numel(), _st(p)), "cc_bertadam_step_f32")
+                state['step'] += 1
+        return loss
+
+
+def prep_optim_params_groups(args, model, coef_lr=1.):
+    """utils/optimization.py:173-208 (BertAdam branch): CLIP parameters at lr * coef_lr, newly added modules at lr, no weight
+    decay for biases / LayerNorm."""
+    model = getattr(model, 'module', model)
+    named = list(model.named_parameters())
+    no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']
+    no_clip = args.new_added_modules
+    dec = [(n, p) for n, p in named if not any(nd in n for nd in no_decay)]
+    nodec = [(n, p) for n, p in named if any(nd in n for nd in no_decay)]
+    is_clip = lambda n: "clip." in n and not any(nd in n for nd in no_clip)
+    return [{'params': [p for n, p in dec if is_clip(n)], 'weight_decay': args.wd, 'lr': args.lr * coef_lr},
+            {'params': [p for n, p in nodec if is_clip(n)], 'weight_decay': 0.0, 'lr': args.lr * coef_lr},
+            {'params': [p for n, p in dec if not is_clip(n)], 'weight_decay': args.wd},
+            {'params': [p for n, p in nodec if not is_clip(n)], 'weight_decay': 0.0}]
+
+
+# ================================================================================================ train_epoch
+def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_step, scheduler=None, buckets=None,
+                log=None):
+    """main.py:291-378 for this path (fp32 master weights, no GradScaler: the HIP backward scales the gradients it feeds the
+    matrix cores per tensor on the device): zero_grad -> forward (training branch of CLIP4Clip.forward) -> backward ->
+    [gradient average over the ranks, dist.GradientBuckets] -> [clip_grad_norm_] -> optimizer.step -> clamp logit_scale.
+    ``model``: a centerclip_amd.clip4clip.CLIP4Clip in training mode.  -> (mean loss, global_step)."""
+    model.train()
+    total_loss, nb = 0.0, 0
+    for step, batch in enumerate(train_dataloader):
+        optimizer.zero_grad()
+        if scheduler is not None:
+            scheduler(optimizer, global_step=global_step)
+        input_ids, input_mask, segment_ids, video, video_mask = tuple(t.to(device=device, non_blocking=True) for t in batch)
+        output = model(input_ids, segment_ids, input_mask, video, video_mask)
+        loss = output['loss'].mean()
+        if args.gradient_accumulation_steps > 1:
+            loss = loss / args.gradient_accumulation_steps
+        loss.backward()
+        if (step + 1) % args.gradient_accumulation_steps == 0:
+            if buckets is not None:
+                buckets.reduce()
+            if getattr(args, "clip_grad_norm", None) is not None:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_grad_norm)
+            optimizer.step()
+            global_step += 1
+        with torch.no_grad():                                    # (main.py:336-340; tracked, so the cached copies refresh)
+            model.clip.logit_scale.clamp_(0.1, 4.6052)
+        if log is not None:
+            log(epoch, step, float(loss), float(output['sim_loss']), global_step)
+        total_loss += float(loss)
+        nb += 1
+    return total_loss / max(nb, 1), global_step

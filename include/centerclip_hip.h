@@ -674,6 +674,13 @@ size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
 int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
 int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);
 int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale_b, void* stream);
+/* One BertAdam step on one parameter tensor (utils/optimization.py:100-170: the optimizer main.py:161-167 builds): grad is
+ * clipped in place to max_grad_norm (clip_grad_norm_ on the single tensor; <= 0: no clipping), next_m = b1 m + (1-b1) g,
+ * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.
+ * lr_scheduled = lr * schedule(step / t_total, warmup) is host arithmetic (centerclip_amd.train.BertAdam).  All tensors fp32. */
+size_t cc_bertadam_workspace_bytes(void);
+int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v, int64_t n, float lr_scheduled, float b1,
+                         float b2, float e, float weight_decay, float max_grad_norm, void* ws, size_t ws_bytes, void* stream);
 
 /* ==========================================================================================
  * Diagnostics (not on the product path; process-wide state, not thread-safe).

@@ -50,6 +50,60 @@ def gen_block_grads(out):
         print(tag, "done", tuple(z.shape), flush=True)
 
 
+def gen_train_grads(out):
+    """tr_*: one training step's loss and torch.autograd's gradient of every parameter of the reference CLIP (the small model
+    of clip_golden.npz: its state dict, video and captions), through encode_image (k-medoids block included), encode_text,
+    the meanP similarity of CLIP4Clip._loose_similarity and the symmetric CrossEn of the training branch
+    (modules/clip4clip.py:245-262; evaluated with training=False so that the all_gather of :351-355 - the identity on one
+    rank - is skipped, the arithmetic is the training branch's)."""
+    import types
+    sys.path.insert(0, HERE)
+    from gen_golden_clip import _import_reference, ref_args
+    rclip, rc4c, _, _ = _import_reference()
+    import modules.losses as rlosses
+    g = np.load(os.path.join(GOLD, "clip_golden.npz"))
+    E, RES, P, VW, VL, CTX, VOCAB, TW, TH, TL, B, T = (int(v) for v in g["cfg"])
+    model = rclip.CLIP(E, RES, VL, VW, P, CTX, VOCAB, TW, TH, TL, linear_patch='2d', video_frames=T,
+                       args=ref_args(T, [4, 2, 2], [16, 6, 6])).float().train()
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+                           for k in g.files if k.startswith("sd/")})
+    video, ids = torch.from_numpy(g["video"]), torch.from_numpy(g["t_ids"])[:B]
+    vfeat, closs = model.encode_image(video, video_frame=T)
+    tfeat = model.encode_text(ids)
+    fake = types.SimpleNamespace(sim_header="meanP", training=False, pre_visual_pooling=0,
+                                 clip=types.SimpleNamespace(logit_scale=model.logit_scale))
+    fake._mean_pooling_for_similarity_visual = types.MethodType(rc4c.CLIP4Clip._mean_pooling_for_similarity_visual, fake)
+    vis, seq = vfeat.view(B, -1, E), tfeat.view(B, 1, E)
+    vmask = torch.ones(B, vis.shape[1], dtype=torch.long)
+    sim = rc4c.CLIP4Clip._loose_similarity(fake, seq, vis, torch.ones(B, CTX, dtype=torch.long), vmask)
+    ce = rlosses.CrossEn()
+    loss = (ce(sim) + ce(sim.T)) / 2
+    loss.backward()
+    out["tr_loss"], out["tr_sim"] = np.float32(loss.item()), sim.detach().numpy()
+    out["tr_vfeat"], out["tr_tfeat"] = vfeat.detach().numpy(), tfeat.detach().numpy()
+    n = 0
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None:
+            out["tr_grad/" + k] = p_.grad.numpy()
+            n += 1
+    print("train grads:", n, "tensors, loss", float(loss), flush=True)
+    # three BertAdam steps of the reference optimizer (utils/optimization.py) on two tensors with given gradients
+    from utils.optimization import BertAdam
+    rng = np.random.default_rng(9)
+    p0 = [torch.nn.Parameter(torch.from_numpy(rng.standard_normal(s_).astype(np.float32))) for s_ in ((37, 5), (300,))]
+    opt = BertAdam([{'params': [p0[0]], 'weight_decay': 0.2}, {'params': [p0[1]], 'weight_decay': 0.0}], lr=1e-2, warmup=0.1,
+                   t_total=20, schedule='warmup_linear', b1=0.9, b2=0.98, e=1e-6, max_grad_norm=1.0)
+    out["ba_p0"], out["ba_p1"] = p0[0].detach().numpy().copy(), p0[1].detach().numpy().copy()
+    for it in range(3):
+        gr = [rng.standard_normal(tuple(p_.shape)).astype(np.float32) * (3.0 if it == 1 else 0.05) for p_ in p0]
+        for p_, g_ in zip(p0, gr):
+            p_.grad = torch.from_numpy(g_.copy())
+        out[f"ba_g{it}_0"], out[f"ba_g{it}_1"] = gr
+        opt.step()
+        out[f"ba_after{it}_0"], out[f"ba_after{it}_1"] = p0[0].detach().numpy().copy(), p0[1].detach().numpy().copy()
+    out["ba_m_0"], out["ba_v_0"] = opt.state[p0[0]]['next_m'].numpy().copy(), opt.state[p0[0]]['next_v'].numpy().copy()
+
+
 def main():
     sys.path.insert(0, os.path.join("/root/reference", "modules"))
     import cluster.fast_kmeans as fk
@@ -62,6 +116,7 @@ def main():
         out[f"{tag}_assign"], out[f"{tag}_medoids"] = a.numpy().astype(np.int16), m.numpy().astype(np.int16)
         print(tag, "done", tuple(m.shape), flush=True)
     gen_block_grads(out)
+    gen_train_grads(out)
     path = os.path.join(GOLD, "r4_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,5 +1,7 @@
 """Round-4 GPU tests: the split-K form of the residual Linear (two workgroups per 256x256 tile swapping accumulator
 halves inside one launch) against float64 and against the single-workgroup tile."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -264,3 +266,97 @@ def test_inproj_attention_packed_captions():
         want = ops.attention_f16(qkv, 1, n, heads, causal=True)
         assert torch.equal(got[o:o + n], want), (s, n)
     assert not got[Mv:].any()                                                        # rows behind the packed captions: untouched
+
+
+# ----------------------------------------------------------------------------- N4: a whole training step
+def _golden_clip():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_golden.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k]) for k in g.files
+          if k.startswith("sd/")}
+    return g, sd
+
+
+def _train_cfg(T):
+    from argparse import Namespace
+    return Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=T, target_frames_blocks=[4, 2, 2],
+                     cluster_num_blocks=[16, 6, 6], cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False, loose_type=True,
+                     sim_header='meanP', linear_patch='2d')
+
+
+def test_training_step_gradients_against_reference_autograd():
+    """CLIP4Clip.forward in training mode (the towers of centerclip_amd.train: patch embedding, ln_pre, blocks with the k-medoids
+    module in front of block 2, heads; meanP similarity + symmetric CrossEn) and loss.backward(): the loss, the features and
+    the gradient of EVERY parameter against torch.autograd on the reference model (fixture tr_* of r4_golden.npz)."""
+    from centerclip_amd.clip4clip import CLIP4Clip
+    g, sd = _golden_clip()
+    r4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r4_golden.npz"))
+    B, T = int(g["cfg"][10]), int(g["cfg"][11])
+    model = CLIP4Clip.from_state_dict(sd, _train_cfg(T)).float().to("cuda:0").train()
+    video = torch.from_numpy(g["video"]).view(B, 1, T, 3, 64, 64).cuda()
+    ids = torch.from_numpy(g["t_ids"])[:B].cuda()
+    vmask = torch.ones(B, 1, T, dtype=torch.long, device="cuda:0")
+    out = model(ids, torch.zeros_like(ids), (ids > 0).long(), video, vmask)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"].detach()) - float(r4["tr_loss"])) < 2e-3 * max(1.0, abs(float(r4["tr_loss"])))
+    assert relerr(out["visual_output"].detach().reshape(-1, 64).cpu(), torch.from_numpy(r4["tr_vfeat"])) < 2e-3
+    assert relerr(out["sequence_output"].detach().reshape(-1, 64).cpu(), torch.from_numpy(r4["tr_tfeat"])) < 2e-3
+    named = dict(model.clip.named_parameters())
+    keys = [k[len("tr_grad/"):] for k in r4.files if k.startswith("tr_grad/")]
+    assert len(keys) == 74
+    worst = (0.0, None)
+    for k in keys:
+        want = torch.from_numpy(r4["tr_grad/" + k])
+        p = named[k]
+        assert p.grad is not None, k
+        e = relerr(p.grad.detach().float().cpu().reshape(want.shape), want)
+        worst = max(worst, (e, k))
+        assert e < 1e-2, (k, e)                                   # relative to the tensor's largest entry; fp16 operands
+    print("worst gradient error", worst)
+    # every parameter the reference reaches is reached here too, and nothing else
+    assert {k for k, p in named.items() if p.grad is not None} == set(keys)
+
+
+def test_bertadam_matches_reference_optimizer():
+    """centerclip_amd.train.BertAdam (cc_bertadam_step_f32) vs three steps of utils/optimization.BertAdam: clipping engaged in
+    step 2 (|g| large), weight decay in group 1 only, warmup_linear schedule."""
+    from centerclip_amd.train import BertAdam, warmup_linear
+    r4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r4_golden.npz"))
+    p0 = [torch.nn.Parameter(torch.from_numpy(r4["ba_p0"].copy()).cuda()), torch.nn.Parameter(torch.from_numpy(r4["ba_p1"].copy()).cuda())]
+    opt = BertAdam([{'params': [p0[0]], 'weight_decay': 0.2}, {'params': [p0[1]], 'weight_decay': 0.0}], lr=1e-2, warmup=0.1,
+                   t_total=20, schedule='warmup_linear', b1=0.9, b2=0.98, e=1e-6, max_grad_norm=1.0)
+    assert opt.get_lr() == []
+    for it in range(3):
+        for j in range(2):
+            p0[j].grad = torch.from_numpy(r4[f"ba_g{it}_{j}"].copy()).cuda()
+        opt.step()
+        for j in range(2):
+            np.testing.assert_allclose(p0[j].detach().cpu().numpy(), r4[f"ba_after{it}_{j}"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(opt.state[p0[0]]['next_m'].cpu().numpy(), r4["ba_m_0"], rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(opt.state[p0[0]]['next_v'].cpu().numpy(), r4["ba_v_0"], rtol=2e-6, atol=1e-10)
+    assert opt.state[p0[0]]['step'] == 3 and abs(opt.get_lr()[0] - 1e-2 * warmup_linear(3 / 20, 0.1)) < 1e-12
+
+
+def test_train_epoch_runs_and_lowers_the_loss():
+    """main.py:291-378 on this path: a few steps of train_epoch on one synthetic batch (fp32 master weights, BertAdam with
+    the reference's parameter groups): the loss goes down and logit_scale stays clamped."""
+    from argparse import Namespace
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd.train import BertAdam, prep_optim_params_groups, train_epoch
+    g, sd = _golden_clip()
+    B, T = int(g["cfg"][10]), int(g["cfg"][11])
+    model = CLIP4Clip.from_state_dict(sd, _train_cfg(T)).float().to("cuda:0")
+    video = torch.from_numpy(g["video"]).view(B, 1, T, 3, 64, 64)
+    ids = torch.from_numpy(g["t_ids"])[:B]
+    batch = (ids, (ids > 0).long(), torch.zeros_like(ids), video, torch.ones(B, 1, T, dtype=torch.long))
+    args = Namespace(lr=1e-3, wd=0.2, new_added_modules=["Cross", "cluster_embed"], gradient_accumulation_steps=1, clip_grad_norm=None)
+    opt = BertAdam(prep_optim_params_groups(args, model, coef_lr=1.0), lr=args.lr, warmup=0.1, t_total=40,
+                   schedule='warmup_cosine', b1=0.9, b2=0.98, e=1e-6, max_grad_norm=1.0)
+    losses = []
+    gs = 0
+    for ep in range(3):
+        l, gs = train_epoch(ep, args, model, [batch] * 4, "cuda:0", opt, gs)
+        losses.append(l)
+    assert gs == 12 and np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses
+    assert 0.1 <= float(model.clip.logit_scale) <= 4.6052
