@@ -413,7 +413,7 @@ def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_
         with torch.no_grad():                                    # (main.py:336-340; tracked, so the cached copies refresh)
             model.clip.logit_scale.clamp_(0.1, 4.6052)
         if log is not None:
-            log(epoch, step, float(loss), float(output['sim_loss']), global_step)
-        total_loss += float(loss)
+            log(epoch, step, float(loss.detach()), float(output['sim_loss'].detach()), global_step)
+        total_loss += float(loss.detach())
         nb += 1
     return total_loss / max(nb, 1), global_step

@@ -129,6 +129,34 @@ def main():
         want_g.append(t_ / world)
     gb.reduce()
     assert all(torch.allclose(p_.grad, w_, rtol=0, atol=1e-5) for p_, w_ in zip(params, want_g)), "gradient buckets"
+    # one step of train_epoch (main.py:291-378) on the small model with the gradients averaged by GradientBuckets over RCCL:
+    # every rank ends with the same parameters
+    import numpy as np
+    from argparse import Namespace
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd.train import BertAdam, prep_optim_params_groups, train_epoch
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_golden.npz"))
+    sd = {k[3:]: torch.from_numpy(gold[k].astype(np.float32) if gold[k].dtype == np.float16 else gold[k]) for k in gold.files
+          if k.startswith("sd/")}
+    Tt = int(gold["cfg"][11])
+    tcfg = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=Tt, target_frames_blocks=[4, 2, 2],
+                     cluster_num_blocks=[16, 6, 6], cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False, loose_type=True,
+                     sim_header='meanP', linear_patch='2d')
+    tm = CLIP4Clip.from_state_dict(sd, tcfg).float().to(dev)
+    gv = torch.Generator().manual_seed(900 + rank)                      # a different batch on every rank
+    tvideo = torch.randn(2, 1, Tt, 3, 64, 64, generator=gv)
+    tids = torch.from_numpy(gold["t_ids"])[:2]
+    tbatch = (tids, (tids > 0).long(), torch.zeros_like(tids), tvideo, torch.ones(2, 1, Tt, dtype=torch.long))
+    targs = Namespace(lr=1e-3, wd=0.2, new_added_modules=["Cross"], gradient_accumulation_steps=1, clip_grad_norm=None)
+    topt = BertAdam(prep_optim_params_groups(targs, tm), lr=targs.lr, warmup=0.1, t_total=10, schedule='warmup_cosine', b1=0.9,
+                    b2=0.98, e=1e-6, max_grad_norm=1.0)
+    tloss, tgs = train_epoch(0, targs, tm, [tbatch], dev, topt, 0, buckets=GradientBuckets(tm.parameters()))
+    assert tgs == 1 and np.isfinite(tloss)
+    flat = torch.cat([p_.detach().reshape(-1) for p_ in tm.parameters()])
+    ref_flat = flat.clone()
+    dist.broadcast(ref_flat, src=0)
+    assert torch.equal(flat, ref_flat), "parameters differ between ranks after a data-parallel step"
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:
