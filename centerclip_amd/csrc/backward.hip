@@ -235,7 +235,12 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
 // ---- fp32 gradients through the fp16 matrix cores: |x| max -> scale = 2^k with scale * max in [8192, 16384) -> fp16 copy
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ in, int64_t n, unsigned* __restrict__ out_bits) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(in[i]));
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? (n >> 2) : 0;     // (vector loads where the view is aligned)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(in[i]));
     m = cc_wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // (non-negative floats order as their bits)
 }
@@ -274,10 +279,15 @@ inline unsigned grid_for(int64_t n, int per_block) {
 // update = m / (sqrt(v) + e) [+ weight_decay * p], p -= lr_scheduled * update.  Two launches: the sum of squares (a fixed
 // grid, double atomics would make it order dependent: per-block partials reduced in block order by the second kernel), then
 // the elementwise step.  No bias correction - this is the BERT variant.
-constexpr int BA_BLOCKS = 64;
+constexpr int BA_BLOCKS = 512;
 __global__ __launch_bounds__(256) void bertadam_norm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? (n >> 2) : 0;       // (gradients may be views of a flat bucket)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = (double)g[i];
         s += v * v;
     }
@@ -414,7 +424,7 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
     if (!ws || ws_bytes < cc_bertadam_workspace_bytes()) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(ws);
-    const int nb = (int)((n + 255) / 256 < BA_BLOCKS ? (n + 255) / 256 : BA_BLOCKS);
+    const int nb = (int)((n + 1023) / 1024 < BA_BLOCKS ? (n + 1023) / 1024 : BA_BLOCKS);
     if (max_grad_norm > 0.f) hipLaunchKernelGGL(bertadam_norm_kernel, dim3(nb), dim3(256), 0, st, grad, n, partial);
     hipLaunchKernelGGL(bertadam_step_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, param, grad, next_m, next_v, n, partial, nb,
                        lr_scheduled, b1, b2, e, weight_decay, max_grad_norm);

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--graph", type=int, default=1, help="also time the step captured into a hipGraph")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -57,7 +58,36 @@ def main():
     train_epoch(0, targs, model, loader, device, opt, 0, buckets=buckets, log=log)
     if rank == 0:
         steady = (t[-1] - t[2]) / max(len(t) - 3, 1) if len(t) > 3 else float("nan")
-        print("steady step %.0f ms = %.1f clips/s per rank (unfused per-op training path)" % (steady * 1e3, a.batch / steady))
+        print("steady step %.0f ms = %.1f clips/s per rank (unfused per-op training path, launched op by op)" % (steady * 1e3, a.batch / steady))
+    if a.graph and world == 1:
+        # the same step (forward, backward, optimizer) captured once into a hipGraph and replayed on static input buffers: no
+        # op of it synchronises with the host, so what remains is the GPU time of the unfused kernels
+        batch = next(iter(loader))
+        static = [x.to(device).clone() for x in batch]
+        model.train()
+
+        def one_step():
+            opt.zero_grad(set_to_none=False)
+            out = model(static[0], static[2], static[1], static[3], static[4])
+            out['loss'].backward()
+            opt.step()
+            return out['loss'].detach()
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gloss = one_step()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            graph.replay()
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / 10 * 1e3
+        print("captured step: %.1f ms = %.0f clips/s (loss %.4f)" % (ms, a.batch / ms * 1e3, float(gloss)))
     if world > 1:
         torch.distributed.destroy_process_group()
 
