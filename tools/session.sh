@@ -1,11 +1,6 @@
 #!/bin/bash
+# the last GPU session's command list (rewritten per session)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_spectral_gpu.py tests/test_cluster_gpu.py -x -q 2>&1 | tail -3
-python - <<'PY'
-import torch, bench, json
-dev = torch.device("cuda:0")
-for name in ("cfg5 ViT-B/16", "cfg6 ViT-B/16 ActivityNet (per GPU)"):
-    sh = bench.CLUSTER_SHAPES[name]
-    print(name, json.dumps(bench.cluster_bench(sh, dev, iters=10)), flush=True)
-    print(name, "spectral", json.dumps(bench.spectral_cluster_bench(sh, dev)), flush=True)
-PY
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+bash tools/refresh_profiles.sh r04 > gpurun_out/refresh.log 2>&1
+bash tools/pmc_insitu.sh > gpurun_out/pmc_insitu.log 2>&1
