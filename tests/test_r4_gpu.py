@@ -360,3 +360,17 @@ def test_train_epoch_runs_and_lowers_the_loss():
         losses.append(l)
     assert gs == 12 and np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses
     assert 0.1 <= float(model.clip.logit_scale) <= 4.6052
+
+
+def test_inproj_attention_argument_range():
+    """Outside the one-launch form's range the entry point says so (the towers then run the two launches)."""
+    from centerclip_amd import ops
+    h16, st, wf, c1, c2 = _inproj_inputs(4 * 57, 128, 3)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 4, 57, 2)               # L > 56
+    h16, st, wf, c1, c2 = _inproj_inputs(8, 64, 4)
+    got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1)                # one token per sequence: softmax of one score
+    qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1)
+    assert torch.equal(got, qkv[:, 128:192])                                        # attention output = v
+    with pytest.raises(RuntimeError, match="invalid"):
+        ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1, seq_off=torch.zeros(8, dtype=torch.int32, device="cuda"))
