@@ -616,9 +616,27 @@ __device__ __forceinline__ void text_embed_row(const TextEmbedArgs& e, int row, 
     if (e.seq_off) {
         // compaction: this wave works out where caption b starts (the EOT positions of the captions before it: Bt is a
         // batch of captions, a few wave reductions over L2-resident ids) and drops the row if it lies behind the EOT
-        int off = 0;
-        for (int bb = 0; bb < b; ++bb) off += text_eot_position(ids, bb, Lt, lane) + 1;
-        const int my_eot = text_eot_position(ids, b, Lt, lane);
+        // (lane l scans caption base + l on its own - Lt independent loads - and one wave sum per 64 captions adds the
+        // lengths: a chain of one scan + one reduction instead of one wave reduction per earlier caption, which made the last
+        // caption's rows the long pole of the whole pre-stage launch: up to 16 dependent reductions)
+        int off = 0, my_eot = 0;
+        for (int base = 0; base <= b; base += 64) {
+            const int bb = base + lane;
+            unsigned long long key = 0ull;
+            if (bb <= b) {
+                const long long* row_ids = ids + (int64_t)bb * Lt;
+                for (int u = 0; u < Lt; ++u) {
+                    const unsigned long long k2 = ((unsigned long long)(row_ids[u] + 0x40000000LL) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)u);
+                    key = k2 > key ? k2 : key;
+                }
+            }
+            const int pos = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            int len = bb < b ? pos + 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+            off += len;
+            if (b - base < 64) my_eot = __shfl(pos, b - base, 64);
+        }
         if (t == 0 && lane == 0) {
             e.seq_off[b] = off;
             e.seq_len[b] = my_eot + 1;
