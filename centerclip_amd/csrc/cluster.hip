@@ -88,6 +88,16 @@ typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
 #define GPLANE (GT * GK)            /* halfs per plane */
 
+// development builds (-DCC_DEV_KNOBS) only: per-workgroup real-time stamps (entry, first stage in LDS, loop done, exit), 100 MHz
+#ifdef CC_DEV_KNOBS
+__device__ long long* g_gram_prof = nullptr;
+#define GRAM_STAMP(slot)                                                                                              \
+    do {                                                                                                              \
+        if (g_gram_prof && threadIdx.x == 0 && blockIdx.x < 4096) g_gram_prof[(int64_t)blockIdx.x * 4 + (slot)] = (long long)wall_clock64(); \
+    } while (0)
+#else
+#define GRAM_STAMP(slot) do { } while (0)
+#endif
 template <int METRIC>
 __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict__ x, cc_token_layout lay, int N,
                                                         int W, float* sqn, float* nrm, float* inv, int own_norms,
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
     // own_norms: the row norms come out of this kernel (sum of squares of the rows it stages anyway; the diagonal
     // tiles publish sqn / nrm / inv for the selection kernel) instead of a separate pass over the tokens (K0).
     extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds_raw[];   // [2 buffers][A,B][hi,lo][GPLANE] halfs + 2 x GT floats
+    GRAM_STAMP(0);
     auto plane = [&](int buf, int which, int hl) {
         return reinterpret_cast<_Float16*>(gram_lds_raw) + ((buf * 2 + which) * 2 + hl) * GPLANE;
     };
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         if (u < nk) gload(u, u);
     lstore(0, 0);
     __syncthreads();
+    GRAM_STAMP(1);
     const int g = lane >> 4, l15 = lane & 15;
     auto frag = [&](const _Float16* pl, int row, int ks) {     // 8 consecutive k of `row` at k = ks*32 + g*8
         return *reinterpret_cast<const gh8*>(pl + row * GK + ((((ks << 2) | g) ^ (row & 7)) << 3));
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
       }
     }
 
+    GRAM_STAMP(2);
     float* lsq = reinterpret_cast<float*>(gram_lds_raw + (size_t)2 * 2 * 2 * GPLANE * sizeof(_Float16));   // [2][GT]
     if (own_norms) {
         // the 16 threads of a row (lchunk) sit in one DPP row: quad swaps, half mirror, mirror
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(256) void gram_dist_kernel(const float* __restrict_
         if (lane == 0)
             chunkmax[((int64_t)p * tiles_pp + (((int)blockIdx.x >> 3) % tiles_pp)) * 4 + wave] = cc_float_to_ordered_int(lmax);
     }
+    GRAM_STAMP(3);
 }
 
 // Minkowski-p distance for p != 2 (p == 1 is the shipped MSR-VTT setting, scripts/msrvtt.sh:87).
@@ -1596,6 +1610,9 @@ bool p_supported(int metric, float p) { return metric == CC_METRIC_COSINE || (p 
 extern "C" {
 
 #ifdef CC_DEV_KNOBS
+int cc_debug_set_gram_profile(long long* buf) {     // development builds only; buf [4096, 4] int64 device memory or NULL
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gram_prof), &buf, sizeof(buf)) == hipSuccess ? CC_OK : CC_ERR_HIP;
+}
 int cc_debug_set_select_profile(long long* buf) {   // development builds only; buf [P,16] int64 device memory or NULL
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), &buf, sizeof(buf)) == hipSuccess ? CC_OK : CC_ERR_HIP;
 }
