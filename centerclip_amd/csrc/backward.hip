@@ -242,7 +242,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ i
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(in[i]));
     m = cc_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // (non-negative floats order as their bits)
+    // one atomic per workgroup (28.8 k wave atomics on one address took three times as long as reading the tensor)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));   // (non-negative floats order as their bits)
 }
 __global__ __launch_bounds__(256) void cast_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int64_t n,
                                                           const float* __restrict__ amax, float* __restrict__ scale_out) {
@@ -257,6 +262,53 @@ __global__ __launch_bounds__(256) void cast_scaled_kernel(const float* __restric
             *reinterpret_cast<h4*>(out + i) = o;
         } else {
             for (int64_t j = i; j < n; ++j) out[j] = (_Float16)(in[j] * scale);
+        }
+    }
+}
+// The same cast for a matrix in [rows, cols], writing the fp16 copy row-major AND transposed [cols, rows_pad] (zero columns
+// behind `rows`): the two operand layouts a Linear's backward multiplies (dX = dY W: dY row-major; dW = dY^T X: both operands
+// with the row count as the contraction, cc_linear_f16 wants it contiguous and a multiple of 64).  One read of the fp32
+// matrix, 64 x 64 tiles through LDS.  in_f16 != null: the source is already fp16 (activations saved by the forward), no scale.
+// amax == null: scale 1 (weights).
+typedef _Float16 bh8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, const _Float16* __restrict__ in_f16,
+                                                             _Float16* __restrict__ out, _Float16* __restrict__ out_t, int rows,
+                                                             int cols, int rows_pad, const float* __restrict__ amax,
+                                                             float* __restrict__ scale_out) {
+    __shared__ _Float16 tile[64][72];
+    float scale = 1.f;
+    if (amax) {
+        const float a = *amax;
+        scale = (a > 0.f && isfinite(a)) ? exp2f(floorf(log2f(16384.0f / a))) : 1.0f;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && scale_out) *scale_out = scale;
+    }
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                 // 64 rows x 16 column quads
+        const int idx = q * 256 + tid, r = idx >> 4, c = (idx & 15) * 4;
+        const int gr = r0 + r, gc = c0 + c;
+        h4 o = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (gr < rows && gc < cols) {                             // (cols % 4 == 0)
+            if (in_f16) {
+                o = *reinterpret_cast<const h4*>(in_f16 + (int64_t)gr * cols + gc);
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(in + (int64_t)gr * cols + gc);
+                o = h4{(_Float16)(v.x * scale), (_Float16)(v.y * scale), (_Float16)(v.z * scale), (_Float16)(v.w * scale)};
+            }
+            if (out) *reinterpret_cast<h4*>(out + (int64_t)gr * cols + gc) = o;
+        }
+        *reinterpret_cast<h4*>(&tile[r][c]) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                                 // 64 columns x 8 row octets
+        const int idx = q * 256 + tid, c = idx >> 3, r = (idx & 7) * 8;
+        const int gc = c0 + c, gr = r0 + r;
+        if (gc < cols && gr < rows_pad) {                         // (rows_pad % 8 == 0)
+            bh8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = tile[r + e][c];
+            *reinterpret_cast<bh8*>(out_t + (int64_t)gc * rows_pad + gr) = o;
         }
     }
 }
@@ -304,9 +356,17 @@ __global__ __launch_bounds__(256) void bertadam_step_kernel(float* __restrict__ 
                                                              float max_norm) {
     float coef = 1.f;
     if (max_norm > 0.f) {
-        double tot = 0.0;
-        for (int b = 0; b < nblocks; ++b) tot += partial[b];
-        const float c = max_norm / ((float)sqrt(tot) + 1e-6f);
+        // the block partials, summed by the first wave in a fixed order (lane l takes l, l + 64, ...; then the wave tree)
+        __shared__ double tot_s;
+        if (threadIdx.x < 64) {
+            double t = 0.0;
+            for (int b = threadIdx.x; b < nblocks; b += 64) t += partial[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (threadIdx.x == 0) tot_s = t;
+        }
+        __syncthreads();
+        const float c = max_norm / ((float)sqrt(tot_s) + 1e-6f);
         coef = c < 1.f ? c : 1.f;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -398,7 +458,7 @@ int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_sc
     if (!in || !out_f16 || !amax_scratch || !scale_out || n <= 0) return CC_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, st, in, n, reinterpret_cast<unsigned*>(amax_scratch));
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256 * 16) < 2048 ? grid_for(n, 256 * 16) : 2048), dim3(256), 0, st, in, n, reinterpret_cast<unsigned*>(amax_scratch));
     hipLaunchKernelGGL(cast_scaled_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, in, static_cast<_Float16*>(out_f16), n,
                        amax_scratch, scale_out);
     CC_LAUNCH_CHECK();
@@ -428,6 +488,28 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
     if (max_grad_norm > 0.f) hipLaunchKernelGGL(bertadam_norm_kernel, dim3(nb), dim3(256), 0, st, grad, n, partial);
     hipLaunchKernelGGL(bertadam_step_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, param, grad, next_m, next_v, n, partial, nb,
                        lr_scheduled, b1, b2, e, weight_decay, max_grad_norm);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+/* fp16 operand copies of a matrix for the backward of a Linear: `in` fp32 [rows, cols] (or in_f16, already fp16) ->
+ * out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = its transpose with zero columns behind `rows`
+ * (rows_pad >= rows, a multiple of 64; cols % 4 == 0).  scaled != 0: fp32 input scaled by the device-chosen power of two of
+ * cc_cast_scaled_f16 (amax_scratch: one device float; *scale_out receives the scale); otherwise scale 1. */
+int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
+                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, void* stream) {
+    if ((!in && !in_f16) || !out_t_f16 || rows <= 0 || cols <= 0 || (cols & 3) || rows_pad < rows || (rows_pad & 63)) return CC_ERR_INVALID;
+    if (scaled && (!in || !amax_scratch || !scale_out)) return CC_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (scaled) {
+        if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
+        const unsigned ab = grid_for((int64_t)rows * cols, 256 * 16);
+        hipLaunchKernelGGL(absmax_kernel, dim3(ab < 2048 ? ab : 2048), dim3(256), 0, st, in, (int64_t)rows * cols,
+                           reinterpret_cast<unsigned*>(amax_scratch));
+    }
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, rows_pad / 64), dim3(256), 0, st, in,
+                       static_cast<const _Float16*>(in_f16), static_cast<_Float16*>(out_f16), static_cast<_Float16*>(out_t_f16), rows,
+                       cols, rows_pad, scaled ? amax_scratch : nullptr, scaled ? scale_out : nullptr);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

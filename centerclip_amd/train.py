@@ -35,20 +35,35 @@ def _check(rc, what):
     L.check(rc, what)
 
 
-def _pad_rows_t(t16, mult=64):
-    """[M, C] fp16 -> its transpose [C, Mp] with the row count padded to a multiple of 64 by zeros (the contraction dim)."""
-    M, C = t16.shape
-    Mp = -(-M // mult) * mult
-    out = torch.zeros(C, Mp, device=t16.device, dtype=torch.float16)
-    out[:, :M] = t16.t()
-    return out
+def _pad64(n):
+    return -(-n // 64) * 64
+
+
+def _cast_transpose(x, scaled, want_out=True):
+    """One read of a matrix -> its fp16 operand copies for a Linear's backward (cc_cast_transpose_f16):
+    x fp32 [M, C] -> (x16 [M, C], x16^T [C, Mp] zero padded to a multiple of 64, scale or None); x fp16 -> (x, x^T, None).
+    scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor)."""
+    x = x.contiguous()
+    M, C = x.shape
+    Mp = _pad64(M)
+    out_t = torch.empty(C, Mp, device=x.device, dtype=torch.float16)
+    lib = L.lib()
+    if x.dtype == torch.float16:
+        _check(lib.cc_cast_transpose_f16(None, L.ptr(x), None, L.ptr(out_t), M, C, Mp, 0, None, None, _st(x)), "cc_cast_transpose_f16")
+        return x, out_t, None
+    out = torch.empty(M, C, device=x.device, dtype=torch.float16) if want_out else None
+    scratch = torch.empty(2, device=x.device, dtype=torch.float32) if scaled else None
+    _check(lib.cc_cast_transpose_f16(L.ptr(x), None, L.ptr(out), L.ptr(out_t), M, C, Mp, int(bool(scaled)),
+                                     L.ptr(scratch[0:1]) if scaled else None, L.ptr(scratch[1:2]) if scaled else None, _st(x)),
+           "cc_cast_transpose_f16")
+    return out, out_t, (scratch[1:2] if scaled else None)
 
 
 def _cast_scaled(x32):
     """fp32 tensor -> (fp16 copy scaled by a device-chosen power of two, the scale as a 1-element device tensor)."""
     x32 = x32.contiguous()
     out = torch.empty(x32.shape, device=x32.device, dtype=torch.float16)
-    scratch = torch.zeros(2, device=x32.device, dtype=torch.float32)
+    scratch = torch.empty(2, device=x32.device, dtype=torch.float32)
     _check(L.lib().cc_cast_scaled_f16(L.ptr(x32), L.ptr(out), x32.numel(), L.ptr(scratch[0:1]), L.ptr(scratch[1:2]), _st(x32)),
            "cc_cast_scaled_f16")
     return out, scratch[1:2]
@@ -79,12 +94,23 @@ def _ln_backward(x, gamma, dy, dres, eps=1e-5):
     return dx, dg, db
 
 
-def _grad_linear(dy32, x16, w16_t):
-    """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32."""
+def _wt16(w):
+    """W [N, K] (fp32 master weight or fp16) -> W^T [K, Np] fp16, the dgrad's operand (columns behind N are zeros and are
+    sliced away: cc_linear_f16 takes the row stride from the shape, so the view must be made contiguous only when N % 64)."""
+    w = w.detach()
+    N, K = w.shape
+    _, wt, _ = _cast_transpose(w.float() if w.dtype not in (torch.float16, torch.float32) else w, scaled=False, want_out=False)
+    return wt if wt.shape[1] == N else wt[:, :N].contiguous()
+
+
+def _grad_linear(dy32, x16, w16_t, need_dx=True):
+    """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
+    The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X)."""
     db = _column_sums(dy32)
-    dy16, scale = _cast_scaled(dy32)
-    dx = _unscale(ops.linear_f16(dy16, w16_t, None, "f32"), scale)                       # dY W
-    dw = _unscale(ops.linear_f16(_pad_rows_t(dy16), _pad_rows_t(x16), None, "f32"), scale)   # dY^T X
+    dy16, dy16_t, scale = _cast_transpose(dy32, scaled=True)
+    dx = _unscale(ops.linear_f16(dy16, w16_t, None, "f32"), scale) if need_dx else None      # dY W
+    _, x16_t, _ = _cast_transpose(x16, scaled=False)
+    dw = _unscale(ops.linear_f16(dy16_t, x16_t, None, "f32"), scale)                          # dY^T X
     return dx, dw, db
 
 
@@ -118,7 +144,7 @@ def block_backward(block, saved, dz_lnd):
     """dz [L, N, W] -> (dx [L, N, W], {parameter name: gradient}) for the forward that produced ``saved``."""
     Lt, N, W = saved["shape"]
     M = N * Lt
-    f16t = lambda t: t.detach().to(torch.float16).t().contiguous()                      # W^T as the dgrad's operand
+    f16t = _wt16                                                                        # W^T as the dgrad's operand
     f32 = lambda t: t.detach().float().contiguous()
     dz = dz_lnd.detach().float().permute(1, 0, 2).contiguous().view(M, W)
     g = {}
@@ -192,8 +218,8 @@ class LinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x16, w = ctx.saved_tensors
-        dx, dw, db = _grad_linear(dy.contiguous().float(), x16, w.detach().to(torch.float16).t().contiguous())
-        return (dx if ctx.need_dx else None), dw.to(w.dtype), (db if ctx.has_bias else None)
+        dx, dw, db = _grad_linear(dy.contiguous().float(), x16, _wt16(w) if ctx.need_dx else None, need_dx=ctx.need_dx)
+        return dx, dw.to(w.dtype), (db if ctx.has_bias else None)
 
 
 class LayerNormFunction(torch.autograd.Function):

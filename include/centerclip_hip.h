@@ -674,6 +674,12 @@ size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
 int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
 int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);
 int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale_b, void* stream);
+/* The fp16 operand copies a Linear's backward multiplies, from ONE read of the matrix: `in` fp32 [rows, cols] (or in_f16, a
+ * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = the transpose with zero columns
+ * behind `rows` (rows_pad >= rows, a multiple of 64: the contraction of dW = dY^T X; cols % 4 == 0).  scaled != 0: the fp32
+ * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale). */
+int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
+                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, void* stream);
 /* One BertAdam step on one parameter tensor (utils/optimization.py:100-170: the optimizer main.py:161-167 builds): grad is
  * clipped in place to max_grad_norm (clip_grad_norm_ on the single tensor; <= 0: no clipping), next_m = b1 m + (1-b1) g,
  * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.
