@@ -193,13 +193,18 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
         P[i][j] = (causal && j > i) ? -INFINITY : s * 0.125f;
     }
     __syncthreads();
-    if (tid < L) {
+    // the row passes: four threads per row (adjacent lanes), every fourth column each, combined by two lane exchanges - one
+    // thread per row walked its 64 columns through LDS latency five times and was two thirds of the kernel
+    const int rr = tid >> 2, rs = tid & 3;
+    {
         float mx = -INFINITY;
-        for (int j = 0; j < L; ++j) mx = fmaxf(mx, P[tid][j]);
+        if (rr < L) for (int j = rs; j < L; j += 4) mx = fmaxf(mx, P[rr][j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
         float sum = 0.f;
-        for (int j = 0; j < L; ++j) { const float e = expf(P[tid][j] - mx); P[tid][j] = e; sum += e; }
+        if (rr < L) for (int j = rs; j < L; j += 4) { const float e = expf(P[rr][j] - mx); P[rr][j] = e; sum += e; }
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
         const float inv = 1.0f / sum;
-        for (int j = 0; j < L; ++j) P[tid][j] *= inv;
+        if (rr < L) for (int j = rs; j < L; j += 4) P[rr][j] *= inv;
     }
     __syncthreads();
     // dP = dO V^T ; dS = P (dP - sum_j dP P)
@@ -210,10 +215,11 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
         dS[i][j] = s;
     }
     __syncthreads();
-    if (tid < L) {
+    {
         float dot = 0.f;
-        for (int j = 0; j < L; ++j) dot = fmaf(dS[tid][j], P[tid][j], dot);
-        for (int j = 0; j < L; ++j) dS[tid][j] = P[tid][j] * (dS[tid][j] - dot);
+        if (rr < L) for (int j = rs; j < L; j += 4) dot = fmaf(dS[rr][j], P[rr][j], dot);
+        dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+        if (rr < L) for (int j = rs; j < L; j += 4) dS[rr][j] = P[rr][j] * (dS[rr][j] - dot);
     }
     __syncthreads();
     // dV = P^T dO ; dQ = dS K / 8 ; dK = dS^T Q / 8
