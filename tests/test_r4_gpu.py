@@ -374,3 +374,24 @@ def test_inproj_attention_argument_range():
     assert torch.equal(got, qkv[:, 128:192])                                        # attention output = v
     with pytest.raises(RuntimeError, match="invalid"):
         ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1, seq_off=torch.zeros(8, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("M,C", [(9600, 768), (323, 512), (50, 64), (64, 3072), (1, 4)])
+def test_cast_transpose_operand_copies(M, C):
+    """cc_cast_transpose_f16: one read of a matrix -> its fp16 copy and the zero-padded transpose a wgrad GEMM multiplies; scaled
+    (gradients: the device-chosen power of two of cc_cast_scaled_f16), unscaled (weights), fp16 input (saved activations)."""
+    from centerclip_amd import train as cctrain
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 3e-4).cuda()
+    Mp = -(-M // 64) * 64
+    out, out_t, scale = cctrain._cast_transpose(x, scaled=True)
+    ref16, ref_scale = cctrain._cast_scaled(x)
+    torch.cuda.synchronize()
+    assert float(scale) == float(ref_scale) and float(scale) >= 1.0 and float(torch.log2(scale)) % 1 == 0
+    assert torch.equal(out, ref16) and out_t.shape == (C, Mp)
+    assert torch.equal(out_t[:, :M], ref16.t()) and not out_t[:, M:].any()
+    out, out_t, scale = cctrain._cast_transpose(x, scaled=False)
+    assert scale is None and torch.equal(out, x.half()) and torch.equal(out_t[:, :M], x.half().t()) and not out_t[:, M:].any()
+    xh = x.half() * 1000
+    same, out_t, _ = cctrain._cast_transpose(xh, scaled=False)
+    assert same.data_ptr() == xh.data_ptr() and torch.equal(out_t[:, :M], xh.t()) and not out_t[:, M:].any()
