@@ -185,12 +185,28 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
         dO[t][d] = d_out[(row0 + t) * W + head * AB_D + d];
     }
     __syncthreads();
-    // S = Q K^T / 8 (+ causal mask), P = softmax rows
-    for (int idx = tid; idx < L * L; idx += 256) {
-        const int i = idx / L, j = idx % L;
-        float s = 0.f;
-        for (int d = 0; d < AB_D; ++d) s = fmaf(Q[i][d], K[j][d], s);
-        P[i][j] = (causal && j > i) ? -INFINITY : s * 0.125f;
+    // S = Q K^T / 8 (+ causal mask), P = softmax rows.  The products are register tiled - thread (bi, bj) owns the 4 x 4 block of
+    // rows 4 bi.. and columns 4 bj..: 8 LDS reads per 16 multiply-adds instead of 2 per multiply-add (the kernel is bound by its
+    // LDS reads); every element is still one dot product in d order.
+    const int bi = tid >> 4, bj = tid & 15;                    // 16 x 16 blocks of 4 x 4 cover 64 x 64
+    if (4 * bi < L && 4 * bj < L) {
+        float acc[4][4] = {};
+        for (int d = 0; d < AB_D; ++d) {
+            float qa[4], kb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { qa[u] = Q[min(4 * bi + u, L - 1)][d]; kb[u] = K[min(4 * bj + u, L - 1)][d]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc[u][w] = fmaf(qa[u], kb[w], acc[u][w]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int i = 4 * bi + u, j = 4 * bj + w;
+                if (i < L && j < L) P[i][j] = (causal && j > i) ? -INFINITY : acc[u][w] * 0.125f;
+            }
     }
     __syncthreads();
     // the row passes: four threads per row (adjacent lanes), every fourth column each, combined by two lane exchanges - one
@@ -208,11 +224,24 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
     }
     __syncthreads();
     // dP = dO V^T ; dS = P (dP - sum_j dP P)
-    for (int idx = tid; idx < L * L; idx += 256) {
-        const int i = idx / L, j = idx % L;
-        float s = 0.f;
-        for (int d = 0; d < AB_D; ++d) s = fmaf(dO[i][d], V[j][d], s);
-        dS[i][j] = s;
+    if (4 * bi < L && 4 * bj < L) {
+        float acc[4][4] = {};
+        for (int d = 0; d < AB_D; ++d) {
+            float oa[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { oa[u] = dO[min(4 * bi + u, L - 1)][d]; vb[u] = V[min(4 * bj + u, L - 1)][d]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc[u][w] = fmaf(oa[u], vb[w], acc[u][w]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int i = 4 * bi + u, j = 4 * bj + w;
+                if (i < L && j < L) dS[i][j] = acc[u][w];
+            }
     }
     __syncthreads();
     {
@@ -222,19 +251,39 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
         if (rr < L) for (int j = rs; j < L; j += 4) dS[rr][j] = P[rr][j] * (dS[rr][j] - dot);
     }
     __syncthreads();
-    // dV = P^T dO ; dQ = dS K / 8 ; dK = dS^T Q / 8
-    for (int idx = tid; idx < L * AB_D; idx += 256) {
-        const int t = idx / AB_D, d = idx % AB_D;
-        float dv = 0.f, dq = 0.f, dk = 0.f;
-        for (int j = 0; j < L; ++j) {
-            dv = fmaf(P[j][t], dO[j][d], dv);
-            dq = fmaf(dS[t][j], K[j][d], dq);
-            dk = fmaf(dS[j][t], Q[j][d], dk);
+    // dV = P^T dO ; dQ = dS K / 8 ; dK = dS^T Q / 8: thread (bt, bd) owns tokens 4 bt.. x features 4 bd..
+    {
+        const int bt = tid >> 4, bd = tid & 15;
+        if (4 * bt < L) {
+            float dv[4][4] = {}, dq[4][4] = {}, dk[4][4] = {};
+            for (int j = 0; j < L; ++j) {
+                float pj[4], sj[4], st[4], od[4], kd[4], qd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = min(4 * bt + u, L - 1);
+                    pj[u] = P[j][t]; sj[u] = dS[j][t]; st[u] = dS[t][j];
+                    od[u] = dO[j][4 * bd + u]; kd[u] = K[j][4 * bd + u]; qd[u] = Q[j][4 * bd + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        dv[u][w] = fmaf(pj[u], od[w], dv[u][w]);
+                        dq[u][w] = fmaf(st[u], kd[w], dq[u][w]);
+                        dk[u][w] = fmaf(sj[u], qd[w], dk[u][w]);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = 4 * bt + u;
+                if (t < L) {
+                    float* o = d_qkv + (row0 + t) * 3 * W + head * AB_D + 4 * bd;
+                    *reinterpret_cast<float4*>(o) = make_float4(dq[u][0] * 0.125f, dq[u][1] * 0.125f, dq[u][2] * 0.125f, dq[u][3] * 0.125f);
+                    *reinterpret_cast<float4*>(o + W) = make_float4(dk[u][0] * 0.125f, dk[u][1] * 0.125f, dk[u][2] * 0.125f, dk[u][3] * 0.125f);
+                    *reinterpret_cast<float4*>(o + 2 * W) = make_float4(dv[u][0], dv[u][1], dv[u][2], dv[u][3]);
+                }
+            }
         }
-        float* o = d_qkv + (row0 + t) * 3 * W + head * AB_D + d;
-        o[0] = dq * 0.125f;
-        o[W] = dk * 0.125f;
-        o[2 * W] = dv;
     }
 }
 
