@@ -136,7 +136,9 @@ def declare(lib):
     lib.cc_cast_scaled_f16.restype = c.c_int
     lib.cc_unscale_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.cc_unscale_f32.restype = c.c_int
-    lib.cc_cast_transpose_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.cc_cast_transpose_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.cc_cast_transpose_colsum_workspace_bytes.argtypes = [i32, i32]
+    lib.cc_cast_transpose_colsum_workspace_bytes.restype = sz
     lib.cc_cast_transpose_f16.restype = c.c_int
     lib.cc_bertadam_workspace_bytes.argtypes = []
     lib.cc_bertadam_workspace_bytes.restype = sz

@@ -329,8 +329,9 @@ typedef _Float16 bh8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, const _Float16* __restrict__ in_f16,
                                                              _Float16* __restrict__ out, _Float16* __restrict__ out_t, int rows,
                                                              int cols, int rows_pad, const float* __restrict__ amax,
-                                                             float* __restrict__ scale_out) {
+                                                             float* __restrict__ scale_out, float* __restrict__ col_partial) {
     __shared__ _Float16 tile[64][72];
+    __shared__ float csum[16][64];                                // col_partial: column sums of the tile's (unscaled) fp32 rows
     float scale = 1.f;
     if (amax) {
         const float a = *amax;
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && scale_out) *scale_out = scale;
     }
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                 // 64 rows x 16 column quads
         const int idx = q * 256 + tid, r = idx >> 4, c = (idx & 15) * 4;
@@ -349,12 +351,20 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
             } else {
                 const float4 v = *reinterpret_cast<const float4*>(in + (int64_t)gr * cols + gc);
                 o = h4{(_Float16)(v.x * scale), (_Float16)(v.y * scale), (_Float16)(v.z * scale), (_Float16)(v.w * scale)};
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;                  // rows q*16 + tid/16, ascending in q
             }
             if (out) *reinterpret_cast<h4*>(out + (int64_t)gr * cols + gc) = o;
         }
         *reinterpret_cast<h4*>(&tile[r][c]) = o;
     }
+    if (col_partial) *reinterpret_cast<float4*>(&csum[tid >> 4][(tid & 15) * 4]) = cs;
     __syncthreads();
+    if (col_partial && tid < 64 && c0 + tid < cols) {             // fixed order: the 16 row groups of the tile, ascending
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += csum[u][tid];
+        col_partial[(int64_t)blockIdx.y * cols + c0 + tid] = t;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                                 // 64 columns x 8 row octets
         const int idx = q * 256 + tid, c = idx >> 3, r = (idx & 7) * 8;
@@ -550,11 +560,18 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
 /* fp16 operand copies of a matrix for the backward of a Linear: `in` fp32 [rows, cols] (or in_f16, already fp16) ->
  * out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = its transpose with zero columns behind `rows`
  * (rows_pad >= rows, a multiple of 64; cols % 4 == 0).  scaled != 0: fp32 input scaled by the device-chosen power of two of
- * cc_cast_scaled_f16 (amax_scratch: one device float; *scale_out receives the scale); otherwise scale 1. */
+ * cc_cast_scaled_f16 (amax_scratch: one device float; *scale_out receives the scale); otherwise scale 1.  col_sums != null
+ * (fp32 input only): the column sums of the unscaled matrix [cols] from the same read (a Linear's bias gradient), per 64-row
+ * tile partials in ws (cc_cast_transpose_colsum_workspace_bytes) added in tile order. */
+size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols) {
+    return rows_pad > 0 && cols > 0 ? (size_t)(rows_pad / 64) * cols * sizeof(float) : 0;
+}
 int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
-                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, void* stream) {
+                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, float* col_sums, void* ws,
+                          size_t ws_bytes, void* stream) {
     if ((!in && !in_f16) || !out_t_f16 || rows <= 0 || cols <= 0 || (cols & 3) || rows_pad < rows || (rows_pad & 63)) return CC_ERR_INVALID;
     if (scaled && (!in || !amax_scratch || !scale_out)) return CC_ERR_INVALID;
+    if (col_sums && (!in || !ws || ws_bytes < cc_cast_transpose_colsum_workspace_bytes(rows_pad, cols))) return col_sums && in ? CC_ERR_WORKSPACE : CC_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (scaled) {
         if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
@@ -564,7 +581,11 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
     }
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, rows_pad / 64), dim3(256), 0, st, in,
                        static_cast<const _Float16*>(in_f16), static_cast<_Float16*>(out_f16), static_cast<_Float16*>(out_t_f16), rows,
-                       cols, rows_pad, scaled ? amax_scratch : nullptr, scaled ? scale_out : nullptr);
+                       cols, rows_pad, scaled ? amax_scratch : nullptr, scaled ? scale_out : nullptr,
+                       col_sums ? static_cast<float*>(ws) : nullptr);
+    if (col_sums)
+        hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), rows_pad / 64,
+                           cols, col_sums);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -39,7 +39,7 @@ def _pad64(n):
     return -(-n // 64) * 64
 
 
-def _cast_transpose(x, scaled, want_out=True):
+def _cast_transpose(x, scaled, want_out=True, col_sums=False):
     """One read of a matrix -> its fp16 operand copies for a Linear's backward (cc_cast_transpose_f16):
     x fp32 [M, C] -> (x16 [M, C], x16^T [C, Mp] zero padded to a multiple of 64, scale or None); x fp16 -> (x, x^T, None).
     scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor)."""
@@ -49,13 +49,18 @@ def _cast_transpose(x, scaled, want_out=True):
     out_t = torch.empty(C, Mp, device=x.device, dtype=torch.float16)
     lib = L.lib()
     if x.dtype == torch.float16:
-        _check(lib.cc_cast_transpose_f16(None, L.ptr(x), None, L.ptr(out_t), M, C, Mp, 0, None, None, _st(x)), "cc_cast_transpose_f16")
+        _check(lib.cc_cast_transpose_f16(None, L.ptr(x), None, L.ptr(out_t), M, C, Mp, 0, None, None, None, None, 0, _st(x)),
+               "cc_cast_transpose_f16")
         return x, out_t, None
     out = torch.empty(M, C, device=x.device, dtype=torch.float16) if want_out else None
     scratch = torch.empty(2, device=x.device, dtype=torch.float32) if scaled else None
+    cs = torch.empty(C, device=x.device, dtype=torch.float32) if col_sums else None
+    ws = L.workspace(lib.cc_cast_transpose_colsum_workspace_bytes(Mp, C), x.device) if col_sums else None
     _check(lib.cc_cast_transpose_f16(L.ptr(x), None, L.ptr(out), L.ptr(out_t), M, C, Mp, int(bool(scaled)),
-                                     L.ptr(scratch[0:1]) if scaled else None, L.ptr(scratch[1:2]) if scaled else None, _st(x)),
-           "cc_cast_transpose_f16")
+                                     L.ptr(scratch[0:1]) if scaled else None, L.ptr(scratch[1:2]) if scaled else None, L.ptr(cs),
+                                     L.ptr(ws), ws.numel() if col_sums else 0, _st(x)), "cc_cast_transpose_f16")
+    if col_sums:
+        return out, out_t, (scratch[1:2] if scaled else None), cs
     return out, out_t, (scratch[1:2] if scaled else None)
 
 
@@ -106,8 +111,7 @@ def _wt16(w):
 def _grad_linear(dy32, x16, w16_t, need_dx=True):
     """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
     The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X)."""
-    db = _column_sums(dy32)
-    dy16, dy16_t, scale = _cast_transpose(dy32, scaled=True)
+    dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True)      # (+ the bias gradient from the same read)
     dx = _unscale(ops.linear_f16(dy16, w16_t, None, "f32"), scale) if need_dx else None      # dY W
     _, x16_t, _ = _cast_transpose(x16, scaled=False)
     dw = _unscale(ops.linear_f16(dy16_t, x16_t, None, "f32"), scale)                          # dY^T X

@@ -677,9 +677,13 @@ int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale
 /* The fp16 operand copies a Linear's backward multiplies, from ONE read of the matrix: `in` fp32 [rows, cols] (or in_f16, a
  * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = the transpose with zero columns
  * behind `rows` (rows_pad >= rows, a multiple of 64: the contraction of dW = dY^T X; cols % 4 == 0).  scaled != 0: the fp32
- * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale). */
+ * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale).
+ * col_sums (may be null; fp32 input only): the column sums of the unscaled matrix [cols] from the same read - the Linear's bias
+ * gradient - via per-tile partials in ws (cc_cast_transpose_colsum_workspace_bytes), added in tile order. */
+size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols);
 int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
-                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, void* stream);
+                          int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, float* col_sums, void* ws,
+                          size_t ws_bytes, void* stream);
 /* One BertAdam step on one parameter tensor (utils/optimization.py:100-170: the optimizer main.py:161-167 builds): grad is
  * clipped in place to max_grad_norm (clip_grad_norm_ on the single tensor; <= 0: no clipping), next_m = b1 m + (1-b1) g,
  * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.

@@ -392,6 +392,9 @@ def test_cast_transpose_operand_copies(M, C):
     assert torch.equal(out_t[:, :M], ref16.t()) and not out_t[:, M:].any()
     out, out_t, scale = cctrain._cast_transpose(x, scaled=False)
     assert scale is None and torch.equal(out, x.half()) and torch.equal(out_t[:, :M], x.half().t()) and not out_t[:, M:].any()
+    _, _, _, cs = cctrain._cast_transpose(x, scaled=True, col_sums=True)            # the bias gradient from the same read
+    want = x.double().sum(dim=0)
+    assert float((cs.double() - want).abs().max()) <= 1e-5 * float(x.abs().sum(dim=0).max()) + 1e-12
     xh = x.half() * 1000
     same, out_t, _ = cctrain._cast_transpose(xh, scaled=False)
     assert same.data_ptr() == xh.data_ptr() and torch.equal(out_t[:, :M], xh.t()) and not out_t[:, M:].any()
