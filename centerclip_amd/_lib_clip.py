@@ -85,6 +85,8 @@ def declare(lib):
     lib.cc_contrastive_grad_workspace_bytes.restype = sz
     lib.cc_contrastive_loss_grad_f32.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_contrastive_loss_grad_f32.restype = c.c_int
+    lib.cc_contrastive_loss_grad_dev_f32.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.cc_contrastive_loss_grad_dev_f32.restype = c.c_int
     lib.cc_normalize_rows_f32.argtypes = [vp, vp, i32, i32, vp]
     lib.cc_normalize_rows_f32.restype = c.c_int
     lib.cc_loose_similarity_grouped_f32.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, f32, vp, i32,
@@ -142,7 +144,7 @@ def declare(lib):
     lib.cc_cast_transpose_f16.restype = c.c_int
     lib.cc_bertadam_workspace_bytes.argtypes = []
     lib.cc_bertadam_workspace_bytes.restype = sz
-    lib.cc_bertadam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, sz, vp]
+    lib.cc_bertadam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, sz, vp]
     lib.cc_bertadam_step_f32.restype = c.c_int
     lib.cc_similarity_plane_row_bytes.argtypes = [i32]
     lib.cc_similarity_plane_row_bytes.restype = sz

@@ -124,7 +124,8 @@ class CLIP4Clip(nn.Module):
             seq, vis, vmask = sequence_output.contiguous(), visual_output.contiguous(), video_mask.contiguous()
             if ccdist.world_size() > 1:              # ONE collective for the three tensors, gradient slices of the own shard back
                 vis, vmask, seq = PackedAllGather.apply(vis, vmask, seq)
-            sim_loss, _, _ = contrastive_loss(seq, vis, vmask, self.clip.logit_scale, self._logit_scale_value())
+            # (logit_scale is read on the device: the optimizer changes it every step, and a host copy would be a synchronisation)
+            sim_loss, _, _ = contrastive_loss(seq, vis, vmask, self.clip.logit_scale)
             output_dict['loss'] = sim_loss + cluster_loss
             output_dict['cluster_loss'] = cluster_loss
             output_dict['sim_loss'] = sim_loss

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void bertadam_norm_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bertadam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                              float* __restrict__ v, int64_t n, const double* __restrict__ partial,
                                                              int nblocks, float lr, float b1, float b2, float eps, float wd,
-                                                             float max_norm) {
+                                                             float max_norm, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;                                      // (a captured step: the schedule's value arrives through memory)
     float coef = 1.f;
     if (max_norm > 0.f) {
         // the block partials, summed by the first wave in a fixed order (lane l takes l, l + 64, ...; then the wave tree)
@@ -542,9 +543,11 @@ size_t cc_bertadam_workspace_bytes(void) { return BA_BLOCKS * sizeof(double); }
 
 /* One BertAdam step on one parameter tensor (utils/optimization.py:100-170; all tensors fp32, n elements): grad is clipped in
  * place to max_grad_norm (<= 0: no clipping), next_m / next_v updated, param -= lr_scheduled * (m / (sqrt(v) + e) + wd * param).
- * lr_scheduled = lr * schedule(step / t_total, warmup) is the caller's (host arithmetic, centerclip_amd.train.BertAdam). */
+ * lr_scheduled = lr * schedule(step / t_total, warmup) is the caller's (host arithmetic, centerclip_amd.train.BertAdam);
+ * lr_dev != null: read from that device float instead (a step captured into a hipGraph is replayed with new values). */
 int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v, int64_t n, float lr_scheduled, float b1,
-                         float b2, float e, float weight_decay, float max_grad_norm, void* ws, size_t ws_bytes, void* stream) {
+                         float b2, float e, float weight_decay, float max_grad_norm, const float* lr_dev, void* ws, size_t ws_bytes,
+                         void* stream) {
     if (!param || !grad || !next_m || !next_v || n <= 0) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_bertadam_workspace_bytes()) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -552,7 +555,7 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
     const int nb = (int)((n + 1023) / 1024 < BA_BLOCKS ? (n + 1023) / 1024 : BA_BLOCKS);
     if (max_grad_norm > 0.f) hipLaunchKernelGGL(bertadam_norm_kernel, dim3(nb), dim3(256), 0, st, grad, n, partial);
     hipLaunchKernelGGL(bertadam_step_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, param, grad, next_m, next_v, n, partial, nb,
-                       lr_scheduled, b1, b2, e, weight_decay, max_grad_norm);
+                       lr_scheduled, b1, b2, e, weight_decay, max_grad_norm, lr_dev);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -696,7 +696,8 @@ __global__ __launch_bounds__(256) void ctr_prepare_kernel(const float* __restric
 }
 
 // S[i][j] = c * that_i . phat_j: one wave per (i, j)
-__global__ __launch_bounds__(256) void ctr_sim_kernel(CtrWs w, int n, int E, float c) {
+__global__ __launch_bounds__(256) void ctr_sim_kernel(CtrWs w, int n, int E, float c, const float* __restrict__ ls_dev) {
+    if (ls_dev) c = expf(*ls_dev);                               // (training: the parameter itself, no host read of it)
     const int lane = threadIdx.x & 63;
     const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= (int64_t)n * n) return;
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(256) void ctr_grad_sim_kernel(CtrWs w, int n, float
 __global__ __launch_bounds__(256) void ctr_grad_feat_kernel(const float* __restrict__ visual, const long long* __restrict__ mask,
                                                             int64_t mrs, int64_t mcs, int n, int Tn, int E, float c, CtrWs w,
                                                             float* __restrict__ d_text, float* __restrict__ d_visual,
-                                                            float* __restrict__ d_ls) {
+                                                            float* __restrict__ d_ls, const float* __restrict__ ls_dev) {
+    if (ls_dev) c = expf(*ls_dev);
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     constexpr int MAXE = 16;                                           // E <= 1024
@@ -828,6 +830,17 @@ extern "C" int cc_contrastive_loss_grad_f32(const float* text, const float* visu
                                             int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
                                             float logit_scale, float grad_scale, float* loss3, float* d_text, float* d_visual,
                                             float* d_logit_scale, void* ws, size_t ws_bytes, void* stream) {
+    return cc_contrastive_loss_grad_dev_f32(text, visual, video_mask, mask_row_stride, mask_col_stride, n, Tn, E, logit_scale, nullptr,
+                                            grad_scale, loss3, d_text, d_visual, d_logit_scale, ws, ws_bytes, stream);
+}
+
+/* the same with logit_scale read from device memory when logit_scale_dev != null (the nn.Parameter itself: a training step then
+ * neither synchronises with the host for its value nor bakes it into a captured graph) */
+extern "C" int cc_contrastive_loss_grad_dev_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                                int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
+                                                float logit_scale, const float* logit_scale_dev, float grad_scale, float* loss3,
+                                                float* d_text, float* d_visual, float* d_logit_scale, void* ws, size_t ws_bytes,
+                                                void* stream) {
     if (!text || !visual || !video_mask || !loss3 || !d_text || !d_visual || !d_logit_scale) return CC_ERR_INVALID;
     if (n <= 0 || Tn <= 0 || E <= 0) return CC_ERR_INVALID;
     if (E > 1024) return CC_ERR_UNSUPPORTED;
@@ -839,7 +852,7 @@ extern "C" int cc_contrastive_loss_grad_f32(const float* text, const float* visu
     hipLaunchKernelGGL(ctr_prepare_kernel, dim3((2 * n + 3) / 4), dim3(256), 0, st, text, visual, mk, mask_row_stride,
                        mask_col_stride, n, Tn, E, w);
     CC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctr_sim_kernel, dim3((unsigned)(((int64_t)n * n + 3) / 4)), dim3(256), 0, st, w, n, E, c);
+    hipLaunchKernelGGL(ctr_sim_kernel, dim3((unsigned)(((int64_t)n * n + 3) / 4)), dim3(256), 0, st, w, n, E, c, logit_scale_dev);
     CC_LAUNCH_CHECK();
     hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.S, n, (int64_t)n, (int64_t)1, w.nce);
     CC_LAUNCH_CHECK();
@@ -850,7 +863,7 @@ extern "C" int cc_contrastive_loss_grad_f32(const float* text, const float* visu
     hipLaunchKernelGGL(ctr_grad_sim_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w, n, grad_scale);
     CC_LAUNCH_CHECK();
     hipLaunchKernelGGL(ctr_grad_feat_kernel, dim3((2 * n + 1 + 3) / 4), dim3(256), 0, st, visual, mk, mask_row_stride,
-                       mask_col_stride, n, Tn, E, c, w, d_text, d_visual, d_logit_scale);
+                       mask_col_stride, n, Tn, E, c, w, d_text, d_visual, d_logit_scale, logit_scale_dev);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -44,9 +44,13 @@ class _ContrastiveLoss(torch.autograd.Function):
         mask = video_mask.reshape(vis.shape[0], -1).to(torch.long)
         if text.shape[0] != vis.shape[0]:
             raise ValueError("the contrastive loss pairs text i with video i: %d texts, %d videos" % (text.shape[0], vis.shape[0]))
-        if scale_value is None:                      # (a device -> host read; callers with a cached value pass it)
-            scale_value = float(logit_scale)
-        loss3, d_text, d_vis, d_ls = torch.ops.centerclip.contrastive_loss_grad(text, vis, mask, float(scale_value))
+        if scale_value is None and logit_scale.is_cuda and logit_scale.dtype == torch.float32:
+            # the parameter's own memory: no device -> host read (a training step stays asynchronous and can be captured)
+            loss3, d_text, d_vis, d_ls = torch.ops.centerclip.contrastive_loss_grad_dev(text, vis, mask, logit_scale.detach())
+        else:
+            if scale_value is None:                  # (a device -> host read; callers with a cached value pass it)
+                scale_value = float(logit_scale)
+            loss3, d_text, d_vis, d_ls = torch.ops.centerclip.contrastive_loss_grad(text, vis, mask, float(scale_value))
         ctx.save_for_backward(d_text, d_vis, d_ls)
         ctx.shapes = (sequence_output.shape, visual_output.shape, sequence_output.dtype, visual_output.dtype)
         l_tv, l_vt, loss = loss3[0], loss3[1], loss3[2]          # bind the views once: the marks below apply to THESE objects

@@ -955,6 +955,27 @@ def _(text, visual, video_mask, logit_scale):
     return text.new_empty((3,)), torch.empty_like(text), torch.empty_like(visual), text.new_empty((1,))
 
 
+@custom_op(NS + "::contrastive_loss_grad_dev", mutates_args=(), device_types="cuda")
+def contrastive_loss_grad_dev(text: torch.Tensor, visual: torch.Tensor, video_mask: torch.Tensor,
+                              logit_scale: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """contrastive_loss_grad with logit_scale read from the device (a 0-d / 1-element fp32 tensor: the parameter itself)."""
+    n, Tn, E = visual.shape
+    loss3 = _e(3, like=text, dtype=torch.float32)
+    d_text, d_visual = torch.empty_like(text), torch.empty_like(visual)
+    d_ls = _e(1, like=text, dtype=torch.float32)
+    ws = L.workspace(L.lib().cc_contrastive_grad_workspace_bytes(n, Tn, E), text.device)
+    L.check(L.lib().cc_contrastive_loss_grad_dev_f32(L.ptr(text), L.ptr(visual), L.ptr(video_mask), video_mask.stride(0),
+                                                     video_mask.stride(1), n, Tn, E, 0.0, L.ptr(logit_scale), 1.0, L.ptr(loss3),
+                                                     L.ptr(d_text), L.ptr(d_visual), L.ptr(d_ls), L.ptr(ws), ws.numel(), _st(text)),
+            "cc_contrastive_loss_grad_dev_f32")
+    return loss3, d_text, d_visual, d_ls
+
+
+@contrastive_loss_grad_dev.register_fake
+def _(text, visual, video_mask, logit_scale):
+    return text.new_empty((3,)), torch.empty_like(text), torch.empty_like(visual), text.new_empty((1,))
+
+
 @custom_op(NS + "::rank_counts_ref", mutates_args=(), device_types="cuda")
 def rank_counts_ref(sim: torch.Tensor, ref_vals: torch.Tensor, transpose: bool) -> torch.Tensor:
     """(#greater, #equal) than ref_vals[i] per row of sim (per COLUMN with transpose=True, through the strides): the
@@ -1005,7 +1026,7 @@ def _(sim):
     return sim.new_empty((3,))
 
 
-OPS = ("contrastive_loss", "contrastive_loss_grad", "spectral_laplacian", "spectral_graph_laplacian", "spectral_embedding", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
+OPS = ("contrastive_loss", "contrastive_loss_grad", "contrastive_loss_grad_dev", "spectral_laplacian", "spectral_graph_laplacian", "spectral_embedding", "svd_sign_flip", "linear_f16", "linear_f16_out", "layernorm", "attention_f16", "fold_layernorm_linear", "row_stats",
        "linear_ln_f16", "inproj_attention_f16", "linear_resid_stats_f16", "head_project", "token_cluster", "token_cluster_train", "token_cluster_backward", "token_apply_selection",
        "batch_kmedoids", "kmedoids_from_dist",
        "pairwise_distance", "pairwise_distance_cross", "token_norms", "vit_encode", "text_encode", "clip_encode_out", "clip_encode",

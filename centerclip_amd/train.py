@@ -335,7 +335,10 @@ class BertAdam(torch.optim.Optimizer):
     step is one cc_bertadam_step_f32 call per parameter (no host synchronisation)."""
 
     def __init__(self, params, lr, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
-                 weight_decay=0.01, max_grad_norm=1.0):
+                 weight_decay=0.01, max_grad_norm=1.0, capturable=False):
+        # capturable (not in the reference): the scheduled learning rate of each group reaches the kernels through a device
+        # float, so a step captured into a hipGraph can be replayed with the schedule's next value (GraphedTrainStep)
+        self.capturable = bool(capturable)
         if lr < 0.0:
             raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
         if schedule not in SCHEDULES:
@@ -373,7 +376,11 @@ class BertAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib = L.lib()
-        for group in self.param_groups:
+        capturing = self.capturable and torch.cuda.is_current_stream_capturing()
+        if not hasattr(self, "_lr_dev"):
+            self._lr_dev = {}                                     # group index -> 1-element device tensor (not optimizer state)
+        for gi, group in enumerate(self.param_groups):
+            lr_set = False
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -390,12 +397,36 @@ class BertAdam(torch.optim.Optimizer):
                     state['next_m'] = torch.zeros_like(p)
                     state['next_v'] = torch.zeros_like(p)
                 ws = L.workspace(lib.cc_bertadam_workspace_bytes(), p.device)
+                lr_dev = None
+                if self.capturable:
+                    lr_dev = self._lr_dev.get(gi)
+                    if lr_dev is None or lr_dev.device != p.device:
+                        lr_dev = self._lr_dev[gi] = torch.zeros(1, device=p.device, dtype=torch.float32)
+                    if not capturing and not lr_set:
+                        lr_dev.fill_(float(self._lr(group, state['step'])))
+                        lr_set = True
                 _check(lib.cc_bertadam_step_f32(L.ptr(p), L.ptr(grad), L.ptr(state['next_m']), L.ptr(state['next_v']), p.numel(),
                                                 float(self._lr(group, state['step'])), float(group['b1']), float(group['b2']),
                                                 float(group['e']), float(group['weight_decay']), float(group['max_grad_norm']),
-                                                L.ptr(ws), ws.numel(), _st(p)), "cc_bertadam_step_f32")
-                state['step'] += 1
+                                                L.ptr(lr_dev), L.ptr(ws), ws.numel(), _st(p)), "cc_bertadam_step_f32")
+                if not capturing:
+                    state['step'] += 1
         return loss
+
+    def refresh_lr(self):
+        """capturable: write every group's scheduled learning rate (from the host-side step counts) into its device float -
+        call before replaying a captured step."""
+        for gi, group in enumerate(self.param_groups):
+            steps = [self.state[p]['step'] for p in group['params'] if p in self.state and len(self.state[p])]
+            if steps and getattr(self, "_lr_dev", {}).get(gi) is not None:
+                self._lr_dev[gi].fill_(float(self._lr(group, steps[0])))
+
+    def advance(self):
+        """capturable: count one replayed step for every parameter that has state."""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p in self.state and len(self.state[p]):
+                    self.state[p]['step'] += 1
 
 
 def prep_optim_params_groups(args, model, coef_lr=1.):
@@ -447,3 +478,53 @@ def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_
         total_loss += float(loss.detach())
         nb += 1
     return total_loss / max(nb, 1), global_step
+
+
+class GraphedTrainStep:
+    """One training step (forward, backward, optimizer, logit_scale clamp - main.py:300-340 for one batch) captured into a
+    hipGraph and replayed on static input buffers: no op of the step synchronises with the host, so the replay runs at the GPU
+    time of its kernels instead of the host's launch rate (cfg-2 shape: 26 ms against 55-80 ms launched op by op).
+    Single process (a captured step cannot contain the RCCL exchange of GradientBuckets); fixed batch shape; an optimizer
+    built with capturable=True.  The first call warms up eagerly (2 steps on the given batch) and captures."""
+
+    def __init__(self, model, optimizer, gradient_accumulation_steps=1):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs BertAdam(..., capturable=True)")
+        if gradient_accumulation_steps != 1:
+            raise NotImplementedError("GraphedTrainStep: gradient accumulation is not built")
+        self.model, self.optimizer = model, optimizer
+        self.graph = self.static = self.loss = None
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.model(self.static[0], self.static[2], self.static[1], self.static[3], self.static[4])
+        loss = out['loss'].mean()
+        loss.backward()
+        self.optimizer.step()
+        with torch.no_grad():
+            self.model.clip.logit_scale.clamp_(0.1, 4.6052)
+        return loss.detach()
+
+    def __call__(self, batch):
+        """batch = (input_ids, input_mask, segment_ids, video, video_mask) as the dataloaders yield it -> the step's loss (a
+        device tensor that the next call overwrites)."""
+        dev = next(self.model.parameters()).device
+        if self.graph is None:
+            self.model.train()
+            self.static = [t.to(dev).clone() for t in batch]
+            for _ in range(2):
+                self._step()
+            torch.cuda.synchronize()
+            self.optimizer.refresh_lr()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step()
+            self.graph.replay()                                   # (the capture pass does not execute; this replay does:
+            self.optimizer.advance()                              #  the batch has now been stepped on three times)
+            return self.loss
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+        self.optimizer.refresh_lr()
+        self.graph.replay()
+        self.optimizer.advance()
+        return self.loss

@@ -60,31 +60,20 @@ def main():
         steady = (t[-1] - t[2]) / max(len(t) - 3, 1) if len(t) > 3 else float("nan")
         print("steady step %.0f ms = %.1f clips/s per rank (unfused per-op training path, launched op by op)" % (steady * 1e3, a.batch / steady))
     if a.graph and world == 1:
-        # the same step (forward, backward, optimizer) captured once into a hipGraph and replayed on static input buffers: no
-        # op of it synchronises with the host, so what remains is the GPU time of the unfused kernels
+        # the same step (forward, backward, optimizer, clamp) as ONE hipGraph on static input buffers (train.GraphedTrainStep):
+        # no op of it synchronises with the host, so what remains is the GPU time of the unfused kernels
+        from centerclip_amd.train import GraphedTrainStep
+        gopt = BertAdam(prep_optim_params_groups(targs, model, coef_lr=1e-3), lr=targs.lr, warmup=0.1, t_total=100 * a.steps,
+                        schedule='warmup_cosine', b1=0.9, b2=0.98, e=1e-6, max_grad_norm=1.0, capturable=True)
+        stepper = GraphedTrainStep(model, gopt)
         batch = next(iter(loader))
-        static = [x.to(device).clone() for x in batch]
-        model.train()
-
-        def one_step():
-            opt.zero_grad(set_to_none=False)
-            out = model(static[0], static[2], static[1], static[3], static[4])
-            out['loss'].backward()
-            opt.step()
-            return out['loss'].detach()
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            gloss = one_step()
-        torch.cuda.synchronize()
+        gloss = stepper(batch)
         for _ in range(3):
-            graph.replay()
+            stepper(batch)
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(10):
-            graph.replay()
+            gloss = stepper(batch)
         torch.cuda.synchronize()
         ms = (time.time() - t0) / 10 * 1e3
         print("captured step: %.1f ms = %.0f clips/s (loss %.4f)" % (ms, a.batch / ms * 1e3, float(gloss)))

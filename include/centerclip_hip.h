@@ -614,6 +614,13 @@ int cc_contrastive_loss_grad_f32(const float* text, const float* visual, const i
                                  int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
                                  float logit_scale, float grad_scale, float* loss3, float* d_text, float* d_visual,
                                  float* d_logit_scale, void* ws, size_t ws_bytes, void* stream);
+/* the same with logit_scale read from device memory when logit_scale_dev != null (the nn.Parameter itself: a training step then
+ * neither waits on the host for its value nor bakes it into a captured hipGraph) */
+int cc_contrastive_loss_grad_dev_f32(const float* text, const float* visual, const int64_t* video_mask,
+                                     int64_t mask_row_stride, int64_t mask_col_stride, int32_t n, int32_t Tn, int32_t E,
+                                     float logit_scale, const float* logit_scale_dev, float grad_scale, float* loss3,
+                                     float* d_text, float* d_visual, float* d_logit_scale, void* ws, size_t ws_bytes,
+                                     void* stream);
 
 /* N1 - the rank extraction of compute_metrics (utils/metrics.py:11-26) on the device: for row i with
  * ground-truth column g = diag_offset + i, counts[2i] = #{j: sim[i,j] > sim[i,g]} and counts[2i+1] =
@@ -689,8 +696,11 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
  * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.
  * lr_scheduled = lr * schedule(step / t_total, warmup) is host arithmetic (centerclip_amd.train.BertAdam).  All tensors fp32. */
 size_t cc_bertadam_workspace_bytes(void);
+/* (lr_dev, may be null: the scheduled learning rate read from a device float instead of lr_scheduled - a training step captured
+ * into a hipGraph is replayed with the schedule's new value written there first) */
 int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v, int64_t n, float lr_scheduled, float b1,
-                         float b2, float e, float weight_decay, float max_grad_norm, void* ws, size_t ws_bytes, void* stream);
+                         float b2, float e, float weight_decay, float max_grad_norm, const float* lr_dev, void* ws, size_t ws_bytes,
+                         void* stream);
 
 /* ==========================================================================================
  * Diagnostics (not on the product path; process-wide state, not thread-safe).

@@ -398,3 +398,34 @@ def test_cast_transpose_operand_copies(M, C):
     xh = x.half() * 1000
     same, out_t, _ = cctrain._cast_transpose(xh, scaled=False)
     assert same.data_ptr() == xh.data_ptr() and torch.equal(out_t[:, :M], xh.t()) and not out_t[:, M:].any()
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """train.GraphedTrainStep (forward + backward + BertAdam captured into one hipGraph, the schedule's value through a device
+    float) against the same steps launched op by op: identical parameters after 2 warm-up + 3 replayed steps."""
+    from argparse import Namespace
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd.train import BertAdam, prep_optim_params_groups, train_epoch, GraphedTrainStep
+    g, sd = _golden_clip()
+    B, T = int(g["cfg"][10]), int(g["cfg"][11])
+    video = torch.from_numpy(g["video"]).view(B, 1, T, 3, 64, 64)
+    ids = torch.from_numpy(g["t_ids"])[:B]
+    batch = (ids, (ids > 0).long(), torch.zeros_like(ids), video, torch.ones(B, 1, T, dtype=torch.long))
+    args = Namespace(lr=1e-3, wd=0.2, new_added_modules=["Cross"], gradient_accumulation_steps=1, clip_grad_norm=None)
+
+    def make(capturable):
+        m = CLIP4Clip.from_state_dict(sd, _train_cfg(T)).float().to("cuda:0")
+        o = BertAdam(prep_optim_params_groups(args, m), lr=args.lr, warmup=0.2, t_total=20, schedule='warmup_linear', b1=0.9, b2=0.98,
+                     e=1e-6, max_grad_norm=1.0, capturable=capturable)
+        return m, o
+    m0, o0 = make(False)
+    train_epoch(0, args, m0, [batch] * 5, "cuda:0", o0, 0)
+    m1, o1 = make(True)
+    stepper = GraphedTrainStep(m1, o1)
+    for _ in range(3):                                                  # first call: 2 eager steps + capture + 1 replay
+        loss = stepper(batch)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert all(st["step"] == 5 for st in o1.state.values())
+    for (k, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p0, p1), k
