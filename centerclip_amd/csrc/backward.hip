@@ -446,6 +446,34 @@ __global__ __launch_bounds__(256) void bertadam_step_kernel(float* __restrict__ 
         p[i] = pi - lr * upd;
     }
 }
+// small tensors (biases, LayerNorm parameters: two thirds of a CLIP model's tensors): norm and step in ONE single-workgroup launch
+__global__ __launch_bounds__(256) void bertadam_small_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                                              float wd, float max_norm, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        __shared__ double red[4];
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) { const double x = (double)g[i]; s += x * x; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float c = max_norm / ((float)sqrt((red[0] + red[1]) + (red[2] + red[3])) + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] * b1 + (1.f - b1) * gi;
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float upd = mi / (sqrtf(vi) + eps);
+        const float pi = p[i];
+        if (wd > 0.f) upd += wd * pi;
+        g[i] = gi; m[i] = mi; v[i] = vi;
+        p[i] = pi - lr * upd;
+    }
+}
 
 extern "C" {
 
@@ -551,6 +579,12 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
     if (!param || !grad || !next_m || !next_v || n <= 0) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_bertadam_workspace_bytes()) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n <= 8192) {
+        hipLaunchKernelGGL(bertadam_small_kernel, dim3(1), dim3(256), 0, st, param, grad, next_m, next_v, (int)n, lr_scheduled, b1, b2, e,
+                           weight_decay, max_grad_norm, lr_dev);
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
     double* partial = static_cast<double*>(ws);
     const int nb = (int)((n + 1023) / 1024 < BA_BLOCKS ? (n + 1023) / 1024 : BA_BLOCKS);
     if (max_grad_norm > 0.f) hipLaunchKernelGGL(bertadam_norm_kernel, dim3(nb), dim3(256), 0, st, grad, n, partial);
