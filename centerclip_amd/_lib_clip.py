@@ -138,12 +138,16 @@ def declare(lib):
     lib.cc_cast_scaled_f16.restype = c.c_int
     lib.cc_unscale_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.cc_unscale_f32.restype = c.c_int
+    lib.cc_linear_unscaled_f16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.cc_linear_unscaled_f16.restype = c.c_int
     lib.cc_cast_transpose_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.cc_cast_transpose_colsum_workspace_bytes.argtypes = [i32, i32]
     lib.cc_cast_transpose_colsum_workspace_bytes.restype = sz
     lib.cc_cast_transpose_f16.restype = c.c_int
     lib.cc_bertadam_workspace_bytes.argtypes = []
     lib.cc_bertadam_workspace_bytes.restype = sz
+    lib.cc_bertadam_multi_f32.argtypes = [vp, i32, f32, f32, f32, f32, vp]
+    lib.cc_bertadam_multi_f32.restype = c.c_int
     lib.cc_bertadam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, sz, vp]
     lib.cc_bertadam_step_f32.restype = c.c_int
     lib.cc_similarity_plane_row_bytes.argtypes = [i32]

@@ -19,7 +19,7 @@ namespace {
 constexpr int LNB_ROWS = 32;        // rows per workgroup (4 waves x 8 rows)
 
 // One wave per row; lane l owns columns l*4 + t*256 (t < 4: W <= 1024).  Per-workgroup partial sums of dgamma / dbeta go
-// to part [blocks][2][W]; lnb_reduce_kernel adds them in block order.
+// to part [blocks][2][W]; column_reduce_kernel adds them (eight segments in block order, then the segments).
 __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, int64_t x_stride,
                                                                  const float* __restrict__ gamma, const float* __restrict__ dy,
                                                                  const float* __restrict__ dres, float* __restrict__ dx,
@@ -96,19 +96,6 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(256) void lnb_reduce_kernel(const float* __restrict__ part, int blocks, int W,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < blocks; ++i) {
-        a += part[((int64_t)i * 2 + 0) * W + w];
-        b += part[((int64_t)i * 2 + 1) * W + w];
-    }
-    dgamma[w] = a;
-    dbeta[w] = b;
-}
-
 __global__ __launch_bounds__(256) void quick_gelu_backward_kernel(const _Float16* __restrict__ u_pre, const float* __restrict__ du,
                                                                   float* __restrict__ out, int64_t n) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
@@ -151,13 +138,27 @@ __global__ __launch_bounds__(256) void column_partial_kernel(const float* __rest
     for (int r = r0; r < r1; ++r) s += in[(int64_t)r * cols + c];
     part[(int64_t)blockIdx.y * cols + c] = s;
 }
+// out[c] = sum over chunks of part[chunk][c]: 32 columns x 8 chunk segments per workgroup, each segment added in chunk order and
+// the eight segment sums in segment order (fixed bits; a three-workgroup serial loop over 300 partials took 27 us).  Columns
+// >= split go to out2[c - split] (the LayerNorm backward's [blocks][2][W] partials: dgamma | dbeta).
 __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restrict__ part, int chunks, int cols,
-                                                            float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+                                                            float* __restrict__ out, float* __restrict__ out2, int split) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int per = (chunks + 7) / 8, i0 = seg * per, i1 = min(chunks, i0 + per);
     float s = 0.f;
-    for (int i = 0; i < chunks; ++i) s += part[(int64_t)i * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int i = i0; i < i1; ++i) s += part[(int64_t)i * cols + c];
+    red[seg][cl] = s;
+    __syncthreads();
+    if (seg == 0 && c < cols) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][cl];
+        if (c < split) out[c] = t;
+        else out2[c - split] = t;
+    }
 }
 
 // Attention backward, one workgroup per (sequence, head), head_dim 64, L <= 64.  q, k, v rows of qkv [nseq*L, 3W] fp16
@@ -446,11 +447,10 @@ __global__ __launch_bounds__(256) void bertadam_step_kernel(float* __restrict__ 
         p[i] = pi - lr * upd;
     }
 }
-// small tensors (biases, LayerNorm parameters: two thirds of a CLIP model's tensors): norm and step in ONE single-workgroup launch
-__global__ __launch_bounds__(256) void bertadam_small_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                              float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
-                                                              float wd, float max_norm, const float* __restrict__ lr_dev) {
-    if (lr_dev) lr = *lr_dev;
+// small tensors (biases, LayerNorm parameters: two thirds of a CLIP model's tensors): norm and step by ONE workgroup
+__device__ __forceinline__ void bertadam_small_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float wd,
+                                                    float max_norm) {
     float coef = 1.f;
     if (max_norm > 0.f) {
         __shared__ double red[4];
@@ -474,6 +474,26 @@ __global__ __launch_bounds__(256) void bertadam_small_kernel(float* __restrict__
         p[i] = pi - lr * upd;
     }
 }
+__global__ __launch_bounds__(256) void bertadam_small_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                                              float wd, float max_norm, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;
+    bertadam_small_body(p, g, m, v, n, lr, b1, b2, eps, wd, max_norm);
+}
+// ... and all of a model's small tensors in one launch: workgroup i takes items[i] (cc_bertadam_item, include/centerclip_hip.h)
+struct BertAdamItem {
+    float* p; float* g; float* m; float* v;
+    const float* lr_dev;
+    int32_t n;
+    float lr, wd;
+    int32_t pad_;
+};
+static_assert(sizeof(BertAdamItem) == 56, "cc_bertadam_item layout");
+__global__ __launch_bounds__(256) void bertadam_multi_small_kernel(const BertAdamItem* __restrict__ items, float b1, float b2, float eps,
+                                                                    float max_norm) {
+    const BertAdamItem it = items[blockIdx.x];
+    bertadam_small_body(it.p, it.g, it.m, it.v, it.n, it.lr_dev ? *it.lr_dev : it.lr, b1, b2, eps, it.wd, max_norm);
+}
 
 extern "C" {
 
@@ -491,8 +511,8 @@ int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gam
     const int blocks = (rows + LNB_ROWS - 1) / LNB_ROWS;
     hipLaunchKernelGGL(layernorm_backward_kernel, dim3(blocks), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
                        static_cast<float*>(ws), rows, W, eps);
-    hipLaunchKernelGGL(lnb_reduce_kernel, dim3((W + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), blocks, W,
-                       dgamma, dbeta);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * W + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), blocks, 2 * W,
+                       dgamma, dbeta, W);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -525,8 +545,8 @@ int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, 
     const int chunks = (rows + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(column_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, st, in, rows, cols,
                        static_cast<float*>(ws));
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), chunks,
-                       cols, out);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), chunks,
+                       cols, out, out, cols);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -594,6 +614,16 @@ int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v
     return CC_OK;
 }
 
+/* BertAdam steps of `count` small tensors (n <= CC_BERTADAM_MULTI_MAX_N each) in one launch: items_dev = count cc_bertadam_item
+ * records in device memory (include/centerclip_hip.h); per tensor the arithmetic - and the bits - of cc_bertadam_step_f32. */
+int cc_bertadam_multi_f32(const void* items_dev, int32_t count, float b1, float b2, float e, float max_grad_norm, void* stream) {
+    if (!items_dev || count <= 0) return CC_ERR_INVALID;
+    hipLaunchKernelGGL(bertadam_multi_small_kernel, dim3(count), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const BertAdamItem*>(items_dev), b1, b2, e, max_grad_norm);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 /* fp16 operand copies of a matrix for the backward of a Linear: `in` fp32 [rows, cols] (or in_f16, already fp16) ->
  * out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = its transpose with zero columns behind `rows`
  * (rows_pad >= rows, a multiple of 64; cols % 4 == 0).  scaled != 0: fp32 input scaled by the device-chosen power of two of
@@ -621,8 +651,8 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
                        cols, rows_pad, scaled ? amax_scratch : nullptr, scaled ? scale_out : nullptr,
                        col_sums ? static_cast<float*>(ws) : nullptr);
     if (col_sums)
-        hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), rows_pad / 64,
-                           cols, col_sums);
+        hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), rows_pad / 64,
+                           cols, col_sums, col_sums, cols);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -52,6 +52,9 @@ struct GemmArgs {
     // any value >= n_valid (unaligned rows fall back to scalar stores).  The similarity GEMM of similarity.hip.
     float out_scale;
     int n_valid;
+    // EPI_F32 only: when non-null the product is also divided by *out_unscale_dev (a power-of-two operand scale chosen on the
+    // device by cc_cast_scaled_f16 / cc_cast_transpose_f16: the backward's dgrad / wgrad GEMMs undo it in their epilogue).
+    const float* out_unscale_dev;
     // Split-K workspace (host side only reads it from p[0]): CC_GEMM_SK_WS_BYTES of device memory whose first
     // CC_GEMM_SK_FLAG_BYTES are zero before the first launch that uses it (every launch leaves them zero again).  Null:
     // the dispatcher never picks a split-K form.

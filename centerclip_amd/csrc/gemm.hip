@@ -1078,7 +1078,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     float* dst = reinterpret_cast<float*>(g.C) + ((int64_t)f * (g.patch_n + 1) + tok) * g.ldc + ncol;
                     *reinterpret_cast<float4*>(dst) = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
                 } else {
-                    const float sc = g.out_scale != 0.f ? g.out_scale : 1.f;
+                    float sc = g.out_scale != 0.f ? g.out_scale : 1.f;
+                    if (g.out_unscale_dev) sc /= *g.out_unscale_dev;      // power of two: exact
                     const int nv = g.n_valid > 0 ? g.n_valid : g.N;
                     float* dst = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol;
                     if (ncol + 3 < nv && (g.ldc & 3) == 0) {
@@ -1674,6 +1675,17 @@ int cc_linear_ws_f16(const void* a_f16, const void* w_f16, const float* bias, vo
     g.M = M; g.N = N; g.K = K; g.ldc = ldc;
     g.sk_ws = ws;
     return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
+}
+int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32_t M, int32_t N, int32_t K,
+                           const float* scale_dev, void* stream) {
+    if (!a_f16 || !w_f16 || !c || !scale_dev) return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(a_f16);
+    g.W = static_cast<const _Float16*>(w_f16);
+    g.C = c;
+    g.M = M; g.N = N; g.K = K; g.ldc = N;
+    g.out_unscale_dev = scale_dev;
+    return cc_gemm_dispatch(g, EPI_F32, 0, static_cast<hipStream_t>(stream));
 }
 int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
                   int32_t ldc, int32_t epilogue, int32_t tile, void* stream) {

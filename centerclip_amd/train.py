@@ -79,6 +79,18 @@ def _unscale(x32, scale):
     return x32
 
 
+def _linear_unscaled(a16, w16, scale):
+    """(a w^T) / scale in fp32: the GEMM with the operand's device-chosen scale undone in its epilogue."""
+    M, K = a16.shape
+    N = w16.shape[0]
+    assert a16.dtype == torch.float16 and w16.dtype == torch.float16 and a16.is_contiguous() and w16.is_contiguous()
+    assert w16.shape[1] == K and scale.dtype == torch.float32
+    out = torch.empty(M, N, device=a16.device, dtype=torch.float32)
+    _check(L.lib().cc_linear_unscaled_f16(L.ptr(a16), L.ptr(w16), L.ptr(out), M, N, K, L.ptr(scale), _st(a16)),
+           "cc_linear_unscaled_f16")
+    return out
+
+
 def _column_sums(x32):
     rows, cols = x32.shape
     out = torch.empty(cols, device=x32.device, dtype=torch.float32)
@@ -112,9 +124,9 @@ def _grad_linear(dy32, x16, w16_t, need_dx=True):
     """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
     The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X)."""
     dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True)      # (+ the bias gradient from the same read)
-    dx = _unscale(ops.linear_f16(dy16, w16_t, None, "f32"), scale) if need_dx else None      # dY W
+    dx = _linear_unscaled(dy16, w16_t, scale) if need_dx else None                            # dY W
     _, x16_t, _ = _cast_transpose(x16, scaled=False)
-    dw = _unscale(ops.linear_f16(dy16_t, x16_t, None, "f32"), scale)                          # dY^T X
+    dw = _linear_unscaled(dy16_t, x16_t, scale)                                               # dY^T X
     return dx, dw, db
 
 
@@ -141,7 +153,9 @@ def block_forward_train(block, x_lnd):
     z = y.clone()
     ops.linear_f16(u, f16(block.mlp["c_proj"].weight), f32(block.mlp["c_proj"].bias), "f32_resid", out=z)
     saved = dict(x=x, n1=n1, qkv=qkv, att=att, y=y, n2=n2, u_pre=u_pre, u=u, shape=(Lt, N, W), causal=causal)
-    return z.view(N, Lt, W).permute(1, 0, 2).contiguous(), saved
+    # (a VIEW of the frame-major rows: the next block's permute + contiguous then costs nothing - a chain of plain blocks never
+    # copies its activations between the two layouts)
+    return z.view(N, Lt, W).permute(1, 0, 2), saved
 
 
 def block_backward(block, saved, dz_lnd):
@@ -168,7 +182,7 @@ def block_backward(block, saved, dz_lnd):
                                              int(saved["causal"]), _st(dz)), "cc_attention_backward_f16")
     dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight))
     dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy)
-    return dx.view(N, Lt, W).permute(1, 0, 2).contiguous(), g
+    return dx.view(N, Lt, W).permute(1, 0, 2), g
 
 
 _PARAM_ORDER = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias", "ln_1.weight",
@@ -372,6 +386,41 @@ class BertAdam(torch.optim.Optimizer):
                 lr.append(self._lr(group, state['step']))
         return lr
 
+    _MULTI_MAX_N = 8192                     # CC_BERTADAM_MULTI_MAX_N (include/centerclip_hip.h)
+
+    def _multi_small(self, items, hyper, capturing, device):
+        """All small tensors of groups with the same (b1, b2, e, max_grad_norm) in ONE launch (cc_bertadam_multi_f32): the
+        records (cc_bertadam_item: four tensor pointers, the group's device learning rate, n, weight decay) are staged through
+        pinned memory and re-sent only when a pointer changed.  A captured step owns its own staging buffers (the graph replays
+        the host-to-device copy), allocated during the eager warm-up that precedes the capture."""
+        import numpy as np
+        rec = np.zeros(len(items), dtype=np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('lr_dev', '<u8'),
+                                                   ('n', '<i4'), ('lr', '<f4'), ('wd', '<f4'), ('pad', '<i4')]))
+        for i, (p, grad, m, v, lr_dev, wd) in enumerate(items):
+            rec[i] = (p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), lr_dev.data_ptr(), p.numel(), 0.0, wd, 0)
+        raw = rec.tobytes()
+        slot = self._multi.setdefault(hyper, {})
+        if capturing:
+            host, dev = slot.pop("spare", (None, None))
+            if host is None or host.numel() != len(raw):
+                raise RuntimeError("BertAdam: run one eager step with the same parameters before capturing (staging buffers)")
+            host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dev.copy_(host, non_blocking=True)
+            self._multi_keep.append((host, dev))                  # the graph reads both on every replay
+        else:
+            if slot.get("raw") != raw:
+                host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+                if slot.get("dev") is None or slot["dev"].numel() != len(raw):
+                    slot["dev"] = torch.empty(len(raw), dtype=torch.uint8, device=device)
+                slot["dev"].copy_(host, non_blocking=True)
+                slot["raw"] = raw
+            if "spare" not in slot or slot["spare"][0].numel() != len(raw):
+                slot["spare"] = (torch.empty(len(raw), dtype=torch.uint8).pin_memory(),
+                                 torch.empty(len(raw), dtype=torch.uint8, device=device))
+            dev = slot["dev"]
+        b1, b2, e, max_norm = hyper
+        _check(L.lib().cc_bertadam_multi_f32(L.ptr(dev), len(items), b1, b2, e, max_norm, _st(dev)), "cc_bertadam_multi_f32")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -379,6 +428,8 @@ class BertAdam(torch.optim.Optimizer):
         capturing = self.capturable and torch.cuda.is_current_stream_capturing()
         if not hasattr(self, "_lr_dev"):
             self._lr_dev = {}                                     # group index -> 1-element device tensor (not optimizer state)
+            self._multi, self._multi_keep = {}, []
+        small = {}                                                # (b1, b2, e, max_grad_norm) -> records of the small tensors
         for gi, group in enumerate(self.param_groups):
             lr_set = False
             for p in group['params']:
@@ -405,12 +456,18 @@ class BertAdam(torch.optim.Optimizer):
                     if not capturing and not lr_set:
                         lr_dev.fill_(float(self._lr(group, state['step'])))
                         lr_set = True
-                _check(lib.cc_bertadam_step_f32(L.ptr(p), L.ptr(grad), L.ptr(state['next_m']), L.ptr(state['next_v']), p.numel(),
-                                                float(self._lr(group, state['step'])), float(group['b1']), float(group['b2']),
-                                                float(group['e']), float(group['weight_decay']), float(group['max_grad_norm']),
-                                                L.ptr(lr_dev), L.ptr(ws), ws.numel(), _st(p)), "cc_bertadam_step_f32")
+                if self.capturable and p.numel() <= self._MULTI_MAX_N:
+                    hyper = (float(group['b1']), float(group['b2']), float(group['e']), float(group['max_grad_norm']))
+                    small.setdefault(hyper, []).append((p, grad, state['next_m'], state['next_v'], lr_dev, float(group['weight_decay'])))
+                else:
+                    _check(lib.cc_bertadam_step_f32(L.ptr(p), L.ptr(grad), L.ptr(state['next_m']), L.ptr(state['next_v']), p.numel(),
+                                                    float(self._lr(group, state['step'])), float(group['b1']), float(group['b2']),
+                                                    float(group['e']), float(group['weight_decay']), float(group['max_grad_norm']),
+                                                    L.ptr(lr_dev), L.ptr(ws), ws.numel(), _st(p)), "cc_bertadam_step_f32")
                 if not capturing:
                     state['step'] += 1
+        for hyper, items in small.items():
+            self._multi_small(items, hyper, capturing, items[0][0].device)
         return loss
 
     def refresh_lr(self):
@@ -496,7 +553,7 @@ class GraphedTrainStep:
         self.graph = self.static = self.loss = None
 
     def _step(self):
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=True)       # (captured: the gradients live in the graph's pool, no fill + accumulate)
         out = self.model(self.static[0], self.static[2], self.static[1], self.static[3], self.static[4])
         loss = out['loss'].mean()
         loss.backward()

@@ -681,6 +681,11 @@ size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
 int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
 int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);
 int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale_b, void* stream);
+/* c [M, N] fp32 = (a [M, K] w [N, K]^T) / *scale_dev: cc_linear_f16's "f32" form with the unscale above folded into the
+ * epilogue (the dgrad / wgrad products of an operand cast by cc_cast_scaled_f16 / cc_cast_transpose_f16; the division by a
+ * power of two is exact, so the result equals cc_linear_f16 followed by cc_unscale_f32 bit for bit). */
+int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32_t M, int32_t N, int32_t K,
+                           const float* scale_dev, void* stream);
 /* The fp16 operand copies a Linear's backward multiplies, from ONE read of the matrix: `in` fp32 [rows, cols] (or in_f16, a
  * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = the transpose with zero columns
  * behind `rows` (rows_pad >= rows, a multiple of 64: the contraction of dW = dY^T X; cols % 4 == 0).  scaled != 0: the fp32
@@ -701,6 +706,20 @@ size_t cc_bertadam_workspace_bytes(void);
 int cc_bertadam_step_f32(float* param, float* grad, float* next_m, float* next_v, int64_t n, float lr_scheduled, float b1,
                          float b2, float e, float weight_decay, float max_grad_norm, const float* lr_dev, void* ws, size_t ws_bytes,
                          void* stream);
+/* All of a model's small tensors (biases, LayerNorm weights: n <= CC_BERTADAM_MULTI_MAX_N, the size up to which
+ * cc_bertadam_step_f32 itself uses one workgroup) in ONE launch: items_dev = `count` records below in device memory, one
+ * workgroup each; per tensor the arithmetic and the bits of cc_bertadam_step_f32 (lr_dev != null: the learning rate is read
+ * from that device float, otherwise `lr`).  The records hold device pointers: the caller keeps them valid until the launch
+ * has run (centerclip_amd.train.BertAdam stages them through pinned memory). */
+#define CC_BERTADAM_MULTI_MAX_N 8192
+typedef struct cc_bertadam_item {
+    float* param; float* grad; float* next_m; float* next_v;
+    const float* lr_dev;
+    int32_t n;
+    float lr, weight_decay;
+    int32_t reserved;
+} cc_bertadam_item;                                            /* 56 bytes */
+int cc_bertadam_multi_f32(const void* items_dev, int32_t count, float b1, float b2, float e, float max_grad_norm, void* stream);
 
 /* ==========================================================================================
  * Diagnostics (not on the product path; process-wide state, not thread-safe).

@@ -400,6 +400,22 @@ def test_cast_transpose_operand_copies(M, C):
     assert same.data_ptr() == xh.data_ptr() and torch.equal(out_t[:, :M], xh.t()) and not out_t[:, M:].any()
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 3072, 9600), (9600, 768, 2304), (320, 512, 512)])
+def test_linear_with_the_operand_scale_undone_in_the_epilogue(M, N, K):
+    """cc_linear_unscaled_f16 = cc_linear_f16 ("f32") followed by cc_unscale_f32, bit for bit (the scale is a power of two)."""
+    from centerclip_amd import ops, train as cctrain
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = (torch.randn(M, K, generator=g) * 2e-5).cuda()
+    w16 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().half()
+    dy16, scale = cctrain._cast_scaled(dy)
+    want = cctrain._unscale(ops.linear_f16(dy16, w16, None, "f32"), scale)
+    got = cctrain._linear_unscaled(dy16, w16, scale)
+    torch.cuda.synchronize()
+    assert float(scale) > 1.0 and torch.equal(got, want)
+    ref = dy.double() @ w16.double().t()
+    assert float((got.double() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 def test_graphed_train_step_equals_eager_steps():
     """train.GraphedTrainStep (forward + backward + BertAdam captured into one hipGraph, the schedule's value through a device
     float) against the same steps launched op by op: identical parameters after 2 warm-up + 3 replayed steps."""
