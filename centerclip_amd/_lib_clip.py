@@ -122,13 +122,13 @@ def declare(lib):
     lib.cc_similarity_workspace_bytes.restype = sz
     lib.cc_layernorm_backward_workspace_bytes.argtypes = [i32, i32]
     lib.cc_layernorm_backward_workspace_bytes.restype = sz
-    lib.cc_layernorm_backward_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, sz, vp]
+    lib.cc_layernorm_backward_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, sz, vp]
     lib.cc_layernorm_backward_f32.restype = c.c_int
     lib.cc_quick_gelu_f16.argtypes = [vp, vp, i64, vp]
     lib.cc_quick_gelu_f16.restype = c.c_int
-    lib.cc_quick_gelu_backward_f16.argtypes = [vp, vp, vp, i64, vp]
+    lib.cc_quick_gelu_backward_f16.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.cc_quick_gelu_backward_f16.restype = c.c_int
-    lib.cc_attention_backward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.cc_attention_backward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.cc_attention_backward_f16.restype = c.c_int
     lib.cc_column_sums_workspace_bytes.argtypes = [i32, i32]
     lib.cc_column_sums_workspace_bytes.restype = sz

@@ -18,14 +18,32 @@ namespace {
 
 constexpr int LNB_ROWS = 32;        // rows per workgroup (4 waves x 8 rows)
 
+// The largest magnitude of what a workgroup wrote, into *bits (non-negative floats order as their bit patterns): the next
+// cc_cast_transpose_f16 of that tensor (scaled = 2) then needs no pass of its own over it.  One atomic per workgroup; every
+// thread of the 256 calls it.
+__device__ __forceinline__ void publish_absmax(float m, unsigned* __restrict__ bits) {
+    __shared__ float wmax_[4];
+    m = cc_wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax_[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (a workgroup whose maximum does not exceed the published one skips the atomic - a stale read only costs an atomic that
+        //  changes nothing; after the first few workgroups almost all skip, so the grid need not be capped for it)
+        const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax_[0], wmax_[1]), fmaxf(wmax_[2], wmax_[3])));
+        if (mine > __atomic_load_n(bits, __ATOMIC_RELAXED)) atomicMax(bits, mine);
+    }
+}
+
 // One wave per row; lane l owns columns l*4 + t*256 (t < 4: W <= 1024).  Per-workgroup partial sums of dgamma / dbeta go
 // to part [blocks][2][W]; column_reduce_kernel adds them (eight segments in block order, then the segments).
 __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, int64_t x_stride,
                                                                  const float* __restrict__ gamma, const float* __restrict__ dy,
                                                                  const float* __restrict__ dres, float* __restrict__ dx,
-                                                                 float* __restrict__ part, int rows, int W, float eps) {
+                                                                 float* __restrict__ part, int rows, int W, float eps,
+                                                                 unsigned* __restrict__ amax_bits) {
     __shared__ float red[2][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float am = 0.f;
     float4 dg[4], db[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) dg[t] = db[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
                 *reinterpret_cast<float4*>(dx + (int64_t)row * W + w) = o;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
         }
     }
@@ -94,10 +113,13 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
         part[((int64_t)blockIdx.x * 2 + 0) * W + w] = ((red[0][0][w] + red[0][1][w]) + red[0][2][w]) + red[0][3][w];
         part[((int64_t)blockIdx.x * 2 + 1) * W + w] = ((red[1][0][w] + red[1][1][w]) + red[1][2][w]) + red[1][3][w];
     }
+    if (amax_bits) publish_absmax(am, amax_bits);
 }
 
 __global__ __launch_bounds__(256) void quick_gelu_backward_kernel(const _Float16* __restrict__ u_pre, const float* __restrict__ du,
-                                                                  float* __restrict__ out, int64_t n) {
+                                                                  float* __restrict__ out, int64_t n,
+                                                                  unsigned* __restrict__ amax_bits) {
+    float am = 0.f;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
         const h4 x = *reinterpret_cast<const h4*>(u_pre + i);
         const float4 d = *reinterpret_cast<const float4*>(du + i);
@@ -108,9 +130,11 @@ __global__ __launch_bounds__(256) void quick_gelu_backward_kernel(const _Float16
             const float xv = (float)x[e];
             const float s = 1.0f / (1.0f + expf(-1.702f * xv));
             o[e] = dd[e] * (s + 1.702f * xv * s * (1.0f - s));
+            am = fmaxf(am, fabsf(o[e]));
         }
         *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    if (amax_bits) publish_absmax(am, amax_bits);
 }
 
 // u = QuickGELU(u_pre) on fp16 (the training forward keeps the pre-activation for the backward pass)
@@ -167,7 +191,8 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restr
 constexpr int AB_L = 64, AB_D = 64;
 constexpr int AB_SMEM = (4 * AB_L * (AB_D + 1) + 2 * AB_L * (AB_L + 1)) * 4;
 __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ d_out,
-                                                                 float* __restrict__ d_qkv, int L, int heads, int W, int causal) {
+                                                                 float* __restrict__ d_qkv, int L, int heads, int W, int causal,
+                                                                 unsigned* __restrict__ amax_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];          // AB_SMEM bytes (> the 64 KB static limit)
     float (*Q)[AB_D + 1] = reinterpret_cast<float (*)[AB_D + 1]>(ab_smem);
     float (*K)[AB_D + 1] = Q + AB_L;
@@ -253,6 +278,7 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
     }
     __syncthreads();
     // dV = P^T dO ; dQ = dS K / 8 ; dK = dS^T Q / 8: thread (bt, bd) owns tokens 4 bt.. x features 4 bd..
+    float am = 0.f;
     {
         const int bt = tid >> 4, bd = tid & 15;
         if (4 * bt < L) {
@@ -282,10 +308,219 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(const _Float16*
                     *reinterpret_cast<float4*>(o) = make_float4(dq[u][0] * 0.125f, dq[u][1] * 0.125f, dq[u][2] * 0.125f, dq[u][3] * 0.125f);
                     *reinterpret_cast<float4*>(o + W) = make_float4(dk[u][0] * 0.125f, dk[u][1] * 0.125f, dk[u][2] * 0.125f, dk[u][3] * 0.125f);
                     *reinterpret_cast<float4*>(o + 2 * W) = make_float4(dv[u][0], dv[u][1], dv[u][2], dv[u][3]);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        am = fmaxf(fmaxf(am, fabsf(dv[u][w])), 0.125f * fmaxf(fabsf(dq[u][w]), fabsf(dk[u][w])));
                 }
             }
         }
     }
+    if (amax_bits) publish_absmax(am, amax_bits);
+}
+
+// Attention backward on the matrix cores (L <= 64, head_dim 64): the five 64 x 64 x 64 products of a head as fp16 MFMAs with fp32
+// accumulators instead of fp32 FMAs (the fp32 kernel above spends 95 us per ViT-B/32 block on 3.7 GFLOP of VALU work; the
+// tensors it moves are worth 30 us).  One workgroup per (sequence, head), wave w owns queries 16w..16w+15 for S / dP / dS / dQ
+// and keys 16w..16w+15 for dV / dK.  fp16 operands: q, k, v as stored; dO scaled by a power of two chosen from the head's own
+// largest |dO| (exact to apply and remove); P; dS scaled by a second power of two from the head's largest |dS| - the same
+// operand precision the dgrad / wgrad GEMMs around it have.  MFMA convention (transformer.hip): D[x row 4 lg + e][y row l15] =
+// sum_k X[x row][k] Y[y row][k], a fragment = 8 consecutive k of row (lane & 15) at k = 32 ks + 8 (lane >> 4).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ABM_S = 72;                                        // LDS row stride (halves): 144 B rows, 16-byte aligned
+constexpr int ABM_SMEM = (6 * 64 + 4 * 16) * ABM_S * 2 + 64;
+__device__ __forceinline__ float pow2_scale_for(float amax) {    // 2^k with 2^k amax in [8192, 16384): cc_cast_scaled_f16's rule
+    return (amax > 0.f && isfinite(amax)) ? exp2f(fminf(floorf(log2f(16384.0f / amax)), 100.f)) : 1.0f;
+}
+__global__ __launch_bounds__(256) void attention_backward_mfma_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ d_out,
+                                                                      float* __restrict__ d_qkv, int L, int heads, int W, int causal,
+                                                                      unsigned* __restrict__ amax_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char abm_smem[];
+    _Float16* Kt = reinterpret_cast<_Float16*>(abm_smem);        // [d][token]
+    _Float16* Qt = Kt + 64 * ABM_S;                              // [d][token]
+    _Float16* dOt = Qt + 64 * ABM_S;                             // [d][token]   (scaled)
+    _Float16* dO16 = dOt + 64 * ABM_S;                           // [token][d]   (scaled)
+    _Float16* Pt = dO16 + 64 * ABM_S;                            // [key][query]
+    _Float16* dSt = Pt + 64 * ABM_S;                             // [key][query] (scaled)
+    _Float16* dSw = dSt + 64 * ABM_S;                            // per wave [16 queries][keys] (scaled)
+    float* wred = reinterpret_cast<float*>(dSw + 4 * 16 * ABM_S);      // [8]: two cross-wave maxima
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const int64_t row0 = (int64_t)seq * L;
+    const int64_t ld = 3 * (int64_t)W;
+    const _Float16* base = qkv + row0 * ld + head * 64;
+    const float* dob = d_out + row0 * W + head * 64;
+
+    // ---- stage: K^T, Q^T (fp16 as stored) and dO (fp32 -> scaled fp16, both layouts); token rows >= L are zeros
+    float4 dof[2][2];
+    h8 kc[2], qc[2];
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+        if (r < L) {
+            kc[c] = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + W + ch * 8);
+            qc[c] = *reinterpret_cast<const h8*>(base + (int64_t)r * ld + ch * 8);
+            dof[c][0] = *reinterpret_cast<const float4*>(dob + (int64_t)r * W + ch * 8);
+            dof[c][1] = *reinterpret_cast<const float4*>(dob + (int64_t)r * W + ch * 8 + 4);
+        } else {
+            kc[c] = qc[c] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            dof[c][0] = dof[c][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(dof[c][h].x), fabsf(dof[c][h].y))), fmaxf(fabsf(dof[c][h].z), fabsf(dof[c][h].w)));
+    }
+    am = cc_wave_max(am);
+    if (lane == 0) wred[wave] = am;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            Kt[(ch * 8 + e) * ABM_S + r] = kc[c][e];
+            Qt[(ch * 8 + e) * ABM_S + r] = qc[c][e];
+        }
+    }
+    __syncthreads();
+    const float s_o = pow2_scale_for(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+        const float v[8] = {dof[c][0].x, dof[c][0].y, dof[c][0].z, dof[c][0].w, dof[c][1].x, dof[c][1].y, dof[c][1].z, dof[c][1].w};
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (_Float16)(v[e] * s_o);
+            dOt[(ch * 8 + e) * ABM_S + r] = o[e];
+        }
+        *reinterpret_cast<h8*>(dO16 + r * ABM_S + ch * 8) = o;
+    }
+    // ---- the wave's query strip: S = Q K^T / 8 -> P, dP = dO V^T (operands of the key side straight from global memory)
+    const int qi = wave * 16 + l15;                               // the query this lane's accumulators belong to
+    const int qrow = min(qi, L - 1);
+    h8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)qrow * ld + (ks * 4 + lg) * 8);
+    f32x4 p[4];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int kr = min(kt * 16 + l15, L - 1);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const h8 kf = *reinterpret_cast<const h8*>(base + (int64_t)kr * ld + W + (ks * 4 + lg) * 8);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = kt * 16 + lg * 4 + e;
+            const bool ok = key < L && (!causal || key <= qi);
+            a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+            mx = fmaxf(mx, a[e]);
+        }
+        p[kt] = a;
+    }
+    mx = cc_rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pe = (p[kt][e] > -1.0e38f) ? __expf(p[kt][e] - mx) : 0.f;
+            p[kt][e] = pe;
+            sum += pe;
+        }
+    sum = cc_rows_sum(sum);
+    const float inv = (qi < L) ? 1.0f / sum : 0.f;                // (padding queries contribute nothing)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[kt][e] *= inv;
+    __syncthreads();                                              // dO16 / dOt / Kt / Qt complete
+    f32x4 ds[4];
+    float dot = 0.f;
+    {
+        h8 of[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) of[ks] = *reinterpret_cast<const h8*>(dO16 + qi * ABM_S + (ks * 4 + lg) * 8);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int kr = min(kt * 16 + l15, L - 1);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const h8 vf = *reinterpret_cast<const h8*>(base + (int64_t)kr * ld + 2 * W + (ks * 4 + lg) * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, of[ks], a, 0, 0, 0);
+            }
+            ds[kt] = a;                                           // dP (times s_o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = fmaf(a[e], p[kt][e], dot);
+        }
+    }
+    dot = cc_rows_sum(dot);
+    float ams = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ds[kt][e] = p[kt][e] * (ds[kt][e] - dot);             // dS (times s_o); 0 where P is 0
+            ams = fmaxf(ams, fabsf(ds[kt][e]));
+        }
+    ams = cc_wave_max(ams);
+    if (lane == 0) wred[4 + wave] = ams;
+    __syncthreads();
+    const float s_s = pow2_scale_for(fmaxf(fmaxf(wred[4], wred[5]), fmaxf(wred[6], wred[7])));
+    _Float16* dSm = dSw + wave * 16 * ABM_S;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        h4 d4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = kt * 16 + lg * 4 + e;
+            d4[e] = (_Float16)(ds[kt][e] * s_s);
+            Pt[key * ABM_S + qi] = (_Float16)p[kt][e];
+            dSt[key * ABM_S + qi] = d4[e];
+        }
+        *reinterpret_cast<h4*>(dSm + l15 * ABM_S + kt * 16 + lg * 4) = d4;
+    }
+    __syncthreads();
+    // ---- dQ (this wave's queries) = dS K / 8;  dV, dK (this wave's keys) = P^T dO, dS^T Q / 8
+    const float un_v = 1.0f / s_o, un_q = 0.125f * un_v / s_s;
+    const bool live = qi < L;                                     // qi doubles as the key index of dV / dK rows
+    float* orow = d_qkv + (row0 + qi) * ld + head * 64;
+    float amo = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
+        const int d = dt * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int ko = kb * 32 + lg * 8;
+            const h8 ktf = *reinterpret_cast<const h8*>(Kt + d * ABM_S + ko);
+            const h8 dsf = *reinterpret_cast<const h8*>(dSm + l15 * ABM_S + ko);
+            aq = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf, aq, 0, 0, 0);
+            const h8 otf = *reinterpret_cast<const h8*>(dOt + d * ABM_S + ko);
+            const h8 ptf = *reinterpret_cast<const h8*>(Pt + qi * ABM_S + ko);
+            av = __builtin_amdgcn_mfma_f32_16x16x32_f16(otf, ptf, av, 0, 0, 0);
+            const h8 qtf = *reinterpret_cast<const h8*>(Qt + d * ABM_S + ko);
+            const h8 stf = *reinterpret_cast<const h8*>(dSt + qi * ABM_S + ko);
+            ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, stf, ak, 0, 0, 0);
+        }
+        if (live) {
+            const float4 oq = make_float4(aq[0] * un_q, aq[1] * un_q, aq[2] * un_q, aq[3] * un_q);
+            const float4 ok_ = make_float4(ak[0] * un_q, ak[1] * un_q, ak[2] * un_q, ak[3] * un_q);
+            const float4 ov = make_float4(av[0] * un_v, av[1] * un_v, av[2] * un_v, av[3] * un_v);
+            float* o = orow + dt * 16 + lg * 4;
+            *reinterpret_cast<float4*>(o) = oq;
+            *reinterpret_cast<float4*>(o + W) = ok_;
+            *reinterpret_cast<float4*>(o + 2 * W) = ov;
+            amo = fmaxf(amo, fmaxf(fmaxf(fmaxf(fabsf(oq.x), fabsf(oq.y)), fmaxf(fabsf(oq.z), fabsf(oq.w))),
+                                   fmaxf(fmaxf(fabsf(ok_.x), fabsf(ok_.y)), fmaxf(fabsf(ok_.z), fabsf(ok_.w)))));
+            amo = fmaxf(amo, fmaxf(fmaxf(fabsf(ov.x), fabsf(ov.y)), fmaxf(fabsf(ov.z), fabsf(ov.w))));
+        }
+    }
+    if (amax_bits) publish_absmax(amo, amax_bits);
 }
 
 // ---- fp32 gradients through the fp16 matrix cores: |x| max -> scale = 2^k with scale * max in [8192, 16384) -> fp16 copy
@@ -302,8 +537,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ i
     __shared__ float wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));   // (non-negative floats order as their bits)
+    if (threadIdx.x == 0) {
+        const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));   // (non-negative floats order as their bits)
+        if (mine > __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMax(out_bits, mine);
+    }
 }
 __global__ __launch_bounds__(256) void cast_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int64_t n,
                                                           const float* __restrict__ amax, float* __restrict__ scale_out) {
@@ -503,24 +740,24 @@ size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W) {
 }
 
 int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gamma, const float* dy, const float* dres,
-                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, void* ws,
-                              size_t ws_bytes, void* stream) {
+                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, float* dx_amax,
+                              void* ws, size_t ws_bytes, void* stream) {
     if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || rows <= 0 || W <= 0 || (W & 3) || W > 1024) return CC_ERR_INVALID;
     if (!ws || ws_bytes < cc_layernorm_backward_workspace_bytes(rows, W)) return CC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int blocks = (rows + LNB_ROWS - 1) / LNB_ROWS;
     hipLaunchKernelGGL(layernorm_backward_kernel, dim3(blocks), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                       static_cast<float*>(ws), rows, W, eps);
+                       static_cast<float*>(ws), rows, W, eps, reinterpret_cast<unsigned*>(dx_amax));
     hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * W + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), blocks, 2 * W,
                        dgamma, dbeta, W);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
 
-int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, void* stream) {
+int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, float* out_amax, void* stream) {
     if (!u_pre_f16 || !du || !du_pre || n <= 0 || (n & 3)) return CC_ERR_INVALID;
     hipLaunchKernelGGL(quick_gelu_backward_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const _Float16*>(u_pre_f16), du, du_pre, n);
+                       static_cast<const _Float16*>(u_pre_f16), du, du_pre, n, reinterpret_cast<unsigned*>(out_amax));
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -552,7 +789,7 @@ int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, 
 }
 
 int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L, int32_t heads,
-                              int32_t W, int32_t causal, void* stream) {
+                              int32_t W, int32_t causal, float* out_amax, void* stream) {
     if (!qkv_f16 || !d_out || !d_qkv || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * AB_D) return CC_ERR_INVALID;
     if (L > AB_L) return CC_ERR_UNSUPPORTED;
     static bool configured = false;              // benign race (idempotent call)
@@ -562,8 +799,24 @@ int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_
             return CC_ERR_HIP;
         configured = true;
     }
+#ifndef CC_ATTENTION_BACKWARD_FP32
+    {
+        static bool configured_m = false;        // benign race (idempotent call)
+        if (!configured_m) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_backward_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ABM_SMEM) != hipSuccess)
+                return CC_ERR_HIP;
+            configured_m = true;
+        }
+        hipLaunchKernelGGL(attention_backward_mfma_kernel, dim3(nseq * heads), dim3(256), ABM_SMEM, static_cast<hipStream_t>(stream),
+                           static_cast<const _Float16*>(qkv_f16), d_out, d_qkv, L, heads, W, causal,
+                           reinterpret_cast<unsigned*>(out_amax));
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
+#endif
     hipLaunchKernelGGL(attention_backward_kernel, dim3(nseq * heads), dim3(256), AB_SMEM, static_cast<hipStream_t>(stream),
-                       static_cast<const _Float16*>(qkv_f16), d_out, d_qkv, L, heads, W, causal);
+                       static_cast<const _Float16*>(qkv_f16), d_out, d_qkv, L, heads, W, causal, reinterpret_cast<unsigned*>(out_amax));
     CC_LAUNCH_CHECK();
     return CC_OK;
 }
@@ -640,7 +893,7 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
     if (scaled && (!in || !amax_scratch || !scale_out)) return CC_ERR_INVALID;
     if (col_sums && (!in || !ws || ws_bytes < cc_cast_transpose_colsum_workspace_bytes(rows_pad, cols))) return col_sums && in ? CC_ERR_WORKSPACE : CC_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (scaled) {
+    if (scaled == 1) {                                            // (2: *amax_scratch already holds the largest magnitude)
         if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) return CC_ERR_HIP;
         const unsigned ab = grid_for((int64_t)rows * cols, 256 * 16);
         hipLaunchKernelGGL(absmax_kernel, dim3(ab < 2048 ? ab : 2048), dim3(256), 0, st, in, (int64_t)rows * cols,

@@ -1333,6 +1333,13 @@ static int pick_tile(const GemmArgs& g, int epi) {
     // the small tile with 128-deep k-steps: c_proj of the clustered blocks 25.5 -> 21.2 us alone, 2.158 vs 2.166 ms per step;
     // since the round-3 loop (pinned phase-start wait) their out_proj (K = 768) gains too: 9.8 vs 10.7 us alone, 2.048-2.058
     // vs 2.059-2.061 ms per step in 3 same-session A/B rounds
+    // (the backward's wgrad GEMMs - fp32 output, the row count as the contraction: the 128-deep tile holds one workgroup per CU
+    // (96 KB of stage buffers), so a grid of 2.25 rounds runs three; the 64-deep one packs several per CU and does not care:
+    // dW c_fc 3072 x 768 x 9600 80.9 vs 105.8 us, while dW in_proj (432 workgroups = 1.7 rounds) stays 58.8 vs 69.7)
+    if (epi == EPI_F32) {
+        const long wgs = mt64 * (g.N / 64);
+        if (wgs > 256 && (double)wgs / (double)((wgs + 255) / 256 * 256) < 0.8) return 4;
+    }
     return (g.K % 128 == 0 && g.K >= 768) ? 8 : 4;
 }
 

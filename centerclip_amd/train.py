@@ -39,10 +39,12 @@ def _pad64(n):
     return -(-n // 64) * 64
 
 
-def _cast_transpose(x, scaled, want_out=True, col_sums=False):
+def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None):
     """One read of a matrix -> its fp16 operand copies for a Linear's backward (cc_cast_transpose_f16):
     x fp32 [M, C] -> (x16 [M, C], x16^T [C, Mp] zero padded to a multiple of 64, scale or None); x fp16 -> (x, x^T, None).
-    scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor)."""
+    scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor); amax: a 2-float
+    device tensor whose first entry already holds the largest |x| (written by the kernel that produced x) - the pass over x that
+    finds it is skipped, the scale lands in the second entry."""
     x = x.contiguous()
     M, C = x.shape
     Mp = _pad64(M)
@@ -53,10 +55,10 @@ def _cast_transpose(x, scaled, want_out=True, col_sums=False):
                "cc_cast_transpose_f16")
         return x, out_t, None
     out = torch.empty(M, C, device=x.device, dtype=torch.float16) if want_out else None
-    scratch = torch.empty(2, device=x.device, dtype=torch.float32) if scaled else None
+    scratch = (amax if amax is not None else torch.empty(2, device=x.device, dtype=torch.float32)) if scaled else None
     cs = torch.empty(C, device=x.device, dtype=torch.float32) if col_sums else None
     ws = L.workspace(lib.cc_cast_transpose_colsum_workspace_bytes(Mp, C), x.device) if col_sums else None
-    _check(lib.cc_cast_transpose_f16(L.ptr(x), None, L.ptr(out), L.ptr(out_t), M, C, Mp, int(bool(scaled)),
+    _check(lib.cc_cast_transpose_f16(L.ptr(x), None, L.ptr(out), L.ptr(out_t), M, C, Mp, (2 if amax is not None else 1) if scaled else 0,
                                      L.ptr(scratch[0:1]) if scaled else None, L.ptr(scratch[1:2]) if scaled else None, L.ptr(cs),
                                      L.ptr(ws), ws.numel() if col_sums else 0, _st(x)), "cc_cast_transpose_f16")
     if col_sums:
@@ -100,14 +102,14 @@ def _column_sums(x32):
     return out
 
 
-def _ln_backward(x, gamma, dy, dres, eps=1e-5):
+def _ln_backward(x, gamma, dy, dres, eps=1e-5, amax=None):
     rows, W = x.shape
     dx = torch.empty_like(x)
     dg, db = torch.empty(W, device=x.device), torch.empty(W, device=x.device)
     lib = L.lib()
     ws = L.workspace(lib.cc_layernorm_backward_workspace_bytes(rows, W), x.device)
     _check(lib.cc_layernorm_backward_f32(L.ptr(x), W, L.ptr(gamma), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(dg), L.ptr(db),
-                                         rows, W, float(eps), L.ptr(ws), ws.numel(), _st(x)), "cc_layernorm_backward_f32")
+                                         rows, W, float(eps), L.ptr(amax), L.ptr(ws), ws.numel(), _st(x)), "cc_layernorm_backward_f32")
     return dx, dg, db
 
 
@@ -120,13 +122,24 @@ def _wt16(w):
     return wt if wt.shape[1] == N else wt[:, :N].contiguous()
 
 
-def _grad_linear(dy32, x16, w16_t, need_dx=True):
+def _w16_pair(w):
+    """fp32 master weight [N, K] -> (W fp16 for the forward GEMM, W^T [K, N] fp16 for the backward's dgrad) from ONE read."""
+    w = w.detach()
+    if w.dtype != torch.float32:
+        return w.to(torch.float16).contiguous(), None
+    w16, wt, _ = _cast_transpose(w, scaled=False)
+    N = w.shape[0]
+    return w16, (wt if wt.shape[1] == N else wt[:, :N].contiguous())
+
+
+def _grad_linear(dy32, x16, w16_t, need_dx=True, amax=None):
     """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
     The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X)."""
-    dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True)      # (+ the bias gradient from the same read)
-    dx = _linear_unscaled(dy16, w16_t, scale) if need_dx else None                            # dY W
+    dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True, amax=amax)   # (+ the bias gradient, same read)
     _, x16_t, _ = _cast_transpose(x16, scaled=False)
     dw = _linear_unscaled(dy16_t, x16_t, scale)                                               # dY^T X
+    # (dX last: the kernel that consumes it runs next and finds it in the memory-side cache)
+    dx = _linear_unscaled(dy16, w16_t, scale) if need_dx else None                            # dY W
     return dx, dw, db
 
 
@@ -138,21 +151,23 @@ def block_forward_train(block, x_lnd):
     Lt, N, W = x_lnd.shape
     M = N * Lt
     causal = block.attn_mask is not None
-    f16 = lambda t: t.detach().to(torch.float16).contiguous()
     f32 = lambda t: t.detach().float().contiguous()
     x = x_lnd.detach().float().permute(1, 0, 2).contiguous().view(M, W)              # frame-major rows (row = seq*L + token)
+    wq, wo, wf, wp = (_w16_pair(w) for w in (block.attn.in_proj_weight, block.attn.out_proj.weight, block.mlp["c_fc"].weight,
+                                             block.mlp["c_proj"].weight))
     n1 = ops.layernorm(x, f32(block.ln_1.weight), f32(block.ln_1.bias), out_f16=True)
-    qkv = ops.linear_f16(n1, f16(block.attn.in_proj_weight), f32(block.attn.in_proj_bias), "f16")
+    qkv = ops.linear_f16(n1, wq[0], f32(block.attn.in_proj_bias), "f16")
     att = ops.attention_f16(qkv, N, Lt, block.n_head, causal=causal)
     y = x.clone()
-    ops.linear_f16(att, f16(block.attn.out_proj.weight), f32(block.attn.out_proj.bias), "f32_resid", out=y)
+    ops.linear_f16(att, wo[0], f32(block.attn.out_proj.bias), "f32_resid", out=y)
     n2 = ops.layernorm(y, f32(block.ln_2.weight), f32(block.ln_2.bias), out_f16=True)
-    u_pre = ops.linear_f16(n2, f16(block.mlp["c_fc"].weight), f32(block.mlp["c_fc"].bias), "f16")
+    u_pre = ops.linear_f16(n2, wf[0], f32(block.mlp["c_fc"].bias), "f16")
     u = torch.empty_like(u_pre)
     _check(L.lib().cc_quick_gelu_f16(L.ptr(u_pre), L.ptr(u), u.numel(), _st(u)), "cc_quick_gelu_f16")
     z = y.clone()
-    ops.linear_f16(u, f16(block.mlp["c_proj"].weight), f32(block.mlp["c_proj"].bias), "f32_resid", out=z)
-    saved = dict(x=x, n1=n1, qkv=qkv, att=att, y=y, n2=n2, u_pre=u_pre, u=u, shape=(Lt, N, W), causal=causal)
+    ops.linear_f16(u, wp[0], f32(block.mlp["c_proj"].bias), "f32_resid", out=z)
+    wt = dict(in_proj=wq[1], out_proj=wo[1], c_fc=wf[1], c_proj=wp[1])                  # W^T of the same read, for the dgrads
+    saved = dict(x=x, n1=n1, qkv=qkv, att=att, y=y, n2=n2, u_pre=u_pre, u=u, shape=(Lt, N, W), causal=causal, wt=wt)
     # (a VIEW of the frame-major rows: the next block's permute + contiguous then costs nothing - a chain of plain blocks never
     # copies its activations between the two layouts)
     return z.view(N, Lt, W).permute(1, 0, 2), saved
@@ -162,25 +177,29 @@ def block_backward(block, saved, dz_lnd):
     """dz [L, N, W] -> (dx [L, N, W], {parameter name: gradient}) for the forward that produced ``saved``."""
     Lt, N, W = saved["shape"]
     M = N * Lt
-    f16t = _wt16                                                                        # W^T as the dgrad's operand
+    wt = saved.get("wt", {})
+    f16t = lambda w, key: wt[key] if wt.get(key) is not None else _wt16(w)              # W^T as the dgrad's operand
     f32 = lambda t: t.detach().float().contiguous()
     dz = dz_lnd.detach().float().permute(1, 0, 2).contiguous().view(M, W)
     g = {}
     # z = y + c_proj(u)
-    du, g["mlp.c_proj.weight"], g["mlp.c_proj.bias"] = _grad_linear(dz, saved["u"], f16t(block.mlp["c_proj"].weight))
+    du, g["mlp.c_proj.weight"], g["mlp.c_proj.bias"] = _grad_linear(dz, saved["u"], f16t(block.mlp["c_proj"].weight, "c_proj"))
     # u = QuickGELU(u_pre)
+    # (the three gradients this function produces AND multiplies publish their largest magnitude from the producing kernel:
+    #  the fp16 cast of each then needs no pass of its own to choose the scale)
+    am = torch.zeros(3, 2, device=dz.device, dtype=torch.float32)
     du_pre = torch.empty_like(du)
-    _check(L.lib().cc_quick_gelu_backward_f16(L.ptr(saved["u_pre"]), L.ptr(du), L.ptr(du_pre), du.numel(), _st(du)),
+    _check(L.lib().cc_quick_gelu_backward_f16(L.ptr(saved["u_pre"]), L.ptr(du), L.ptr(du_pre), du.numel(), L.ptr(am[0]), _st(du)),
            "cc_quick_gelu_backward_f16")
     # u_pre = c_fc(ln_2(y))
-    dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = _grad_linear(du_pre, saved["n2"], f16t(block.mlp["c_fc"].weight))
-    dy, g["ln_2.weight"], g["ln_2.bias"] = _ln_backward(saved["y"], f32(block.ln_2.weight), dn2, dz)      # + the residual branch
+    dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = _grad_linear(du_pre, saved["n2"], f16t(block.mlp["c_fc"].weight, "c_fc"), amax=am[0])
+    dy, g["ln_2.weight"], g["ln_2.bias"] = _ln_backward(saved["y"], f32(block.ln_2.weight), dn2, dz, amax=am[1])   # + the residual branch
     # y = x + out_proj(att)
-    datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight))
+    datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight, "out_proj"), amax=am[1])
     dqkv = torch.empty(M, 3 * W, device=dz.device, dtype=torch.float32)
     _check(L.lib().cc_attention_backward_f16(L.ptr(saved["qkv"]), L.ptr(datt), L.ptr(dqkv), N, Lt, block.n_head, W,
-                                             int(saved["causal"]), _st(dz)), "cc_attention_backward_f16")
-    dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight))
+                                             int(saved["causal"]), L.ptr(am[2]), _st(dz)), "cc_attention_backward_f16")
+    dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight, "in_proj"), amax=am[2])
     dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy)
     return dx.view(N, Lt, W).permute(1, 0, 2), g
 

@@ -670,13 +670,16 @@ int cc_group_max_rows_f32(const float* sim, int32_t rows, int32_t cols, int64_t 
  *                               device float.  cc_unscale_f32 divides an fp32 product by one or two such scales.
  * ========================================================================================== */
 size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W);
+/* (dx_amax / out_amax below, may be null: one device float that holds 0 - or an earlier maximum - on entry and max(it, the
+ *  largest magnitude written) on exit, so that cc_cast_transpose_f16(scaled = 2) can scale that tensor without reading it
+ *  first; one atomic per workgroup of the producing kernel) */
 int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gamma, const float* dy, const float* dres,
-                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, void* ws,
-                              size_t ws_bytes, void* stream);
+                              float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t W, float eps, float* dx_amax,
+                              void* ws, size_t ws_bytes, void* stream);
 int cc_quick_gelu_f16(const void* in_f16, void* out_f16, int64_t n, void* stream);     /* QuickGELU on fp16 (training forward) */
-int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, void* stream);
+int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, float* out_amax, void* stream);
 int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L,
-                              int32_t heads, int32_t W, int32_t causal, void* stream);
+                              int32_t heads, int32_t W, int32_t causal, float* out_amax, void* stream);
 size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
 int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
 int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);
@@ -689,7 +692,9 @@ int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32
 /* The fp16 operand copies a Linear's backward multiplies, from ONE read of the matrix: `in` fp32 [rows, cols] (or in_f16, a
  * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = the transpose with zero columns
  * behind `rows` (rows_pad >= rows, a multiple of 64: the contraction of dW = dY^T X; cols % 4 == 0).  scaled != 0: the fp32
- * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale).
+ * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale);
+ * scaled == 2: *amax_scratch already holds the tensor's largest magnitude (written by the kernel that produced the tensor,
+ * see dx_amax / out_amax above) and the pass that finds it is skipped.
  * col_sums (may be null; fp32 input only): the column sums of the unscaled matrix [cols] from the same read - the Linear's bias
  * gradient - via per-tile partials in ws (cc_cast_transpose_colsum_workspace_bytes), added in tile order. */
 size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols);

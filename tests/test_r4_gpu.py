@@ -416,6 +416,67 @@ def test_linear_with_the_operand_scale_undone_in_the_epilogue(M, N, K):
     assert float((got.double() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("nseq,L,heads,causal", [(6, 50, 2, False), (5, 32, 3, True), (3, 64, 1, False), (4, 17, 2, True)])
+def test_attention_backward_on_the_matrix_cores(nseq, L, heads, causal):
+    """cc_attention_backward_f16 (fp16 MFMA operands, per-head power-of-two scales for dO and dS) against torch.autograd in fp64
+    on the same fp16 q, k, v: every part of d_qkv within 2e-3 of its largest entry, gradients of tiny magnitude included."""
+    from centerclip_amd import _lib as L_, train as cctrain                                 # noqa: F401
+    from centerclip_amd.torch_ops import _st
+    W = heads * 64
+    g = torch.Generator().manual_seed(nseq * 100 + L)
+    qkv = torch.randn(nseq * L, 3 * W, generator=g).cuda().half()
+    for mag in (1.0, 3e-7):
+        d_out = (torch.randn(nseq * L, W, generator=g) * mag).cuda()
+        # sequences get different magnitudes: the scale is chosen per head of a sequence
+        d_out.view(nseq, L, W)[0] *= 64.0
+        got = torch.empty(nseq * L, 3 * W, device="cuda")
+        am = torch.zeros(2, device="cuda")
+        L_.check(L_.lib().cc_attention_backward_f16(L_.ptr(qkv), L_.ptr(d_out), L_.ptr(got), nseq, L, heads, W, int(causal),
+                                                    L_.ptr(am), _st(got)), "cc_attention_backward_f16")
+        x = qkv.double().view(nseq, L, 3, heads, 64).permute(2, 0, 3, 1, 4).detach().requires_grad_(True)   # [3, n, h, L, 64]
+        sc = x[0] @ x[1].transpose(-1, -2) / 8.0
+        if causal:
+            sc = sc + torch.full((L, L), float("-inf"), device="cuda", dtype=torch.float64).triu_(1)
+        out = (sc.softmax(dim=-1) @ x[2]).permute(0, 2, 1, 3).reshape(nseq * L, W)
+        (out * d_out.double()).sum().backward()
+        want = x.grad.permute(1, 3, 0, 2, 4).reshape(nseq * L, 3 * W)
+        torch.cuda.synchronize()
+        for part in range(3):
+            a, b = got[:, part * W:(part + 1) * W].double(), want[:, part * W:(part + 1) * W]
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), (part, mag)
+        assert float(am[0]) == float(got.abs().max())
+
+
+def test_gradient_producers_publish_their_largest_magnitude():
+    """cc_layernorm_backward_f32 / cc_quick_gelu_backward_f16 / cc_attention_backward_f16 with an amax pointer: the float equals
+    the largest |output|, and cc_cast_transpose_f16(scaled = 2) on it gives the copies and the scale of the two-pass form."""
+    from centerclip_amd import _lib as L, train as cctrain
+    from centerclip_amd.torch_ops import _st
+    g = torch.Generator().manual_seed(77)
+    rows, W, heads, Lt = 12 * 50, 128, 2, 50
+    am = torch.zeros(3, 2, device="cuda")
+    x = torch.randn(rows, W, generator=g).cuda()
+    dy = (torch.randn(rows, W, generator=g) * 3e-4).cuda()
+    dres = (torch.randn(rows, W, generator=g) * 1e-4).cuda()
+    dx, _, _ = cctrain._ln_backward(x, torch.ones(W, device="cuda"), dy, dres, amax=am[0])
+    u_pre = torch.randn(rows, 4 * W, generator=g).cuda().half()
+    du = (torch.randn(rows, 4 * W, generator=g) * 2e-5).cuda()
+    du_pre = torch.empty_like(du)
+    L.check(L.lib().cc_quick_gelu_backward_f16(L.ptr(u_pre), L.ptr(du), L.ptr(du_pre), du.numel(), L.ptr(am[1]), _st(du)), "gelu bwd")
+    qkv = torch.randn(rows, 3 * W, generator=g).cuda().half()
+    datt = (torch.randn(rows, W, generator=g) * 1e-3).cuda()
+    dqkv = torch.empty(rows, 3 * W, device="cuda")
+    L.check(L.lib().cc_attention_backward_f16(L.ptr(qkv), L.ptr(datt), L.ptr(dqkv), rows // Lt, Lt, heads, W, 0, L.ptr(am[2]),
+                                              _st(datt)), "attention bwd")
+    torch.cuda.synchronize()
+    for i, t in enumerate((dx, du_pre, dqkv)):
+        assert float(am[i, 0]) == float(t.abs().max()) > 0.0
+        a16, a16t, scale = cctrain._cast_transpose(t, scaled=True)
+        b16, b16t, scale2 = cctrain._cast_transpose(t, scaled=True, amax=am[i])
+        torch.cuda.synchronize()
+        assert float(scale) == float(scale2) and torch.equal(a16, b16) and torch.equal(a16t, b16t)
+
+
 def test_graphed_train_step_equals_eager_steps():
     """train.GraphedTrainStep (forward + backward + BertAdam captured into one hipGraph, the schedule's value through a device
     float) against the same steps launched op by op: identical parameters after 2 warm-up + 3 replayed steps."""
