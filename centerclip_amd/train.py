@@ -11,7 +11,7 @@
 * backward: the four Linear layers' dgrad (dX = dY W) and wgrad (dW = dY^T X) run on the SAME fp16 MFMA GEMM kernel with
   swapped operand roles - ``cc_linear_f16(a, w)`` computes a w^T, so dX = linear(dY, W^T) and dW = linear(dY^T, X^T) with the
   row count (padded to 64) as the contraction; gradients enter the matrix cores as fp16 with a per-tensor power-of-two scale
-  chosen on the device (cc_cast_scaled_f16 / cc_unscale_f32: no host synchronisation); LayerNorm, QuickGELU, attention
+  chosen on the device (cc_cast_transpose_f16 / cc_linear_unscaled_f16: no host synchronisation); LayerNorm, QuickGELU, attention
   and bias gradients are the fp32 kernels of csrc/backward.hip.
 * ``ResidualAttentionBlockFunction`` wires both into torch.autograd (d/dx and the 12 parameter gradients), so a block can sit
   in a graph that ends in losses.contrastive_loss; dist.GradientBuckets then averages the gradients over the ranks.
@@ -20,9 +20,10 @@ Round 4, later: the towers themselves (encode_image_train / encode_text_train be
 a token-cluster module in front, the heads), BertAdam (utils/optimization.py) on cc_bertadam_step_f32 and train_epoch
 (main.py:291-378) - CLIP4Clip.forward in training mode runs on them, so a training step reaches every parameter.  What is NOT
 here: linear_patch='3d' and mean_residual in training, fp16 GradScaler semantics (the master weights are fp32 and the HIP
-backward scales per tensor on the device), and any tuning - per-op launches from Python, checked against torch.autograd on the
-reference model (tests/test_r4_gpu.py, fixture tests/golden/r4_golden.npz) to 2e-3 of each tensor's largest entry.
-Transposed fp16 copies (W^T, dY^T, X^T) are made with torch (data movement at the edge of the C ABI).
+backward scales per tensor on the device), and fusion - per-op launches from Python, checked against torch.autograd on the
+reference model (tests/test_r4_gpu.py, fixture tests/golden/r4_golden.npz) to 1e-2 of each tensor's largest entry.
+Transposed fp16 copies (W^T, dY^T, X^T) come from cc_cast_transpose_f16 (one read per matrix); the scale of a gradient operand
+is divided out in the consuming GEMM's epilogue (cc_linear_unscaled_f16).
 """
 import torch
 
@@ -559,7 +560,7 @@ def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_
 class GraphedTrainStep:
     """One training step (forward, backward, optimizer, logit_scale clamp - main.py:300-340 for one batch) captured into a
     hipGraph and replayed on static input buffers: no op of the step synchronises with the host, so the replay runs at the GPU
-    time of its kernels instead of the host's launch rate (cfg-2 shape: 26 ms against 55-80 ms launched op by op).
+    time of its kernels instead of the host's launch rate (cfg-2 shape: 19 ms against 40-100 ms launched op by op).
     Single process (a captured step cannot contain the RCCL exchange of GradientBuckets); fixed batch shape; an optimizer
     built with capturable=True.  The first call warms up eagerly (2 steps on the given batch) and captures."""
 
