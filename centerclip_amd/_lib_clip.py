@@ -128,7 +128,9 @@ def declare(lib):
     lib.cc_quick_gelu_f16.restype = c.c_int
     lib.cc_quick_gelu_backward_f16.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.cc_quick_gelu_backward_f16.restype = c.c_int
-    lib.cc_attention_backward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.cc_attention_backward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]
+    lib.cc_attention_backward_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.cc_attention_backward_workspace_bytes.restype = sz
     lib.cc_attention_backward_f16.restype = c.c_int
     lib.cc_column_sums_workspace_bytes.argtypes = [i32, i32]
     lib.cc_column_sums_workspace_bytes.restype = sz

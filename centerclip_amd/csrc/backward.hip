@@ -4,7 +4,7 @@
 // holds what is not a GEMM:
 //   layernorm_backward      dx = rstd (g - mean(g) - xhat mean(g xhat)),  g = dy gamma;  dgamma = sum dy xhat, dbeta = sum dy
 //   quick_gelu_backward     d/dx [x sigmoid(1.702 x)] = s + 1.702 x s (1 - s)
-//   attention_backward      dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8   (L <= 64)
+//   attention_backward      dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8   (L <= 256)
 //   column_sums             bias gradients
 //   absmax / cast_scaled / unscale   gradients travel through the fp16 matrix cores with a per-tensor power-of-two scale
 //                           chosen on the device (no host synchronisation), removed again from the fp32 product
@@ -523,6 +523,321 @@ __global__ __launch_bounds__(256) void attention_backward_mfma_kernel(const _Flo
     if (amax_bits) publish_absmax(amo, amax_bits);
 }
 
+// ---- 64 < L <= 256 (ViT-B/16: 197 tokens per frame, 161 in its clustered blocks): the same arithmetic as two launches.
+//   q side: one workgroup per (sequence, head, 64 queries); wave w holds its 16 queries' rows of S, P, dP and dS against ALL keys in
+//           registers (16 accumulators each at L = 256), writes dQ and, per query, log-sum-exp and D = sum_j P dP to `stats`
+//   k side: one workgroup per (sequence, head, 64 keys); loops over the query tiles, rebuilds P^T = exp(S^T / 8 - lse) and
+//           dS^T = P^T (dP^T - D) for its keys from those two numbers and accumulates dV = P^T dO, dK = dS^T Q / 8
+// Scales: dO by a power of two from the query tile's largest |dO| (q side: workgroup; k side: per query tile, divided out of each
+// tile's product before it is added), dS by a power of two from the WAVE's largest |dS| (both contractions that consume a wave's
+// dS are that wave's own).
+template <int NK64>
+__global__ __launch_bounds__(256) void attention_backward_q_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ d_out,
+                                                                   float* __restrict__ d_qkv, float* __restrict__ stats, int L, int heads,
+                                                                   int W, int causal, unsigned* __restrict__ amax_bits) {
+    constexpr int LP = NK64 * 64, NKT = NK64 * 4, KS = LP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char abq_smem[];
+    _Float16* Kt = reinterpret_cast<_Float16*>(abq_smem);        // [d][key]
+    _Float16* dO16 = Kt + 64 * KS;                               // [query of the tile][d] (scaled)
+    _Float16* dSw = dO16 + 64 * ABM_S;                           // per wave [16 queries][keys] (scaled)
+    float* wred = reinterpret_cast<float*>(dSw + 4 * 16 * KS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int QT = (L + 63) >> 6;
+    const int qt = blockIdx.x % QT, sh = blockIdx.x / QT, seq = sh / heads, head = sh - seq * heads;
+    const int64_t row0 = (int64_t)seq * L, ld = 3 * (int64_t)W;
+    const _Float16* base = qkv + row0 * ld + head * 64;
+    const float* dob = d_out + row0 * W + head * 64;
+    // ---- stage K^T (all keys) and this tile's dO
+#pragma unroll
+    for (int c = 0; c < NK64 * 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+        const h8 kc = r < L ? *reinterpret_cast<const h8*>(base + (int64_t)r * ld + W + ch * 8) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Kt[(ch * 8 + e) * KS + r] = kc[e];
+    }
+    float4 dof[2][2];
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7, gi = qt * 64 + r;
+        if (gi < L) {
+            dof[c][0] = *reinterpret_cast<const float4*>(dob + (int64_t)gi * W + ch * 8);
+            dof[c][1] = *reinterpret_cast<const float4*>(dob + (int64_t)gi * W + ch * 8 + 4);
+        } else {
+            dof[c][0] = dof[c][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(dof[c][h].x), fabsf(dof[c][h].y))), fmaxf(fabsf(dof[c][h].z), fabsf(dof[c][h].w)));
+    }
+    am = cc_wave_max(am);
+    if (lane == 0) wred[wave] = am;
+    __syncthreads();
+    const float s_o = pow2_scale_for(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+        const float v[8] = {dof[c][0].x, dof[c][0].y, dof[c][0].z, dof[c][0].w, dof[c][1].x, dof[c][1].y, dof[c][1].z, dof[c][1].w};
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * s_o);
+        *reinterpret_cast<h8*>(dO16 + r * ABM_S + ch * 8) = o;
+    }
+    // ---- S row strip -> P
+    const int ql = wave * 16 + l15, qi = qt * 64 + ql;
+    const int qrow = min(qi, L - 1);
+    h8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)qrow * ld + (ks * 4 + lg) * 8);
+    f32x4 p[NKT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int kr = min(kt * 16 + l15, L - 1);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const h8 kf = *reinterpret_cast<const h8*>(base + (int64_t)kr * ld + W + (ks * 4 + lg) * 8);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = kt * 16 + lg * 4 + e;
+            const bool ok = key < L && (!causal || key <= qi);
+            a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+            mx = fmaxf(mx, a[e]);
+        }
+        p[kt] = a;
+    }
+    mx = cc_rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pe = (p[kt][e] > -1.0e38f) ? __expf(p[kt][e] - mx) : 0.f;
+            p[kt][e] = pe;
+            sum += pe;
+        }
+    sum = cc_rows_sum(sum);
+    const bool liveq = qi < L;
+    const float inv = liveq ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[kt][e] *= inv;
+    __syncthreads();                                              // dO16 and Kt complete
+    // ---- dP strip, D, dS
+    f32x4 ds[NKT];
+    float dot = 0.f;
+    {
+        h8 of[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) of[ks] = *reinterpret_cast<const h8*>(dO16 + ql * ABM_S + (ks * 4 + lg) * 8);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int kr = min(kt * 16 + l15, L - 1);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const h8 vf = *reinterpret_cast<const h8*>(base + (int64_t)kr * ld + 2 * W + (ks * 4 + lg) * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, of[ks], a, 0, 0, 0);
+            }
+            ds[kt] = a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = fmaf(a[e], p[kt][e], dot);
+        }
+    }
+    dot = cc_rows_sum(dot);
+    if (liveq && lg == 0) {
+        float* st = stats + ((row0 + qi) * heads + head) * 2;
+        st[0] = mx + __logf(sum);                                 // log-sum-exp of the scaled, masked scores
+        st[1] = dot / s_o;                                        // D = sum_j P dP (unscaled)
+    }
+    float ams = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ds[kt][e] = p[kt][e] * (ds[kt][e] - dot);
+            ams = fmaxf(ams, fabsf(ds[kt][e]));
+        }
+    const float s_s = pow2_scale_for(cc_wave_max(ams));           // per wave: dQ of these 16 queries contracts this strip only
+    _Float16* dSm = dSw + wave * 16 * KS;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const h4 d4 = {(_Float16)(ds[kt][0] * s_s), (_Float16)(ds[kt][1] * s_s), (_Float16)(ds[kt][2] * s_s), (_Float16)(ds[kt][3] * s_s)};
+        *reinterpret_cast<h4*>(dSm + l15 * KS + kt * 16 + lg * 4) = d4;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dQ = dS K / 8
+    const float un_q = 0.125f / s_o / s_s;
+    float amo = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+        const int d = dt * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < LP / 32; ++kb) {
+            const int ko = kb * 32 + lg * 8;
+            aq = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(Kt + d * KS + ko),
+                                                        *reinterpret_cast<const h8*>(dSm + l15 * KS + ko), aq, 0, 0, 0);
+        }
+        if (liveq) {
+            const float4 oq = make_float4(aq[0] * un_q, aq[1] * un_q, aq[2] * un_q, aq[3] * un_q);
+            *reinterpret_cast<float4*>(d_qkv + (row0 + qi) * ld + head * 64 + dt * 16 + lg * 4) = oq;
+            amo = fmaxf(amo, fmaxf(fmaxf(fabsf(oq.x), fabsf(oq.y)), fmaxf(fabsf(oq.z), fabsf(oq.w))));
+        }
+    }
+    if (amax_bits) publish_absmax(amo, amax_bits);
+}
+
+constexpr int ABK_SMEM = 5 * 64 * ABM_S * 2 + (128 + 8) * 4;
+__global__ __launch_bounds__(256) void attention_backward_kv_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ d_out,
+                                                                    float* __restrict__ d_qkv, const float* __restrict__ stats, int L,
+                                                                    int heads, int W, int causal, unsigned* __restrict__ amax_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char abk_smem[];
+    _Float16* Qt = reinterpret_cast<_Float16*>(abk_smem);        // [d][query of the tile]
+    _Float16* dOt = Qt + 64 * ABM_S;                             // [d][query]   (scaled)
+    _Float16* dO16 = dOt + 64 * ABM_S;                           // [query][d]   (scaled)
+    _Float16* Pt = dO16 + 64 * ABM_S;                            // [key of the tile][query]   (rows 16w.. are wave w's own)
+    _Float16* dSt = Pt + 64 * ABM_S;                             // [key][query] (scaled per wave)
+    float* lse = reinterpret_cast<float*>(dSt + 64 * ABM_S);     // [64] + D [64]
+    float* dd = lse + 64;
+    float* wred = dd + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int QT = (L + 63) >> 6;
+    const int kt64 = blockIdx.x % QT, sh = blockIdx.x / QT, seq = sh / heads, head = sh - seq * heads;
+    const int64_t row0 = (int64_t)seq * L, ld = 3 * (int64_t)W;
+    const _Float16* base = qkv + row0 * ld + head * 64;
+    const float* dob = d_out + row0 * W + head * 64;
+    const int kl = wave * 16 + l15, kj = kt64 * 64 + kl;          // this lane's key (the y row of every product below)
+    const int krow = min(kj, L - 1);
+    h8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)krow * ld + W + (ks * 4 + lg) * 8);
+        vf[ks] = *reinterpret_cast<const h8*>(base + (int64_t)krow * ld + 2 * W + (ks * 4 + lg) * 8);
+    }
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q_end = causal ? QT : QT;                           // (causal: tiles behind the key tile are all masked but cost little)
+    for (int qt = 0; qt < q_end; ++qt) {
+        __syncthreads();                                          // the previous tile's operands are no longer read
+        float4 dof[2][2];
+        h8 qc[2];
+        float am = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7, gi = qt * 64 + r;
+            if (gi < L) {
+                qc[c] = *reinterpret_cast<const h8*>(base + (int64_t)gi * ld + ch * 8);
+                dof[c][0] = *reinterpret_cast<const float4*>(dob + (int64_t)gi * W + ch * 8);
+                dof[c][1] = *reinterpret_cast<const float4*>(dob + (int64_t)gi * W + ch * 8 + 4);
+            } else {
+                qc[c] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                dof[c][0] = dof[c][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(dof[c][h].x), fabsf(dof[c][h].y))), fmaxf(fabsf(dof[c][h].z), fabsf(dof[c][h].w)));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Qt[(ch * 8 + e) * ABM_S + r] = qc[c][e];
+        }
+        am = cc_wave_max(am);
+        if (lane == 0) wred[wave] = am;
+        if (tid < 64) {
+            const int gi = qt * 64 + tid;
+            const float* st = stats + ((row0 + min(gi, L - 1)) * heads + head) * 2;
+            lse[tid] = st[0];
+            dd[tid] = st[1];
+        }
+        __syncthreads();
+        const float s_o = pow2_scale_for(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int idx = c * 256 + tid, r = idx >> 3, ch = idx & 7;
+            const float v[8] = {dof[c][0].x, dof[c][0].y, dof[c][0].z, dof[c][0].w, dof[c][1].x, dof[c][1].y, dof[c][1].z, dof[c][1].w};
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (_Float16)(v[e] * s_o);
+                dOt[(ch * 8 + e) * ABM_S + r] = o[e];
+            }
+            *reinterpret_cast<h8*>(dO16 + r * ABM_S + ch * 8) = o;
+        }
+        __syncthreads();
+        // ---- P^T and dS^T of (this wave's 16 keys) x (the tile's 64 queries): lane = key l15, queries it*16 + 4 lg + e
+        f32x4 pt[4], dst[4];
+        float ams = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int qr = min(qt * 64 + it * 16 + l15, L - 1);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const h8 qf = *reinterpret_cast<const h8*>(base + (int64_t)qr * ld + (ks * 4 + lg) * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, kf[ks], a, 0, 0, 0);
+                const h8 of = *reinterpret_cast<const h8*>(dO16 + (it * 16 + l15) * ABM_S + (ks * 4 + lg) * 8);
+                b = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, vf[ks], b, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int il = it * 16 + lg * 4 + e, gi = qt * 64 + il;
+                const bool ok = gi < L && kj < L && (!causal || kj <= gi);
+                const float pe = ok ? __expf(a[e] * 0.125f - lse[il]) : 0.f;
+                pt[it][e] = pe;
+                dst[it][e] = pe * (b[e] - dd[il] * s_o);
+                ams = fmaxf(ams, fabsf(dst[it][e]));
+            }
+        }
+        const float s_s = pow2_scale_for(cc_wave_max(ams));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const h4 p4 = {(_Float16)pt[it][0], (_Float16)pt[it][1], (_Float16)pt[it][2], (_Float16)pt[it][3]};
+            const h4 d4 = {(_Float16)(dst[it][0] * s_s), (_Float16)(dst[it][1] * s_s), (_Float16)(dst[it][2] * s_s), (_Float16)(dst[it][3] * s_s)};
+            *reinterpret_cast<h4*>(Pt + kl * ABM_S + it * 16 + lg * 4) = p4;
+            *reinterpret_cast<h4*>(dSt + kl * ABM_S + it * 16 + lg * 4) = d4;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- dV += P^T dO / s_o ; dK += dS^T Q / (8 s_o s_s)
+        const float un_v = 1.0f / s_o, un_k = 0.125f * un_v / s_s;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int ko = kb * 32 + lg * 8;
+                av = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(dOt + d * ABM_S + ko),
+                                                            *reinterpret_cast<const h8*>(Pt + kl * ABM_S + ko), av, 0, 0, 0);
+                ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(Qt + d * ABM_S + ko),
+                                                            *reinterpret_cast<const h8*>(dSt + kl * ABM_S + ko), ak, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dv[dt][e] = fmaf(av[e], un_v, dv[dt][e]);
+                dk[dt][e] = fmaf(ak[e], un_k, dk[dt][e]);
+            }
+        }
+    }
+    float amo = 0.f;
+    if (kj < L) {
+        float* o = d_qkv + (row0 + kj) * ld + head * 64 + lg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<float4*>(o + W + dt * 16) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+            *reinterpret_cast<float4*>(o + 2 * W + dt * 16) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amo = fmaxf(amo, fmaxf(fabsf(dk[dt][e]), fabsf(dv[dt][e])));
+        }
+    }
+    if (amax_bits) publish_absmax(amo, amax_bits);
+}
+
 // ---- fp32 gradients through the fp16 matrix cores: |x| max -> scale = 2^k with scale * max in [8192, 16384) -> fp16 copy
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ in, int64_t n, unsigned* __restrict__ out_bits) {
     float m = 0.f;
@@ -732,6 +1047,28 @@ __global__ __launch_bounds__(256) void bertadam_multi_small_kernel(const BertAda
     bertadam_small_body(it.p, it.g, it.m, it.v, it.n, it.lr_dev ? *it.lr_dev : it.lr, b1, b2, eps, it.wd, max_norm);
 }
 
+template <int NK64>
+static int launch_attention_backward_long(const _Float16* qkv, const float* d_out, float* d_qkv, float* stats, int nseq, int L, int heads,
+                                          int W, int causal, unsigned* amax, hipStream_t st) {
+    constexpr int smem = (64 * (NK64 * 64 + 8) + 64 * ABM_S + 4 * 16 * (NK64 * 64 + 8)) * 2 + 64;
+    static bool configured = false;              // benign race (idempotent calls)
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_backward_q_kernel<NK64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_backward_kv_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ABK_SMEM) != hipSuccess)
+            return CC_ERR_HIP;
+        configured = true;
+    }
+    const int QT = (L + 63) / 64;
+    hipLaunchKernelGGL(attention_backward_q_kernel<NK64>, dim3(nseq * heads * QT), dim3(256), smem, st, qkv, d_out, d_qkv, stats, L, heads,
+                       W, causal, amax);
+    hipLaunchKernelGGL(attention_backward_kv_kernel, dim3(nseq * heads * QT), dim3(256), ABK_SMEM, st, qkv, d_out, d_qkv, stats, L, heads,
+                       W, causal, amax);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
 extern "C" {
 
 size_t cc_layernorm_backward_workspace_bytes(int32_t rows, int32_t W) {
@@ -788,10 +1125,26 @@ int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, 
     return CC_OK;
 }
 
+size_t cc_attention_backward_workspace_bytes(int32_t nseq, int32_t L, int32_t heads) {
+    if (nseq <= 0 || L <= AB_L || heads <= 0) return 0;         // (short sequences: one launch, no scratch)
+    return (size_t)nseq * L * heads * 2 * sizeof(float);
+}
+
 int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L, int32_t heads,
-                              int32_t W, int32_t causal, float* out_amax, void* stream) {
+                              int32_t W, int32_t causal, float* out_amax, void* ws, size_t ws_bytes, void* stream) {
     if (!qkv_f16 || !d_out || !d_qkv || nseq <= 0 || L <= 0 || heads <= 0 || W != heads * AB_D) return CC_ERR_INVALID;
-    if (L > AB_L) return CC_ERR_UNSUPPORTED;
+    if (L > 256) return CC_ERR_UNSUPPORTED;
+    if (L > AB_L) {
+        if (!ws || ws_bytes < cc_attention_backward_workspace_bytes(nseq, L, heads)) return CC_ERR_WORKSPACE;
+        const _Float16* q = static_cast<const _Float16*>(qkv_f16);
+        unsigned* am = reinterpret_cast<unsigned*>(out_amax);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        switch ((L + 63) / 64) {
+            case 2: return launch_attention_backward_long<2>(q, d_out, d_qkv, static_cast<float*>(ws), nseq, L, heads, W, causal, am, st);
+            case 3: return launch_attention_backward_long<3>(q, d_out, d_qkv, static_cast<float*>(ws), nseq, L, heads, W, causal, am, st);
+            default: return launch_attention_backward_long<4>(q, d_out, d_qkv, static_cast<float*>(ws), nseq, L, heads, W, causal, am, st);
+        }
+    }
     static bool configured = false;              // benign race (idempotent call)
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_backward_kernel),

@@ -198,8 +198,11 @@ def block_backward(block, saved, dz_lnd):
     # y = x + out_proj(att)
     datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight, "out_proj"), amax=am[1])
     dqkv = torch.empty(M, 3 * W, device=dz.device, dtype=torch.float32)
+    ab_bytes = L.lib().cc_attention_backward_workspace_bytes(N, Lt, block.n_head)       # (0 for Lt <= 64)
+    ab_ws = L.workspace(ab_bytes, dz.device) if ab_bytes else None
     _check(L.lib().cc_attention_backward_f16(L.ptr(saved["qkv"]), L.ptr(datt), L.ptr(dqkv), N, Lt, block.n_head, W,
-                                             int(saved["causal"]), L.ptr(am[2]), _st(dz)), "cc_attention_backward_f16")
+                                             int(saved["causal"]), L.ptr(am[2]), L.ptr(ab_ws), ab_bytes, _st(dz)),
+           "cc_attention_backward_f16")
     dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight, "in_proj"), amax=am[2])
     dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy)
     return dx.view(N, Lt, W).permute(1, 0, 2), g

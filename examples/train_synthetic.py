@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--graph", type=int, default=1, help="also time the step captured into a hipGraph")
+    ap.add_argument("--b16", type=int, default=0, help="ViT-B/16 instead (cfg-5 shape: 197 tokens per frame, 12 frames -> 4 segments, "
+                                                       "K = 100; the attention backward's two-launch form)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -39,6 +41,8 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl")
     c = bench.CFG2
+    if a.b16:
+        c = dict(c, name="cfg5-shaped: ViT-B/16", patch=16, T_new=4, K=100)
     args = bench.task_config(c)
     model = CLIP4Clip.from_state_dict(bench.random_state_dict(c, seed=0), args).float().to(device)
     targs = Namespace(lr=1e-7, wd=0.2, new_added_modules=["Cross", "cluster_embed"], gradient_accumulation_steps=1,

@@ -663,7 +663,10 @@ int cc_group_max_rows_f32(const float* sim, int32_t rows, int32_t cols, int64_t 
  *   cc_quick_gelu_backward_f16  du_pre = du * d/dx [x sigmoid(1.702 x)] at x = u_pre (fp16, the c_fc output before the
  *                               activation, clip.py:192-194); n % 4 == 0
  *   cc_attention_backward_f16   qkv [nseq*L, 3W] fp16 (as cc_attention_f16), d_out [nseq*L, W] fp32 -> d_qkv [nseq*L, 3W] fp32
- *                               (softmax(q k^T / 8 + mask) v per 64-wide head); L <= 64
+ *                               (softmax(q k^T / 8 + mask) v per 64-wide head); fp16 MFMA operands (dO and dS scaled by
+ *                               powers of two chosen on the device), fp32 accumulators.  L <= 64: one launch, a workgroup
+ *                               per (sequence, head).  64 < L <= 256 (ViT-B/16): a query-side launch (dQ; log-sum-exp and
+ *                               D = sum_j P dP per query into ws) and a key-side launch (dV, dK)
  *   cc_column_sums_f32          out [cols] = column sums of in [rows, cols] (bias gradients)
  *   cc_cast_scaled_f16          fp32 -> fp16 with a power-of-two scale chosen on the device from the tensor's largest
  *                               magnitude (scale * max in [8192, 16384)); *scale_out (device) receives it; amax_scratch: one
@@ -678,8 +681,10 @@ int cc_layernorm_backward_f32(const float* x, int64_t x_stride, const float* gam
                               void* ws, size_t ws_bytes, void* stream);
 int cc_quick_gelu_f16(const void* in_f16, void* out_f16, int64_t n, void* stream);     /* QuickGELU on fp16 (training forward) */
 int cc_quick_gelu_backward_f16(const void* u_pre_f16, const float* du, float* du_pre, int64_t n, float* out_amax, void* stream);
+size_t cc_attention_backward_workspace_bytes(int32_t nseq, int32_t L, int32_t heads);    /* 0 for L <= 64 (ws may be null) */
 int cc_attention_backward_f16(const void* qkv_f16, const float* d_out, float* d_qkv, int32_t nseq, int32_t L,
-                              int32_t heads, int32_t W, int32_t causal, float* out_amax, void* stream);
+                              int32_t heads, int32_t W, int32_t causal, float* out_amax, void* ws, size_t ws_bytes,
+                              void* stream);
 size_t cc_column_sums_workspace_bytes(int32_t rows, int32_t cols);
 int cc_column_sums_f32(const float* in, int32_t rows, int32_t cols, float* out, void* ws, size_t ws_bytes, void* stream);
 int cc_cast_scaled_f16(const float* in, void* out_f16, int64_t n, float* amax_scratch, float* scale_out, void* stream);

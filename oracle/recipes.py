@@ -341,6 +341,10 @@ MINOR_SEED = 911          # mean_residual / training-mode sparse_sampling fixtur
 BLOCK_GRAD_CASES = {
     "bg_visual": dict(seed=91, L=50, N=6, W=128, heads=2, causal=False),
     "bg_text": dict(seed=92, L=12, N=5, W=128, heads=2, causal=True),
+    # sequences longer than 64 tokens (the attention backward's two-launch form): ViT-B/16's 197 tokens per frame, CLIP's
+    # native 77-token context with the causal mask
+    "bg_visual_b16": dict(seed=93, L=197, N=3, W=128, heads=2, causal=False),
+    "bg_text77": dict(seed=94, L=77, N=4, W=128, heads=2, causal=True),
 }
 
 

@@ -175,7 +175,7 @@ def test_p1_lattice_vit_b16_shipped_shape():
     assert np.array_equal(a.cpu().numpy(), g4["p1m_b16_assign"].astype(np.int64))
 
 
-@pytest.mark.parametrize("tag", ["bg_visual", "bg_text"])
+@pytest.mark.parametrize("tag", ["bg_visual", "bg_text", "bg_visual_b16", "bg_text77"])
 def test_block_backward_against_reference_autograd(tag):
     """N4: forward and backward of one ResidualAttentionBlock (centerclip_amd/train.py: dgrad / wgrad on the forward GEMM
     kernel with swapped operand roles + csrc/backward.hip) against the reference block and torch.autograd on it
@@ -416,10 +416,14 @@ def test_linear_with_the_operand_scale_undone_in_the_epilogue(M, N, K):
     assert float((got.double() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("nseq,L,heads,causal", [(6, 50, 2, False), (5, 32, 3, True), (3, 64, 1, False), (4, 17, 2, True)])
+@pytest.mark.parametrize("nseq,L,heads,causal", [(6, 50, 2, False), (5, 32, 3, True), (3, 64, 1, False), (4, 17, 2, True),
+                                                 (3, 197, 2, False), (2, 161, 1, False), (3, 77, 2, True), (2, 256, 1, False),
+                                                 (2, 65, 1, True), (1, 130, 2, True)])
 def test_attention_backward_on_the_matrix_cores(nseq, L, heads, causal):
     """cc_attention_backward_f16 (fp16 MFMA operands, per-head power-of-two scales for dO and dS) against torch.autograd in fp64
-    on the same fp16 q, k, v: every part of d_qkv within 2e-3 of its largest entry, gradients of tiny magnitude included."""
+    on the same fp16 q, k, v: every part of d_qkv within 2e-3 of its largest entry, gradients of tiny magnitude included.
+    L <= 64: the one-launch form; 64 < L <= 256 (ViT-B/16's 197 tokens, its clustered 161, the text tower's 77): the
+    query-side + key-side pair."""
     from centerclip_amd import _lib as L_, train as cctrain                                 # noqa: F401
     from centerclip_amd.torch_ops import _st
     W = heads * 64
@@ -431,8 +435,11 @@ def test_attention_backward_on_the_matrix_cores(nseq, L, heads, causal):
         d_out.view(nseq, L, W)[0] *= 64.0
         got = torch.empty(nseq * L, 3 * W, device="cuda")
         am = torch.zeros(2, device="cuda")
+        nb = L_.lib().cc_attention_backward_workspace_bytes(nseq, L, heads)
+        assert (nb == 0) == (L <= 64)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
         L_.check(L_.lib().cc_attention_backward_f16(L_.ptr(qkv), L_.ptr(d_out), L_.ptr(got), nseq, L, heads, W, int(causal),
-                                                    L_.ptr(am), _st(got)), "cc_attention_backward_f16")
+                                                    L_.ptr(am), L_.ptr(ws), nb, _st(got)), "cc_attention_backward_f16")
         x = qkv.double().view(nseq, L, 3, heads, 64).permute(2, 0, 3, 1, 4).detach().requires_grad_(True)   # [3, n, h, L, 64]
         sc = x[0] @ x[1].transpose(-1, -2) / 8.0
         if causal:
@@ -467,7 +474,7 @@ def test_gradient_producers_publish_their_largest_magnitude():
     datt = (torch.randn(rows, W, generator=g) * 1e-3).cuda()
     dqkv = torch.empty(rows, 3 * W, device="cuda")
     L.check(L.lib().cc_attention_backward_f16(L.ptr(qkv), L.ptr(datt), L.ptr(dqkv), rows // Lt, Lt, heads, W, 0, L.ptr(am[2]),
-                                              _st(datt)), "attention bwd")
+                                              None, 0, _st(datt)), "attention bwd")
     torch.cuda.synchronize()
     for i, t in enumerate((dx, du_pre, dqkv)):
         assert float(am[i, 0]) == float(t.abs().max()) > 0.0
