@@ -22,6 +22,7 @@ dataset - not the GEMM - is what is sharded:
 The [Nt, Nv] matrix never exists on one device and never travels.  A sharded loader in the single-process mode, or
 ranks disagreeing on the dataset size, raise instead of returning a silently wrong matrix.
 """
+import contextlib
 import time
 
 import numpy as np
@@ -161,9 +162,12 @@ def _item_positions(loader, world, rank, shard):
     return positions, None
 
 
-def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend):
+def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend, in_flight=1):
     """main.py:381-499 -> (R1, all_infer_time, info_str).  ``shard=True``: clip-sharded over the ranks of the default
-    process group (module docstring) - every rank must call it and every rank returns the same numbers."""
+    process group (module docstring) - every rank must call it and every rank returns the same numbers.
+    ``in_flight`` (not in the reference; GPU only): 2 keeps two batches in flight - batch b runs on instance b % 2 of the
+    model (``CLIP4Clip.replica()``) on a stream of its own, so the small-grid kernels of one batch (k-medoids selection,
+    launch tails) run under the other's GEMMs: 1.84 -> 1.60 ms per 16-clip batch at the cfg-2 shape, identical features."""
     log = log or (lambda s: None)
     be = backend
     world, rank = (ccdist.world_size(), ccdist.rank()) if shard else (1, 0)
@@ -179,6 +183,14 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
     positions, n_items = _item_positions(test_dataloader, world, rank, shard)
     cache = _Cache()
     model.eval()
+    lanes = None                               # in_flight > 1: [(model instance, stream)], batch b on lane b % in_flight
+    if in_flight > 1:
+        if not (torch.cuda.is_available() and torch.device(device).type == "cuda"):
+            raise ValueError("eval_epoch(in_flight > 1) needs a GPU")
+        here = torch.cuda.current_stream(device)
+        lanes = [(model, torch.cuda.Stream(device))] + [(core.replica().eval(), torch.cuda.Stream(device)) for _ in range(in_flight - 1)]
+        for _, s_ in lanes:
+            s_.wait_stream(here)
     t_start = time.time()
     total = 0
     with torch.no_grad():
@@ -193,21 +205,23 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
                 continue
             if keep.numel() < b:                       # (only a DistributedSampler's padded tail)
                 batch, pos = tuple(t[keep] for t in batch), pos[keep]
-            input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
-            if not multi:
-                out = model(input_ids, segment_ids, input_mask, video, video_mask)
-                cache.add_text(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1)), pos)
-                cache.add_video(_video_operand(core, out['visual_output'], video_mask, be), pos)
-                continue
-            seq = model(input_ids, segment_ids, input_mask)['sequence_output']
-            cache.add_text(be.text_operand(seq.reshape(seq.shape[0], -1)), pos)
-            rows = [i for i, p in enumerate(pos.tolist()) if p in video_of_last]      # items that carry their clip's video
-            if rows:
-                vout = model(video=video[rows, ...], video_mask=video_mask[rows, ...])['visual_output']
-                cache.add_video(_video_operand(core, vout, video_mask[rows, ...], be),
-                                torch.as_tensor([video_of_last[int(pos[i])] for i in rows], dtype=torch.long))
+            net, lane_stream = lanes[bid % in_flight] if lanes else (model, None)
+            with (torch.cuda.stream(lane_stream) if lane_stream is not None else contextlib.nullcontext()):
+                input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
+                if not multi:
+                    out = net(input_ids, segment_ids, input_mask, video, video_mask)
+                    cache.add_text(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1)), pos)
+                    cache.add_video(_video_operand(core, out['visual_output'], video_mask, be), pos)
+                    continue
+                seq = net(input_ids, segment_ids, input_mask)['sequence_output']
+                cache.add_text(be.text_operand(seq.reshape(seq.shape[0], -1)), pos)
+                rows = [i for i, p in enumerate(pos.tolist()) if p in video_of_last]      # items that carry their clip's video
+                if rows:
+                    vout = net(video=video[rows, ...], video_mask=video_mask[rows, ...])['visual_output']
+                    cache.add_video(_video_operand(core, vout, video_mask[rows, ...], be),
+                                    torch.as_tensor([video_of_last[int(pos[i])] for i in rows], dtype=torch.long))
         if torch.cuda.is_available():
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()               # (also joins the lanes' streams: the cached rows are read on this one below)
         all_infer_time = time.time() - t_start
         log('The total model inference time of the program is {:.2f} Seconds\n'.format(all_infer_time))
         if args is not None and getattr(args, "inference_speed_test", False):

@@ -336,6 +336,34 @@ def test_eval_epoch_against_the_reference(g2, g3, name):
     assert list(info_b) == [str(s) for s in g3[f"ev_{name}_info"]] and abs(r1b - float(g3[f"ev_{name}_r1"])) < 1e-4
 
 
+@pytest.mark.parametrize("name", sorted(EVAL_CASES))
+@pytest.mark.parametrize("cluster", [0, 1])
+def test_eval_epoch_two_batches_in_flight(g2, name, cluster):
+    """eval_epoch(in_flight=2): batch b on instance b % 2 of the model (CLIP4Clip.replica) and a stream of its own - the one
+    GEMM over the cached operand planes sees bit-identical operands, so matrix, R@1 and metric strings equal in_flight=1."""
+    from centerclip_amd import eval as ev
+    model, sd, cfg = _small_model(g2, cluster_inter=cluster)
+    batches, attrs = eval_case_batches(EVAL_CASES[name], cfg)
+    loader = _Loader(batches)
+    loader.dataset = Namespace(**attrs)
+    sims = []
+
+    class Spy(ev.HipBackend):
+        @staticmethod
+        def dot_operands(t_op, v_op, n_video, mult):
+            sims.append(ev.HipBackend.dot_operands(t_op, v_op, n_video, mult).clone())
+            return sims[-1]
+    one = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy)
+    two = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy, in_flight=2)
+    three = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy, in_flight=3)
+    assert torch.equal(sims[0], sims[1]) and torch.equal(sims[0], sims[2])
+    assert one[0] == two[0] == three[0] and list(one[2]) == list(two[2]) == list(three[2])
+    rep = model.replica()
+    assert rep is not model and rep.training == model.training
+    for (k, a), (_, b) in zip(model.state_dict().items(), rep.state_dict().items()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
+
+
 # ------------------------------------------------------------------------------------------------ N4: loss gradient
 @pytest.mark.parametrize("tag,n", [("lg_a", 6), ("lg_b", 33)])
 def test_contrastive_loss_gradients_against_reference_autograd(g2, g3, tag, n):
