@@ -47,6 +47,17 @@ HBM_PEAK_GBS = 8000.0               # HBM3E spec peak
 
 CFG2 = dict(name="cfg2 MSR-VTT-shaped: ViT-B/32 224^2, 12 frames -> 3 segments @block 7, K=49, batch 16, 32 words",
             B=16, T=12, T_new=3, K=49, cluster_block=7, words=32, patch=32, res=224, width=768, layers=12)
+# The towers of the other BASELINE.json configs at their per-GPU batch: timed by forward_config_bench()
+# next to the headline and selectable as the timed workload with --workload (that is how profiles/r05_forward_cfg* were taken)
+FORWARD_CFGS = {
+    "cfg2": CFG2,
+    "cfg3": dict(name="cfg3 MSVD-shaped (per GPU): ViT-B/32 224^2, 12 frames -> 4 segments @block 7, K=49, batch 64, 32 words",
+                 B=64, T=12, T_new=4, K=49, cluster_block=7, words=32, patch=32, res=224, width=768, layers=12),
+    "cfg4": dict(name="cfg4 ActivityNet-shaped (per GPU): ViT-B/32 224^2, 64 frames -> 8 segments @block 7, K=49, batch 8, 77 words",
+                 B=8, T=64, T_new=8, K=49, cluster_block=7, words=77, patch=32, res=224, width=768, layers=12),
+    "cfg5": dict(name="cfg5 ViT-B/16 224^2 (per GPU): 12 frames -> 4 segments @block 7, 196 tokens/frame, K=100, split 4, batch 16, 32 words",
+                 B=16, T=12, T_new=4, K=100, cluster_block=7, words=32, patch=16, res=224, width=768, layers=12, split=4),
+}
 # cluster-op shapes of the other BASELINE.json configs: reported as µs/call + Mtokens/s
 CLUSTER_SHAPES = {"cfg2": dict(B=16, T=12, T_new=3, n=49, K=49, split=16),
                   "cfg3 MSVD-shaped (per GPU)": dict(B=64, T=12, T_new=4, n=49, K=49, split=16),      # P = 256 problems: fills the chip
@@ -60,8 +71,20 @@ def task_config(c):
     return Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=c["T"],
                      target_frames_blocks=[c["T"]] * (c["cluster_block"] - 1) + [c["T_new"]] * (13 - c["cluster_block"]),
                      cluster_num_blocks=[c["K"]] * 12, cluster_distance='euclidean', cluster_threshold=1e-6,
-                     cluster_iter_limit=100, minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None,
+                     cluster_iter_limit=100, minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/%d' % c["patch"], aggregation=None,
                      pre_norm=False, loose_type=True, sim_header='meanP', linear_patch='2d')
+
+
+def algorithmic_flops_per_clip(c):
+    """2 flops per multiply-add; the cluster op fires before the attention of block `cluster_block`; the
+    projection heads count the CLS / EOT rows only."""
+    W, p, T, Tn, cb = c["width"], c["patch"], c["T"], c["T_new"], c["cluster_block"]
+    n = (c["res"] // p) ** 2
+    L0, L1, Lt = 1 + n, 1 + c["K"], c["words"]
+    f_vis = (T * n * 2 * (3 * p * p) * W + (cb - 1) * T * L0 * (24 * W * W + 4 * L0 * W)
+             + (13 - cb) * Tn * L1 * (24 * W * W + 4 * L1 * W) + Tn * 2 * W * 512)
+    f_txt = 12 * Lt * (24 * 512 * 512 + 4 * Lt * 512) + 2 * 512 * 512
+    return float(f_vis + f_txt)
 
 
 def random_state_dict(c, seed):
@@ -144,24 +167,88 @@ def kernel_symbol(M, N, K, epi):
     return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk, 2 if t == 9 else 1)
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of a kernel symbol from the COMMITTED rocprofv3 PMC passes (tools/pmc.sh ->
-    profiles/*traffic_pmc.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  Not measured in this run;
-    None when no counter pass exists for the symbol."""
+PMC_PASSES = {   # one counter group per rocprofv3 run (4 TCC slots; counters + kernel trace only)
+    "read": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+    "write": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"],
+}
+_PMC_CACHE = {}
+
+
+def pmc_counters_live():
+    """The L2 <-> fabric request counters of every kernel INSIDE this invocation's step: bench.py re-runs its own step (3 eager
+    steps of the same workload, no side measurements) under `rocprofv3 --pmc <group> --kernel-trace`, one counter group per
+    child run, and averages the counters per kernel symbol.  -> {kernel name: {counter: average per launch, "launches": n}} or
+    {"error": reason}.  Calibration of the byte arithmetic (profiles/r05_traffic_reconcile.txt): a 512 MiB device copy reads
+    4,194,510 requests = 128 B each (TCC_EA0_RDREQ_128B is not populated on gfx950; RDREQ - 32B - 64B are the 128-byte ones) and
+    writes 8,388,608 requests of 64 B; FETCH_SIZE of the same launch reads exactly half of the bytes - the guide's x2 rule, which
+    also holds for the GEMM's LDS-DMA loads (one-column-tile launch: 59 MB A + 8 x 0.79 MB W expected, 65.4 MB counted)."""
+    if "data" in _PMC_CACHE:
+        return _PMC_CACHE["data"]
+    import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
-    if not files:
-        return None
-    data = json.load(open(files[-1]))
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        _PMC_CACHE["data"] = {"error": "rocprofv3 not found"}
+        return _PMC_CACHE["data"]
+    out = {}
+    base = tempfile.mkdtemp(prefix="cc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("WORLD_SIZE", None)
+    try:
+        for name, counters in PMC_PASSES.items():
+            d = os.path.join(base, name)
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", sys.executable,
+                                               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--min-seconds", "0",
+                                               "--no-extras", "--no-cpu-baseline", "--no-graph"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                _PMC_CACHE["data"] = {"error": "rocprofv3 pass '%s' failed (rc %d): %s" % (name, r.returncode, r.stderr.decode(errors="replace")[-300:])}
+                return _PMC_CACHE["data"]
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, cs in acc.items():
+                e = out.setdefault(k, {})
+                for c_, v in cs.items():
+                    e[c_] = sum(v) / len(v)
+                    e["launches"] = len(v)
+    except Exception as exc:                     # noqa: BLE001
+        _PMC_CACHE["data"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        return _PMC_CACHE["data"]
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    _PMC_CACHE["data"] = out
+    return out
+
+
+def pmc_bytes(c):
+    """Bytes across the L2 <-> fabric interface from one kernel's averaged request counters (see pmc_counters_live)."""
+    rd, r32, r64 = c.get("TCC_EA0_RDREQ_sum", 0.0), c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0)
+    wr, w64 = c.get("TCC_EA0_WRREQ_sum", 0.0), c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+    fetch = 128.0 * (rd - r32 - r64) + 64.0 * r64 + 32.0 * r32
+    write = 64.0 * w64 + 32.0 * (wr - w64)
+    return fetch, write
+
+
+def pmc_traffic(symbol):
+    """Fabric bytes per launch of a kernel symbol, measured in THIS invocation (pmc_counters_live); None + the reason when the
+    counter passes could not run."""
+    data = pmc_counters_live()
+    if "error" in data:
+        return {"hbm_bytes_per_launch": None, "source": "not measured: " + data["error"]}
     key = symbol.replace(" ", "")
-    # (profiles committed before the split-K template argument existed name the one-workgroup forms without it)
-    keys = (key, key[:-3] + ">") if key.endswith(",1>") else (key,)
     for name, v in data.items():
-        if any(k in name.replace(" ", "") for k in keys):
-            return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "fetch_bytes": round(v["fetch_bytes_per_launch"]),
-                    "write_bytes": round(v["write_bytes_per_launch"]),
-                    "source": "committed profile profiles/%s (PMC pass of an earlier run, not measured here)" % os.path.basename(files[-1])}
-    return None
+        if key in name.replace(" ", ""):
+            fetch, write = pmc_bytes(v)
+            return {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+                    "launches_counted": v.get("launches"),
+                    "counters": {k: round(x, 1) for k, x in v.items() if k != "launches"},
+                    "source": "measured in this run: rocprofv3 --pmc on 3 eager steps of the same workload (bench.pmc_counters_live)"}
+    return {"hbm_bytes_per_launch": None, "source": "not measured: no launch of %s in the counter passes" % symbol}
 
 
 def insitu_gemm_times(step, reps=6, rider_rows=None, rider_rows_launched=None):
@@ -291,7 +378,9 @@ def gemm_roofline(c, device, insitu=None):
     roof = dict(bound="mfma", kernel=sym, roles=roles, achieved=round(tf, 1), peak=MFMA_F16_PEAK_TFLOPS,
                 unit="TFLOP/s", frac=round(tf / MFMA_F16_PEAK_TFLOPS, 4), measured=how,
                 traffic=tr["hbm_bytes_per_launch"] if tr else None,
-                traffic_unit="bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE), from a committed profile - not measured in this run",
+                traffic_unit=("bytes per launch across the L2 <-> fabric interface (Infinity-Cache hits included): 128 B x (TCC_EA0_RDREQ - "
+                              "32B - 64B) + 64 B x RDREQ_64B + 32 B x RDREQ_32B + 64 B x WRREQ_64B + 32 B x (WRREQ - WRREQ_64B), "
+                              "averaged over the symbol's launches inside the step; counter passes of this invocation"),
                 traffic_detail=tr, avg_launch_us=round(avg_us, 2), launches_per_step=n_l,
                 algorithmic_flops_per_launch=flops_per_launch,
                 step_share_us=round(share, 1),
@@ -303,6 +392,48 @@ def gemm_roofline(c, device, insitu=None):
     gemm_us = sum(r["step_share_us"] for r in rows)
     gemm_flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"] for r in rows)
     return roof, rows, gemm_us, gemm_flops
+
+
+def forward_config_bench(key, device, seed=0):
+    """One of the other BASELINE.json towers (cfg 3 / 4 / 5) at its per-GPU batch: the same step as the headline (both towers
+    in one enqueue -> similarity logits), captured into a hipGraph and replayed; clips/s, whole-step fraction of the fp16
+    MFMA peak on SURVEY 8(d)'s algorithmic flops, and the launches of every GEMM symbol inside the step (HIP event pairs,
+    as `roofline` does for the headline).  The kernel tables of the same steps: profiles/r05_forward_<key>_kernel_stats.txt
+    (`rocprofv3 --kernel-trace --stats -- python bench.py --workload <key> --no-extras --no-cpu-baseline`)."""
+    from centerclip_amd.clip4clip import CLIP4Clip
+    c = FORWARD_CFGS[key]
+    sd = random_state_dict(c, seed=seed)
+    model = CLIP4Clip.from_state_dict(dict(sd), task_config(c)).to(device).eval()
+    ids, amask, video, vmask = synthetic_batch(c, device, seed=500 + seed)
+    tt = torch.zeros_like(ids)
+
+    def step():
+        out = model(ids, tt, amask, video, vmask)
+        return model.get_similarity_logits(out["sequence_output"], out["visual_output"], amask, vmask)[0]
+    with torch.no_grad():
+        logits = step()
+        torch.cuda.synchronize()
+        assert logits.shape == (c["B"], c["B"]) and bool(torch.isfinite(logits).all())
+        ms = graph_time_ms(step, launches=1, replays=max(5, int(200 / max(1.0, 0.5 * c["B"]))))
+        rows_text = int((ids.argmax(dim=-1) + 1).sum())
+        ins = insitu_gemm_times(step, reps=3, rider_rows=rows_text, rider_rows_launched=int(ids.numel()))
+    flops = algorithmic_flops_per_clip(c) * c["B"]
+    sym, dom = max(ins.items(), key=lambda kv: kv[1]["us"])
+    gemm_us = sum(v["us_per_step"] for v in ins.values())
+    res = dict(workload=c["name"], ms_per_step=round(ms, 3), clips_per_s=round(c["B"] / ms * 1e3, 1), launch="hipGraph replay",
+               algorithmic_gflop_per_clip=round(flops / c["B"] / 1e9, 1),
+               whole_step_tflops=round(flops / ms / 1e9, 1), whole_step_frac_of_f16_mfma_peak=round(flops / ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+               gemm_launch_time_share_of_step=round(gemm_us / (ms * 1e3), 3),
+               roofline=dict(bound="mfma", kernel=sym, achieved=round(dom["tflops"], 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=round(dom["tflops"] / MFMA_F16_PEAK_TFLOPS, 4), avg_launch_us=round(dom["avg_us"], 2),
+                             launches_per_step=dom["launches_per_step"], step_share_us=round(dom["us_per_step"], 1),
+                             measured="in situ: HIP event pair around every launch of the symbol inside the eagerly enqueued step"),
+               by_symbol_in_situ={k: dict(avg_us=round(v["avg_us"], 2), launches_per_step=v["launches_per_step"],
+                                          step_share_us=round(v["us_per_step"], 1), tflops=round(v["tflops"], 1),
+                                          frac=round(v["tflops"] / MFMA_F16_PEAK_TFLOPS, 4), shapes=v["shapes"]) for k, v in ins.items()})
+    del model, video
+    torch.cuda.empty_cache()
+    return res
 
 
 def cluster_bench(c, device, iters=30):
@@ -337,17 +468,16 @@ def spectral_cluster_bench(c, device):
 
 
 def cluster_pmc_traffic():
-    """HBM bytes of one cfg-2 token-cluster call = sum over its kernels, from the committed PMC passes (None if absent)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
-    if not files:
+    """Fabric bytes of the token-cluster call inside the step = sum over its kernels, from this invocation's counter passes
+    (None when they could not run)."""
+    data = pmc_counters_live()
+    if "error" in data:
         return None
-    data = json.load(open(files[-1]))
     total, seen = 0.0, 0
     for key in ("gram_dist_kernel", "kmedoids_select_kernel"):     # K1, K2 (K0 is folded into K1, K3 into K2's tail)
         for name, v in data.items():
             if key in name:
-                total += v["hbm_bytes_per_launch"]
+                total += sum(pmc_bytes(v))
                 seen += 1
                 break
     return round(total) if seen == 2 else None
@@ -595,7 +725,12 @@ def main():
                     help="2: the timed steps alternate between two model instances / hipGraphs on two streams (two batches in "
                          "flight, the serving-loop form; 1 GPU only).  The default, and the judged line, is 1: `roofline` and the "
                          "rocprofv3 profile are per-kernel statements, which two overlapping steps blur")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(FORWARD_CFGS),
+                    help="the configuration the timed steps run (default cfg2 = BASELINE.json's metric configuration, the judged "
+                         "line); cfg3 / cfg4 / cfg5 time the other towers at their per-GPU batch - used for their rocprofv3 tables")
     a = ap.parse_args()
+    if a.workload != "cfg2":             # a profiling aid: the step alone (the side measurements are cfg2's)
+        a.no_extras = a.no_cpu_baseline = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
@@ -623,7 +758,7 @@ def main():
 
     from centerclip_amd.clip4clip import CLIP4Clip
     from centerclip_amd import dist as ccdist
-    c = CFG2
+    c = FORWARD_CFGS[a.workload]
     sd = random_state_dict(c, seed=0)                    # same weights on every rank
     model = CLIP4Clip.from_state_dict(dict(sd), task_config(c)).to(device).eval()
     ids, amask, video, vmask = synthetic_batch(c, device, seed=100 + rank)
@@ -740,6 +875,8 @@ def main():
             if world == 1:
                 extras["token_cluster_spectral"] = {name: spectral_cluster_bench(sh, device) for name, sh in CLUSTER_SHAPES.items()}
             extras["similarity_10k_x_1k"] = similarity_bench(device, world)
+            if world == 1 and a.workload == "cfg2":      # the other BASELINE.json towers, one GPU's share each
+                extras["forward_other_configs"] = {k: forward_config_bench(k, device) for k in ("cfg3", "cfg4", "cfg5")}
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         clips = c["B"] * world * a.steps
@@ -760,9 +897,9 @@ def main():
                           "parallelism": "dp%d (clips sharded, one RCCL all-gather of preallocated feature records)" % world if world > 1 else "single GPU"}}
         res.update(extras)
         if "token_cluster" in res:
-            res["token_cluster"]["cfg2"]["roofline"]["traffic"] = cluster_pmc_traffic()
-            res["token_cluster"]["cfg2"]["roofline"]["traffic_unit"] = ("bytes per call, sum over K1 + K2 (PMC: 2*FETCH_SIZE + "
-                                                                         "WRITE_SIZE), from a committed profile - not measured in this run")
+            res["token_cluster"]["cfg2"]["roofline"]["traffic"] = cluster_pmc_traffic() if (world == 1 and not a.no_extras) else None
+            res["token_cluster"]["cfg2"]["roofline"]["traffic_unit"] = ("bytes per call across the L2 <-> fabric interface, sum over K1 + K2 "
+                                                                         "inside the step (TCC_EA0 request counters, counter passes of this invocation)")
             res["token_cluster_mtokens_per_s"] = res["token_cluster"]["cfg2"].get("mtokens_per_s_all_ranks",
                                                                                   res["token_cluster"]["cfg2"]["mtokens_per_s"])
         if world == 1 and not a.no_extras:

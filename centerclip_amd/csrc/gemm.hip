@@ -50,6 +50,11 @@ __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// EPI_ATTN_LN: keys per V^T slot of a sequence of at most L tokens - 32 or 64 (short form: up to 8 / 5 sequences per row tile,
+// every operand of an item in registers), else L rounded up to whole 32-key blocks (long form, L <= 256: ViT-B/16's 197-token
+// frames, its 101-token clustered blocks, CLIP's native 77-token captions)
+__host__ __device__ inline int attn_slot_keys(int L) { return L <= 32 ? 32 : (L <= 64 ? 64 : ((L + 31) & ~31)); }
+
 __device__ __forceinline__ float quick_gelu(float x) {      // x * sigmoid(1.702 x), modules/clip.py:192-194
     // 5 VALU ops (v_exp_f32 + v_rcp_f32, ~1 ulp each): the epilogue of a 128x128 tile evaluates this
     // 64 times per lane, an IEEE divide + expf here costs more than the tile's MFMA work.
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // grouped rasterisation inside the XCD's run: the ~64 tiles an XCD has in flight form an
     // 8-row x 8-column patch, so both operand panels (8 A row-tiles + 8 W column-tiles) stay in its
     // 4 MiB L2 instead of streaming the whole weight matrix past it for every row of tiles.
-    constexpr int GROUP_M = 8;
+    // (round 5: the group height comes from the host, raster_group_rows() below - 8 in every shipped build)
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 8;
     const int per_group = GROUP_M * g.tiles_n;
     const int group = bid / per_group, first_m = group * GROUP_M;
     const int gsz = min(g.tiles_m - first_m, GROUP_M);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // ATTN: thread r also finds where tile row r lands in the V^T tile (sequence slot * slot width + token), -1 = no sequence
     int att_vcol = -1;
     if (ATTN && tid < BM) {
-        const int nst = min(g.att_spt, g.att_nseq - att_s0), slotw = g.att_L > 32 ? 64 : 32;
+        const int nst = min(g.att_spt, g.att_nseq - att_s0), slotw = attn_slot_keys(g.att_L);
         if (!g.att_seq_off) {
             const int sq = tid / g.att_L;
             if (sq < nst) att_vcol = sq * slotw + (tid - sq * g.att_L);
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         _Float16* Pw = Vt + 64 * VS + wave * (16 * PS);
         int* stab = reinterpret_cast<int*>(smem + ATTN_TAB_OFF);   // [j]: first tile row of sequence j, [8 + j]: its length
         const int nst = min(g.att_spt, g.att_nseq - att_s0);
-        const int slot = g.att_L > 32 ? 64 : 32;
+        const int slot = attn_slot_keys(g.att_L);
         // dev builds: -DCC_ATTN_STAMP_AT=n moves the third timeline stamp to point n of this epilogue, taken by thread
         // CC_ATTN_STAMP_TID (default 0; 448 = the first lane of a wave that writes V)
 #if defined(CC_DEV_KNOBS) && defined(CC_ATTN_STAMP_AT)
@@ -636,7 +642,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         // Wave column wc holds the d-slice [16 wc, 16 wc + 16) of q (fragment 0), k (1) and v (2, transposed: a lane has rows
         // lg*4 .. +3 of column d = 16 wc + l15).  Rows (2a, 2a + 1) belong to one sequence when the sequences are uniform and
         // of even length: V^T then takes 4-byte writes (two keys of one d).
-        const bool pairs = !g.att_seq_off && (g.att_L & 1) == 0;
+        // (one sequence per tile: tile row = key, any parity; the partner of the last key is a clamped row - finite, and P = 0 there)
+        const bool pairs = !g.att_seq_off && ((g.att_L & 1) == 0 || g.att_spt == 1);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = wr * WTM + i * 16 + l15;
@@ -827,7 +834,120 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        if (slot == 64) run_items(std::integral_constant<int, 4>{});
+        // Long sequences (64 < slot <= 256 keys): the scores of one (sequence, 16-query tile) item stay in registers - up to 16 key
+        // tiles of S^T = K Q^T, K fragments streamed from LDS - and so does P: the accumulator layout of S^T (a lane holds keys
+        // kt*16 + lg*4 + 0..3 of query l15) IS an MFMA B operand of O^T = V^T P^T once the 32 keys of a k-block are taken in the
+        // order [kt0: lg*4 + 0..3 | kt1: lg*4 + 0..3] - the contraction over keys does not care about their order as long as the
+        // V^T fragment uses the same one (two 8-byte LDS reads per fragment instead of one 16-byte read).  No P strip, no wave
+        // barrier between the softmax and the PV MFMAs.  Causal sequences skip the key tiles behind the query tile.
+        auto run_items_long = [&]() {
+            for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qtmax; it += NWAVES) {
+                const int sq = it / qtmax, qt = it - sq * qtmax;   // wave-uniform
+                const int off = stab[sq], L = stab[8 + sq];
+                if (qt * 16 >= L) continue;
+                const int q = qt * 16 + l15;
+                int nkt = (((L + 15) >> 4) + 1) & ~1;               // key tiles of this sequence, whole 32-key blocks
+                if (CAUSAL) nkt = min(nkt, (qt + 2) & ~1);
+                nkt = __builtin_amdgcn_readfirstlane(nkt);
+                h8 qf[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    qf[ks] = *reinterpret_cast<const h8*>(Qs + (off + min(q, L - 1)) * QS + (ks * 4 + lg) * 8);
+                f32x4 sc[16];
+#pragma unroll
+                for (int kt = 0; kt < 16; ++kt) {
+                    sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kt < nkt) {
+                        const int kr = off + min(kt * 16 + l15, L - 1);
+                        const h8 k0 = *reinterpret_cast<const h8*>(Ks + kr * QS + lg * 8);
+                        const h8 k1 = *reinterpret_cast<const h8*>(Ks + kr * QS + (4 + lg) * 8);
+                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], sc[kt], 0, 0, 0);
+                        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], a, 0, 0, 0);
+                    }
+                }
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < 16; ++kt) {
+                    if (kt < nkt) {
+                        f32x4 a = sc[kt];
+                        if (kt * 16 + 15 < L && (!CAUSAL || kt < qt)) {     // wave-uniform: no key of this tile is masked
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                a[e] = a[e] * 0.125f;
+                                mx = fmaxf(mx, a[e]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int key = kt * 16 + lg * 4 + e;
+                                const bool ok = key < L && (!CAUSAL || key <= q);
+                                a[e] = ok ? a[e] * 0.125f : -3.0e38f;
+                                mx = fmaxf(mx, a[e]);
+                            }
+                        }
+                        sc[kt] = a;
+                    }
+                }
+                mx = cc_rows_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 16; ++kt) {
+                    if (kt < nkt) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pexp = __expf(sc[kt][e] - mx);   // (a masked key: exp2 of -4e38 or -inf = 0 exactly)
+                            sc[kt][e] = pexp;
+                            sum += pexp;
+                        }
+                    }
+                }
+                sum = cc_rows_sum(sum);
+                const float inv = 1.0f / sum;
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const _Float16* vbase = Vt + l15 * VS + sq * slot + lg * 4;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    if (2 * kb < nkt) {
+                        const f32x4 pa = sc[2 * kb], pb = sc[2 * kb + 1];
+                        const h8 pf = {(_Float16)(pa[0] * inv), (_Float16)(pa[1] * inv), (_Float16)(pa[2] * inv), (_Float16)(pa[3] * inv),
+                                       (_Float16)(pb[0] * inv), (_Float16)(pb[1] * inv), (_Float16)(pb[2] * inv), (_Float16)(pb[3] * inv)};
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const h4 va = *reinterpret_cast<const h4*>(vbase + dt * 16 * VS + kb * 32);
+                            const h4 vb = *reinterpret_cast<const h4*>(vbase + dt * 16 * VS + kb * 32 + 16);
+                            const h8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                        }
+                    }
+                }
+                // the 16 x 64 output tile through the wave's strip -> 16-byte write-through stores (as the short form)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                    *reinterpret_cast<h4*>(Pw + l15 * PS + dt * 16 + lg * 4) = oh;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int qr = h * 8 + (lane >> 3), qq = qt * 16 + qr;
+                    const h8 ov = *reinterpret_cast<const h8*>(Pw + qr * PS + (lane & 7) * 8);
+                    if (qq < L) {
+                        const int64_t e = (int64_t)(row0 + off + qq) * g.ldc + tn * 64 + (lane & 7) * 8;
+                        if ((int64_t)g.M * g.ldc < (int64_t)0x3fffffff)      // (32-bit byte offset of the buffer form)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb), (int)(e * 2), 0, 16);
+                        else
+                            *reinterpret_cast<h8*>(Cb + e) = ov;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);                // the strip is rewritten by this wave's next item
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        if (slot > 64) run_items_long();
+        else if (slot == 64) run_items(std::integral_constant<int, 4>{});
         else run_items(std::integral_constant<int, 2>{});
         GEMM_STAMP(3);
         return;
@@ -1162,11 +1282,49 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     return CC_OK;
 }
 
+// Rows of tiles per rasterisation group (GemmArgs::group_m).  Workgroup b runs on XCD b % 8 and the kernel hands every XCD a
+// contiguous run of R = tiles / 8 tiles of the 1-D order "groups of gm tile rows, inside a group down the rows first"; what
+// the run pulls through its XCD's L2 is (tile rows it touches) x BM + (tile columns it touches) x BN rows of K halfs.  The
+// estimate below counts both for gm in {1, 2, 4, 8, 16} and keeps the cheapest (ties: the larger patch, 8 = the value every
+// launch used before round 5).
+static int raster_group_rows(int tiles_m, int tiles_n, int BM, int BN) {
+#ifndef CC_RASTER_ADAPTIVE
+    // Measured (profiles/r05_traffic_reconcile.txt): walking whole rows of tiles where the output is narrow (N = 768: gm = 1)
+    // does bring the A operand's fabric reads from 2.0x to ~1.2x of its size - and the launches get SLOWER (cfg-2 step 1.782 ->
+    // 1.840 ms in two same-session A/B rounds, ~4.5 us per N = 768 launch): the fetch volume is not what bounds them.  The
+    // estimate stays for -DCC_RASTER_ADAPTIVE builds; every shipped launch uses the 8-row groups of rounds 1-4.
+    return 8;
+#endif
+    const double R = (double)tiles_m * tiles_n / 8.0;
+    if (R < 4.0) return 8;
+    int best = 8;
+    double best_cost = 0.0;
+    const int cand[5] = {8, 16, 4, 2, 1};
+    for (int c = 0; c < 5; ++c) {
+        const int gm = cand[c] < tiles_m ? cand[c] : tiles_m;
+        const double per_group = (double)gm * tiles_n;
+        double rows, cols;
+        if (R <= per_group) {
+            rows = gm;
+            cols = R / gm + 1.0;
+            if (cols > tiles_n) cols = tiles_n;
+        } else {
+            rows = gm * (R / per_group + 1.0);
+            cols = tiles_n;
+        }
+        if (rows > tiles_m) rows = tiles_m;
+        const double cost = rows * BM + cols * BN;
+        if (c == 0 || cost < best_cost * 0.97) { best = cand[c]; best_cost = cost; }
+    }
+    return best;
+}
+
 template <int BM, int BN, int WM, int WN, int BK = GEMM_BK>
 int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     GemmPair pr{};
     g0.tiles_m = (g0.M + BM - 1) / BM;
     g0.tiles_n = g0.N / BN;
+    g0.group_m = raster_group_rows(g0.tiles_m, g0.tiles_n, BM, BN);
     pr.p[0] = g0;
     pr.tiles0 = g0.tiles_m * g0.tiles_n;
     int total = pr.tiles0;
@@ -1174,6 +1332,7 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1] = *g1;
         pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
         pr.p[1].tiles_n = g1->N / BN;
+        pr.p[1].group_m = raster_group_rows(pr.p[1].tiles_m, pr.p[1].tiles_n, BM, BN);
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
         // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
         // (2.172 vs 2.182 ms per step over 5 A/B rounds; dev builds: CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
@@ -1294,6 +1453,32 @@ static bool epi_is_f16(int epi) {
 static int tile_bn(int tile) { return (tile == 5 || tile == 9 || tile == 10) ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
 static int tile_bk(int tile) { return (tile == 8 || tile == 9) ? 128 : GEMM_BK; }     // (9: two k-halves of whole 64-deep steps)
 
+// Residual epilogue (out_proj / c_proj) and the patch embedding at N % 128 == 0, M >= 4,800: the tile by a two-parameter time
+// model per tile fitted to tools/resid_sweep.py on MI355X (gpurun_out/s2 of round 5 -> profiles/r05_resid_tile_sweep.txt):
+//   launch = rounds x (a + b K) us,  rounds = whole rounds of the workgroup slots + (0.55 + 0.45 f) for a last round filled to f
+// (a partly filled round runs faster than a full one - fewer workgroups share the L2 / fabric - but never in proportion);
+// 128x128: 512 slots (two workgroups per CU), a = 9.1, b = 0.0182;  256x128: 256 slots, 9.3, 0.0170;  256x256: 256 slots, 17.2,
+// 0.0281.  The fit reproduces the 24 measured launches (M = 3,200 ... 38,400, K = 768 / 3,072) within 10 %; what it changes
+// against rounds 1-4: M = 12,800 (cfg 3's clustered blocks) 128x128 -> 256x256 (93 -> 74 us at K = 3,072), M = 25,600 (cfg 4)
+// and M = 6,464 (cfg 5's clustered blocks) 128x128 -> 256x128 (176 -> 166, 51 -> 46 us).  -> tile id, 0 = no opinion.
+static int pick_resid_tile(int M, int N, int K) {
+    if (M < 4800 || (N % 128)) return 0;
+    auto rounds = [](long tiles, long slots) {
+        const long full = tiles / slots, rest = tiles % slots;
+        return (double)full + (rest ? 0.55 + 0.45 * (double)rest / (double)slots : 0.0);
+    };
+    const long m128 = (M + 127) / 128, m256 = (M + 255) / 256;
+    double best = rounds(m128 * (N / 128), 512) * (9.1 + 0.0182 * K);
+    int tile = 1;
+    const double t6 = rounds(m256 * (N / 128), 256) * (9.3 + 0.0170 * K);
+    if (t6 < best) { best = t6; tile = 6; }
+    if ((N % 256) == 0) {
+        const double t5 = rounds(m256 * (N / 256), 256) * (17.2 + 0.0281 * K);
+        if (t5 < best) { best = t5; tile = 5; }
+    }
+    return tile;
+}
+
 static int pick_tile(const GemmArgs& g, int epi) {
     // measured on MI355X (tools/gemm_sweep.py): the 128x128 tile wins whenever it still yields
     // >= ~1.5 workgroups per CU; below that trade tile efficiency for parallelism.
@@ -1312,6 +1497,12 @@ static int pick_tile(const GemmArgs& g, int epi) {
         if (t192 >= 256 && (double)t192 / (double)((t192 + 255) / 256 * 256) >= 0.65 && (!ok256 || r192 * 10 < r256 * 9))
             return 7;
     }
+#ifndef CC_NO_RESID_TILE_MODEL
+    if (epi == EPI_F32_RESID_STATS || epi == EPI_F32_RESID || epi == EPI_F32_PATCH) {
+        const int t = pick_resid_tile(g.M, g.N, g.K);
+        if (t) return t;
+    }
+#endif
     if (ok256) return 5;
     // residual epilogue at N = 768: the 256x128 tile (8 waves, one workgroup per CU) when its grid is one nearly full
     // round of the 256 CUs - half the A-panel re-reads of the 128x128 tile (stand-alone c_proj 55.5 vs 58.7 us = 816
@@ -1410,7 +1601,7 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
 // tile rows x its 192 weight rows), so the tile's q, k, v stay in LDS (EPI_ATTN_LN above).  Sequences per tile: as many as fit
 // 256 rows and the V^T slots (5 of 64 keys, or 8 of 32 keys).
 static bool attn_problem_ok(const GemmArgs& g) {
-    return g.att_L > 0 && g.att_L <= 56 && g.att_nseq > 0 && g.N == 3 * g.K && (g.K % 64) == 0 && g.ldc == g.K && g.ln_stats &&
+    return g.att_L > 0 && g.att_L <= 256 && g.att_nseq > 0 && g.N == 3 * g.K && (g.K % 64) == 0 && g.ldc == g.K && g.ln_stats &&
            g.ln_c1 && g.bias && !g.row_step && !g.row_map;
 }
 bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1) {
@@ -1422,7 +1613,8 @@ bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1) {
 int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1)) || !cc_gemm_attn_applies(g0, g1)) return CC_ERR_INVALID;
     auto shape = [](GemmArgs& g) {
-        const int by_rows = 256 / g.att_L, by_slots = g.att_L > 32 ? 5 : 8;
+        // (V^T rows hold ATTN_VS - 8 = 320 keys; the sequence table 8 entries; L in (56, 64] takes the long form's path with 64-key slots)
+        const int by_rows = 256 / g.att_L, slots = (ATTN_VS - 8) / attn_slot_keys(g.att_L), by_slots = slots < 8 ? slots : 8;
         g.att_spt = by_rows < by_slots ? by_rows : by_slots;
         g.tiles_m = (g.att_nseq + g.att_spt - 1) / g.att_spt;
         g.tiles_n = g.K / 64;

@@ -111,6 +111,10 @@ class GradientBuckets:
       G = 8).  The two halves of consecutive buckets can overlap (async_op) - reduce() issues every bucket's reduce-scatter
       before waiting for the first.
     * the averaged gradients are scattered back into .grad (views of the flat buckets after the first call: no copies).
+    * a parameter that NO rank produced a gradient for keeps ``.grad = None`` (as a single process and DistributedDataParallel
+      leave it: the optimizer then skips it - no weight decay, no moment decay, no step count): every bucket carries one
+      has-gradient flag per parameter behind its gradients, summed by the same collective; the flags are read on the host
+      only on a rank that itself holds a ``None`` gradient.
 
     Values: the mean over ranks of every gradient, as DistributedDataParallel produces (its bucket order differs, so sums
     may differ in the last bit; asserted against an all-reduce mean in tests/test_dist_cpu.py)."""
@@ -132,7 +136,7 @@ class GradientBuckets:
             self.buckets.append(self._make(cur, cur_n))
 
     def _make(self, plist, n):
-        pad = -(-n // self.world) * self.world
+        pad = -(-(n + len(plist)) // self.world) * self.world      # gradients | one has-gradient flag per parameter | padding
         flat = torch.zeros(pad, dtype=torch.float32, device=plist[0].device)
         slots, off = [], 0
         for p in plist:
@@ -141,14 +145,21 @@ class GradientBuckets:
         return flat, slots
 
     def reduce(self):
-        """Average .grad of every parameter over the ranks (in place).  Parameters without a gradient count as zeros."""
+        """Average .grad of every parameter over the ranks (in place).  A parameter without a gradient on this rank counts as
+        zeros in the mean; one without a gradient on every rank keeps ``.grad = None``."""
+        missing = False
         for flat, slots in self.buckets:
+            flags = []
             for p, off, n in slots:
                 dst = flat[off:off + n]
+                flags.append(0.0 if p.grad is None else 1.0)
                 if p.grad is None:
                     dst.zero_()
+                    missing = True
                 elif p.grad.data_ptr() != dst.data_ptr():
                     dst.copy_(p.grad.reshape(-1))
+            n_grad = slots[-1][1] + slots[-1][2]
+            flat[n_grad:n_grad + len(slots)].copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
         if self.world > 1:
             works, shards = [], []
             for flat, _ in self.buckets:
@@ -160,7 +171,12 @@ class GradientBuckets:
                 shard.div_(self.world)
                 dist.all_gather_into_tensor(flat, shard)
         for flat, slots in self.buckets:
-            for p, off, n in slots:
+            n_grad = slots[-1][1] + slots[-1][2]
+            # (the mean of the flags: > 0 where at least one rank had a gradient; a host read only where it can matter)
+            have = flat[n_grad:n_grad + len(slots)].cpu().tolist() if missing else None
+            for i, (p, off, n) in enumerate(slots):
+                if have is not None and p.grad is None and have[i] == 0.0:
+                    continue                                       # globally unused: stays None
                 p.grad = flat[off:off + n].view_as(p)
         return self
 

@@ -156,12 +156,12 @@ def block_forward_train(block, x_lnd):
     x = x_lnd.detach().float().permute(1, 0, 2).contiguous().view(M, W)              # frame-major rows (row = seq*L + token)
     wq, wo, wf, wp = (_w16_pair(w) for w in (block.attn.in_proj_weight, block.attn.out_proj.weight, block.mlp["c_fc"].weight,
                                              block.mlp["c_proj"].weight))
-    n1 = ops.layernorm(x, f32(block.ln_1.weight), f32(block.ln_1.bias), out_f16=True)
+    n1 = ops.layernorm(x, f32(block.ln_1.weight), f32(block.ln_1.bias), eps=block.ln_1.eps, out_f16=True)
     qkv = ops.linear_f16(n1, wq[0], f32(block.attn.in_proj_bias), "f16")
     att = ops.attention_f16(qkv, N, Lt, block.n_head, causal=causal)
     y = x.clone()
     ops.linear_f16(att, wo[0], f32(block.attn.out_proj.bias), "f32_resid", out=y)
-    n2 = ops.layernorm(y, f32(block.ln_2.weight), f32(block.ln_2.bias), out_f16=True)
+    n2 = ops.layernorm(y, f32(block.ln_2.weight), f32(block.ln_2.bias), eps=block.ln_2.eps, out_f16=True)
     u_pre = ops.linear_f16(n2, wf[0], f32(block.mlp["c_fc"].bias), "f16")
     u = torch.empty_like(u_pre)
     _check(L.lib().cc_quick_gelu_f16(L.ptr(u_pre), L.ptr(u), u.numel(), _st(u)), "cc_quick_gelu_f16")
@@ -194,7 +194,7 @@ def block_backward(block, saved, dz_lnd):
            "cc_quick_gelu_backward_f16")
     # u_pre = c_fc(ln_2(y))
     dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = _grad_linear(du_pre, saved["n2"], f16t(block.mlp["c_fc"].weight, "c_fc"), amax=am[0])
-    dy, g["ln_2.weight"], g["ln_2.bias"] = _ln_backward(saved["y"], f32(block.ln_2.weight), dn2, dz, amax=am[1])   # + the residual branch
+    dy, g["ln_2.weight"], g["ln_2.bias"] = _ln_backward(saved["y"], f32(block.ln_2.weight), dn2, dz, eps=block.ln_2.eps, amax=am[1])   # + the residual branch
     # y = x + out_proj(att)
     datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight, "out_proj"), amax=am[1])
     dqkv = torch.empty(M, 3 * W, device=dz.device, dtype=torch.float32)
@@ -204,7 +204,7 @@ def block_backward(block, saved, dz_lnd):
                                              int(saved["causal"]), L.ptr(am[2]), L.ptr(ab_ws), ab_bytes, _st(dz)),
            "cc_attention_backward_f16")
     dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight, "in_proj"), amax=am[2])
-    dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy)
+    dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy, eps=block.ln_1.eps)
     return dx.view(N, Lt, W).permute(1, 0, 2), g
 
 
@@ -565,7 +565,9 @@ class GraphedTrainStep:
     hipGraph and replayed on static input buffers: no op of the step synchronises with the host, so the replay runs at the GPU
     time of its kernels instead of the host's launch rate (cfg-2 shape: 19 ms against 40-100 ms launched op by op).
     Single process (a captured step cannot contain the RCCL exchange of GradientBuckets); fixed batch shape; an optimizer
-    built with capturable=True.  The first call warms up eagerly (2 steps on the given batch) and captures."""
+    built with capturable=True.  The first call warms up eagerly (2 steps on the given batch) and captures - on a snapshot:
+    parameters, moments and step counts are put back before the one replay that counts, so that EVERY call, the first
+    included, is exactly one optimizer step (main.py:300-340) and the schedule position equals the caller's step count."""
 
     def __init__(self, model, optimizer, gradient_accumulation_steps=1):
         if not getattr(optimizer, "capturable", False):
@@ -585,6 +587,36 @@ class GraphedTrainStep:
             self.model.clip.logit_scale.clamp_(0.1, 4.6052)
         return loss.detach()
 
+    def _tensors(self):
+        seen, out = set(), []
+        for p in list(self.model.parameters()) + [p for g in self.optimizer.param_groups for p in g['params']]:
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def _snapshot(self):
+        """Copies of everything a step changes: every parameter, and per parameter the optimizer's (step, next_m, next_v)."""
+        snap = []
+        for p in self._tensors():
+            st = self.optimizer.state.get(p, {})
+            snap.append((p, p.detach().clone(), st.get('step'), st['next_m'].clone() if 'next_m' in st else None,
+                         st['next_v'].clone() if 'next_v' in st else None))
+        return snap
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        """In place (the captured graph holds the addresses of the parameters and of the moments the warm-up created);
+        Tensor.copy_ bumps the version counter, so cached fp16 / folded copies of the weights refresh."""
+        for p, value, step, m, v in snap:
+            p.copy_(value)
+            st = self.optimizer.state.get(p)
+            if not st:
+                continue
+            st['step'] = 0 if step is None else step
+            st['next_m'].zero_() if m is None else st['next_m'].copy_(m)
+            st['next_v'].zero_() if v is None else st['next_v'].copy_(v)
+
     def __call__(self, batch):
         """batch = (input_ids, input_mask, segment_ids, video, video_mask) as the dataloaders yield it -> the step's loss (a
         device tensor that the next call overwrites)."""
@@ -592,15 +624,17 @@ class GraphedTrainStep:
         if self.graph is None:
             self.model.train()
             self.static = [t.to(dev).clone() for t in batch]
-            for _ in range(2):
+            snap = self._snapshot()
+            for _ in range(2):                                    # allocator / staging-buffer warm-up (the optimizer's records)
                 self._step()
             torch.cuda.synchronize()
-            self.optimizer.refresh_lr()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph):                    # (the capture pass does not execute)
                 self.loss = self._step()
-            self.graph.replay()                                   # (the capture pass does not execute; this replay does:
-            self.optimizer.advance()                              #  the batch has now been stepped on three times)
+            self._restore(snap)                                   # the two warm-up steps never happened
+            self.optimizer.refresh_lr()
+            self.graph.replay()
+            self.optimizer.advance()
             return self.loss
         for dst, src in zip(self.static, batch):
             dst.copy_(src, non_blocking=True)

@@ -65,7 +65,15 @@ def _import_main():
             sys.modules[name] = types.ModuleType(name)
     sys.modules["torch.utils.tensorboard"].SummaryWriter = object
     sys.modules["dataloaders.data_dataloaders"].DATALOADER_DICT = {}
-    import main as rmain
+    # (_import_reference() restores sys.path, so /root/reference is no longer on it: `import main` needs it in front, and
+    # /root/reference/modules out of the way - `utils` must resolve to the package, not to modules/utils.py)
+    ref, mods_dir = "/root/reference", os.path.join("/root/reference", "modules")
+    saved = list(sys.path)
+    sys.path[:] = [ref] + [p_ for p_ in sys.path if p_ not in (ref, mods_dir)]
+    try:
+        import main as rmain
+    finally:
+        sys.path[:] = saved
     return rmain, rc4c
 
 

@@ -160,8 +160,9 @@ def case_gradient_buckets(rank, world):
     torch.manual_seed(3)
     shapes = [(7, 5), (13,), (64, 33), (1,), (3, 3, 3), (129,)]
     params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    unused = torch.nn.Parameter(torch.zeros(6))                          # no rank ever produces a gradient for it
     frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
-    gb = GradientBuckets(params + [frozen], bucket_bytes=4096)          # -> several buckets
+    gb = GradientBuckets(params + [unused, frozen], bucket_bytes=4096)  # -> several buckets
     ok = len(gb.buckets) > 2
     for step in range(2):
         g = torch.Generator().manual_seed(100 * step + rank)
@@ -176,6 +177,7 @@ def case_gradient_buckets(rank, world):
         gb.reduce()
         ok = ok and all(torch.allclose(p.grad, w_, rtol=0, atol=1e-6) for p, w_ in zip(params, want))
         ok = ok and frozen.grad is None
+        ok = ok and unused.grad is None                                  # globally unused: None, as DDP / one process leave it
     return bool(ok)
 
 
@@ -191,8 +193,9 @@ def test_gradient_buckets_single_process_keeps_gradients():
     from centerclip_amd.dist import GradientBuckets
     p = torch.nn.Parameter(torch.zeros(5))
     p.grad = torch.arange(5.0)
-    GradientBuckets([p]).reduce()
-    assert torch.equal(p.grad, torch.arange(5.0))
+    q = torch.nn.Parameter(torch.zeros(3))                               # never gets a gradient
+    GradientBuckets([p, q]).reduce()
+    assert torch.equal(p.grad, torch.arange(5.0)) and q.grad is None
 
 
 def test_packed_features_world2():

@@ -248,6 +248,52 @@ def test_inproj_attention_one_launch_is_bit_identical(nseq, L, heads, causal):
     assert relerr(got.float(), ref) < 2e-3
 
 
+@pytest.mark.parametrize("nseq,L,heads,causal", [(24, 197, 12, False), (16, 101, 12, False), (9, 77, 8, True), (5, 64, 2, False),
+                                                  (3, 57, 2, True), (2, 256, 1, False), (7, 130, 3, True), (1, 161, 2, False)])
+def test_inproj_attention_one_launch_long_sequences(nseq, L, heads, causal):
+    """Round 5: the one-launch form for 56 < L <= 256 (ViT-B/16's 197-token frames and 101 / 161-token clustered blocks, CLIP's
+    77-token captions): whole sequences x one head per workgroup, scores and P in registers (the PV contraction takes the 32
+    keys of a block in the accumulator's own order), against the two launches - same fp16 q, k, v, another summation order
+    inside the matrix cores, so equal to the rounding of the fp16 output - and against the fp32 formula of modules/clip.py:210-214."""
+    from centerclip_amd import ops
+    W = heads * 64
+    h16, st, wf, c1, c2 = _inproj_inputs(nseq * L, W, 300 + L)
+    qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1)
+    want = ops.attention_f16(qkv, nseq, L, heads, causal=causal)
+    got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, nseq, L, heads, causal=causal)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert relerr(got.float(), want.float()) < 2e-3
+    q, k, v = (t.view(nseq, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().split(W, dim=1))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=s.device).triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(nseq * L, W)
+    assert relerr(got.float(), ref) < 2e-3
+    again = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, nseq, L, heads, causal=causal)
+    assert torch.equal(got, again)                                                   # fixed order: the same bits on every run
+
+
+def test_inproj_attention_packed_long_captions():
+    """Packed variable-length captions with the 77-token context (3 sequence slots of 96 keys per row tile): every caption
+    against the two-launch result of that caption alone."""
+    from centerclip_amd import ops
+    heads, W, L = 8, 512, 77
+    lens = [77, 5, 40, 1, 76, 20, 9, 65, 33, 2, 77]                                 # 11 captions: 4 row tiles of 3
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    Mv = int(sum(lens))
+    h16, st, wf, c1, c2 = _inproj_inputs(len(lens) * L, W, 9)
+    seq_off = torch.from_numpy(off).cuda()
+    seq_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, len(lens), L, heads, causal=True, seq_off=seq_off, seq_len=seq_len)
+    torch.cuda.synchronize()
+    for s, (o, n) in enumerate(zip(off, lens)):
+        qkv = ops.linear_ln_f16(h16[o:o + n].contiguous(), wf, c1, c2, st[o:o + n].contiguous(), 1)
+        want = ops.attention_f16(qkv, 1, n, heads, causal=True)
+        assert relerr(got[o:o + n].float(), want.float()) < 2e-3, (s, n)
+    assert not got[Mv:].any()                                                        # rows behind the packed captions: untouched
+
+
 def test_inproj_attention_packed_captions():
     """Variable-length sequences packed back to back (the compacted captions of the text tower): every caption must equal
     the two-launch result of that caption alone."""
@@ -365,9 +411,9 @@ def test_train_epoch_runs_and_lowers_the_loss():
 def test_inproj_attention_argument_range():
     """Outside the one-launch form's range the entry point says so (the towers then run the two launches)."""
     from centerclip_amd import ops
-    h16, st, wf, c1, c2 = _inproj_inputs(4 * 57, 128, 3)
+    h16, st, wf, c1, c2 = _inproj_inputs(2 * 257, 128, 3)
     with pytest.raises(RuntimeError, match="unsupported"):
-        ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 4, 57, 2)               # L > 56
+        ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 2, 257, 2)              # L > 256
     h16, st, wf, c1, c2 = _inproj_inputs(8, 64, 4)
     got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1)                # one token per sequence: softmax of one score
     qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1)
@@ -486,7 +532,8 @@ def test_gradient_producers_publish_their_largest_magnitude():
 
 def test_graphed_train_step_equals_eager_steps():
     """train.GraphedTrainStep (forward + backward + BertAdam captured into one hipGraph, the schedule's value through a device
-    float) against the same steps launched op by op: identical parameters after 2 warm-up + 3 replayed steps."""
+    float) against the same steps launched op by op: identical parameters after 3 calls = 3 optimizer steps (the first
+    call's eager warm-up runs on a snapshot that is put back before its replay: one call, one step - main.py:300-340)."""
     from argparse import Namespace
     from centerclip_amd.clip4clip import CLIP4Clip
     from centerclip_amd.train import BertAdam, prep_optim_params_groups, train_epoch, GraphedTrainStep
@@ -503,13 +550,16 @@ def test_graphed_train_step_equals_eager_steps():
                      e=1e-6, max_grad_norm=1.0, capturable=capturable)
         return m, o
     m0, o0 = make(False)
-    train_epoch(0, args, m0, [batch] * 5, "cuda:0", o0, 0)
+    train_epoch(0, args, m0, [batch] * 3, "cuda:0", o0, 0)
     m1, o1 = make(True)
     stepper = GraphedTrainStep(m1, o1)
-    for _ in range(3):                                                  # first call: 2 eager steps + capture + 1 replay
+    loss = stepper(batch)                                               # first call: warm-up on a snapshot + capture + 1 replay
+    torch.cuda.synchronize()
+    assert all(st["step"] == 1 for st in o1.state.values())
+    for _ in range(2):
         loss = stepper(batch)
     torch.cuda.synchronize()
     assert np.isfinite(float(loss))
-    assert all(st["step"] == 5 for st in o1.state.values())
+    assert all(st["step"] == 3 for st in o1.state.values())
     for (k, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
         assert torch.equal(p0, p1), k
