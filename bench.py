@@ -150,21 +150,17 @@ def graph_time_ms(fn, launches=20, replays=4):
 
 
 TILES = {1: (128, 128, 2, 2, 64), 2: (128, 64, 2, 2, 64), 3: (64, 128, 2, 2, 64), 4: (64, 64, 2, 2, 64),
-         5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128),
-         9: (256, 256, 2, 4, 64),          # 9: split-K, two workgroups per tile (last template argument 2)
-         10: (128, 256, 2, 4, 64), 11: (256, 256, 2, 4, 64)}     # 11: the persistent form, its own kernel (gemm_persist_kernel<epi>)
+         5: (256, 256, 2, 4, 64), 6: (256, 128, 4, 2, 64), 7: (256, 192, 2, 4, 64), 8: (64, 64, 2, 2, 128), 10: (128, 256, 2, 4, 64)}
 
 
 def kernel_symbol(M, N, K, epi):
     """Name of the gemm_f16_kernel instantiation a stand-alone launch of this shape runs on (as rocprofv3 prints it)."""
     from centerclip_amd import _lib as L
     if epi == 8:                                 # in_proj + attention in one launch: always the 256x192 tile
-        return "gemm_f16_kernel<256, 192, 2, 4, 8, 64, 1>"
+        return "gemm_f16_kernel<256, 192, 2, 4, 8, 64>"
     t = L.lib().cc_linear_tile_for(M, N, K, epi)
-    if t == 11:
-        return "gemm_persist_kernel<%d>" % epi
     bm, bn, wm, wn, bk = TILES[t]
-    return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk, 2 if t == 9 else 1)
+    return "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
 
 
 PMC_PASSES = {   # one counter group per rocprofv3 run (4 TCC slots; counters + kernel trace only)
@@ -279,8 +275,7 @@ def insitu_gemm_times(step, reps=6, rider_rows=None, rider_rows_launched=None):
     for i in range(n):
         assert lib.cc_debug_gemm_timing_read(i, ctypes.byref(us), info) == 0
         bm, bn, wm, wn, epi, bk, m0, n0, k0, m1, n1, k1 = list(info)
-        sym = ("gemm_persist_kernel<%d>" % epi if (bk >> 16) == 3 else
-               "gemm_f16_kernel<%d, %d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk & 0xffff, max(1, bk >> 16)))
+        sym = "gemm_f16_kernel<%d, %d, %d, %d, %d, %d>" % (bm, bn, wm, wn, epi, bk)
         e = out.setdefault(sym, dict(us=0.0, launches=0, flops=0.0, shapes={}))
         e["us"] += us.value
         e["launches"] += 1
@@ -311,9 +306,9 @@ def gemm_roofline(c, device, insitu=None):
     n0, n1 = c["cluster_block"] - 1, 13 - c["cluster_block"]
     # (name, M, N, K, epilogue id, calls per step)
     shapes = [("patch_embed", B * T * 49, W, 3 * 32 * 32, 3, 1),
-              ("in_proj+attention" if L0 <= 56 else "in_proj", M0, 3 * W, W, 8 if L0 <= 56 else 5, n0), ("out_proj", M0, W, W, 7, n0),
+              ("in_proj+attention" if L0 <= 256 else "in_proj", M0, 3 * W, W, 8 if L0 <= 256 else 5, n0), ("out_proj", M0, W, W, 7, n0),
               ("c_fc", M0, 4 * W, W, 6, n0), ("c_proj", M0, W, 4 * W, 7, n0),
-              ("in_proj+attention@clustered" if L1 <= 56 else "in_proj@clustered", M1, 3 * W, W, 8 if L1 <= 56 else 5, n1),
+              ("in_proj+attention@clustered" if L1 <= 256 else "in_proj@clustered", M1, 3 * W, W, 8 if L1 <= 256 else 5, n1),
               ("out_proj@clustered", M1, W, W, 7, n1 - 1),
               ("c_fc@clustered", M1, 4 * W, W, 6, n1 - 1), ("c_proj@clustered", M1, W, 4 * W, 7, n1 - 1)]
     # (block 12 runs out_proj / c_fc / c_proj on the B * T_new CLS rows only - gemm_rows_kernel, 0.06 GFLOP, not listed)

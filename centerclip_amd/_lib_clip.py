@@ -54,25 +54,12 @@ def declare(lib):
     lib.cc_row_stats_f16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.cc_linear_ln_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp]
     lib.cc_linear_resid_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), vp, vp, i32, vp, i32, i32, i32, i32, vp]
-    lib.cc_linear_ws_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]
-    lib.cc_linear_ws_f16.restype = c.c_int
-    lib.cc_linear_ln_ws_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
-    lib.cc_linear_ln_ws_f16.restype = c.c_int
     lib.cc_inproj_attention_f16.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.cc_inproj_attention_f16.restype = c.c_int
     lib.cc_linear_tile_for.argtypes = [i32, i32, i32, i32]
     lib.cc_linear_tile_for.restype = c.c_int
     lib.cc_linear_resid_stats_slots.argtypes = [i32, i32, i32, i32]
     lib.cc_linear_resid_stats_slots.restype = c.c_int
-    lib.cc_linear_resid_stats_slots_ws.argtypes = [i32, i32, i32, i32, i32]
-    lib.cc_linear_resid_stats_slots_ws.restype = c.c_int
-    lib.cc_linear_splitk_workspace_bytes.argtypes = []
-    lib.cc_linear_splitk_workspace_bytes.restype = sz
-    lib.cc_linear_splitk_flag_bytes.argtypes = []
-    lib.cc_linear_splitk_flag_bytes.restype = sz
-    lib.cc_linear_resid_stats_ws_f16.argtypes = [vp, vp, vp, vp, vp, vp, c.POINTER(i32), vp, vp, i32, vp, i32, i32, i32, i32,
-                                                 vp, sz, vp]
-    lib.cc_linear_resid_stats_ws_f16.restype = c.c_int
     lib.cc_attention_strided_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i64, i64, vp]
     lib.cc_attention_strided_f16.restype = c.c_int
     lib.cc_text_encode_hidden.argtypes = [c.POINTER(TextModel), vp, i32, i32, vp, vp, vp, sz, vp]

@@ -56,10 +56,6 @@ struct GemmArgs {
     // EPI_F32 only: when non-null the product is also divided by *out_unscale_dev (a power-of-two operand scale chosen on the
     // device by cc_cast_scaled_f16 / cc_cast_transpose_f16: the backward's dgrad / wgrad GEMMs undo it in their epilogue).
     const float* out_unscale_dev;
-    // Split-K workspace (host side only reads it from p[0]): CC_GEMM_SK_WS_BYTES of device memory whose first
-    // CC_GEMM_SK_FLAG_BYTES are zero before the first launch that uses it (every launch leaves them zero again).  Null:
-    // the dispatcher never picks a split-K form.
-    void* sk_ws;
     // EPI_ATTN_LN (cc_gemm_attn_dispatch2): N = 3W, W = heads * 64; a tile is att_spt whole sequences (rows) x one head
     // (its 64 q, 64 k and 64 v columns); sequence s = att_L tokens at row s * att_L, or - compacted captions -
     // att_seq_len[s] tokens at row att_seq_off[s] (att_L is then the upper bound)
@@ -68,21 +64,12 @@ struct GemmArgs {
     const int* att_seq_len;
 };
 
-// Split-K exchange area: [flags: 4096 ints][slots of 256 KB: one 256x256 fp32 partial tile, or two half tiles]
-#define CC_GEMM_SK_FLAG_BYTES (16 * 1024)
-#define CC_GEMM_SK_SLOT_BYTES (256 * 1024)
-#define CC_GEMM_SK_MAX_SLOTS 256
-#define CC_GEMM_SK_WS_BYTES ((size_t)CC_GEMM_SK_FLAG_BYTES + (size_t)CC_GEMM_SK_MAX_SLOTS * CC_GEMM_SK_SLOT_BYTES)
-
 // Up to two independent GEMM problems with the same epilogue in ONE launch (horizontal fusion of the
 // visual and the text tower: the small text problem rides in the tail round of the large one).
 struct GemmPair {
     GemmArgs p[2];
     int tiles0;          // workgroups [0, tiles0) -> p[0], the rest -> p[1]
     int rider_prio;      // raise the wave priority of p[1]'s workgroups
-    int* sk_flags;       // split-K forms: the exchange area (see CC_GEMM_SK_WS_BYTES)
-    unsigned char* sk_slots;
-    int* sk_error;       // set to 1 when a bounded spin gave up (never in a healthy run)
 };
 
 int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st);
@@ -91,10 +78,6 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
 // The same product for a FEW selected rows (GemmArgs::row_step / row_map; epilogues EPI_F16_GELU_LN, EPI_F32_RESID and
 // EPI_F32_RESID_STATS; N % 32 == 0, K % 32 == 0; with statistics N <= 32 * CC_LN_MAX_SLOTS): latency-bound, so the K
 // range is split over the 8 waves of a workgroup and the grid has one workgroup per 32 output columns.
-// gemm_persist.hip: the persistent 256x256 form (one workgroup per CU walking a range of the launch's k-steps; tiles cut
-// between two workgroups are summed through the exchange scratch g0.sk_ws).  fp16-output epilogues.
-bool cc_gemm_persist_applies(const GemmArgs& g0, const GemmArgs* g1, int epi);
-int cc_gemm_persist_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st);
 // diagnostics (cc_debug_gemm_timing_*): while armed, -> true and a start / stop event pair for this launch
 bool cc_gemm_timing_claim(const int rec12[12], hipEvent_t* start, hipEvent_t* stop);
 bool cc_gemm_rows_ok(int N, int K, int epi);
@@ -142,7 +125,7 @@ struct AttArgs {
 int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st);
 // in_proj (LayerNorm folded) + attention in one launch (gemm.hip, EPI_ATTN_LN): g.A = centred fp16 rows, g.W / bias / ln_* as
 // for EPI_F16_LN, g.C = attention output [M, W] fp16; the att_* fields describe the sequences.  applies(): head width 64,
-// att_L <= 64 and the folded form available - otherwise the caller runs the two launches.
+// att_L <= 256 and the folded form available - otherwise the caller runs the two launches.
 bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1);
 int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st);
 

@@ -37,7 +37,6 @@ struct VitWs {
     _Float16* u;
     void* cluster;
     size_t cluster_bytes;
-    void* sk;        // split-K exchange area of the GEMMs (CC_GEMM_SK_WS_BYTES; flags zeroed at the start of every encode)
     size_t total;
 };
 
@@ -75,7 +74,6 @@ VitWs carve_vit(const cc_vit_model* m, int B, int T, void* ws) {
     }
     v.cluster_bytes = cb;
     v.cluster = c.take<char>(cb);
-    v.sk = c.take<char>(CC_GEMM_SK_WS_BYTES);
     v.total = c.off;
     return v;
 }
@@ -92,7 +90,6 @@ struct BlockCtx {          // one tower's activations for the current block
     _Float16* u;
     int nseq, L, W, heads, causal;
     int slots0, slots1;    // partial-sum slots per row currently held in st0 / st1
-    void* sk;              // split-K exchange area (the carrier's context only)
     // compacted captions (text tower): device-side row count and per-caption (offset, length); null = dense [nseq, L]
     const int* m_dev;
     const int* seq_off;
@@ -139,7 +136,6 @@ int run_block_pair(const cc_block_weights* w0, BlockCtx* c0, const cc_block_weig
         g.M = M; g.N = N; g.K = K; g.ldc = N;
         g.ln_eps = 1e-5f;
         g.m_dev = c->m_dev;
-        g.sk_ws = c->sk;
         return g;
     };
     // the phases behind the attention: every row, or the rows the head will read (GemmArgs::row_step / row_map) with the
@@ -319,16 +315,6 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
         const int g = vm->resolution / vm->patch, n = g * g, F = B * T;
         W = vm->width;
         tokens = n;
-        // The split-K GEMM forms hand accumulator halves over through v.sk and need its flags zero (each launch leaves them
-        // zero; a caller's uninitialised workspace must not read as "partner ready").  The dispatcher picks those forms only
-        // in a -DCC_SPLITK_AUTO build (measured slower) - every other build leaves the towers without the
-        // scratch (the forms cannot be chosen) and saves the 4.5 us fill launch per encode.
-#ifdef CC_SPLITK_AUTO
-        if (hipMemsetAsync(v.sk, 0, CC_GEMM_SK_FLAG_BYTES, st) != hipSuccess) return CC_ERR_HIP;
-        cv.sk = v.sk;
-#else
-        cv.sk = nullptr;
-#endif
         // patch embedding: conv1 as im2col GEMM, + positional embedding, CLS row, ln_pre (clip.py:324-338)
         const bool patch3d = vm->conv2_weight_f16 != nullptr;      // linear_patch '3d' (clip.py:306-317)
         rc = patch3d ? cc_launch_im2col3d(*video, v.im2col, F, T, vm->resolution, vm->patch, st)

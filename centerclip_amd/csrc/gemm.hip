@@ -93,28 +93,19 @@ __device__ __forceinline__ float dpp_f32(float x) {          // lane exchange in
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 
-// sc1 (write-through / L1-bypassing) 16-byte accesses for data handed from one workgroup to another inside a launch:
-// correct wherever the two workgroups run (the per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed)
+// buffer descriptor over a whole output tensor: the epilogues' write-through (sc1) 16-byte stores go through it
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(void* base) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
 }
 
-// SK = 2: split-K over two workgroups per output tile (the N = 768 residual GEMMs: 114 tiles of 256x256 would leave more
-// than half of the CUs idle, the 256x128 tile that fills them is 30 % slower per flop).  Workgroup ids b and b + 8 (same
-// XCD, dispatched back to back) form a pair: each runs one half of the k range over the whole tile, then they swap
-// halves of the accumulator - the fragment-row groups i = 2*ii + 1 go from k-half 0 to k-half 1 and the groups i = 2*ii
-// the other way, in accumulator layout (1 KB per fragment and wave: fully coalesced both ways), through sc1 stores /
-// loads and one flag per direction - and each finishes the epilogue of its 128 rows.  own + partner's is a two-term sum,
-// so the result does not depend on which of the two arrives first.
-template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     GEMM_PROF_INIT();
     GEMM_STAMP(0);
     const bool second = (int)blockIdx.x >= pr.tiles0;
     GemmArgs g = second ? pr.p[1] : pr.p[0];
     if (g.m_dev) g.M = *g.m_dev;                             // device-side row count (compacted captions): wave-uniform
-    static_assert(SK == 1 || (SK == 2 && EPI == EPI_F32_RESID_STATS && BM == 256 && BN == 256), "split-K form");
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -126,13 +117,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // tiles (tn fastest) so tiles sharing an A panel hit the same L2.
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = (int)blockIdx.x - (second ? pr.tiles0 : 0);
-    int khalf = 0, sk_pair = 0;
-    if constexpr (SK == 2) {                                 // ids 16u .. 16u+7: k-half 0 of tiles 8u .. 8u+7; 16u+8 .. 16u+15: k-half 1
-        khalf = (bid >> 3) & 1;
-        bid = ((bid >> 4) << 3) | (bid & 7);
-        if (bid >= nwg) return;                              // (the grid is rounded up to whole groups of 16)
-        sk_pair = (second ? (pr.tiles0 >> 1) : 0) + bid;
-    }
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -149,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int tm = first_m + in_group % gsz, tn = in_group / gsz;
     // (EPI_ATTN_LN: a row tile is att_spt whole sequences, a column tile the q | k | v columns of head tn)
     constexpr bool ATTN = (EPI == EPI_ATTN_LN);
-    static_assert(!ATTN || (BM == 256 && BN == 192 && WM == 2 && WN == 4 && BK == 64 && SK == 1), "in_proj + attention form");
+    static_assert(!ATTN || (BM == 256 && BN == 192 && WM == 2 && WN == 4 && BK == 64), "in_proj + attention form");
     const int att_s0 = ATTN ? tm * g.att_spt : 0;
     const int row0 = ATTN ? (g.att_seq_off ? g.att_seq_off[att_s0] : att_s0 * g.att_L) : tm * BM, col0 = tn * BN;
     if (row0 >= g.M) return;                                 // (only with m_dev: the grid was sized for the upper bound)
@@ -164,14 +148,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
     for (int q = 0; q < A_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
+        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8;
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
         // (ATTN: wave column wc multiplies the d-slice [16 wc, 16 wc + 16) of q, of k and of v: LDS row 48 wc + 16 sec + dd)
         const int wrow = ATTN ? ((r % 48) >> 4) * (g.N / 3) + tn * 64 + (r / 48) * 16 + (r & 15) : col0 + r;
-        bsrc[q] = g.W + (int64_t)wrow * g.K + c * 8 + (SK == 2 ? khalf * (g.K / 2) : 0);
+        bsrc[q] = g.W + (int64_t)wrow * g.K + c * 8;
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
@@ -188,7 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK / SK);
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / BK);
     // The rider's tiles are the ones that spill into a second round when the carrier alone fills the slots (the
     // clustered blocks): served first by the CU's arbiters they free their slots sooner for the tiles still queued.
     const bool rider_first = second && pr.rider_prio;
@@ -329,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #ifdef CC_NO_RESID_PREFETCH
     constexpr bool RES_PREFETCH = false;
 #else
-    constexpr bool RES_PREFETCH = RESID && NST == 3 && SK == 1 && HALF_SHIFTED && BK == GEMM_BK;
+    constexpr bool RES_PREFETCH = RESID && NST == 3 && HALF_SHIFTED && BK == GEMM_BK;
 #endif
     constexpr int PF_LPRF = ((BN / WN) / 4 <= 8) ? 8 : 16, PF_RPP = 64 / PF_LPRF, PF_PASSES = 16 / PF_RPP;
     f32x4 resall[RES_PREFETCH ? MI : 1][RES_PREFETCH ? PF_PASSES : 1];
@@ -816,7 +800,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     if (qq < L) {
                         const int64_t e = (int64_t)(row0 + off + qq) * g.ldc + tn * 64 + (lane & 7) * 8;
                         if ((int64_t)g.M * g.ldc < (int64_t)0x3fffffff)      // (32-bit byte offset of the buffer form)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb), (int)(e * 2), 0, 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), wt_rsrc(Cb), (int)(e * 2), 0, 16);
                         else
                             *reinterpret_cast<h8*>(Cb + e) = ov;
                     }
@@ -937,7 +921,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     if (qq < L) {
                         const int64_t e = (int64_t)(row0 + off + qq) * g.ldc + tn * 64 + (lane & 7) * 8;
                         if ((int64_t)g.M * g.ldc < (int64_t)0x3fffffff)      // (32-bit byte offset of the buffer form)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb), (int)(e * 2), 0, 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), wt_rsrc(Cb), (int)(e * 2), 0, 16);
                         else
                             *reinterpret_cast<h8*>(Cb + e) = ov;
                     }
@@ -1018,7 +1002,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     const bool wt_out = GELU && (int64_t)g.M * g.ldc < (int64_t)0x3fffffff;   // (32-bit byte offset of the buffer form)
 #endif
                     if (wt_out)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), sk_rsrc(Cb),
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), wt_rsrc(Cb),
                                                                (int)(((int64_t)m * g.ldc + col0 + wc * WTN + lc) * 2), 0, 16);
                     else
                         *reinterpret_cast<h8*>(Cb + (int64_t)m * g.ldc + col0 + wc * WTN + lc) = ov;
@@ -1054,8 +1038,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     }
     const int er = lane / LPRF, ec = (lane % LPRF) * 4;           // this lane's row (within a pass) and column
     const int ncol = col0 + wc * WTN + ec;
-    // (split-K: register group i = 2*ii holds the fragment-row group 2*ii + khalf after the exchange below)
-    auto out_row = [&](int i, int ps) { return row0 + wr * WTM + (i + khalf) * 16 + ps * RPP + er; };
+    auto out_row = [&](int i, int ps) { return row0 + wr * WTM + i * 16 + ps * RPP + er; };
     // The fp32 residual rows come from HBM: they are fetched one fragment-row group ahead (issued before this
     // group's stores - a load behind a store to the same buffer cannot be hoisted by the compiler).
     float4 resv[2][PASSES];
@@ -1075,62 +1058,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // they stand (16 half-used cache lines per instruction in any register-layout form; whole rows through the LDS strip
     // here) - the fetch stays in the epilogue, where the sum order is the same for every tile.
     constexpr bool RESID_LOAD = RESID;
-    if constexpr (SK == 2) {
-        // ---- swap accumulator halves with the partner workgroup (see the comment above the kernel)
-        constexpr int HALF_SLOT = CC_GEMM_SK_SLOT_BYTES / 2, FR = (MI / 2) * NI;     // 16 fragments of 1 KB per wave each way
-        const __amdgpu_buffer_rsrc_t wr_rs = sk_rsrc(pr.sk_slots + (size_t)(sk_pair * 2 + khalf) * HALF_SLOT);
-        const __amdgpu_buffer_rsrc_t rd_rs = sk_rsrc(pr.sk_slots + (size_t)(sk_pair * 2 + (khalf ^ 1)) * HALF_SLOT);
-        const int xoff = (wave * FR * 64 + lane) * 16;
-        if (khalf == 0) {
-#pragma unroll
-            for (int ii = 0; ii < MI / 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[2 * ii + 1][j]), wr_rs,
-                                                           xoff + (ii * NI + j) * 1024, 0, 16);
-        } else {
-#pragma unroll
-            for (int ii = 0; ii < MI / 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[2 * ii][j]), wr_rs,
-                                                           xoff + (ii * NI + j) * 1024, 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's half has left the CU ...
-        __syncthreads();                                           // ... and so has everybody else's
-        int* myflag = pr.sk_flags + sk_pair * 2 + khalf;
-        int* pflag = pr.sk_flags + sk_pair * 2 + (khalf ^ 1);
-        if (tid == 0) __hip_atomic_store(myflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (khalf) {                                              // own groups into the even register groups
-#pragma unroll
-            for (int ii = 0; ii < MI / 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[2 * ii][j] = acc[2 * ii + 1][j];
-        }
-        if (RESID_LOAD) fetch_residual(0, 0);                      // (in flight while the partner finishes)
-        if (tid == 0) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > 20000000ll) { *pr.sk_error = 1; break; }   // 0.2 s: never in a healthy run
-            }
-            __hip_atomic_store(pflag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zeros
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ii = 0; ii < MI / 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_rs, xoff + (ii * NI + j) * 1024, 0, 16));
-                acc[2 * ii][j] += o;
-            }
-    } else {
-        if (RESID_LOAD && !res_have) fetch_residual(0, 0);
-    }
+    if (RESID_LOAD && !res_have) fetch_residual(0, 0);
     static_assert(!RES_PREFETCH || (PF_LPRF == LPRF && PF_RPP == RPP && PF_PASSES == PASSES), "prefetch geometry = epilogue geometry");
 #pragma unroll
-    for (int i = 0; i < MI; i += SK) {
-        if (RESID_LOAD && !res_have && i + SK < MI) fetch_residual(((i / SK) + 1) & 1, i + SK);
+    for (int i = 0; i < MI; ++i) {
+        if (RESID_LOAD && !res_have && i + 1 < MI) fetch_residual((i + 1) & 1, i + 1);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float4 bb = biasv[j];
@@ -1147,7 +1079,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 if (RESID_LOAD) {
                     float4 c;
                     if constexpr (RES_PREFETCH) { const f32x4 t = resall[i][ps]; c = make_float4(t[0], t[1], t[2], t[3]); }
-                    else c = resv[(i / SK) & 1][ps];
+                    else c = resv[i & 1][ps];
                     v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
                 }
                 // write-through (sc1): the rows leave the XCD's L2 while the launch runs instead of in the write-back at its
@@ -1159,7 +1091,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #endif
                 if (m < g.M) {
                     if (wt_ok)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), sk_rsrc(g.C),
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), wt_rsrc(g.C),
                                                                (int)(((int64_t)m * g.ldc + ncol) * 4), 0, 16);
                     else
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + ncol) = v;
@@ -1167,7 +1099,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 if (STATS) {
                     // the consumer multiplies fp16(h - c_row): without the centring the rounding error of the copy scales
                     // with |mean| / sigma of the row (LayerNorm itself is shift invariant, so the consumer is unchanged)
-                    const float cr = centred ? rowsh[wr * WTM + (i + khalf) * 16 + ps * RPP + er] : 0.f;
+                    const float cr = centred ? rowsh[wr * WTM + i * 16 + ps * RPP + er] : 0.f;
                     const h4 o = {(_Float16)(v.x - cr), (_Float16)(v.y - cr), (_Float16)(v.z - cr), (_Float16)(v.w - cr)};
                     if (m < g.M) *reinterpret_cast<h4*>(g.c16 + (int64_t)m * g.ldc + ncol) = o;
                     if (centred && g.shift_out && tn == 0 && wc == 0 && (lane % LPRF) == 0 && m < g.M) g.shift_out[m] = cr;
@@ -1213,7 +1145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 }
             }
         }
-        if (i + SK < MI) {                                        // the strip is rewritten by the next group
+        if (i + 1 < MI) {                                         // the strip is rewritten by the next group
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
@@ -1239,7 +1171,7 @@ struct GemmTiming {
     bool armed = false;
     int count = 0, cap = 0;
     hipEvent_t* ev = nullptr;          // [2 * cap]: kernel start, kernel stop
-    int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK | SK << 16, M0, N0, K0, M1, N1, K1
+    int (*info)[12] = nullptr;         // BM, BN, WM, WN, EPI, BK, M0, N0, K0, M1, N1, K1
 } g_timing;
 
 }  // namespace
@@ -1253,11 +1185,11 @@ bool cc_gemm_timing_claim(const int rec12[12], hipEvent_t* start, hipEvent_t* st
 }
 namespace {
 
-template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK, int SK = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     constexpr size_t smem_loop = (size_t)GEMM_NST(BM, BN, WM * WN, BK) * (size_t)(BM + BN) * BK * 2;
     constexpr size_t smem = (EPI == EPI_ATTN_LN && smem_loop < ATTN_SMEM) ? (size_t)ATTN_SMEM : smem_loop;
-    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK, SK>;
+    auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK>;
     if (smem > 64 * 1024) {
         static bool configured = false;      // per instantiation; benign race (idempotent call)
         if (!configured) {
@@ -1270,7 +1202,7 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     const int tid = (g_timing.armed && g_timing.count < g_timing.cap) ? g_timing.count++ : -1;
     if (tid >= 0) {
         const bool two = total > pr.tiles0;
-        const int rec[12] = {BM, BN, WM, WN, EPI, BK | (SK << 16), pr.p[0].M, pr.p[0].N, pr.p[0].K,
+        const int rec[12] = {BM, BN, WM, WN, EPI, BK, pr.p[0].M, pr.p[0].N, pr.p[0].K,
                              two ? pr.p[1].M : 0, two ? pr.p[1].N : 0, two ? pr.p[1].K : 0};
         memcpy(g_timing.info[tid], rec, sizeof(rec));
         hipExtLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), (unsigned)smem, st, g_timing.ev[2 * tid],
@@ -1358,54 +1290,6 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     }
 }
 
-// 256x256 tiles, two workgroups per tile (split-K, see the kernel): the residual epilogue only
-int launch_tile_sk2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
-    GemmPair pr{};
-    auto groups = [](const GemmArgs& g) { return (g.tiles_m * g.tiles_n + 7) / 8; };   // groups of 8 tiles = 16 workgroups
-    g0.tiles_m = (g0.M + 255) / 256;
-    g0.tiles_n = g0.N / 256;
-    pr.p[0] = g0;
-    pr.tiles0 = groups(g0) * 16;
-    int total = pr.tiles0;
-    if (g1) {
-        pr.p[1] = *g1;
-        pr.p[1].tiles_m = (g1->M + 255) / 256;
-        pr.p[1].tiles_n = g1->N / 256;
-        total += groups(pr.p[1]) * 16;
-    } else {
-        pr.p[1] = g0;
-    }
-    if (total / 2 > CC_GEMM_SK_MAX_SLOTS / 2 * 2 || !g0.sk_ws) return CC_ERR_INVALID;
-    pr.sk_flags = static_cast<int*>(g0.sk_ws);
-    pr.sk_error = pr.sk_flags + CC_GEMM_SK_FLAG_BYTES / 4 - 1;
-    pr.sk_slots = static_cast<unsigned char*>(g0.sk_ws) + CC_GEMM_SK_FLAG_BYTES;
-    return launch_one<256, 256, 2, 4, EPI_F32_RESID_STATS, GEMM_BK, 2>(pr, total, st);
-}
-
-// The split-K form pays when its grid is one nearly full round of workgroups that are all resident at once (the partners
-// wait for each other) - the N = 768 residual GEMMs of the full-size blocks.
-static int g_num_cus = 0;
-bool sk2_applies(const GemmArgs& g0, const GemmArgs* g1) {
-#ifndef CC_SPLITK_AUTO
-    // Measured (profiles/r04_splitk.txt): slower than the one-workgroup 256x128 tile on the shapes it was built for (out_proj
-    // 33.6 vs 25.4 us, c_proj 60.6 vs 55.8 us) - these launches are bound by the fp32 residual stream of their epilogue, which
-    // the exchange doubles.  The form stays selectable (tile 9) and tested; the dispatcher does not pick it.
-    return false;
-#endif
-    if (!g0.sk_ws || g0.row_step || g0.row_map) return false;
-    auto ok = [](const GemmArgs& g) { return (g.N % 256) == 0 && (g.K % 128) == 0; };
-    if (!ok(g0) || (g1 && !ok(*g1))) return false;
-    auto wgs = [](const GemmArgs& g) { return ((((g.M + 255) / 256) * (g.N / 256) + 7) / 8) * 16; };
-    const int total = wgs(g0) + (g1 ? wgs(*g1) : 0);
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        const bool have = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
-        g_num_cus = have ? prop.multiProcessorCount : 256;         // (no device: the host-side queries answer for an MI355X)
-    }
-    return total <= g_num_cus && total <= CC_GEMM_SK_MAX_SLOTS && total * 4 >= g_num_cus * 3;
-}
-
 // tiles whose wave tile is 48 columns wide exist for the fp16-output epilogues and the plain fp32 one
 template <int BM, int BN, int WM, int WN>
 int launch_tile_f16(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
@@ -1450,8 +1334,8 @@ static bool gemm_shape_ok(const GemmArgs& g) {
 static bool epi_is_f16(int epi) {
     return epi == EPI_F16 || epi == EPI_F16_GELU || epi == EPI_F16_LN || epi == EPI_F16_GELU_LN;
 }
-static int tile_bn(int tile) { return (tile == 5 || tile == 9 || tile == 10) ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
-static int tile_bk(int tile) { return (tile == 8 || tile == 9) ? 128 : GEMM_BK; }     // (9: two k-halves of whole 64-deep steps)
+static int tile_bn(int tile) { return (tile == 5 || tile == 10) ? 256 : tile == 7 ? 192 : (tile == 1 || tile == 3 || tile == 6) ? 128 : 64; }
+static int tile_bk(int tile) { return tile == 8 ? 128 : GEMM_BK; }
 
 // Residual epilogue (out_proj / c_proj) and the patch embedding at N % 128 == 0, M >= 4,800: the tile by a two-parameter time
 // model per tile fitted to tools/resid_sweep.py on MI355X (gpurun_out/s2 of round 5 -> profiles/r05_resid_tile_sweep.txt):
@@ -1535,18 +1419,13 @@ static int pick_tile(const GemmArgs& g, int epi) {
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (4 waves); 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves;
-// 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0); 9 = 256x256 split-K (two
-// workgroups per tile, residual epilogue, needs the exchange scratch); 10 = 128x256 (8 waves); 11 = 256x256 persistent
-// (gemm_persist.hip: fp16-output epilogues, needs the exchange scratch and at least one tile per CU)
+// 7 only for the fp16-output epilogues); 8 = 64x64 with 128-deep k-steps (K % 128 == 0); 10 = 128x256 (8 waves).
+// (Ids 9 and 11 were the split-K and persistent stream-K forms of round 4: built, bit-checked, measured slower than the tiled
+// kernel - profiles/r04_splitk.txt, r04_persist.txt - and removed in round 5.)
 int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* slots_out) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1))) return CC_ERR_INVALID;
-    if (tile == 11) {                              // the persistent 256x256 form: selectable, never picked (measured slower)
-        if (!cc_gemm_persist_applies(g0, g1, epi)) return CC_ERR_INVALID;
-        return cc_gemm_persist_dispatch2(g0, g1, epi, st);
-    }
     if (tile == 0) {
         tile = pick_tile(g0, epi);
-        if (epi == EPI_F32_RESID_STATS && sk2_applies(g0, g1)) tile = 9;
 #ifdef CC_DEV_KNOBS
         // tuning aid (development builds only, -DCC_DEV_KNOBS): CC_TILE_E<epi>_<S|B>[_K<k>]=<tile> overrides the choice for
         // small (M < 5000) / big problems; the environment is scanned once
@@ -1559,24 +1438,23 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
             char name[32];
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c", epi, g0.M < 5000 ? 'S' : 'B');
             const char* ov = getenv(name);
-            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10) tile = atoi(ov);
+            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10 && atoi(ov) != 9) tile = atoi(ov);
             snprintf(name, sizeof(name), "CC_TILE_E%d_%c_K%d", epi, g0.M < 5000 ? 'S' : 'B', g0.K);   // one shape only
             ov = getenv(name);
-            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10) tile = atoi(ov);
+            if (ov && atoi(ov) >= 1 && atoi(ov) <= 10 && atoi(ov) != 9) tile = atoi(ov);
         }
 #endif
-        if (g1 && tile != 9) {                     // the rider must be divisible by the carrier's BN
+        if (g1) {                                  // the rider must be divisible by the carrier's BN
             if (g1->N % tile_bn(tile)) tile = (g1->N % 128 == 0 && (tile == 5 || tile == 7 || tile == 6)) ? 1 : 4;
             if (g1->K % tile_bk(tile)) tile = 4;
         }
     }
     if (tile == 7 && !epi_is_f16(epi) && epi != EPI_F32) return CC_ERR_INVALID;
-    if (tile == 9 && (epi != EPI_F32_RESID_STATS || !g0.sk_ws)) return CC_ERR_INVALID;
     if ((g0.K % tile_bk(tile)) || (g1 && (g1->K % tile_bk(tile)))) return CC_ERR_INVALID;
     const int bn = tile_bn(tile);
     if ((g0.N % bn) || (g1 && (g1->N % bn))) return CC_ERR_INVALID;
     if (slots_out) {
-        const int wn = (tile == 5 || tile == 9 || tile == 10) ? 4 : 2;
+        const int wn = (tile == 5 || tile == 10) ? 4 : 2;
         slots_out[0] = g0.N / bn * wn;
         slots_out[1] = g1 ? g1->N / bn * wn : 0;
         if (slots_out[0] > CC_LN_MAX_SLOTS || slots_out[1] > CC_LN_MAX_SLOTS) return CC_ERR_UNSUPPORTED;
@@ -1590,7 +1468,6 @@ int cc_gemm_dispatch2(GemmArgs g0, const GemmArgs* g1, int epi, int tile, hipStr
         case 6: return launch_tile<256, 128, 4, 2>(g0, g1, epi, st);
         case 7: return launch_tile_f16<256, 192, 2, 4>(g0, g1, epi, st);
         case 8: return launch_tile<64, 64, 2, 2, 128>(g0, g1, epi, st);
-        case 9: return launch_tile_sk2(g0, g1, st);
         case 10: return launch_tile<128, 256, 2, 4>(g0, g1, epi, st);
         default: return CC_ERR_INVALID;
     }
@@ -1861,20 +1738,6 @@ int cc_gemm_dispatch(GemmArgs g, int epi, int tile, hipStream_t st) { return cc_
 
 extern "C" {
 
-int cc_linear_ws_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
-                     int32_t ldc, int32_t epilogue, int32_t tile, void* ws, size_t ws_bytes, void* stream) {
-    if (!a_f16 || !w_f16 || !c) return CC_ERR_INVALID;
-    if (epilogue == EPI_F32_PATCH) return CC_ERR_INVALID;
-    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
-    GemmArgs g{};
-    g.A = static_cast<const _Float16*>(a_f16);
-    g.W = static_cast<const _Float16*>(w_f16);
-    g.bias = bias;
-    g.C = c;
-    g.M = M; g.N = N; g.K = K; g.ldc = ldc;
-    g.sk_ws = ws;
-    return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
-}
 int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32_t M, int32_t N, int32_t K,
                            const float* scale_dev, void* stream) {
     if (!a_f16 || !w_f16 || !c || !scale_dev) return CC_ERR_INVALID;
@@ -1888,7 +1751,15 @@ int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32
 }
 int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c, int32_t M, int32_t N, int32_t K,
                   int32_t ldc, int32_t epilogue, int32_t tile, void* stream) {
-    return cc_linear_ws_f16(a_f16, w_f16, bias, c, M, N, K, ldc, epilogue, tile, nullptr, 0, stream);
+    if (!a_f16 || !w_f16 || !c) return CC_ERR_INVALID;
+    if (epilogue == EPI_F32_PATCH) return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(a_f16);
+    g.W = static_cast<const _Float16*>(w_f16);
+    g.bias = bias;
+    g.C = c;
+    g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+    return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
 }
 
 /* LayerNorm-folded Linear: y = LN(h) W^T + b evaluated as rstd (h16 Wln^T - mu c1) + c2 (see cc_fold_layernorm_linear_f32).
@@ -1896,15 +1767,8 @@ int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void*
 int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
                      int32_t slots, float eps, void* out_f16, int32_t M, int32_t N, int32_t K, int32_t gelu,
                      int32_t tile, void* stream) {
-    return cc_linear_ln_ws_f16(h_f16, w_ln_f16, c1, c2, stats, slots, eps, out_f16, M, N, K, gelu, tile, nullptr, 0, stream);
-}
-int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
-                        int32_t slots, float eps, void* out_f16, int32_t M, int32_t N, int32_t K, int32_t gelu,
-                        int32_t tile, void* ws, size_t ws_bytes, void* stream) {
     if (!h_f16 || !w_ln_f16 || !c1 || !c2 || !stats || !out_f16 || slots <= 0 || slots > CC_LN_MAX_SLOTS) return CC_ERR_INVALID;
-    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
     GemmArgs g{};
-    g.sk_ws = ws;
     g.A = static_cast<const _Float16*>(h_f16);
     g.W = static_cast<const _Float16*>(w_ln_f16);
     g.bias = c2;
@@ -1918,8 +1782,9 @@ int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1
  * in_proj and scaled-dot-product core): att[M, W] fp16 = softmax(q k^T / 8 [+ causal mask]) v per (sequence, head), with
  * q | k | v = LN(h) Wqkv^T + b evaluated as in cc_linear_ln_f16 (w_ln_f16 [3W, W], c1 / c2 [3W], stats [M][slots][2]).
  * nseq sequences of L tokens (row = s * L + t), or - seq_off / seq_len non-null - seq_len[s] <= L tokens from row seq_off[s]
- * (packed back to back); m_dev (may be null): device-side count of valid rows.  W = heads * 64, L <= 56.  The q, k, v rows of a
- * tile stay in LDS; results are bit-identical to cc_linear_ln_f16 followed by cc_attention_f16.
+ * (packed back to back); m_dev (may be null): device-side count of valid rows.  W = heads * 64, L <= 256.  The q, k, v rows of a
+ * tile stay in LDS; for L <= 56 the results are bit-identical to cc_linear_ln_f16 followed by cc_attention_f16, for longer
+ * sequences equal to the rounding of the fp16 output (the scores and P stay in registers, another key order inside the MFMAs).
  * CC_ERR_UNSUPPORTED when the shape is outside the fused form (the caller then runs the two launches). */
 int cc_inproj_attention_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
                             int32_t slots, float eps, void* att_f16, int32_t nseq, int32_t L, int32_t heads, int32_t causal,
@@ -1942,56 +1807,38 @@ int cc_inproj_attention_f16(const void* h_f16, const void* w_ln_f16, const float
 
 /* Host-side query: the tile the dispatcher picks for a stand-alone launch of this shape and epilogue (CC_EPI_* or the
  * internal ids 5 = LN-folded f16, 6 = LN-folded f16 + QuickGELU, 7 = residual + statistics): 1 = 128x128, 2 = 128x64,
- * 3 = 64x128, 4 = 64x64 (4 waves), 5 = 256x256, 7 = 256x192 (8 waves), 8 = 64x64 with 128-deep k-steps, 9 = 256x256 split-K
- * (two workgroups per tile; the answer for the residual epilogue called WITH the split-K scratch); <= 0: unsupported.
+ * 3 = 64x128, 4 = 64x64 (4 waves), 5 = 256x256, 6 = 256x128, 7 = 256x192 (8 waves), 8 = 64x64 with 128-deep k-steps;
+ * <= 0: unsupported.
  * (bench.py names the kernel instantiation a shape runs on with it.) */
 int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K;
     if (!gemm_shape_ok(g) || epilogue < 0 || epilogue > EPI_F32_RESID_STATS) return CC_ERR_INVALID;
-    g.sk_ws = &g;                                    // (any non-null value: only tested) - the answer for a call with the scratch
-    if (epilogue == EPI_F32_RESID_STATS && sk2_applies(g, nullptr)) return 9;
     return pick_tile(g, epilogue);
 }
 
 /* Host-side query: the number of partial-sum slots per row cc_linear_resid_stats_f16 writes for this shape and tile
- * (0 = auto), i.e. (N / tile columns) x (wave columns of the tile); <= 0: the shape / tile is not supported.
- * with_ws != 0: the answer for cc_linear_resid_stats_ws_f16 called with a split-K workspace. */
-int cc_linear_resid_stats_slots_ws(int32_t M, int32_t N, int32_t K, int32_t tile, int32_t with_ws) {
+ * (0 = auto), i.e. (N / tile columns) x (wave columns of the tile); <= 0: the shape / tile is not supported. */
+int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K;
     if (!gemm_shape_ok(g)) return CC_ERR_INVALID;
-    if (tile == 0) {
-        tile = pick_tile(g, EPI_F32_RESID_STATS);
-        g.sk_ws = with_ws ? &g : nullptr;            // (any non-null value: only tested)
-        if (sk2_applies(g, nullptr)) tile = 9;
-    }
-    if (tile < 1 || tile > 10 || tile == 7 || (K % tile_bk(tile)) || (N % tile_bn(tile)) || (tile == 9 && !with_ws)) return CC_ERR_INVALID;
-    const int slots = N / tile_bn(tile) * ((tile == 5 || tile == 9 || tile == 10) ? 4 : 2);
+    if (tile == 0) tile = pick_tile(g, EPI_F32_RESID_STATS);
+    if (tile < 1 || tile > 10 || tile == 7 || tile == 9 || (K % tile_bk(tile)) || (N % tile_bn(tile))) return CC_ERR_INVALID;
+    const int slots = N / tile_bn(tile) * ((tile == 5 || tile == 10) ? 4 : 2);
     return slots > CC_LN_MAX_SLOTS ? CC_ERR_UNSUPPORTED : slots;
 }
-int cc_linear_resid_stats_slots(int32_t M, int32_t N, int32_t K, int32_t tile) {
-    return cc_linear_resid_stats_slots_ws(M, N, K, tile, 0);
-}
-
-/* Scratch of the split-K forms of the residual Linear (tile 9: two workgroups per 256x256 tile that swap accumulator
- * halves).  Its first cc_linear_splitk_flag_bytes() bytes must be zero before the first call that uses it; every call
- * leaves them zero.  One workspace serves any number of calls on ONE stream (calls on different streams need their own). */
-size_t cc_linear_splitk_workspace_bytes(void) { return CC_GEMM_SK_WS_BYTES; }
-size_t cc_linear_splitk_flag_bytes(void) { return CC_GEMM_SK_FLAG_BYTES; }
 
 /* Residual Linear that also emits what the next folded LayerNorm needs: h (fp32, in place) += a W^T + b;
  * h16 = fp16(h - c_row); stats_out [M][*slots_out][2] = per-tile partial (sum, sum of squares) of the fp16 rows;
  * c_row = shift_in[m] + mean of the previous centred copy (stats_in [M][slots_in][2]), written to shift_out [M]
- * (stats_in NULL: c_row = 0).  ws (optional): cc_linear_splitk_workspace_bytes() - with it tile 0 may pick, and tile 9
- * selects, the split-K form. */
-int cc_linear_resid_stats_ws_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
-                                 float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
-                                 int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
-                                 void* ws, size_t ws_bytes, void* stream) {
+ * (stats_in NULL: c_row = 0). */
+int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
+                              float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
+                              int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
+                              void* stream) {
     if (!a_f16 || !w_f16 || !h || !h16_out || !stats_out || !slots_out) return CC_ERR_INVALID;
     if (stats_in && (slots_in <= 0 || slots_in > CC_LN_MAX_SLOTS || !shift_out)) return CC_ERR_INVALID;
-    if (ws && ws_bytes < CC_GEMM_SK_WS_BYTES) return CC_ERR_WORKSPACE;
     GemmArgs g{};
     g.A = static_cast<const _Float16*>(a_f16);
     g.W = static_cast<const _Float16*>(w_f16);
@@ -2001,19 +1848,10 @@ int cc_linear_resid_stats_ws_f16(const void* a_f16, const void* w_f16, const flo
     g.c16 = static_cast<_Float16*>(h16_out);
     g.stats_out = stats_out;
     g.shift_in = shift_in; g.shift_stats = stats_in; g.shift_slots = slots_in; g.shift_out = shift_out;
-    g.sk_ws = ws;
     int slots[2] = {0, 0};
     const int rc = cc_gemm_dispatch2(g, nullptr, EPI_F32_RESID_STATS, tile, static_cast<hipStream_t>(stream), slots);
     *slots_out = slots[0];
     return rc;
-}
-
-int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float* bias, float* h, void* h16_out,
-                              float* stats_out, int32_t* slots_out, const float* shift_in, const float* stats_in,
-                              int32_t slots_in, float* shift_out, int32_t M, int32_t N, int32_t K, int32_t tile,
-                              void* stream) {
-    return cc_linear_resid_stats_ws_f16(a_f16, w_f16, bias, h, h16_out, stats_out, slots_out, shift_in, stats_in, slots_in,
-                                        shift_out, M, N, K, tile, nullptr, 0, stream);
 }
 
 int cc_debug_gemm_timing_begin(int cap) {

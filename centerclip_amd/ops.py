@@ -111,7 +111,7 @@ def linear_ln_f16(h16, w_ln, c1, c2, stats, slots, gelu=False, eps=1e-5, out=Non
 def inproj_attention_f16(h16, w_ln, c1, c2, stats, slots, nseq, L_tok, heads, causal=False, eps=1e-5, seq_off=None, seq_len=None):
     """LayerNorm-folded in_proj + multi-head attention in ONE launch (clip.py:210-214) on frame-major rows (row = s * L_tok + t,
     or seq_len[s] tokens from row seq_off[s]); q, k, v stay in LDS.  -> att [nseq * L_tok, W] fp16, bit-identical to
-    linear_ln_f16 followed by attention_f16.  W = heads * 64, L_tok <= 56."""
+    linear_ln_f16 followed by attention_f16 for L_tok <= 56, equal to the fp16 rounding for 56 < L_tok <= 256.  W = heads * 64."""
     L.require_device(h16, w_ln)
     return _ops.inproj_attention_f16(h16, w_ln, c1, c2, stats, int(slots), float(eps), int(nseq), int(L_tok), int(heads),
                                      bool(causal), seq_off, seq_len)

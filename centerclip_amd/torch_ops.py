@@ -58,30 +58,13 @@ def _e(*shape, like, dtype):
 
 
 # ------------------------------------------------------------------------------------------ Linear / LN / attention
-_SPLITK_WS = {}
-
-
-def _splitk_ws(t):
-    """Split-K exchange area of the residual Linear, one per (device, stream): zeroed once (every call leaves its flags
-    zero), never freed (a captured graph keeps the address)."""
-    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
-    ws = _SPLITK_WS.get(key)
-    if ws is None:
-        nbytes = int(L.lib().cc_linear_splitk_workspace_bytes())
-        ws = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
-        ws[:int(L.lib().cc_linear_splitk_flag_bytes())].zero_()
-        _SPLITK_WS[key] = ws
-    return ws
-
-
 @custom_op(NS + "::linear_f16", mutates_args=(), device_types="cuda")
 def linear_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: str, tile: int) -> torch.Tensor:
     M, K = a.shape
     N = w.shape[0]
     out = _e(M, N, like=a, dtype=torch.float16 if epilogue.startswith("f16") else torch.float32)
-    ws = _splitk_ws(a)
-    L.check(L.lib().cc_linear_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, N, EPI[epilogue], tile, L.ptr(ws),
-                                     ws.numel(), _st(a)), "cc_linear_ws_f16")
+    L.check(L.lib().cc_linear_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, N, EPI[epilogue], tile, _st(a)),
+            "cc_linear_f16")
     return out
 
 
@@ -95,9 +78,8 @@ def linear_f16_out(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    tile: int) -> None:
     """epilogue 'f32_resid': out += a w^T + b in place; the other epilogues overwrite ``out`` (row stride honoured)."""
     M, K = a.shape
-    ws = _splitk_ws(a)
-    L.check(L.lib().cc_linear_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], K, out.stride(0),
-                                     EPI[epilogue], tile, L.ptr(ws), ws.numel(), _st(a)), "cc_linear_ws_f16")
+    L.check(L.lib().cc_linear_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], K, out.stride(0),
+                                  EPI[epilogue], tile, _st(a)), "cc_linear_f16")
 
 
 @linear_f16_out.register_fake
@@ -176,10 +158,8 @@ def linear_ln_f16(h16: torch.Tensor, w_ln: torch.Tensor, c1: torch.Tensor, c2: t
     M, K = h16.shape
     N = w_ln.shape[0]
     out = _e(M, N, like=h16, dtype=torch.float16)
-    ws = _splitk_ws(h16)
-    L.check(L.lib().cc_linear_ln_ws_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
-                                        L.ptr(out), M, N, K, int(gelu), tile, L.ptr(ws), ws.numel(), _st(h16)),
-            "cc_linear_ln_ws_f16")
+    L.check(L.lib().cc_linear_ln_f16(L.ptr(h16), L.ptr(w_ln), L.ptr(c1), L.ptr(c2), L.ptr(stats), int(slots), float(eps),
+                                     L.ptr(out), M, N, K, int(gelu), tile, _st(h16)), "cc_linear_ln_f16")
     return out
 
 
@@ -215,11 +195,9 @@ def linear_resid_stats_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torc
     M, K = a.shape
     N = w.shape[0]
     slots = ctypes.c_int32(0)
-    ws = _splitk_ws(a)
-    L.check(L.lib().cc_linear_resid_stats_ws_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(h), L.ptr(h16), L.ptr(stats),
-                                                 ctypes.byref(slots), L.ptr(shift_in), L.ptr(stats_in), int(slots_in),
-                                                 L.ptr(shift_out), M, N, K, tile, L.ptr(ws), ws.numel(), _st(a)),
-            "cc_linear_resid_stats_ws_f16")
+    L.check(L.lib().cc_linear_resid_stats_f16(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(h), L.ptr(h16), L.ptr(stats),
+                                              ctypes.byref(slots), L.ptr(shift_in), L.ptr(stats_in), int(slots_in),
+                                              L.ptr(shift_out), M, N, K, tile, _st(a)), "cc_linear_resid_stats_f16")
 
 
 @linear_resid_stats_f16.register_fake
@@ -228,11 +206,10 @@ def _(a, w, bias, h, h16, stats, shift_in, stats_in, slots_in, shift_out, tile):
 
 
 def resid_stats_slots(M, N, K, tile=0):
-    """Partial-sum slots per row the residual Linear writes for this shape (a host-side query of the tile choice; the op
-    always passes the split-K scratch)."""
-    n = L.lib().cc_linear_resid_stats_slots_ws(int(M), int(N), int(K), int(tile), 1)
+    """Partial-sum slots per row the residual Linear writes for this shape (a host-side query of the tile choice)."""
+    n = L.lib().cc_linear_resid_stats_slots(int(M), int(N), int(K), int(tile))
     if n <= 0:
-        raise L.CenterClipHipError("cc_linear_resid_stats_slots_ws(%d, %d, %d, %d): unsupported shape / tile" % (M, N, K, tile))
+        raise L.CenterClipHipError("cc_linear_resid_stats_slots(%d, %d, %d, %d): unsupported shape / tile" % (M, N, K, tile))
     return n
 
 

@@ -308,14 +308,6 @@ int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_
 int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
                   int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
                   void* stream);
-/* The same with the exchange scratch of the split forms (cc_linear_splitk_workspace_bytes(), flag bytes zero, one per
- * stream): with it tile 0 may pick, and tile 11 selects, the persistent 256x256 form for the fp16-output epilogues - one
- * workgroup per CU walking an equal share of the launch's k-steps, a tile cut between two workgroups summed through the
- * scratch (N % 256 == 0, at least one tile per CU).  ws NULL = cc_linear_f16. */
-int cc_linear_ws_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
-                     int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
-                     void* ws, size_t ws_bytes, void* stream);
-
 /* LayerNorm over the last dim (fp32 statistics, eps as given) - modules/clip.py:183-189.
  * Row r is read at in + r*in_stride and written at out + r*out_stride (elements); out is fp16
  * when out_f16 != 0, else fp32 (may alias in). */
@@ -340,21 +332,21 @@ int cc_row_stats_f16(const float* h, void* h16_out, float* stats_out, float* shi
 int cc_linear_ln_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
                      const float* stats, int32_t slots, float eps, void* out_f16,
                      int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* stream);
-int cc_linear_ln_ws_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2,
-                        const float* stats, int32_t slots, float eps, void* out_f16,
-                        int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t tile, void* ws, size_t ws_bytes,
-                        void* stream);       /* (with the exchange scratch, see cc_linear_ws_f16) */
 /* in_proj with the LayerNorm folded + the multi-head attention core in ONE launch (modules/clip.py:210-214, the ln_1 ->
  * nn.MultiheadAttention path of ResidualAttentionBlock.attention): att [M, W] fp16 = softmax(q k^T / 8 [causal]) v per
  * (sequence, head) with q | k | v = LN(h) Wqkv^T + b evaluated as in cc_linear_ln_f16 (w_ln_f16 [3W, W], c1 / c2 [3W], stats
  * [M][slots][2]).  A workgroup owns whole sequences x one head and keeps their q, k, v in LDS - they never reach HBM.  Rows:
  * nseq sequences of L tokens (row = s * L + t), or - seq_off / seq_len both non-null (device arrays) - seq_len[s] <= L tokens
- * from row seq_off[s], packed back to back; m_dev (device, may be null) = count of valid rows.  W = heads * 64, L <= 56.
- * Bit-identical to cc_linear_ln_f16 followed by cc_attention_f16.  CC_ERR_UNSUPPORTED outside that shape range. */
+ * from row seq_off[s], packed back to back; m_dev (device, may be null) = count of valid rows.  W = heads * 64, L <= 256.
+ * L <= 56: every operand of a (sequence, 16-query tile) item in registers, bit-identical to cc_linear_ln_f16 followed by
+ * cc_attention_f16.  56 < L <= 256 (round 5: ViT-B/16's 197-token frames, its 101 / 161-token clustered blocks, CLIP's
+ * 77-token captions): scores and P stay in registers, the PV contraction takes the keys of a 32-key block in the accumulator's
+ * own order - equal to the two launches to the rounding of the fp16 output.  CC_ERR_UNSUPPORTED outside that range. */
 int cc_inproj_attention_f16(const void* h_f16, const void* w_ln_f16, const float* c1, const float* c2, const float* stats,
                             int32_t slots, float eps, void* att_f16, int32_t nseq, int32_t L, int32_t heads, int32_t causal,
                             const int32_t* seq_off, const int32_t* seq_len, const int32_t* m_dev, void* stream);
-/* host-side query: the tile (1-11, see cc_linear_f16 / cc_linear_ws_f16; the answer for a call WITH the exchange scratch) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
+/* host-side query: the tile (1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64, 5 = 256x256, 6 = 256x128, 7 = 256x192, 8 = 64x64 with
+ * 128-deep k-steps, 10 = 128x256) the dispatcher picks for this shape / epilogue id (CC_EPI_*; 5, 6 =
  * LN-folded f16 without / with QuickGELU, 7 = residual + statistics); <= 0: unsupported */
 int cc_linear_tile_for(int32_t M, int32_t N, int32_t K, int32_t epilogue);
 /* host-side query: slots per row cc_linear_resid_stats_f16 will write for this shape (tile 0 = auto); <= 0: unsupported */
@@ -363,20 +355,6 @@ int cc_linear_resid_stats_f16(const void* a_f16, const void* w_f16, const float*
                               void* h16_out, float* stats_out, int32_t* slots_out, const float* shift_in,
                               const float* stats_in, int32_t slots_in, float* shift_out,
                               int32_t M, int32_t N, int32_t K, int32_t tile, void* stream);
-/* The same with a split-K scratch (tile 9, or tile 0 when the shape calls for it: the N = 768 residual Linears of the
- * full-size blocks, modules/clip.py:207-211,240,251, run as two workgroups per 256x256 tile that swap accumulator halves).
- * ws: cc_linear_splitk_workspace_bytes(); its first cc_linear_splitk_flag_bytes() bytes must be ZERO before the first
- * call that uses it and every call leaves them zero; one workspace per stream.  ws NULL = cc_linear_resid_stats_f16.
- * cc_linear_resid_stats_slots_ws: the slots query for a call with (with_ws != 0) / without the scratch. */
-size_t cc_linear_splitk_workspace_bytes(void);
-size_t cc_linear_splitk_flag_bytes(void);
-int cc_linear_resid_stats_slots_ws(int32_t M, int32_t N, int32_t K, int32_t tile, int32_t with_ws);
-int cc_linear_resid_stats_ws_f16(const void* a_f16, const void* w_f16, const float* bias, float* h,
-                                 void* h16_out, float* stats_out, int32_t* slots_out, const float* shift_in,
-                                 const float* stats_in, int32_t slots_in, float* shift_out,
-                                 int32_t M, int32_t N, int32_t K, int32_t tile, void* ws, size_t ws_bytes,
-                                 void* stream);
-
 /* Multi-head self-attention core of nn.MultiheadAttention (modules/clip.py:220-226):
  * qkv [nseq*L, 3W] fp16 (row = seq*L + token; q | k | v, heads = contiguous 64-wide slices),
  * out [nseq*L, W] fp16 = softmax(q k^T / 8 + mask) v; causal != 0 adds the strict upper

@@ -1,24 +1,17 @@
 #!/bin/bash
-# round 5, session 2: long-form fused attention (tests + towers), raster A/B, residual tile sweep at the big-M shapes
+# round 5, session 3: whole GPU suite + the default bench line (live counter passes, forward_other_configs) with its wall time
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/s2
-timeout 900 python -m pytest tests/test_r4_gpu.py -x -q -m gpu -k "inproj_attention" > gpurun_out/s2/pytest_attn.txt 2>&1
-tail -5 gpurun_out/s2/pytest_attn.txt
-timeout 900 python -m pytest tests/test_r3_gpu.py -x -q -m gpu -k "paired_towers" > gpurun_out/s2/pytest_towers.txt 2>&1
-tail -5 gpurun_out/s2/pytest_towers.txt
-for i in 1 2; do
-  for v in g8 new; do
-    for k in cfg2 cfg4 cfg5; do
-      echo -n "$v $k "
-      CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python bench.py --workload $k --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 |
-        python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
-    done
-  done
-done > gpurun_out/s2/ab.txt 2>&1
-cat gpurun_out/s2/ab.txt
-python tools/resid_sweep.py big > gpurun_out/s2/resid_sweep_big.txt 2>&1
-cat gpurun_out/s2/resid_sweep_big.txt
-for k in cfg5 cfg4; do
-  bash tools/prof.sh fwd2_$k python bench.py --workload $k --steps 5 --warmup 2 --min-seconds 0.5 > gpurun_out/s2/forward_${k}_kernel_stats.txt 2>&1
-  head -14 gpurun_out/s2/forward_${k}_kernel_stats.txt
-done
+mkdir -p gpurun_out/s3
+( time timeout 2400 python -m pytest tests -x -q -m gpu ) > gpurun_out/s3/pytest_gpu.txt 2>&1
+tail -6 gpurun_out/s3/pytest_gpu.txt
+( time python bench.py ) > gpurun_out/s3/bench.json 2> gpurun_out/s3/bench.err
+tail -4 gpurun_out/s3/bench.err
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/s3/bench.json").read().strip().splitlines()[0])
+print({k: d[k] for k in ("value", "ms_per_step")})
+r = d["roofline"]; print(r["kernel"], r["frac"], r["traffic"], r.get("traffic_detail"))
+print(d["token_cluster"]["cfg2"])
+for k, v in d["forward_other_configs"].items():
+    print(k, v["ms_per_step"], v["clips_per_s"], v["whole_step_frac_of_f16_mfma_peak"], v["roofline"]["kernel"], v["roofline"]["frac"])
+PY
