@@ -502,6 +502,21 @@ def similarity_bench(device, world=1):
                      note="eval_epoch writes the planes batch by batch with the encoders' outputs; its final matrix costs the GEMM",
                      pairs_per_s_gemm_alone=round(Nt * Nv / ms_gemm * 1e3, 0),
                      gemm_issued_f16_mfma_frac=round(3 * 2.0 * Nt * Nv * E / ms_gemm / 1e9 / MFMA_F16_PEAK_TFLOPS, 4))
+        # fewer fp16 products per multiply-add (scaled_dot_planes(..., products)): time of the GEMM alone and the error of the
+        # cosine matrix against float64 on the same unit rows (the contract asks 1e-3 of similarities)
+        tn = (t.double() / t.double().norm(dim=-1, keepdim=True))
+        vh = v.double() / v.double().norm(dim=-1, keepdim=True)
+        vb = vh.mean(dim=1)
+        exact = tn @ (vb / vb.norm(dim=-1, keepdim=True)).t()
+        prods = {}
+        for pr_ in (3, 2, 1):
+            msp = graph_time_ms(lambda pr_=pr_: torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, 1.0, pr_), launches=10, replays=3)
+            err = (torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, 1.0, pr_).double() - exact).abs()
+            prods[str(pr_)] = dict(gemm_us=round(msp * 1e3, 1), pairs_per_s=round(Nt * Nv / msp * 1e3, 0),
+                                   max_abs_err_vs_float64=float("%.3g" % float(err.max())), rms_err=float("%.3g" % float((err ** 2).mean().sqrt())))
+        parts["products"] = prods
+        parts["products_note"] = ("3 (default everywhere): hi.hi + hi.lo + lo.hi, both operands to 22 bits; 2: fp16(text) x video to 22 bits; "
+                                  "1: fp16 x fp16 - eval_epoch(..., similarity_products=p)")
     else:
         t0, t1 = ccdist.shard_rows(Nt)
         v0, v1 = ccdist.shard_rows(Nv)

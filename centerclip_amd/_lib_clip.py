@@ -149,6 +149,8 @@ def declare(lib):
     lib.cc_video_pool_normalize_planes_f32.restype = c.c_int
     lib.cc_scaled_dot_planes_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.cc_scaled_dot_planes_f32.restype = c.c_int
+    lib.cc_scaled_dot_planes_products_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp, i32, vp]
+    lib.cc_scaled_dot_planes_products_f32.restype = c.c_int
     lib.cc_similarity_workspace_bytes.argtypes = [i32, i32, i32]
     lib.cc_video_pool_normalize_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.cc_loose_similarity_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, sz, vp]

@@ -20,6 +20,8 @@ struct GemmArgs {
     void* C;             // fp16 or fp32, row stride ldc
     const float* pos;    // EPI_F32_PATCH: positional embedding [1+n, N]
     int M, N, K, ldc;
+    int lda, ldw;        // row strides of A / W in halfs; 0 = K (gemm_f16_kernel only: the similarity GEMM reads the first
+                         // `products` of three planes per row, so its rows are 3E halfs apart while K = products * E)
     int patch_n;         // EPI_F32_PATCH: patches per frame (out row = f*(n+1) + 1 + i)
     int tiles_m, tiles_n;
     int group_m;         // rows of tiles per rasterisation group (0 = 8), chosen by the launcher (raster_group_rows)

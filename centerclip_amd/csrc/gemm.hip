@@ -148,14 +148,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
     for (int q = 0; q < A_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
-        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * g.K + c * 8;
+        asrc[q] = g.A + (int64_t)min(row0 + r, g.M - 1) * (g.lda ? g.lda : g.K) + c * 8;
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
         const int idx = (q * NWAVES + wave) * 64 + lane, r = idx / CH, c = (idx % CH) ^ (r & (CH - 1));
         // (ATTN: wave column wc multiplies the d-slice [16 wc, 16 wc + 16) of q, of k and of v: LDS row 48 wc + 16 sec + dd)
         const int wrow = ATTN ? ((r % 48) >> 4) * (g.N / 3) + tn * 64 + (r / 48) * 16 + (r & 15) : col0 + r;
-        bsrc[q] = g.W + (int64_t)wrow * g.K + c * 8;
+        bsrc[q] = g.W + (int64_t)wrow * (g.ldw ? g.ldw : g.K) + c * 8;
     }
     auto stage = [&](int buf, int kt) {
         _Float16* la = reinterpret_cast<_Float16*>(smem + buf * (A_BYTES + B_BYTES));
@@ -818,119 +818,150 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        // Long sequences (64 < slot <= 256 keys): the scores of one (sequence, 16-query tile) item stay in registers - up to 16 key
-        // tiles of S^T = K Q^T, K fragments streamed from LDS - and so does P: the accumulator layout of S^T (a lane holds keys
-        // kt*16 + lg*4 + 0..3 of query l15) IS an MFMA B operand of O^T = V^T P^T once the 32 keys of a k-block are taken in the
-        // order [kt0: lg*4 + 0..3 | kt1: lg*4 + 0..3] - the contraction over keys does not care about their order as long as the
-        // V^T fragment uses the same one (two 8-byte LDS reads per fragment instead of one 16-byte read).  No P strip, no wave
-        // barrier between the softmax and the PV MFMAs.  Causal sequences skip the key tiles behind the query tile.
-        auto run_items_long = [&]() {
-            for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qtmax; it += NWAVES) {
-                const int sq = it / qtmax, qt = it - sq * qtmax;   // wave-uniform
+        // Long sequences (64 < slot <= 256 keys).  One item = (sequence, NQ adjacent 16-query tiles): the scores stay in registers
+        // - up to NKTM key tiles of S^T = K Q^T per query tile, every K fragment read from LDS once for the NQ tiles - and so
+        // does P: the accumulator layout of S^T (a lane holds keys kt*16 + lg*4 + 0..3 of query l15) IS an MFMA B operand of
+        // O^T = V^T P^T once the 32 keys of a k-block are taken in the order [kt0: lg*4 + 0..3 | kt1: lg*4 + 0..3] - the
+        // contraction over keys does not care about their order as long as the V^T fragment uses the same one (two 8-byte LDS
+        // reads per fragment instead of one 16-byte read, shared by the NQ tiles).  No P strip, no wave barrier between the
+        // softmax and the PV MFMAs; P = exp2((s - max) / 8 * log2 e) un-normalised in fp16 (<= 1), the row's 1 / sum scales the 16
+        // output values instead of every P.  Two query tiles per item give a wave two independent dependency chains (197
+        // tokens: 7 items on 8 waves in one round instead of 13 in two) - ViT-B/16 in_proj + attention 284 -> see
+        // profiles/r05_forward_cfg5_kernel_stats.txt.  Causal sequences skip the key tiles behind the item's last query tile.
+        auto run_items_long = [&](auto nktm_c, auto nq_c) {
+            constexpr int NKTM = decltype(nktm_c)::value, NQ = decltype(nq_c)::value;
+            constexpr float SC = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) and the exp -> exp2 factor
+            const int qgroups = (qtmax + NQ - 1) / NQ;
+            for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qgroups; it += NWAVES) {
+                const int sq = it / qgroups, qt0 = (it - sq * qgroups) * NQ;   // wave-uniform
                 const int off = stab[sq], L = stab[8 + sq];
-                if (qt * 16 >= L) continue;
-                const int q = qt * 16 + l15;
+                if (qt0 * 16 >= L) continue;
                 int nkt = (((L + 15) >> 4) + 1) & ~1;               // key tiles of this sequence, whole 32-key blocks
-                if (CAUSAL) nkt = min(nkt, (qt + 2) & ~1);
-                nkt = __builtin_amdgcn_readfirstlane(nkt);
-                h8 qf[2];
+                if (CAUSAL) nkt = min(nkt, (qt0 + NQ + 1) & ~1);
+                nkt = __builtin_amdgcn_readfirstlane(min(nkt, NKTM));
+                h8 qf[NQ][2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    qf[ks] = *reinterpret_cast<const h8*>(Qs + (off + min(q, L - 1)) * QS + (ks * 4 + lg) * 8);
-                f32x4 sc[16];
+                for (int u = 0; u < NQ; ++u)
 #pragma unroll
-                for (int kt = 0; kt < 16; ++kt) {
-                    sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int ks = 0; ks < 2; ++ks)
+                        qf[u][ks] = *reinterpret_cast<const h8*>(Qs + (off + min((qt0 + u) * 16 + l15, L - 1)) * QS + (ks * 4 + lg) * 8);
+                f32x4 sc[NQ][NKTM];
+#pragma unroll
+                for (int kt = 0; kt < NKTM; ++kt) {
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) sc[u][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (kt < nkt) {
                         const int kr = off + min(kt * 16 + l15, L - 1);
                         const h8 k0 = *reinterpret_cast<const h8*>(Ks + kr * QS + lg * 8);
                         const h8 k1 = *reinterpret_cast<const h8*>(Ks + kr * QS + (4 + lg) * 8);
-                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], sc[kt], 0, 0, 0);
-                        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], a, 0, 0, 0);
-                    }
-                }
-                float mx = -3.0e38f;
 #pragma unroll
-                for (int kt = 0; kt < 16; ++kt) {
-                    if (kt < nkt) {
-                        f32x4 a = sc[kt];
-                        if (kt * 16 + 15 < L && (!CAUSAL || kt < qt)) {     // wave-uniform: no key of this tile is masked
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                a[e] = a[e] * 0.125f;
-                                mx = fmaxf(mx, a[e]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int key = kt * 16 + lg * 4 + e;
-                                const bool ok = key < L && (!CAUSAL || key <= q);
-                                a[e] = ok ? a[e] * 0.125f : -3.0e38f;
-                                mx = fmaxf(mx, a[e]);
-                            }
-                        }
-                        sc[kt] = a;
-                    }
-                }
-                mx = cc_rows_max(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 16; ++kt) {
-                    if (kt < nkt) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pexp = __expf(sc[kt][e] - mx);   // (a masked key: exp2 of -4e38 or -inf = 0 exactly)
-                            sc[kt][e] = pexp;
-                            sum += pexp;
+                        for (int u = 0; u < NQ; ++u) {
+                            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[u][0], sc[u][kt], 0, 0, 0);
+                            sc[u][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[u][1], a, 0, 0, 0);
                         }
                     }
                 }
-                sum = cc_rows_sum(sum);
-                const float inv = 1.0f / sum;
-                f32x4 o[4];
+                float inv[NQ];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NQ; ++u) {
+                    const int qt = qt0 + u, q = qt * 16 + l15;
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int kt = 0; kt < NKTM; ++kt) {
+                        if (kt < nkt) {
+                            f32x4 a = sc[u][kt];
+                            if (!(kt * 16 + 15 < L && (!CAUSAL || kt < qt))) {   // (wave-uniform) a tile with masked keys
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int key = kt * 16 + lg * 4 + e;
+                                    a[e] = (key < L && (!CAUSAL || key <= q)) ? a[e] : -3.0e38f;
+                                }
+                                sc[u][kt] = a;
+                            }
+                            mx = fmaxf(fmaxf(mx, a[0]), fmaxf(a[1], fmaxf(a[2], a[3])));
+                        }
+                    }
+                    mx = cc_rows_max(mx);
+                    const float mneg = -mx * SC;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < NKTM; ++kt) {
+                        if (kt < nkt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float pexp = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][kt][e], SC, mneg));   // masked: exp2(-5e37) = 0
+                                sc[u][kt][e] = pexp;
+                                sum += pexp;
+                            }
+                        }
+                    }
+                    inv[u] = 1.0f / cc_rows_sum(sum);
+                }
+                f32x4 o[NQ][4];
+#pragma unroll
+                for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const _Float16* vbase = Vt + l15 * VS + sq * slot + lg * 4;
 #pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
+                for (int kb = 0; kb < NKTM / 2; ++kb) {
                     if (2 * kb < nkt) {
-                        const f32x4 pa = sc[2 * kb], pb = sc[2 * kb + 1];
-                        const h8 pf = {(_Float16)(pa[0] * inv), (_Float16)(pa[1] * inv), (_Float16)(pa[2] * inv), (_Float16)(pa[3] * inv),
-                                       (_Float16)(pb[0] * inv), (_Float16)(pb[1] * inv), (_Float16)(pb[2] * inv), (_Float16)(pb[3] * inv)};
+                        h8 pf[NQ];
+#pragma unroll
+                        for (int u = 0; u < NQ; ++u) {
+                            const f32x4 pa = sc[u][2 * kb], pb = sc[u][2 * kb + 1];
+                            pf[u] = h8{(_Float16)pa[0], (_Float16)pa[1], (_Float16)pa[2], (_Float16)pa[3],
+                                       (_Float16)pb[0], (_Float16)pb[1], (_Float16)pb[2], (_Float16)pb[3]};
+                        }
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) {
                             const h4 va = *reinterpret_cast<const h4*>(vbase + dt * 16 * VS + kb * 32);
                             const h4 vb = *reinterpret_cast<const h4*>(vbase + dt * 16 * VS + kb * 32 + 16);
                             const h8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < NQ; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u], o[u][dt], 0, 0, 0);
                         }
                     }
                 }
-                // the 16 x 64 output tile through the wave's strip -> 16-byte write-through stores (as the short form)
+                // each 16 x 64 output tile through the wave's strip -> 16-byte write-through stores (as the short form)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const h4 oh = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
-                    *reinterpret_cast<h4*>(Pw + l15 * PS + dt * 16 + lg * 4) = oh;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
+                for (int u = 0; u < NQ; ++u) {
+                    const int qt = qt0 + u;
+                    if (qt * 16 >= L) break;                       // wave-uniform
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int qr = h * 8 + (lane >> 3), qq = qt * 16 + qr;
-                    const h8 ov = *reinterpret_cast<const h8*>(Pw + qr * PS + (lane & 7) * 8);
-                    if (qq < L) {
-                        const int64_t e = (int64_t)(row0 + off + qq) * g.ldc + tn * 64 + (lane & 7) * 8;
-                        if ((int64_t)g.M * g.ldc < (int64_t)0x3fffffff)      // (32-bit byte offset of the buffer form)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), wt_rsrc(Cb), (int)(e * 2), 0, 16);
-                        else
-                            *reinterpret_cast<h8*>(Cb + e) = ov;
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const h4 oh = {(_Float16)(o[u][dt][0] * inv[u]), (_Float16)(o[u][dt][1] * inv[u]),
+                                       (_Float16)(o[u][dt][2] * inv[u]), (_Float16)(o[u][dt][3] * inv[u])};
+                        *reinterpret_cast<h4*>(Pw + l15 * PS + dt * 16 + lg * 4) = oh;
                     }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int qr = h * 8 + (lane >> 3), qq = qt * 16 + qr;
+                        const h8 ov = *reinterpret_cast<const h8*>(Pw + qr * PS + (lane & 7) * 8);
+                        if (qq < L) {
+                            const int64_t e = (int64_t)(row0 + off + qq) * g.ldc + tn * 64 + (lane & 7) * 8;
+                            if ((int64_t)g.M * g.ldc < (int64_t)0x3fffffff)      // (32-bit byte offset of the buffer form)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), wt_rsrc(Cb), (int)(e * 2), 0, 16);
+                            else
+                                *reinterpret_cast<h8*>(Cb + e) = ov;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);            // the strip is rewritten by the next tile / item
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);                // the strip is rewritten by this wave's next item
-                __builtin_amdgcn_wave_barrier();
             }
         };
-        if (slot > 64) run_items_long();
+        // (the lane's score registers: NQ x NKTM x 4 - two query tiles per item where that stays inside the wave's budget)
+#ifdef CC_ATTN_LONG_NQ1                                        // A/B arm: one query tile per item
+        constexpr int NQL = 1;
+#else
+        constexpr int NQL = 2;
+#endif
+        if (slot > 224) run_items_long(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+        else if (slot > 128) run_items_long(std::integral_constant<int, 14>{}, std::integral_constant<int, NQL>{});
+        else if (slot > 64) run_items_long(std::integral_constant<int, 8>{}, std::integral_constant<int, NQL>{});
         else if (slot == 64) run_items(std::integral_constant<int, 4>{});
         else run_items(std::integral_constant<int, 2>{});
         GEMM_STAMP(3);

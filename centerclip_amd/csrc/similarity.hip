@@ -324,15 +324,22 @@ static void sim_planes(void* ws, int Bt, int Bv, int E, SplitOut& ta, SplitOut& 
     vb = SplitOut{v, E, 1};
 }
 
+// products: how many of the three fp16 products of a multiply-add the GEMM issues - the planes are laid out so that the first
+// `products` planes of both sides are the right ones: 3 = hi.hi + hi.lo + lo.hi (the operands to 22 bits: 2e-6 on a cosine of
+// unit rows, the reference's fp32 product to its own rounding - what the metric fixtures are pinned with), 2 = hi.(hi + lo) =
+// fp16(text) x the video operand to 22 bits (the text side rounded to fp16: ~1e-5 rms on a cosine), 1 = hi.hi (both sides
+// fp16: ~1.5e-5 rms) - all inside the 1e-3 the contract asks of similarities, at 2/3 and 1/3 of the matrix-core work.
 static int dot_planes_launch(const SplitOut& ta, const SplitOut& vb, int Bt, int Bv, int E, float mult, float* logits,
-                             int ldl, hipStream_t st, bool zero_pad = true) {
+                             int ldl, hipStream_t st, bool zero_pad = true, int products = 3) {
+    if (products < 1 || products > 3) return CC_ERR_INVALID;
     GemmArgs g{};
     g.A = ta.hi;
     g.W = vb.hi;
     g.C = logits;
     int bn = 256;
     const int tile = sim_tile(Bt, Bv, &bn);
-    g.M = Bt; g.N = (Bv + bn - 1) / bn * bn; g.K = 3 * E; g.ldc = ldl;
+    g.M = Bt; g.N = (Bv + bn - 1) / bn * bn; g.K = products * E; g.ldc = ldl;
+    g.lda = g.ldw = 3 * E;
     g.n_valid = Bv;
     // the tiles read video rows up to the padded count: their products are dropped (n_valid), but they are read - zeros
     // instead of whatever the workspace held (uninitialised reads under sanitizers, NaN patterns through the matrix cores)
@@ -382,13 +389,20 @@ int cc_video_pool_normalize_planes_f32(const float* visual, const int64_t* video
 
 int cc_scaled_dot_planes_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
                              int32_t video_rows, int32_t E, float mult, float* logits, int32_t ldl, void* stream) {
+    return cc_scaled_dot_planes_products_f32(text_planes, video_planes, Bt, Bv, video_rows, E, mult, 3, logits, ldl, stream);
+}
+
+int cc_scaled_dot_planes_products_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
+                                      int32_t video_rows, int32_t E, float mult, int32_t products, float* logits, int32_t ldl,
+                                      void* stream) {
     if (!text_planes || !video_planes || !logits || Bt <= 0 || Bv <= 0 || E <= 0 || (E & 63) || ldl < Bv) return CC_ERR_INVALID;
+    if (products < 1 || products > 3) return CC_ERR_INVALID;
     int bn = 256;
     (void)sim_tile(Bt, Bv, &bn);
     if (video_rows < (Bv + bn - 1) / bn * bn) return CC_ERR_WORKSPACE;       // the tiles read whole multiples of their width
     const SplitOut ta{const_cast<_Float16*>(static_cast<const _Float16*>(text_planes)), E, 0};
     const SplitOut vb{const_cast<_Float16*>(static_cast<const _Float16*>(video_planes)), E, 1};
-    return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, static_cast<hipStream_t>(stream), false);
+    return dot_planes_launch(ta, vb, Bt, Bv, E, mult, logits, ldl, static_cast<hipStream_t>(stream), false, products);
 }
 
 int cc_loose_similarity_grouped_f32(const float* text, const float* visual, const int64_t* video_mask, int32_t group,

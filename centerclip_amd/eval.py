@@ -56,9 +56,22 @@ class HipBackend:
 
     video_operand_rows = staticmethod(T.padded_video_rows)          # rows to allocate (zeroed) for n videos
 
-    @staticmethod
-    def dot_operands(text_op, video_op, n_video, mult):
-        return torch.ops.centerclip.scaled_dot_planes(text_op.contiguous(), video_op, int(n_video), float(mult))
+    similarity_products = 3            # fp16 products per multiply-add of the final matrix (HipBackend.with_products)
+
+    @classmethod
+    def dot_operands(cls, text_op, video_op, n_video, mult):
+        return torch.ops.centerclip.scaled_dot_planes(text_op.contiguous(), video_op, int(n_video), float(mult),
+                                                      int(cls.similarity_products))
+
+    @classmethod
+    def with_products(cls, products):
+        """A backend whose final matrix issues `products` (3, 2 or 1) of the three fp16 products per multiply-add: 3 = both
+        operands to 22 bits (the default: rank-exact on the reference's fixtures), 2 = the text side rounded to fp16, 1 = both
+        sides fp16 - 2/3 and 1/3 of the GEMM's work, ~1e-5 rms on a cosine, inside the contract's 1e-3
+        (cc_scaled_dot_planes_products_f32; ``eval_epoch(..., similarity_products=2)``)."""
+        if products not in (1, 2, 3):
+            raise ValueError("similarity products: 1, 2 or 3")
+        return type("HipBackendP%d" % products, (cls,), {"similarity_products": int(products)})
 
     @staticmethod
     def counts_cols(sim, gt_cols):
@@ -162,14 +175,17 @@ def _item_positions(loader, world, rank, shard):
     return positions, None
 
 
-def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend, in_flight=1):
+def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend, in_flight=1,
+               similarity_products=None):
     """main.py:381-499 -> (R1, all_infer_time, info_str).  ``shard=True``: clip-sharded over the ranks of the default
     process group (module docstring) - every rank must call it and every rank returns the same numbers.
     ``in_flight`` (not in the reference; GPU only): 2 keeps two batches in flight - batch b runs on instance b % 2 of the
     model (``CLIP4Clip.replica()``) on a stream of its own, so the small-grid kernels of one batch (k-medoids selection,
-    launch tails) run under the other's GEMMs: 1.84 -> 1.60 ms per 16-clip batch at the cfg-2 shape, identical features."""
+    launch tails) run under the other's GEMMs: 1.84 -> 1.60 ms per 16-clip batch at the cfg-2 shape, identical features.
+    ``similarity_products`` (not in the reference): 3, 2 or 1 fp16 products per multiply-add of the final matrix
+    (``HipBackend.with_products``); None = the backend's own (3)."""
     log = log or (lambda s: None)
-    be = backend
+    be = backend.with_products(similarity_products) if similarity_products is not None else backend
     world, rank = (ccdist.world_size(), ccdist.rank()) if shard else (1, 0)
     ds = test_dataloader.dataset
     multi = bool(getattr(ds, 'multi_sentence_per_video', False))

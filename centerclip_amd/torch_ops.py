@@ -827,19 +827,21 @@ def _(visual, mask):
 
 
 @custom_op(NS + "::scaled_dot_planes", mutates_args=(), device_types="cuda")
-def scaled_dot_planes(text_planes: torch.Tensor, video_planes: torch.Tensor, n_video: int, mult: float) -> torch.Tensor:
+def scaled_dot_planes(text_planes: torch.Tensor, video_planes: torch.Tensor, n_video: int, mult: float,
+                      products: int = 3) -> torch.Tensor:
     """[Bt, n_video] = mult * text . video^T from the planes: the GEMM launch alone.  video_planes holds at least
-    padded_video_rows(n_video) rows, zeros behind n_video."""
+    padded_video_rows(n_video) rows, zeros behind n_video.  products: 3 (default: both operands to 22 bits), 2 (the text
+    side rounded to fp16) or 1 (both sides fp16) of the three fp16 products per multiply-add - see cc_scaled_dot_planes_products_f32."""
     Bt, E3 = text_planes.shape
     out = _e(Bt, int(n_video), like=text_planes, dtype=torch.float32)
-    L.check(L.lib().cc_scaled_dot_planes_f32(L.ptr(text_planes), L.ptr(video_planes), Bt, int(n_video), video_planes.shape[0],
-                                             E3 // 3, float(mult), L.ptr(out), int(n_video), _st(text_planes)),
-            "cc_scaled_dot_planes_f32")
+    L.check(L.lib().cc_scaled_dot_planes_products_f32(L.ptr(text_planes), L.ptr(video_planes), Bt, int(n_video),
+                                                      video_planes.shape[0], E3 // 3, float(mult), int(products), L.ptr(out),
+                                                      int(n_video), _st(text_planes)), "cc_scaled_dot_planes_products_f32")
     return out
 
 
 @scaled_dot_planes.register_fake
-def _(text_planes, video_planes, n_video, mult):
+def _(text_planes, video_planes, n_video, mult, products=3):
     return text_planes.new_empty((text_planes.shape[0], n_video), dtype=torch.float32)
 
 

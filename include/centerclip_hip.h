@@ -531,6 +531,12 @@ size_t cc_similarity_workspace_bytes(int32_t Bt, int32_t Bv, int32_t E);
  *   cc_scaled_dot_planes_f32            logits [Bt, Bv] = mult * text . video^T from the planes: ONE GEMM launch, nothing else.
  *                                       The video plane buffer must hold video_rows >= cc_similarity_padded_rows(Bv) rows with
  *                                       the rows behind Bv ZERO (the tiles read whole multiples of their width).
+ *   cc_scaled_dot_planes_products_f32   the same with `products` (3, 2 or 1) of the three fp16 products per multiply-add issued:
+ *                                       3 = hi.hi + hi.lo + lo.hi (both operands to 22 bits: 2e-6 on a cosine of unit rows - the
+ *                                       default everywhere, rank-exact against the reference's fp32 product on its fixtures);
+ *                                       2 = fp16(text) x video-to-22-bits; 1 = fp16 x fp16 (measured on 10k x 1k unit rows:
+ *                                       bench.py `similarity_10k_x_1k.products`).  All are inside the 1e-3 BASELINE.json's
+ *                                       north_star asks of similarities; the GEMM's matrix-core work is products / 3.
  * E % 64 == 0.  Same values as cc_scaled_dot_nt_f32 on the normalised rows. */
 size_t cc_similarity_plane_row_bytes(int32_t E);
 int32_t cc_similarity_padded_rows(int32_t Bv);
@@ -540,6 +546,9 @@ int cc_video_pool_normalize_planes_f32(const float* visual, const int64_t* video
                                        float* pooled, void* planes, void* stream);
 int cc_scaled_dot_planes_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
                              int32_t video_rows, int32_t E, float mult, float* logits, int32_t ldl, void* stream);
+int cc_scaled_dot_planes_products_f32(const void* text_planes, const void* video_planes, int32_t Bt, int32_t Bv,
+                                      int32_t video_rows, int32_t E, float mult, int32_t products, float* logits,
+                                      int32_t ldl, void* stream);
 int cc_video_pool_normalize_f32(const float* visual, const int64_t* video_mask, int32_t Bv, int32_t Tn,
                                 int32_t E, float* pooled, void* stream);
 int cc_loose_similarity_f32(const float* text, const float* visual, const int64_t* video_mask,

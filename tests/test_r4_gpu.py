@@ -61,6 +61,20 @@ def test_similarity_from_cached_operand_planes():
     assert float(((got - want).abs() / want.abs().clamp_min(1e-6)).max()) <= 2.5e-7
     with pytest.raises(RuntimeError):                              # too few (zeroed) padding rows
         torch.ops.centerclip.scaled_dot_planes(tp, vp[:Nv].contiguous(), Nv, 1.0)
+    # fewer fp16 products per multiply-add (round 5): 2 = the text side rounded to fp16, 1 = both sides; against float64 on
+    # the same unit rows - 3 products 5e-6, 2 products 1e-4, 1 product 2e-4 at the worst entry (the contract: 1e-3)
+    tn = t.double() / t.double().norm(dim=-1, keepdim=True)
+    vh = v.double() / v.double().norm(dim=-1, keepdim=True)
+    md = m.double().unsqueeze(-1)
+    vb = (vh * md).sum(1) / md.sum(1).clamp_min(1.0)
+    exact = tn @ (vb / vb.norm(dim=-1, keepdim=True)).t()
+    errs = {}
+    for p_ in (3, 2, 1):
+        c_ = torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, 1.0, p_)
+        errs[p_] = float((c_.double() - exact).abs().max())
+    assert errs[3] <= 5e-6 and errs[2] <= 1e-4 and errs[1] <= 2e-4 and errs[3] < errs[2] <= errs[1] * 1.5
+    with pytest.raises(RuntimeError):
+        torch.ops.centerclip.scaled_dot_planes(tp, vp, Nv, 1.0, 4)
 
 
 def test_p1_lattice_vit_b16_shipped_shape():

@@ -1,17 +1,25 @@
 #!/bin/bash
-# round 5, session 3: whole GPU suite + the default bench line (live counter passes, forward_other_configs) with its wall time
+# round 5, session 4: long-form attention with two query tiles per item (A/B against one), similarity products, tests of both
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/s3
-( time timeout 2400 python -m pytest tests -x -q -m gpu ) > gpurun_out/s3/pytest_gpu.txt 2>&1
-tail -6 gpurun_out/s3/pytest_gpu.txt
-( time python bench.py ) > gpurun_out/s3/bench.json 2> gpurun_out/s3/bench.err
-tail -4 gpurun_out/s3/bench.err
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/s3/bench.json").read().strip().splitlines()[0])
-print({k: d[k] for k in ("value", "ms_per_step")})
-r = d["roofline"]; print(r["kernel"], r["frac"], r["traffic"], r.get("traffic_detail"))
-print(d["token_cluster"]["cfg2"])
-for k, v in d["forward_other_configs"].items():
-    print(k, v["ms_per_step"], v["clips_per_s"], v["whole_step_frac_of_f16_mfma_peak"], v["roofline"]["kernel"], v["roofline"]["frac"])
+mkdir -p gpurun_out/s4
+timeout 900 python -m pytest tests/test_r4_gpu.py -x -q -m gpu -k "inproj_attention or similarity" > gpurun_out/s4/pytest.txt 2>&1
+tail -5 gpurun_out/s4/pytest.txt
+timeout 900 python -m pytest tests/test_r3_gpu.py tests/test_r2_gpu.py -x -q -m gpu > gpurun_out/s4/pytest2.txt 2>&1
+tail -3 gpurun_out/s4/pytest2.txt
+for i in 1 2 3; do
+  for v in nq1 new; do
+    for k in cfg5 cfg4; do
+      echo -n "$v $k "
+      CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python bench.py --workload $k --steps 20 --warmup 3 2>/dev/null | tail -1 |
+        python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
+    done
+  done
+done > gpurun_out/s4/ab.txt 2>&1
+cat gpurun_out/s4/ab.txt
+python - > gpurun_out/s4/sim.json 2> gpurun_out/s4/sim.err <<'PY'
+import json, torch, bench
+print(json.dumps(bench.similarity_bench(torch.device("cuda", 0))))
 PY
+cat gpurun_out/s4/sim.json; tail -3 gpurun_out/s4/sim.err
+bash tools/prof.sh fwd4_cfg5 python bench.py --workload cfg5 --steps 5 --warmup 2 --min-seconds 0.5 > gpurun_out/s4/forward_cfg5_kernel_stats.txt 2>&1
+head -8 gpurun_out/s4/forward_cfg5_kernel_stats.txt
