@@ -137,6 +137,12 @@ def declare(lib):
     lib.cc_bertadam_workspace_bytes.restype = sz
     lib.cc_bertadam_multi_f32.argtypes = [vp, i32, f32, f32, f32, f32, vp]
     lib.cc_bertadam_multi_f32.restype = c.c_int
+    lib.cc_bertadam_norm_blocks.argtypes = [i64]
+    lib.cc_bertadam_norm_blocks.restype = i32
+    lib.cc_bertadam_step_blocks.argtypes = [i64]
+    lib.cc_bertadam_step_blocks.restype = i32
+    lib.cc_bertadam_multi_large_f32.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32, vp, sz, vp]
+    lib.cc_bertadam_multi_large_f32.restype = c.c_int
     lib.cc_bertadam_step_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, sz, vp]
     lib.cc_bertadam_step_f32.restype = c.c_int
     lib.cc_similarity_plane_row_bytes.argtypes = [i32]

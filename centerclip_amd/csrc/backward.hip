@@ -1041,6 +1041,82 @@ struct BertAdamItem {
     int32_t pad_;
 };
 static_assert(sizeof(BertAdamItem) == 56, "cc_bertadam_item layout");
+// ... and all LARGE tensors in two launches (cc_bertadam_multi_large_f32): the workgroups of every tensor's norm pass, then the
+// workgroups of every tensor's step, each finding its tensor by bisection over the records' first-block numbers.  A tensor's
+// workgroups see the block count and block id cc_bertadam_step_f32 would give them, so its arithmetic and bits are the same.
+struct BertAdamBigItem {
+    float* p; float* g; float* m; float* v;
+    const float* lr_dev;
+    int64_t n;
+    float lr, wd;
+    int32_t norm_blk0, norm_blocks, step_blk0, step_blocks;
+};
+static_assert(sizeof(BertAdamBigItem) == 72, "cc_bertadam_big_item layout");
+template <bool STEP>
+__device__ __forceinline__ int bertadam_find(const BertAdamBigItem* __restrict__ items, int count, int blk) {
+    int lo = 0, hi = count - 1;                                   // last item whose first block <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((STEP ? items[mid].step_blk0 : items[mid].norm_blk0) <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void bertadam_multi_norm_kernel(const BertAdamBigItem* __restrict__ items, int count,
+                                                                   double* __restrict__ partial) {
+    const int ii = bertadam_find<false>(items, count, blockIdx.x);
+    const float* __restrict__ g = items[ii].g;
+    const int64_t n = items[ii].n;
+    const int64_t bid = (int)blockIdx.x - items[ii].norm_blk0, nblk = items[ii].norm_blocks;
+    double s = 0.0;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? (n >> 2) : 0;
+    for (int64_t i = bid * 256 + threadIdx.x; i < n4; i += nblk * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    for (int64_t i = (n4 << 2) + bid * 256 + threadIdx.x; i < n; i += nblk * 256) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void bertadam_multi_step_kernel(const BertAdamBigItem* __restrict__ items, int count,
+                                                                   const double* __restrict__ partial, float b1, float b2, float eps,
+                                                                   float max_norm) {
+    const int ii = bertadam_find<true>(items, count, blockIdx.x);
+    const BertAdamBigItem it = items[ii];
+    const float lr = it.lr_dev ? *it.lr_dev : it.lr;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        __shared__ double tot_s;
+        if (threadIdx.x < 64) {
+            double t = 0.0;
+            for (int b = threadIdx.x; b < it.norm_blocks; b += 64) t += partial[it.norm_blk0 + b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (threadIdx.x == 0) tot_s = t;
+        }
+        __syncthreads();
+        const float c = max_norm / ((float)sqrt(tot_s) + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    float* __restrict__ p = it.p; float* __restrict__ g = it.g; float* __restrict__ m = it.m; float* __restrict__ v = it.v;
+    const int64_t bid = (int)blockIdx.x - it.step_blk0;
+    for (int64_t i = bid * 256 + threadIdx.x; i < it.n; i += (int64_t)it.step_blocks * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] * b1 + (1.f - b1) * gi;
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float upd = mi / (sqrtf(vi) + eps);
+        const float pi = p[i];
+        if (it.wd > 0.f) upd += it.wd * pi;
+        g[i] = gi; m[i] = mi; v[i] = vi;
+        p[i] = pi - lr * upd;
+    }
+}
 __global__ __launch_bounds__(256) void bertadam_multi_small_kernel(const BertAdamItem* __restrict__ items, float b1, float b2, float eps,
                                                                     float max_norm) {
     const BertAdamItem it = items[blockIdx.x];
@@ -1226,6 +1302,25 @@ int cc_bertadam_multi_f32(const void* items_dev, int32_t count, float b1, float 
     if (!items_dev || count <= 0) return CC_ERR_INVALID;
     hipLaunchKernelGGL(bertadam_multi_small_kernel, dim3(count), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const BertAdamItem*>(items_dev), b1, b2, e, max_grad_norm);
+    CC_LAUNCH_CHECK();
+    return CC_OK;
+}
+
+/* The same for `count` LARGE tensors (any n) in TWO launches: items_dev = count cc_bertadam_big_item records in device memory,
+ * ordered, with norm_blk0 / step_blk0 = the running sums of norm_blocks / step_blocks = cc_bertadam_norm_blocks(n) /
+ * cc_bertadam_step_blocks(n); ws >= total_norm_blocks doubles.  Per tensor the arithmetic and the bits of cc_bertadam_step_f32. */
+int32_t cc_bertadam_norm_blocks(int64_t n) { return n <= 0 ? 0 : (int32_t)((n + 1023) / 1024 < BA_BLOCKS ? (n + 1023) / 1024 : BA_BLOCKS); }
+int32_t cc_bertadam_step_blocks(int64_t n) { return n <= 0 ? 0 : (int32_t)grid_for(n, 1024); }
+int cc_bertadam_multi_large_f32(const void* items_dev, int32_t count, int32_t total_norm_blocks, int32_t total_step_blocks, float b1,
+                                float b2, float e, float max_grad_norm, void* ws, size_t ws_bytes, void* stream) {
+    if (!items_dev || count <= 0 || total_norm_blocks <= 0 || total_step_blocks <= 0) return CC_ERR_INVALID;
+    if (!ws || ws_bytes < (size_t)total_norm_blocks * sizeof(double)) return CC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BertAdamBigItem* items = static_cast<const BertAdamBigItem*>(items_dev);
+    double* partial = static_cast<double*>(ws);
+    if (max_grad_norm > 0.f)
+        hipLaunchKernelGGL(bertadam_multi_norm_kernel, dim3(total_norm_blocks), dim3(256), 0, st, items, count, partial);
+    hipLaunchKernelGGL(bertadam_multi_step_kernel, dim3(total_step_blocks), dim3(256), 0, st, items, count, partial, b1, b2, e, max_grad_norm);
     CC_LAUNCH_CHECK();
     return CC_OK;
 }

@@ -444,6 +444,50 @@ class BertAdam(torch.optim.Optimizer):
         b1, b2, e, max_norm = hyper
         _check(L.lib().cc_bertadam_multi_f32(L.ptr(dev), len(items), b1, b2, e, max_norm, _st(dev)), "cc_bertadam_multi_f32")
 
+    def _multi_large(self, items, hyper, capturing, device):
+        """All large tensors of groups with the same (b1, b2, e, max_grad_norm) in TWO launches (cc_bertadam_multi_large_f32:
+        every tensor's norm workgroups, then every tensor's step workgroups) instead of two per tensor - ~100 tensors of a
+        ViT-B/32 CLIP: 204 launches -> 2.  Records (cc_bertadam_big_item) staged like the small tensors' (see _multi_small)."""
+        import numpy as np
+        lib = L.lib()
+        rec = np.zeros(len(items), dtype=np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('lr_dev', '<u8'),
+                                                   ('n', '<i8'), ('lr', '<f4'), ('wd', '<f4'), ('nb0', '<i4'), ('nb', '<i4'),
+                                                   ('sb0', '<i4'), ('sb', '<i4')]))
+        nb0 = sb0 = 0
+        for i, (p, grad, m, v, lr_dev, wd) in enumerate(items):
+            nb, sb = int(lib.cc_bertadam_norm_blocks(p.numel())), int(lib.cc_bertadam_step_blocks(p.numel()))
+            rec[i] = (p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), lr_dev.data_ptr(), p.numel(), 0.0, wd, nb0, nb, sb0, sb)
+            nb0 += nb
+            sb0 += sb
+        raw = rec.tobytes()
+        slot = self._multi.setdefault((hyper, "large"), {})
+        if slot.get("partial") is None or slot["partial"].numel() < nb0:
+            if capturing:
+                raise RuntimeError("BertAdam: run one eager step with the same parameters before capturing (partial sums)")
+            slot["partial"] = torch.empty(nb0, dtype=torch.float64, device=device)
+        if capturing:
+            host, dev = slot.pop("spare", (None, None))
+            if host is None or host.numel() != len(raw):
+                raise RuntimeError("BertAdam: run one eager step with the same parameters before capturing (staging buffers)")
+            host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dev.copy_(host, non_blocking=True)
+            self._multi_keep.append((host, dev))
+        else:
+            if slot.get("raw") != raw:
+                host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+                if slot.get("dev") is None or slot["dev"].numel() != len(raw):
+                    slot["dev"] = torch.empty(len(raw), dtype=torch.uint8, device=device)
+                slot["dev"].copy_(host, non_blocking=True)
+                slot["raw"] = raw
+            if "spare" not in slot or slot["spare"][0].numel() != len(raw):
+                slot["spare"] = (torch.empty(len(raw), dtype=torch.uint8).pin_memory(),
+                                 torch.empty(len(raw), dtype=torch.uint8, device=device))
+            dev = slot["dev"]
+        b1, b2, e, max_norm = hyper
+        part = slot["partial"]
+        _check(lib.cc_bertadam_multi_large_f32(L.ptr(dev), len(items), nb0, sb0, b1, b2, e, max_norm, L.ptr(part),
+                                               part.numel() * 8, _st(dev)), "cc_bertadam_multi_large_f32")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -452,7 +496,7 @@ class BertAdam(torch.optim.Optimizer):
         if not hasattr(self, "_lr_dev"):
             self._lr_dev = {}                                     # group index -> 1-element device tensor (not optimizer state)
             self._multi, self._multi_keep = {}, []
-        small = {}                                                # (b1, b2, e, max_grad_norm) -> records of the small tensors
+        small, large = {}, {}                                     # (b1, b2, e, max_grad_norm) -> records of the small / large tensors
         for gi, group in enumerate(self.param_groups):
             lr_set = False
             for p in group['params']:
@@ -482,6 +526,9 @@ class BertAdam(torch.optim.Optimizer):
                 if self.capturable and p.numel() <= self._MULTI_MAX_N:
                     hyper = (float(group['b1']), float(group['b2']), float(group['e']), float(group['max_grad_norm']))
                     small.setdefault(hyper, []).append((p, grad, state['next_m'], state['next_v'], lr_dev, float(group['weight_decay'])))
+                elif self.capturable:
+                    hyper = (float(group['b1']), float(group['b2']), float(group['e']), float(group['max_grad_norm']))
+                    large.setdefault(hyper, []).append((p, grad, state['next_m'], state['next_v'], lr_dev, float(group['weight_decay'])))
                 else:
                     _check(lib.cc_bertadam_step_f32(L.ptr(p), L.ptr(grad), L.ptr(state['next_m']), L.ptr(state['next_v']), p.numel(),
                                                     float(self._lr(group, state['step'])), float(group['b1']), float(group['b2']),
@@ -491,6 +538,8 @@ class BertAdam(torch.optim.Optimizer):
                     state['step'] += 1
         for hyper, items in small.items():
             self._multi_small(items, hyper, capturing, items[0][0].device)
+        for hyper, items in large.items():
+            self._multi_large(items, hyper, capturing, items[0][0].device)
         return loss
 
     def refresh_lr(self):

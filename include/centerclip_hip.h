@@ -717,6 +717,21 @@ typedef struct cc_bertadam_item {
     int32_t reserved;
 } cc_bertadam_item;                                            /* 56 bytes */
 int cc_bertadam_multi_f32(const void* items_dev, int32_t count, float b1, float b2, float e, float max_grad_norm, void* stream);
+/* ... and of `count` LARGE tensors (any n) in TWO launches - every tensor's norm workgroups, then every tensor's step workgroups,
+ * each finding its tensor by bisection: records ordered, norm_blk0 / step_blk0 = running sums of norm_blocks / step_blocks =
+ * cc_bertadam_norm_blocks(n) / cc_bertadam_step_blocks(n) (host-side queries), ws >= total_norm_blocks doubles.  Per tensor the
+ * arithmetic and the bits of cc_bertadam_step_f32.  (A ViT-B/32 CLIP has ~100 such tensors: 204 launches -> 2.) */
+typedef struct cc_bertadam_big_item {
+    float* param; float* grad; float* next_m; float* next_v;
+    const float* lr_dev;
+    int64_t n;
+    float lr, weight_decay;
+    int32_t norm_blk0, norm_blocks, step_blk0, step_blocks;
+} cc_bertadam_big_item;                                        /* 72 bytes */
+int32_t cc_bertadam_norm_blocks(int64_t n);
+int32_t cc_bertadam_step_blocks(int64_t n);
+int cc_bertadam_multi_large_f32(const void* items_dev, int32_t count, int32_t total_norm_blocks, int32_t total_step_blocks,
+                                float b1, float b2, float e, float max_grad_norm, void* ws, size_t ws_bytes, void* stream);
 
 /* ==========================================================================================
  * Diagnostics (not on the product path; process-wide state, not thread-safe).
