@@ -1,16 +1,14 @@
 #!/bin/bash
-# round 5, session 5: fused attention tile skipping the fragment rows behind its last sequence (A/B), tests
+# round 5, session 6: tile 12 (128x192, 4 waves, two workgroups per CU) for the fp16-output LN-folded GEMMs
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/s5
-timeout 900 python -m pytest tests/test_r4_gpu.py tests/test_r3_gpu.py -x -q -m gpu -k "inproj_attention or paired_towers or timed_step or step" > gpurun_out/s5/pytest.txt 2>&1
-tail -4 gpurun_out/s5/pytest.txt
+mkdir -p gpurun_out/s6
+python tools/tile_sweep.py 9600 2400 12800 25600 37824 6464 > gpurun_out/s6/tile_sweep.txt 2>&1
+cat gpurun_out/s6/tile_sweep.txt
+export CENTERCLIP_HIP_LIB=$PWD/ab/lib_dev.so
 for i in 1 2 3; do
-  for v in allrows new; do
-    for k in cfg5 cfg4 cfg2; do
-      echo -n "$v $k "
-      CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python bench.py --workload $k --steps 20 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 |
-        python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
-    done
+  for v in "" "CC_TILE_E6_B=12" "CC_TILE_E6_B=12 CC_TILE_E6_S=12"; do
+    echo -n "[$v] cfg2 "
+    env $v python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
   done
-done > gpurun_out/s5/ab.txt 2>&1
-cat gpurun_out/s5/ab.txt
+done > gpurun_out/s6/ab.txt 2>&1
+cat gpurun_out/s6/ab.txt
