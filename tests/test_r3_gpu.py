@@ -162,9 +162,10 @@ def test_timed_step_with_row_policies_off_matches_oracle_and_the_shipped_step(ti
 # ------------------------------------------------------------------------------------------------ cfg 3 / 4 / 5 towers
 PAIRED = {
     # name: (patch, T, T_new, K, cluster block (1-based), B, words, model name)
-    "cfg3_msvd_12to4_b16": (32, 12, 4, 49, 7, 16, 32, 'ViT-B/32'),
+    # (round 5: cfg 3 and cfg 5 at their full per-GPU batch - 64 and 16 clips - as bench.py's forward_other_configs times them)
+    "cfg3_msvd_12to4_b64": (32, 12, 4, 49, 7, 64, 32, 'ViT-B/32'),
     "cfg4_activitynet_64to8_b8": (32, 64, 8, 49, 7, 8, 77, 'ViT-B/32'),
-    "cfg5_vitb16_12to4_k100_b4": (16, 12, 4, 100, 7, 4, 32, 'ViT-B/16'),
+    "cfg5_vitb16_12to4_k100_b16": (16, 12, 4, 100, 7, 16, 32, 'ViT-B/16'),
 }
 
 
