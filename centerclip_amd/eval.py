@@ -204,7 +204,14 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
         if not (torch.cuda.is_available() and torch.device(device).type == "cuda"):
             raise ValueError("eval_epoch(in_flight > 1) needs a GPU")
         here = torch.cuda.current_stream(device)
-        lanes = [(model, torch.cuda.Stream(device))] + [(core.replica().eval(), torch.cuda.Stream(device)) for _ in range(in_flight - 1)]
+        # the extra instances (weights, folded weights, encoder scratch) and the lane streams are kept on the model and reused by
+        # later calls as long as no parameter changed (a version key); a changed model builds fresh ones
+        key = (in_flight, str(torch.device(device)), tuple((p.data_ptr(), p._version) for p in core.parameters()))
+        kept = getattr(core, "_eval_lanes", None)
+        if kept is None or kept[0] != key:
+            kept = (key, [torch.cuda.Stream(device) for _ in range(in_flight)], [core.replica().eval() for _ in range(in_flight - 1)])
+            core._eval_lanes = kept
+        lanes = list(zip([model] + kept[2], kept[1]))
         for _, s_ in lanes:
             s_.wait_stream(here)
     t_start = time.time()
@@ -224,17 +231,23 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
             net, lane_stream = lanes[bid % in_flight] if lanes else (model, None)
             with (torch.cuda.stream(lane_stream) if lane_stream is not None else contextlib.nullcontext()):
                 input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
+                def keep_rows(t):
+                    # rows produced on a lane's stream are read on the caller's stream at the end: tell the caching allocator,
+                    # so their blocks are not handed out again on the lane while that read is still queued
+                    if lane_stream is not None and t.is_cuda:
+                        t.record_stream(here)
+                    return t
                 if not multi:
                     out = net(input_ids, segment_ids, input_mask, video, video_mask)
-                    cache.add_text(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1)), pos)
-                    cache.add_video(_video_operand(core, out['visual_output'], video_mask, be), pos)
+                    cache.add_text(keep_rows(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1))), pos)
+                    cache.add_video(keep_rows(_video_operand(core, out['visual_output'], video_mask, be)), pos)
                     continue
                 seq = net(input_ids, segment_ids, input_mask)['sequence_output']
-                cache.add_text(be.text_operand(seq.reshape(seq.shape[0], -1)), pos)
+                cache.add_text(keep_rows(be.text_operand(seq.reshape(seq.shape[0], -1))), pos)
                 rows = [i for i, p in enumerate(pos.tolist()) if p in video_of_last]      # items that carry their clip's video
                 if rows:
                     vout = net(video=video[rows, ...], video_mask=video_mask[rows, ...])['visual_output']
-                    cache.add_video(_video_operand(core, vout, video_mask[rows, ...], be),
+                    cache.add_video(keep_rows(_video_operand(core, vout, video_mask[rows, ...], be)),
                                     torch.as_tensor([video_of_last[int(pos[i])] for i in rows], dtype=torch.long))
         if torch.cuda.is_available():
             torch.cuda.synchronize()               # (also joins the lanes' streams: the cached rows are read on this one below)

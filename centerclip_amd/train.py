@@ -133,12 +133,15 @@ def _w16_pair(w):
     return w16, (wt if wt.shape[1] == N else wt[:, :N].contiguous())
 
 
-def _grad_linear(dy32, x16, w16_t, need_dx=True, amax=None):
+def _grad_linear(dy32, x16, w16_t, need_dx=True, amax=None, need_dw=True):
     """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
-    The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X)."""
+    The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X).
+    need_dw False (a frozen layer, main.py's freeze_layer_num): no transposed copies, no wgrad GEMM, dW = None."""
     dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True, amax=amax)   # (+ the bias gradient, same read)
-    _, x16_t, _ = _cast_transpose(x16, scaled=False)
-    dw = _linear_unscaled(dy16_t, x16_t, scale)                                               # dY^T X
+    dw = None
+    if need_dw:
+        _, x16_t, _ = _cast_transpose(x16, scaled=False)
+        dw = _linear_unscaled(dy16_t, x16_t, scale)                                           # dY^T X
     # (dX last: the kernel that consumes it runs next and finds it in the memory-side cache)
     dx = _linear_unscaled(dy16, w16_t, scale) if need_dx else None                            # dY W
     return dx, dw, db
@@ -174,8 +177,11 @@ def block_forward_train(block, x_lnd):
     return z.view(N, Lt, W).permute(1, 0, 2), saved
 
 
-def block_backward(block, saved, dz_lnd):
-    """dz [L, N, W] -> (dx [L, N, W], {parameter name: gradient}) for the forward that produced ``saved``."""
+def block_backward(block, saved, dz_lnd, need=None):
+    """dz [L, N, W] -> (dx [L, N, W], {parameter name: gradient}) for the forward that produced ``saved``.  ``need``
+    (optional): {parameter name: bool} - weight gradients that nobody asked for (frozen layers) are not computed (None)."""
+    need = need or {}
+    nw = lambda key: bool(need.get(key, True))
     Lt, N, W = saved["shape"]
     M = N * Lt
     wt = saved.get("wt", {})
@@ -184,7 +190,7 @@ def block_backward(block, saved, dz_lnd):
     dz = dz_lnd.detach().float().permute(1, 0, 2).contiguous().view(M, W)
     g = {}
     # z = y + c_proj(u)
-    du, g["mlp.c_proj.weight"], g["mlp.c_proj.bias"] = _grad_linear(dz, saved["u"], f16t(block.mlp["c_proj"].weight, "c_proj"))
+    du, g["mlp.c_proj.weight"], g["mlp.c_proj.bias"] = _grad_linear(dz, saved["u"], f16t(block.mlp["c_proj"].weight, "c_proj"), need_dw=nw("mlp.c_proj.weight"))
     # u = QuickGELU(u_pre)
     # (the three gradients this function produces AND multiplies publish their largest magnitude from the producing kernel:
     #  the fp16 cast of each then needs no pass of its own to choose the scale)
@@ -193,17 +199,17 @@ def block_backward(block, saved, dz_lnd):
     _check(L.lib().cc_quick_gelu_backward_f16(L.ptr(saved["u_pre"]), L.ptr(du), L.ptr(du_pre), du.numel(), L.ptr(am[0]), _st(du)),
            "cc_quick_gelu_backward_f16")
     # u_pre = c_fc(ln_2(y))
-    dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = _grad_linear(du_pre, saved["n2"], f16t(block.mlp["c_fc"].weight, "c_fc"), amax=am[0])
+    dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = _grad_linear(du_pre, saved["n2"], f16t(block.mlp["c_fc"].weight, "c_fc"), amax=am[0], need_dw=nw("mlp.c_fc.weight"))
     dy, g["ln_2.weight"], g["ln_2.bias"] = _ln_backward(saved["y"], f32(block.ln_2.weight), dn2, dz, eps=block.ln_2.eps, amax=am[1])   # + the residual branch
     # y = x + out_proj(att)
-    datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight, "out_proj"), amax=am[1])
+    datt, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = _grad_linear(dy, saved["att"], f16t(block.attn.out_proj.weight, "out_proj"), amax=am[1], need_dw=nw("attn.out_proj.weight"))
     dqkv = torch.empty(M, 3 * W, device=dz.device, dtype=torch.float32)
     ab_bytes = L.lib().cc_attention_backward_workspace_bytes(N, Lt, block.n_head)       # (0 for Lt <= 64)
     ab_ws = L.workspace(ab_bytes, dz.device) if ab_bytes else None
     _check(L.lib().cc_attention_backward_f16(L.ptr(saved["qkv"]), L.ptr(datt), L.ptr(dqkv), N, Lt, block.n_head, W,
                                              int(saved["causal"]), L.ptr(am[2]), L.ptr(ab_ws), ab_bytes, _st(dz)),
            "cc_attention_backward_f16")
-    dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight, "in_proj"), amax=am[2])
+    dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = _grad_linear(dqkv, saved["n1"], f16t(block.attn.in_proj_weight, "in_proj"), amax=am[2], need_dw=nw("attn.in_proj_weight"))
     dx, g["ln_1.weight"], g["ln_1.bias"] = _ln_backward(saved["x"], f32(block.ln_1.weight), dn1, dy, eps=block.ln_1.eps)
     return dx.view(N, Lt, W).permute(1, 0, 2), g
 
@@ -221,13 +227,22 @@ class ResidualAttentionBlockFunction(torch.autograd.Function):
     def forward(ctx, block, x, *params):
         z, saved = block_forward_train(block, x)
         ctx.block, ctx.saved = block, saved
+        # (the activations and the forward-time W^T copies live in ctx.saved, outside autograd's version tracking: remember the
+        #  parameters' versions, so that a weight changed in place between forward and backward is an error, as it is for
+        #  tensors kept with save_for_backward, and not a silently stale W^T)
+        ctx.versions = tuple(p._version for p in params)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        dx, g = block_backward(ctx.block, ctx.saved, dz)
         named = dict(ctx.block.named_parameters())
-        return (None, dx) + tuple(g[k].view_as(named[k]).to(named[k].dtype) for k in _PARAM_ORDER)
+        if tuple(named[k]._version for k in _PARAM_ORDER) != ctx.versions:
+            raise RuntimeError("ResidualAttentionBlockFunction: a parameter of the block was modified in place between forward "
+                               "and backward (the saved W^T copies are those of the forward)")
+        need = {k: bool(ctx.needs_input_grad[2 + i]) for i, k in enumerate(_PARAM_ORDER)}
+        dx, g = block_backward(ctx.block, ctx.saved, dz, need=need)
+        return (None, dx) + tuple((g[k].view_as(named[k]).to(named[k].dtype) if (need[k] and g[k] is not None) else None)
+                                  for k in _PARAM_ORDER)
 
 
 def block_apply(block, x_lnd):

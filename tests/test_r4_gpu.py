@@ -128,6 +128,22 @@ def test_block_backward_against_reference_autograd(tag):
     assert torch.equal(xa.grad, dx)
     for k, p_ in blk.named_parameters():
         assert p_.grad is not None and torch.equal(p_.grad.reshape(-1), grads[k].reshape(-1)), k
+    # frozen weights (main.py's freeze_layer_num): no gradient, no wgrad work for them, everything else the same bits;
+    # a parameter changed in place between forward and backward is an error, not a silently stale W^T
+    for p_ in blk.parameters():
+        p_.grad = None
+    blk.mlp["c_fc"].weight.requires_grad_(False)
+    blk.attn.in_proj_weight.requires_grad_(False)
+    xb = xt.clone().requires_grad_(True)
+    (train.block_apply(blk, xb) * dzt).sum().backward()
+    assert torch.equal(xb.grad, dx) and blk.mlp["c_fc"].weight.grad is None and blk.attn.in_proj_weight.grad is None
+    assert torch.equal(blk.mlp["c_proj"].weight.grad.reshape(-1), grads["mlp.c_proj.weight"].reshape(-1))
+    assert torch.equal(blk.mlp["c_fc"].bias.grad.reshape(-1), grads["mlp.c_fc.bias"].reshape(-1))
+    zc = train.block_apply(blk, xt.clone().requires_grad_(True))
+    with torch.no_grad():
+        blk.ln_2.weight.mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        (zc * dzt).sum().backward()
 
 
 # ----------------------------------------------------------------------------- in_proj + attention in one launch

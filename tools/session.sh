@@ -1,7 +1,9 @@
 #!/bin/bash
-# round 5, session 7: the round's committed profiles (PMC traffic + MFMA utilisation stand-alone, bench line, kernel stats of the
-# same bench command) + the parity tests of cfg 3 / cfg 5 at their full per-GPU batch
 cd $GRAFT_REPO_ROOT
-bash tools/refresh_profiles.sh r05 2>&1 | tail -40
-( time timeout 1500 python -m pytest tests/test_r3_gpu.py -x -q -m gpu -k paired_towers -s ) > gpurun_out/profiles/pytest_paired.txt 2>&1
-grep "normalised\|passed\|failed\|real" gpurun_out/profiles/pytest_paired.txt
+mkdir -p gpurun_out/s9
+for v in base dev base dev; do
+  echo "== $v"
+  CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python tools/sel_prof.py 2>&1 | grep "^P="
+  CENTERCLIP_HIP_LIB=$PWD/ab/lib_$v.so python tools/time_cluster.py 2>&1 | grep "gauss   p=2.0"
+done > gpurun_out/s9/ab.txt 2>&1
+cat gpurun_out/s9/ab.txt
