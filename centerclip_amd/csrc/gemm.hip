@@ -828,8 +828,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         // output values instead of every P.  Two query tiles per item give a wave two independent dependency chains (197
         // tokens: 7 items on 8 waves in one round instead of 13 in two) - ViT-B/16 in_proj + attention 284 -> see
         // profiles/r05_forward_cfg5_kernel_stats.txt.  Causal sequences skip the key tiles behind the item's last query tile.
-        auto run_items_long = [&](auto nktm_c, auto nq_c) {
+        // FULL: every sequence of the launch has exactly NKTM key tiles and no causal mask (the ViT's frames): the key-tile count
+        // is a compile-time constant, the guards below fold away and the compiler pipelines the K / V fragment reads of an
+        // item across key tiles instead of waiting for each guarded group (items of a 197-token frame 6.3 -> 4.7 us per workgroup, of two
+        // 101-token frames 4.3 -> 3.1; cfg 5 6.05 -> 5.92 ms per step in three same-session rounds, profiles/r05_attention_two_query_tiles_ab.txt)
+        auto run_items_long = [&](auto nktm_c, auto nq_c, auto full_c) {
             constexpr int NKTM = decltype(nktm_c)::value, NQ = decltype(nq_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
             constexpr float SC = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) and the exp -> exp2 factor
             const int qgroups = (qtmax + NQ - 1) / NQ;
             for (int it = __builtin_amdgcn_readfirstlane(wave); it < nst * qgroups; it += NWAVES) {
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 if (qt0 * 16 >= L) continue;
                 int nkt = (((L + 15) >> 4) + 1) & ~1;               // key tiles of this sequence, whole 32-key blocks
                 if (CAUSAL) nkt = min(nkt, (qt0 + NQ + 1) & ~1);
-                nkt = __builtin_amdgcn_readfirstlane(min(nkt, NKTM));
+                nkt = FULL ? NKTM : __builtin_amdgcn_readfirstlane(min(nkt, NKTM));
                 h8 qf[NQ][2];
 #pragma unroll
                 for (int u = 0; u < NQ; ++u)
@@ -850,7 +855,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 for (int kt = 0; kt < NKTM; ++kt) {
 #pragma unroll
                     for (int u = 0; u < NQ; ++u) sc[u][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (kt < nkt) {
+                    if (FULL || kt < nkt) {
                         const int kr = off + min(kt * 16 + l15, L - 1);
                         const h8 k0 = *reinterpret_cast<const h8*>(Ks + kr * QS + lg * 8);
                         const h8 k1 = *reinterpret_cast<const h8*>(Ks + kr * QS + (4 + lg) * 8);
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int kt = 0; kt < NKTM; ++kt) {
-                        if (kt < nkt) {
+                        if (FULL || kt < nkt) {
                             f32x4 a = sc[u][kt];
                             if (!(kt * 16 + 15 < L && (!CAUSAL || kt < qt))) {   // (wave-uniform) a tile with masked keys
 #pragma unroll
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                     float sum = 0.f;
 #pragma unroll
                     for (int kt = 0; kt < NKTM; ++kt) {
-                        if (kt < nkt) {
+                        if (FULL || kt < nkt) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float pexp = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][kt][e], SC, mneg));   // masked: exp2(-5e37) = 0
@@ -905,7 +910,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
                 const _Float16* vbase = Vt + l15 * VS + sq * slot + lg * 4;
 #pragma unroll
                 for (int kb = 0; kb < NKTM / 2; ++kb) {
-                    if (2 * kb < nkt) {
+                    if (FULL || 2 * kb < nkt) {
                         h8 pf[NQ];
 #pragma unroll
                         for (int u = 0; u < NQ; ++u) {
@@ -959,9 +964,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #else
         constexpr int NQL = 2;
 #endif
-        if (slot > 224) run_items_long(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
-        else if (slot > 128) run_items_long(std::integral_constant<int, 14>{}, std::integral_constant<int, NQL>{});
-        else if (slot > 64) run_items_long(std::integral_constant<int, 8>{}, std::integral_constant<int, NQL>{});
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        const int nkt_all = (((g.att_L + 15) >> 4) + 1) & ~1;       // key tiles of a full-length sequence
+#ifdef CC_ATTN_LONG_GUARDED                                    // A/B arm: always the guarded (run-time key-tile count) form
+        const bool full_ok = false;
+#else
+        const bool full_ok = !CAUSAL && !g.att_seq_off;
+#endif
+        if (slot > 64 && full_ok && nkt_all == 14) run_items_long(integral_constant<int, 14>{}, integral_constant<int, NQL>{}, true_type{});
+        else if (slot > 64 && full_ok && nkt_all == 8) run_items_long(integral_constant<int, 8>{}, integral_constant<int, NQL>{}, true_type{});
+        else if (slot > 64 && full_ok && nkt_all == 12) run_items_long(integral_constant<int, 12>{}, integral_constant<int, NQL>{}, true_type{});
+        else if (slot > 64 && full_ok && nkt_all == 10) run_items_long(integral_constant<int, 10>{}, integral_constant<int, NQL>{}, true_type{});
+        else if (slot > 64 && full_ok && nkt_all == 6) run_items_long(integral_constant<int, 6>{}, integral_constant<int, NQL>{}, true_type{});
+        else if (slot > 224) run_items_long(integral_constant<int, 16>{}, integral_constant<int, 1>{}, false_type{});
+        else if (slot > 128) run_items_long(integral_constant<int, 14>{}, integral_constant<int, NQL>{}, false_type{});
+        else if (slot > 64) run_items_long(integral_constant<int, 8>{}, integral_constant<int, NQL>{}, false_type{});
         else if (slot == 64) run_items(std::integral_constant<int, 4>{});
         else run_items(std::integral_constant<int, 2>{});
         GEMM_STAMP(3);

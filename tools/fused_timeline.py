@@ -6,7 +6,8 @@ import torch
 from centerclip_amd import ops, _lib as L
 lib = L.lib()
 lib.cc_debug_set_gemm_profile.argtypes = [ctypes.c_void_p]
-for nseq, Lt, heads in [(192, 50, 12), (48, 50, 12)]:
+SHAPES = [(192, 50, 12), (48, 50, 12)] if len(sys.argv) < 2 else [(192, 197, 12), (64, 101, 12), (192, 50, 12)]
+for nseq, Lt, heads in SHAPES:
     W, M = heads * 64, nseq * Lt
     h16, st, _ = ops.row_stats(torch.randn(M, W, device="cuda"))
     wf, c1, c2 = ops.fold_layernorm_linear(torch.randn(3 * W, W, device="cuda") * W ** -0.5, torch.randn(3 * W, device="cuda"),
