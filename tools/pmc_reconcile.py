@@ -10,7 +10,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "g*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"] + " grid " + r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 KEEP = ("gemm_f16_kernel", "kmedoids_select", "gram_dist", "attention", "elementwise", "copy", "Memcpy", "im2col", "vectorized")
 res = {}
 for k, cs in acc.items():

@@ -9,7 +9,7 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
-           "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_IO_CREDIT_STALL_sum"; do
+           "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_IO_CREDIT_STALL_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $out/g$i -o g$i --output-format csv -- "$@" > $out/g$i.log 2>&1 || echo "group $i ($grp) failed: $(tail -2 $out/g$i.log | tr '\n' ' ')"
 done
