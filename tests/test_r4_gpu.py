@@ -208,6 +208,46 @@ def test_inproj_attention_one_launch_long_sequences(nseq, L, heads, causal):
     assert torch.equal(got, again)                                                   # fixed order: the same bits on every run
 
 
+def test_inproj_attention_seeded_shape_sweep():
+    """A seeded sweep over the one-launch form's whole range (every path: 32- and 64-key slots, the long form with run-time and
+    compile-time key-tile counts, one to eight sequences per row tile, ragged last tiles, causal and not; uniform and packed
+    variable-length sequences) against the fp32 formula of modules/clip.py:210-214 on the fp16 q, k, v of the same launch inputs."""
+    from centerclip_amd import ops
+    rng = np.random.RandomState(20250929)
+    for case in range(24):
+        L = int(rng.choice([1, 7, 16, 31, 32, 33, 48, 56, 57, 63, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 224, 225, 255, 256]))
+        heads = int(rng.randint(1, 4))
+        causal = bool(rng.randint(0, 2))
+        nseq = int(rng.randint(1, max(2, min(40, 3000 // L))))
+        packed = bool(rng.randint(0, 3) == 0) and L > 1
+        W = heads * 64
+        h16, st, wf, c1, c2 = _inproj_inputs(nseq * L, W, 1000 + case)
+        if packed:
+            lens = rng.randint(1, L + 1, size=nseq).astype(np.int32)
+            lens[rng.randint(0, nseq)] = L
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+            got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, nseq, L, heads, causal=causal,
+                                           seq_off=torch.from_numpy(off).cuda(), seq_len=torch.from_numpy(lens).cuda())
+        else:
+            lens, off = np.full(nseq, L, dtype=np.int32), (np.arange(nseq) * L).astype(np.int32)
+            got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, nseq, L, heads, causal=causal)
+        torch.cuda.synchronize()
+        qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1).float()
+        scale_ref = 0.0
+        for o, n in zip(off.tolist(), lens.tolist()):
+            q, k, v = (t.view(n, heads, 64).permute(1, 0, 2) for t in qkv[o:o + n].split(W, dim=1))
+            sc = q @ k.transpose(-1, -2) / 8.0
+            if causal:
+                sc = sc + torch.full((n, n), float("-inf"), device=sc.device).triu(1)
+            ref = (sc.softmax(-1) @ v).permute(1, 0, 2).reshape(n, W)
+            scale_ref = max(scale_ref, float(ref.abs().max()))
+            err = float((got[o:o + n].float() - ref).abs().max())
+            assert err <= 2e-3 * max(scale_ref, 1e-3), (case, L, heads, causal, nseq, packed, o, n, err)
+        assert torch.isfinite(got.float()).all()
+        if packed:
+            assert not got[int(lens.sum()):].any()
+
+
 def test_inproj_attention_packed_long_captions():
     """Packed variable-length captions with the 77-token context (3 sequence slots of 96 keys per row tile): every caption
     against the two-launch result of that caption alone."""
