@@ -335,6 +335,9 @@ class VisualTransformer(nn.Module):
             T_ = 1
         assert BT % T_ == 0
         if forced_medoids is not None:
+            # one id tensor [B * T_new, K] per cluster block (a list / tuple for plans with several blocks): back to back
+            if isinstance(forced_medoids, (list, tuple)):
+                forced_medoids = torch.cat([m.to(device=x.device, dtype=torch.long).reshape(-1) for m in forced_medoids])
             forced_medoids = forced_medoids.to(device=x.device, dtype=torch.long).contiguous()
         feats, hidden, med = torch.ops.centerclip.vit_encode(x, self._model(), BT // T_, T_, bool(want_hidden),
                                                              bool(want_medoids and has_cluster), forced_medoids)

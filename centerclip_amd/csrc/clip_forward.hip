@@ -350,8 +350,8 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                         : vm ? cc_launch_layernorm2(a, nullptr, 1e-5f, 0, st) : cc_launch_text_embed(te, st);
         if (rc) return rc;
     }
-    // medoids_out receives the ids of the LAST k-medoids block only (it is sized for that block); forced_medoids is a
-    // single id tensor, so it is only meaningful for plans with one cluster block
+    // medoids_out receives the ids of the LAST k-medoids block only (it is sized for that block); forced_medoids holds the id
+    // tensors of ALL cluster blocks back to back, in block order ([B * T_new_i, K_i] int64 each: round 5 - one block before)
     int last_kmed = -1, cluster_blocks = 0;
     for (int i = 0; i < vl; ++i)
         if (vm->cluster_tokens[i] > 0) {
@@ -359,7 +359,8 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
             const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
             if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS || var->algorithm == CC_CLUSTER_SPECTRAL) last_kmed = i;
         }
-    if (forced_medoids && cluster_blocks > 1) return CC_ERR_UNSUPPORTED;
+    (void)cluster_blocks;
+    size_t forced_off = 0;      // first id of the current cluster block inside forced_medoids
     int ti = 0;                 // next text block
     for (int i = 0; i < vl || ti < tl; ++i) {
         const bool hv = i < vl;
@@ -377,7 +378,7 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                                                 var->aggregation == CC_AGGREGATE_MEDOID && !var->cluster_embed &&
                                                 !var->cls_multiplier)))
                     rc = cc_token_gather_rows(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
-                                              forced_medoids, hother, W, (int64_t)(K + 1) * W, v.h16, v.st0, v.sh0, st);
+                                              forced_medoids + forced_off, hother, W, (int64_t)(K + 1) * W, v.h16, v.st0, v.sh0, st);
                 else if (forced_medoids)
                     rc = CC_ERR_UNSUPPORTED;
                 else
@@ -389,6 +390,7 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                                                        nullptr, nullptr, v.cluster, v.cluster_bytes, v.h16, v.st0,
                                                        v.sh0, st);
                 if (rc) return rc;
+                forced_off += (size_t)B * Tn * K;
                 float* tmp = h; h = hother; hother = tmp;
                 frames = Tn;
                 tokens = K;

@@ -454,8 +454,8 @@ size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T);
  * output, clip.py:304-349).  medoids_out (optional): int64 [T_new*B, K] of the LAST k-medoids block of the
  * plan (T_new, K of THAT block; earlier cluster blocks do not write it).
  * forced_medoids (optional, test hook for "embeddings given identical medoid sets"):
- * int64 [T_new*B, K]; when non-NULL the cluster block skips the k-medoids selection and gathers these ids
- * instead.  Plans with more than one cluster block return CC_ERR_UNSUPPORTED with forced_medoids. */
+ * int64 [T_new*B, K] per cluster block, the blocks' tensors back to back in block order; when non-NULL every cluster block
+ * (shipped variant: k-medoids, medoid aggregation) skips the selection and gathers these ids instead. */
 int cc_vit_encode(const cc_vit_model* m, const float* video, int32_t B, int32_t T,
                   float* features, float* hidden_out, int64_t* medoids_out,
                   const int64_t* forced_medoids, void* ws, size_t ws_bytes, void* stream);

@@ -620,6 +620,32 @@ def test_n3_uint8_frames_bit_identical_to_loader_path(g):
         model.visual.encode(torch.zeros(4, 5, 64, 64, dtype=torch.uint8, device=DEV), T)
 
 
+def test_forced_medoids_with_two_cluster_blocks(g):
+    """Round 5: the "given identical medoid sets" hook for plans with MORE than one cluster block (4 -> 2 frames with K = 8 in
+    block 1, 2 -> 1 with K = 4 in block 2): the id tensors of the blocks back to back; features and hidden state vs the fp32
+    oracle given the same ids (clip.py:236-242 twice)."""
+    from centerclip_amd.clip import build_clip_model
+    T = int(g["cfg"][11])
+    args = Namespace(cluster_inter=1, cluster_algo='kmediods++', max_frames=T, target_frames_blocks=[2, 1, 1],
+                     cluster_num_blocks=[8, 4, 4], cluster_distance='euclidean', cluster_threshold=1e-6, cluster_iter_limit=100,
+                     minkowski_norm_p=2.0, pretrained_clip_name='ViT-B/32', aggregation=None, pre_norm=False)
+    model, _ = build_clip_model(golden_state_dict(g), args=args)
+    model = model.to(DEV)
+    video = torch.from_numpy(g["video"])
+    B = video.shape[0] // T
+    n = (video.shape[-1] // int(golden_state_dict(g)["visual.conv1.weight"].shape[-1])) ** 2
+    gen = torch.Generator().manual_seed(5)
+    m0 = torch.stack([torch.randperm((T // 2) * n, generator=gen)[:8].sort().values for _ in range(B * 2)])
+    m1 = torch.stack([torch.randperm(2 * 8, generator=gen)[:4].sort().values for _ in range(B * 1)])
+    feat, hidden = model.visual.encode(video.to(DEV), T, want_hidden=True, forced_medoids=[m0, m1])
+    ref, refh = clo.visual_forward(golden_state_dict(g), video, T, cluster_plan={0: (2, 8), 1: (1, 4)},
+                                   forced_medoids={0: m0, 1: m1}, return_hidden=True)
+    assert feat.shape == ref.shape == (B, ref.shape[1]) and hidden.shape == refh.shape
+    assert float((nrm(feat.cpu()) - nrm(ref)).abs().max()) <= 1e-3 and relerr(hidden.cpu(), refh) <= 1e-3
+    own, _ = model.visual.encode(video.to(DEV), T)                 # (and the plan runs with its own k-medoids in both blocks)
+    assert own.shape == feat.shape and bool(torch.isfinite(own).all())
+
+
 @pytest.mark.parametrize("algo,agg", [("pooling", None), ("sparse_sampling", None), ("kmediods++", "mean")])
 def test_n2_variants_inside_the_fused_forward(g, algo, agg):
     """The per-block cc_cluster_variant array of cc_vit_model: 'pooling' and eval-mode 'sparse_sampling' (no
