@@ -24,7 +24,6 @@ struct GemmArgs {
                          // `products` of three planes per row, so its rows are 3E halfs apart while K = products * E)
     int patch_n;         // EPI_F32_PATCH: patches per frame (out row = f*(n+1) + 1 + i)
     int tiles_m, tiles_n;
-    int group_m;         // rows of tiles per rasterisation group (0 = 8), chosen by the launcher (raster_group_rows)
     // LayerNorm folding
     const float* ln_stats;   // *_LN: [M][ln_slots][2] partial (sum, sum of squares) of the A rows
     const float* ln_c1;      // *_LN: [N]  (c2 travels in `bias`)

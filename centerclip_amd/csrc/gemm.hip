@@ -124,8 +124,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     // grouped rasterisation inside the XCD's run: the ~64 tiles an XCD has in flight form an
     // 8-row x 8-column patch, so both operand panels (8 A row-tiles + 8 W column-tiles) stay in its
     // 4 MiB L2 instead of streaming the whole weight matrix past it for every row of tiles.
-    // (round 5: the group height comes from the host, raster_group_rows() below - 8 in every shipped build)
-    const int GROUP_M = g.group_m > 0 ? g.group_m : 8;
+    // (round 5 measured a group height of 1 for narrow outputs - whole rows of tiles per XCD, the A operand then crosses the
+    // fabric 1.2 instead of 2.0 times - and found the launches SLOWER: profiles/r05_traffic_reconcile.txt; 8 stays)
+    constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * g.tiles_n;
     const int group = bid / per_group, first_m = group * GROUP_M;
     const int gsz = min(g.tiles_m - first_m, GROUP_M);
@@ -1264,49 +1265,11 @@ int launch_one(const GemmPair& pr, int total, hipStream_t st) {
     return CC_OK;
 }
 
-// Rows of tiles per rasterisation group (GemmArgs::group_m).  Workgroup b runs on XCD b % 8 and the kernel hands every XCD a
-// contiguous run of R = tiles / 8 tiles of the 1-D order "groups of gm tile rows, inside a group down the rows first"; what
-// the run pulls through its XCD's L2 is (tile rows it touches) x BM + (tile columns it touches) x BN rows of K halfs.  The
-// estimate below counts both for gm in {1, 2, 4, 8, 16} and keeps the cheapest (ties: the larger patch, 8 = the value every
-// launch used before round 5).
-static int raster_group_rows(int tiles_m, int tiles_n, int BM, int BN) {
-#ifndef CC_RASTER_ADAPTIVE
-    // Measured (profiles/r05_traffic_reconcile.txt): walking whole rows of tiles where the output is narrow (N = 768: gm = 1)
-    // does bring the A operand's fabric reads from 2.0x to ~1.2x of its size - and the launches get SLOWER (cfg-2 step 1.782 ->
-    // 1.840 ms in two same-session A/B rounds, ~4.5 us per N = 768 launch): the fetch volume is not what bounds them.  The
-    // estimate stays for -DCC_RASTER_ADAPTIVE builds; every shipped launch uses the 8-row groups of rounds 1-4.
-    return 8;
-#endif
-    const double R = (double)tiles_m * tiles_n / 8.0;
-    if (R < 4.0) return 8;
-    int best = 8;
-    double best_cost = 0.0;
-    const int cand[5] = {8, 16, 4, 2, 1};
-    for (int c = 0; c < 5; ++c) {
-        const int gm = cand[c] < tiles_m ? cand[c] : tiles_m;
-        const double per_group = (double)gm * tiles_n;
-        double rows, cols;
-        if (R <= per_group) {
-            rows = gm;
-            cols = R / gm + 1.0;
-            if (cols > tiles_n) cols = tiles_n;
-        } else {
-            rows = gm * (R / per_group + 1.0);
-            cols = tiles_n;
-        }
-        if (rows > tiles_m) rows = tiles_m;
-        const double cost = rows * BM + cols * BN;
-        if (c == 0 || cost < best_cost * 0.97) { best = cand[c]; best_cost = cost; }
-    }
-    return best;
-}
-
 template <int BM, int BN, int WM, int WN, int BK = GEMM_BK>
 int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
     GemmPair pr{};
     g0.tiles_m = (g0.M + BM - 1) / BM;
     g0.tiles_n = g0.N / BN;
-    g0.group_m = raster_group_rows(g0.tiles_m, g0.tiles_n, BM, BN);
     pr.p[0] = g0;
     pr.tiles0 = g0.tiles_m * g0.tiles_n;
     int total = pr.tiles0;
@@ -1314,7 +1277,6 @@ int launch_tile(GemmArgs g0, const GemmArgs* g1, int epi, hipStream_t st) {
         pr.p[1] = *g1;
         pr.p[1].tiles_m = (g1->M + BM - 1) / BM;
         pr.p[1].tiles_n = g1->N / BN;
-        pr.p[1].group_m = raster_group_rows(pr.p[1].tiles_m, pr.p[1].tiles_n, BM, BN);
         total += pr.p[1].tiles_m * pr.p[1].tiles_n;
         // single-round carriers (the clustered blocks): the rider's tiles spill into a second round, see the kernel
         // (2.172 vs 2.182 ms per step over 5 A/B rounds; dev builds: CC_RIDER_PRIO=0 switches it off, =2 applies it to every launch)
