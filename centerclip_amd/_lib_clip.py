@@ -91,6 +91,8 @@ def declare(lib):
     lib.cc_group_max_rows_f32.restype = c.c_int
     lib.cc_vit_workspace_bytes.restype = sz
     lib.cc_vit_workspace_bytes.argtypes = [c.POINTER(VitModel), i32, i32]
+    lib.cc_vit_forced_medoids_count.restype = i64
+    lib.cc_vit_forced_medoids_count.argtypes = [c.POINTER(VitModel), i32]
     lib.cc_vit_encode.argtypes = [c.POINTER(VitModel), vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_vit_encode_frames.argtypes = [c.POINTER(VitModel), c.POINTER(Frames), i32, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.cc_vit_encode_frames.restype = c.c_int

@@ -352,14 +352,12 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
     }
     // medoids_out receives the ids of the LAST k-medoids block only (it is sized for that block); forced_medoids holds the id
     // tensors of ALL cluster blocks back to back, in block order ([B * T_new_i, K_i] int64 each: round 5 - one block before)
-    int last_kmed = -1, cluster_blocks = 0;
+    int last_kmed = -1;
     for (int i = 0; i < vl; ++i)
         if (vm->cluster_tokens[i] > 0) {
-            ++cluster_blocks;
             const cc_cluster_variant* var = vm->cluster_variants ? &vm->cluster_variants[i] : nullptr;
             if (!var || var->algorithm == CC_CLUSTER_KMEDOIDS || var->algorithm == CC_CLUSTER_SPECTRAL) last_kmed = i;
         }
-    (void)cluster_blocks;
     size_t forced_off = 0;      // first id of the current cluster block inside forced_medoids
     int ti = 0;                 // next text block
     for (int i = 0; i < vl || ti < tl; ++i) {
@@ -443,6 +441,14 @@ extern "C" {
 size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T) {
     if (!m || B <= 0 || T <= 0 || m->patch <= 0 || m->resolution % m->patch) return 0;
     return carve_vit(m, B, T, nullptr).total;
+}
+
+int64_t cc_vit_forced_medoids_count(const cc_vit_model* m, int32_t B) {
+    if (!m || B <= 0 || m->layers < 0 || m->layers > CC_MAX_LAYERS) return CC_ERR_INVALID;
+    int64_t n = 0;
+    for (int i = 0; i < m->layers; ++i)
+        if (m->cluster_tokens[i] > 0) n += (int64_t)B * m->cluster_frames[i] * m->cluster_tokens[i];
+    return n;
 }
 
 int cc_vit_encode_frames(const cc_vit_model* m, const cc_frames* frames, int32_t B, int32_t T, float* features,

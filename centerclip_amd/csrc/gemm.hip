@@ -1356,7 +1356,8 @@ static int tile_bk(int tile) { return tile == 8 ? 128 : GEMM_BK; }
 // 128x128: 512 slots (two workgroups per CU), a = 9.1, b = 0.0182;  256x128: 256 slots, 9.3, 0.0170;  256x256: 256 slots, 17.2,
 // 0.0281.  The fit reproduces the 24 measured launches (M = 3,200 ... 38,400, K = 768 / 3,072) within 10 %; what it changes
 // against rounds 1-4: M = 12,800 (cfg 3's clustered blocks) 128x128 -> 256x256 (93 -> 74 us at K = 3,072), M = 25,600 (cfg 4)
-// and M = 6,464 (cfg 5's clustered blocks) 128x128 -> 256x128 (176 -> 166, 51 -> 46 us).  -> tile id, 0 = no opinion.
+// and M = 6,464 (cfg 5's clustered blocks) 128x128 -> 256x128 (176 -> 166, 51 -> 46 us); M = 25,600 then -> 128x256 (below).
+// -> tile id, 0 = no opinion.
 static int pick_resid_tile(int M, int N, int K) {
     if (M < 4800 || (N % 128)) return 0;
     auto rounds = [](long tiles, long slots) {
@@ -1371,6 +1372,14 @@ static int pick_resid_tile(int M, int N, int K) {
     if ((N % 256) == 0) {
         const double t5 = rounds(m256 * (N / 256), 256) * (17.2 + 0.0281 * K);
         if (t5 < best) { best = t5; tile = 5; }
+        // 128x256 (8 waves, three stage buffers): a = 11.3, b = 0.0141 - only where its grid is more than one round: as a single
+        // round (M = 9,600: 225 tiles) it is 3-4 % faster than 256x128 stand-alone and 1.5 % SLOWER inside the step (cfg 2 1.886
+        // -> 1.914 ms, three same-session rounds), at M = 25,600 (600 tiles) it wins both ways (cfg 4 4.429 -> 4.349 ms)
+        const long t10n = m128 * (N / 256);
+        const double t10 = rounds(t10n, 256) * (11.3 + 0.0141 * K);
+#ifndef CC_NO_RESID_T10
+        if (t10n > 256 && t10 < best) { best = t10; tile = 10; }
+#endif
     }
     return tile;
 }

@@ -637,6 +637,17 @@ def _(U, S, VT):
 
 
 # ------------------------------------------------------------------------------------------ encoders
+def _check_forced_medoids(lib, m, B: int, forced_medoids: Optional[torch.Tensor]) -> None:
+    """The C entry points take forced_medoids as a bare pointer: the id tensors of ALL cluster blocks back to back.  A
+    buffer of any other length (e.g. the ids of the last block only, as rounds 1-4 took them) would be read past its end."""
+    if forced_medoids is None:
+        return
+    want = int(lib.cc_vit_forced_medoids_count(ctypes.byref(m), B))
+    if (forced_medoids.dtype != torch.long or not forced_medoids.is_contiguous() or forced_medoids.numel() != want):
+        raise ValueError(f"forced_medoids: {want} contiguous int64 ids expected (every cluster block's [B*T_new, K] ids "
+                         f"back to back), got {forced_medoids.numel()} of {forced_medoids.dtype}")
+
+
 @custom_op(NS + "::vit_encode", mutates_args=(), device_types="cuda")
 def vit_encode(frames: torch.Tensor, handle: int, B: int, T: int, want_hidden: bool, want_medoids: bool,
                forced_medoids: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -652,6 +663,7 @@ def vit_encode(frames: torch.Tensor, handle: int, B: int, T: int, want_hidden: b
     hidden = _e(B * frames_out if want_hidden else 0, ltok, meta["width"], like=frames, dtype=torch.float32)
     med = torch.empty((B * med_shape[0], med_shape[1]) if (want_medoids and med_shape) else (0, 0), device=frames.device,
                       dtype=torch.long)
+    _check_forced_medoids(lib, m, B, forced_medoids)
     ws = L.workspace(lib.cc_vit_workspace_bytes(ctypes.byref(m), B, T), frames.device)
     L.check(lib.cc_vit_encode_frames(ctypes.byref(m), ctypes.byref(fr), B, T, L.ptr(feats),
                                      L.ptr(hidden) if want_hidden else None, L.ptr(med) if med.numel() else None,
@@ -705,6 +717,7 @@ def clip_encode_out(frames: torch.Tensor, ids: torch.Tensor, vhandle: int, thand
     fr, frames = frames_descriptor(frames)
     Bt, Lt = ids.shape
     lib = L.lib()
+    _check_forced_medoids(lib, vm, B, forced_medoids)
     ws = L.workspace(lib.cc_clip_workspace_bytes(ctypes.byref(vm), B, T, ctypes.byref(tm), Bt, Lt), frames.device)
     L.check(lib.cc_clip_encode_frames(ctypes.byref(vm), ctypes.byref(fr), B, T, L.ptr(vfeat), L.ptr(medoids_out),
                                       L.ptr(forced_medoids), ctypes.byref(tm), L.ptr(ids), Bt, Lt, L.ptr(tfeat), L.ptr(ws),

@@ -447,6 +447,11 @@ typedef struct cc_frames {
 
 size_t cc_vit_workspace_bytes(const cc_vit_model* m, int32_t B, int32_t T);
 
+/* Number of int64 ids the forced_medoids argument of cc_vit_encode* / cc_clip_encode* must hold for a batch of B clips: the
+ * sum over the tower's cluster blocks of B x cluster_frames[i] x cluster_tokens[i] (0: no cluster block, < 0: bad arguments).
+ * The pointer carries no length - a host-side caller checks its buffer against this before the call. */
+int64_t cc_vit_forced_medoids_count(const cc_vit_model* m, int32_t B);
+
 /* CLIP.encode_image(image, video_frame=T) (modules/clip.py:460-469): video [B*T, 3, res, res]
  * fp32 -> features [B*T_final, embed_dim] fp32 (CLS row of ln_post(hidden) @ proj; only the
  * CLS row is projected - identical values).  hidden_out (optional):

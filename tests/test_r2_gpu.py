@@ -613,9 +613,10 @@ def test_full_width_forward_batch2(name):
 # ------------------------------------------------------------------------------------------------ multi-cluster plans
 def test_two_cluster_blocks_medoids_buffer(gc):
     """A plan with two k-medoids blocks (frames 4 -> 2 -> 1): medoids_out belongs to the LAST one only (the
-    earlier, larger block used to write into the same buffer); forced_medoids is refused for such plans."""
+    earlier, larger block used to write into the same buffer); forced_medoids wants the ids of BOTH blocks (round 5,
+    tests/test_clip_gpu.py::test_forced_medoids_with_two_cluster_blocks) - the last block's alone are refused before the
+    library would read past them."""
     from centerclip_amd.clip import build_clip_model
-    from centerclip_amd._lib import CenterClipHipError
     sd = {k[3:]: torch.from_numpy(gc[k].astype(np.float32) if gc[k].dtype == np.float16 else gc[k])
           for k in gc.files if k.startswith("sd/")}
     T = int(gc["cfg"][11])
@@ -633,7 +634,7 @@ def test_two_cluster_blocks_medoids_buffer(gc):
     assert feat.shape == (B * 1, model.embed_dim) and hidden.shape == (B, 5, model.visual.width)
     assert med.shape == (B * 1, 4) and int(med.min()) >= 0 and int(med.max()) < 2 * 10 and bool((guard == -7).all())
     assert (med[:, 1:] > med[:, :-1]).all()
-    with pytest.raises(CenterClipHipError, match="unsupported"):
+    with pytest.raises(ValueError, match="forced_medoids"):
         model.visual.encode(video, T, forced_medoids=med)
 
 
