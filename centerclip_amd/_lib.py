@@ -36,7 +36,7 @@ class ClusterVariant(ctypes.Structure):
                 ("cls_multiplier", ctypes.c_void_p), ("fixed_ids", ctypes.c_void_p),
                 ("spectral_sigma", ctypes.c_float), ("spectral_graph_mode", ctypes.c_int32),
                 ("spectral_knn_k", ctypes.c_int32), ("spectral_correct_sign", ctypes.c_int32),
-                ("spectral_graph", ctypes.c_void_p)]
+                ("spectral_graph", ctypes.c_void_p), ("mean_residual", ctypes.c_int32)]
 
 
 def _declare(lib):

@@ -276,9 +276,9 @@ class VisualTransformer(nn.Module):
                 m.cluster_frames[i], m.cluster_tokens[i] = tc.after_block_frames, tc.cluster_num
                 if tc.algorithm == 'pooling' and tc.cluster_num != tokens:
                     raise ValueError("'pooling' keeps the token count: cluster_num_blocks[%d] must be %d" % (i, tokens))
-                if getattr(tc, "mean_residual", False):
-                    raise NotImplementedError("mean_residual is built for the module / block-level forwards, not inside the "
-                                              "fused encoder")
+                if getattr(tc, "mean_residual", False) and tc.cluster_num != tokens:
+                    raise ValueError("mean_residual keeps the token count (cluster.py:229): cluster_num_blocks[%d] must be %d"
+                                     % (i, tokens))
                 variants[i], keep = tc.variant(tc.frame_duration * tokens, dev)     # N2: per-block variant
                 pk.keep.extend(keep)
                 any_variant = any_variant or not tc.is_default_variant

@@ -236,12 +236,13 @@ class TokenClusterInter(torch.nn.Module):
             if self.spg is not None:
                 keep.append(self._spg_mask(device))
                 var.spectral_graph = keep[-1].data_ptr()
+        var.mean_residual = int(self.mean_residual)                # (read by the fused encoders, clip.py:239-242)
         return var, keep
 
     @property
     def is_default_variant(self):
         return (self.algorithm == 'kmediods++' and self.aggregation in [None, 'None'] and not self.cluster_embedding
-                and not self.adaptive_cls)
+                and not self.adaptive_cls and not self.mean_residual)
 
     def _run(self, x, tok_stride, frame_stride, BT, Lt, W, frame_major, keep_ids=True):
         L.require_device(x)

@@ -388,6 +388,19 @@ int encode_towers(const cc_vit_model* vm, const cc_frames* video, int B, int T, 
                                                        nullptr, nullptr, v.cluster, v.cluster_bytes, v.h16, v.st0,
                                                        v.sh0, st);
                 if (rc) return rc;
+                if (var && var->mean_residual) {
+                    // clip.py:239-242: x = res_x + attention(ln_1(x')) - ln_1 reads the clustered rows (their fp16 copy and
+                    // statistics are written), the fp32 residual stream restarts from the frame means of every token
+                    if (K != tokens) return CC_ERR_INVALID;                 // cluster.py:229
+                    cc_cluster_variant pool{};
+                    pool.algorithm = CC_CLUSTER_POOLING;
+                    rc = cc_token_cluster_variant_rows(h, W, (int64_t)(tokens + 1) * W, B, frames, Tn, tokens, W, K,
+                                                       vm->cluster_metric, vm->cluster_norm_p, vm->cluster_threshold,
+                                                       vm->cluster_iter_limit, vm->cluster_split_size, vm->cluster_pre_norm,
+                                                       &pool, hother, W, (int64_t)(K + 1) * W, nullptr, nullptr, nullptr,
+                                                       v.cluster, v.cluster_bytes, nullptr, nullptr, nullptr, st);
+                    if (rc) return rc;
+                }
                 forced_off += (size_t)B * Tn * K;
                 float* tmp = h; h = hother; hother = tmp;
                 frames = Tn;

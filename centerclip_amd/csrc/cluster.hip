@@ -478,8 +478,9 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 // and the medoid falls out of a 64-bit LDS min over (key(sum), token).
 //
 // LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | med K i32 | asg, order N u16
-#define SEL_MAX_E 16   /* N <= 1023: ATen's row sum folds its accumulators once (pass 16) below 1024 terms */
-#define SEL_MAX_N 1023
+#define SEL_MAX_E 64   /* N <= 4095: 128 passes of 32 terms = up to 8 runs of 16 passes, each folded into the second level of
+                        * ATen's row sum when it completes; the third level (pass 256, N = 8,192) is never reached */
+#define SEL_MAX_N 4095
 
 // development builds (-DCC_DEV_KNOBS) only: per-problem phase timestamps of K2
 #ifdef CC_DEV_KNOBS
@@ -517,12 +518,13 @@ __device__ __forceinline__ int sum_rank(int j, int N) {
     return (N - vec_end) + l * vs + off;
 }
 
-// mem[] entry: token (bits 0-9) | flags
-#define SEL_F1 0x0400u   /* closes the current run of passes     */
-#define SEL_F2 0x0800u   /* closes the current accumulator (k,l) */
-#define SEL_F3 0x1000u   /* closes the current lane l            */
-#define SEL_TREE 0x2000u /* vector part (not the scalar tail)    */
-#define SEL_LEFT 0x4000u /* left-over vector: joins accumulator 0 */
+// mem[] entry: token (bits 0-11) | flags
+#define SEL_TOK 0x0FFFu
+#define SEL_F1 0x01000u   /* closes the current run of 16 passes  */
+#define SEL_F2 0x02000u   /* closes the current accumulator (k,l) */
+#define SEL_F3 0x04000u   /* closes the current lane l            */
+#define SEL_TREE 0x08000u /* vector part (not the scalar tail)    */
+#define SEL_LEFT 0x10000u /* left-over vector: joins accumulator 0 */
 __device__ __forceinline__ float sel_and(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
 
 struct SelSmem {
@@ -537,7 +539,7 @@ struct SelSmem {
     int* count;                 // length of list
     // member-list form of the update step (D in global memory only, see the kernel)
     unsigned long long* cmask;  // per cluster: membership bits in summation-rank space
-    unsigned short* mem;        // tokens grouped by cluster, each group in summation-rank order
+    unsigned int* mem;          // tokens grouped by cluster, each group in summation-rank order (+ the SEL_* flags)
     unsigned short* cnt;        // members per cluster
     unsigned short* off;        // K + 1 group offsets into mem
 };
@@ -552,7 +554,7 @@ static inline size_t sel_smem_bytes(int N, int K, bool in_lds) {
     if (!in_lds) {
         const int E = (N + 63) / 64;
         b += (size_t)K * E * 8;                     // cmask
-        b += cc_align_up((size_t)N * 2, 8);         // mem
+        b += cc_align_up((size_t)N * 4, 8);         // mem
         b += cc_align_up((size_t)K * 2, 8);         // cnt
         b += cc_align_up((size_t)(K + 1) * 2, 8);   // off
     }
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
         s.dirty = reinterpret_cast<unsigned char*>(q); q += cc_align_up((size_t)K, 8);
         s.count = reinterpret_cast<int*>(q); q += 8;
         s.cmask = reinterpret_cast<unsigned long long*>(q); q += (size_t)K * E * 8;      // (the four below: !IN_LDS only)
-        s.mem = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)N * 2, 8);
+        s.mem = reinterpret_cast<unsigned int*>(q); q += cc_align_up((size_t)N * 4, 8);
         s.cnt = reinterpret_cast<unsigned short*>(q); q += cc_align_up((size_t)K * 2, 8);
         s.off = reinterpret_cast<unsigned short*>(q);
     }
@@ -767,12 +769,17 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
                 }
             }
             if (!done) {
-                float r[TPL];
+                constexpr int RB = TPL <= 16 ? TPL : 8;            // row entries in flight (N > 1,023: TPL up to 64 - the whole
+#pragma unroll                                                     //  row at once would not fit the 128 registers of a lane)
+                for (int e0 = 0; e0 < TPL; e0 += RB) {
+                    float r[RB];
 #pragma unroll
-                for (int e = 0; e < TPL; ++e) r[e] = DREAD(m, min(n0 + e, N - 1));
+                    for (int e = 0; e < RB; ++e) r[e] = (e0 + e < TPL) ? DREAD(m, min(n0 + e0 + e, N - 1)) : 0.f;
 #pragma unroll
-                for (int e = 0; e < TPL; ++e)
-                    if (n0 + e < N) nearest[e] = (i == 0) ? r[e] : fminf(nearest[e], r[e]);
+                    for (int e = 0; e < RB; ++e)
+                        if (e0 + e < TPL && n0 + e0 + e < N)
+                            nearest[e0 + e] = (i == 0) ? r[e] : fminf(nearest[e0 + e], r[e]);
+                }
             }
         }
     }
@@ -876,9 +883,10 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
         __syncthreads();
         const int vec_end = (N < 8) ? 0 : (N & ~7);            // tokens from here on are the sequential tail
         const int rest = (N >> 5) << 5;                        // tokens from here to vec_end: left-over vectors
-        // position in ATen's summation tree: lane (bits 4-6) | accumulator (2-3) | run of passes (0-1; 2 = left-over)
+        // position in ATen's summation tree: lane (bits 7-9) | accumulator (5-6) | run of 16 passes = 512 tokens (0-4;
+        // 31 = left-over vector, which joins accumulator 0 behind all of its runs)
         auto tree_code = [&](int j) {
-            return ((j & 7) << 4) | (j >= rest ? 2 : ((((j >> 3) & 3) << 2) | (j >> 9)));
+            return ((j & 7) << 7) | (j >= rest ? 31 : ((((j >> 3) & 3) << 5) | (j >> 9)));
         };
         for (int t = tid; t < N; t += SEL_THREADS) {
             const int j = s.order[t];
@@ -897,11 +905,11 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
             unsigned e = (unsigned)j;
             if (j < vec_end) {
                 const int jp = tp >= 0 ? (int)s.order[tp] : -1;
-                const int x = (jp < 0 || jp >= vec_end) ? 0x7F : (tree_code(j) ^ tree_code(jp));
-                e |= (x ? SEL_F1 : 0u) | ((x >> 2) ? SEL_F2 : 0u) | ((x >> 4) ? SEL_F3 : 0u) | SEL_TREE |
+                const int x = (jp < 0 || jp >= vec_end) ? 0x3FF : (tree_code(j) ^ tree_code(jp));
+                e |= (x ? SEL_F1 : 0u) | ((x >> 5) ? SEL_F2 : 0u) | ((x >> 7) ? SEL_F3 : 0u) | SEL_TREE |
                      (j >= rest ? SEL_LEFT : 0u);
             }
-            s.mem[pos] = (unsigned short)e;
+            s.mem[pos] = e;
         }
         __syncthreads();
         if (prof) tq2 = (long long)__builtin_readcyclecounter();
@@ -922,15 +930,15 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
                 for (int u = 0; u < 8; ++u) e[u] = (q + u < b1) ? (int)s.mem[q + u] : -1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {                                // padding reads D[i][0], then drops it
-                    const float d = DREAD(i, (e[u] < 0 ? 0 : e[u]) & 0x3FF);
+                    const float d = DREAD(i, (e[u] < 0 ? 0 : e[u]) & (int)SEL_TOK);
                     v[u] = e[u] < 0 ? 0.f : d;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     // x & m keeps x or yields +0; x - (x & m) is then +0 or x, both exact
                     const int ev = e[u] < 0 ? 0 : e[u];                      // padding: no flags, v = 0
-                    const int m1 = -((ev >> 10) & 1), m2 = -((ev >> 11) & 1), m3 = -((ev >> 12) & 1);
-                    const int mt = -((ev >> 13) & 1), ml = -((ev >> 14) & 1);
+                    const int m1 = -((ev >> 12) & 1), m2 = -((ev >> 13) & 1), m3 = -((ev >> 14) & 1);
+                    const int mt = -((ev >> 15) & 1), ml = -((ev >> 16) & 1);
                     const float t1 = sel_and(c, m1);  P += t1;  c -= t1;     // new run of passes / accumulator / lane
                     const float t2 = sel_and(P, m2);  R += t2;  P -= t2;     // new accumulator or lane
                     const float t3 = sel_and(R, m3);  F += t3;  R -= t3;     // new lane
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
     }
     SEL_STAMP(3);
 
-    if (id_sort) {                              // fast_kmeans.py:90-94 (K <= SEL_MAX_N < SEL_THREADS: one medoid per thread)
+    if (id_sort) {                              // fast_kmeans.py:90-94 (K <= SEL_THREADS, checked by run_select: one medoid per thread)
         int mine = 0, rank = 0;
         if (tid < K) {
             mine = s.med[tid];
@@ -1576,7 +1584,7 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
     const size_t lds_limit = 160 * 1024;
     const bool in_lds = sel_smem_bytes(N, K, true) <= lds_limit;
     const size_t smem = sel_smem_bytes(N, K, in_lds);
-    if (smem > lds_limit) return CC_ERR_UNSUPPORTED;
+    if (smem > lds_limit || K > SEL_THREADS) return CC_ERR_UNSUPPORTED;   // (per-cluster masks K x ceil(N / 64) x 8 bytes in LDS)
     const int ne = (N + 63) / 64;
 #define SEL_LAUNCH(INLDS, NEV)                                                                                         \
     do {                                                                                                               \
@@ -1596,6 +1604,9 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
         if (ne <= 4) SEL_LAUNCH(false, 4);
         else if (ne <= 7) SEL_LAUNCH(false, 7);
         else if (ne <= 10) SEL_LAUNCH(false, 10);
+        else if (ne <= 16) SEL_LAUNCH(false, 16);
+        else if (ne <= 25) SEL_LAUNCH(false, 25);           // N <= 1,600: ViT-B/16, 8 frames per segment (1,568)
+        else if (ne <= 40) SEL_LAUNCH(false, 40);
         else SEL_LAUNCH(false, SEL_MAX_E);
     }
 #undef SEL_LAUNCH

@@ -180,6 +180,12 @@ typedef struct cc_cluster_variant {
     int32_t spectral_knn_k;
     int32_t spectral_correct_sign;
     const uint8_t* spectral_graph;
+    /* mean_residual (cluster.py:228-235, clip.py:239-242) - read by the fused encoders only: the block's residual stream
+     * restarts from the frame means of every token (the 'pooling' reduction of the block's input) while ln_1 / the attention
+     * read the clustered tokens.  Needs an unchanged token count (cluster_tokens[i] == incoming tokens, the reference's
+     * assert).  The module-level entry points return the clustered tokens only; their caller forms the means with
+     * algorithm = CC_CLUSTER_POOLING on the same input. */
+    int32_t mean_residual;
 } cc_cluster_variant;
 /* The aggregation step of CC_AGGREGATE_MEAN alone, from a given assignment [T_new*B, fd*n] int64 (values 0..K-1;
  * problem p = s*B + b as everywhere) - the counterpart of cc_token_gather_f32 for cluster means

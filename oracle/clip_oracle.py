@@ -66,22 +66,25 @@ def mha(x, sd, pre, heads, causal):
     return o @ sd[pre + "attn.out_proj.weight"].float().t() + sd[pre + "attn.out_proj.bias"].float()
 
 
-def resblock(x, sd, pre, heads, causal):
-    """ResidualAttentionBlock without the cluster hook (clip.py:240,251), x [N, L, W]."""
-    x = x + mha(layer_norm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"]), sd, pre, heads, causal)
+def resblock(x, sd, pre, heads, causal, res_x=None):
+    """ResidualAttentionBlock without the cluster hook (clip.py:240,251), x [N, L, W]; res_x: the residual the cluster
+    module handed back (mean_residual, clip.py:239-242) - the attention branch is added to it instead of to x."""
+    x = (x if res_x is None else res_x) + mha(layer_norm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"]), sd, pre, heads,
+                                              causal)
     h = layer_norm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
     h = quick_gelu(h @ sd[pre + "mlp.c_fc.weight"].float().t() + sd[pre + "mlp.c_fc.bias"].float())
     return x + h @ sd[pre + "mlp.c_proj.weight"].float().t() + sd[pre + "mlp.c_proj.bias"].float()
 
 
 def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_medoids=None, return_hidden=False,
-                   linear_patch='2d'):
+                   linear_patch='2d', mean_residual=()):
     """VisualTransformer.forward + the ln_post/proj tail of CLIP.encode_image
     (clip.py:304-349,460-469).  video [B*T,3,H,W]; cluster_plan {block_index(0-based): (T_new, K)};
     cluster_cfg dict(distance, threshold, iter_limit, norm_p, split_size, pre_norm[, algorithm, aggregation]).
     forced_medoids {block_index: int64 [T_new*B, K]} replaces the k-medoids result (to compare
-    embeddings "given identical medoid sets").  Returns features [B*T_final, E]
-    (and the hidden state [B*T_final, L, W])."""
+    embeddings "given identical medoid sets").  mean_residual: block indices whose cluster module has
+    mean_residual set (cluster.py:228-235: residual = the mean over each segment's frames of EVERY token, CLS included; the
+    token count must not change).  Returns features [B*T_final, E] (and the hidden state [B*T_final, L, W])."""
     W = sd["visual.conv1.weight"].shape[0]
     p = sd["visual.conv1.weight"].shape[-1]
     heads = W // 64
@@ -99,9 +102,16 @@ def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_med
     frames = T
     cluster_plan = cluster_plan or {}
     for i in range(layers):
+        res_x = None
         if i in cluster_plan:                                                           # :236-242
             T_new, K = cluster_plan[i]
             x_lnd = x.permute(1, 0, 2).contiguous()
+            if i in mean_residual:                                                      # cluster.py:228-235
+                Lt, BT, _ = x_lnd.shape
+                assert Lt == K + 1
+                r = x_lnd.reshape(Lt, BT // frames, frames, W)
+                r = torch.stack([it.mean(dim=2) for it in torch.split(r, frames // T_new, dim=2)], dim=2)
+                res_x = r.contiguous().reshape(Lt, (BT // frames) * T_new, W).permute(1, 0, 2).contiguous()
             if forced_medoids is not None and i in forced_medoids:
                 x_lnd = gather_with_medoids(x_lnd, frames, T_new, forced_medoids[i])
             elif (cluster_cfg or {}).get("algorithm", "kmediods++") != "kmediods++" or \
@@ -120,7 +130,7 @@ def visual_forward(sd, video, T, cluster_plan=None, cluster_cfg=None, forced_med
                                                  c.get("pre_norm", False))
             x = x_lnd.permute(1, 0, 2).contiguous()
             frames = T_new
-        x = resblock(x, sd, "visual.transformer.resblocks.%d." % i, heads, causal=False)
+        x = resblock(x, sd, "visual.transformer.resblocks.%d." % i, heads, causal=False, res_x=res_x)
     feat = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"].float()
     return (feat, x) if return_hidden else feat
 

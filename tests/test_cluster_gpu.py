@@ -383,16 +383,14 @@ def test_edge_minimal_width_and_sizes(cl):
 
 
 def test_edge_maximum_tokens_per_problem(cl):
-    """N = 1023 is the largest supported problem (ATen's row sum folds its accumulators once below 1024 terms, which
-    is what the selection kernel reproduces); N = 784 is ViT-B/16 with 4 frames per segment; N = 1024 is refused, not
-    mis-computed."""
-    for N, K in ((640, 12), (784, 100), (1023, 30)):
+    """N = 1023 was the largest supported problem until round 5 (ATen's row sum folds its accumulators once below 1024 terms);
+    N = 784 is ViT-B/16 with 4 frames per segment; N = 1024 and 1100 take the multi-run walk (tests/test_r5_gpu.py pins it to
+    the reference's indices at N = 1,568 / 1,103 and holds the new limit, 4,095)."""
+    for N, K in ((640, 12), (784, 100), (1023, 30), (1024, 12), (1100, 40)):
         X = lattice(304 + N, (1, N, 16))
         a, m = cl.batch_fast_kmedoids_with_split(dev(X), K, threshold=1e-6, iter_limit=100, split_size=4)
         ao, mo = _exact_oracle_indices(X, K, split=4)
         assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(a.cpu().numpy(), ao), N
-    with pytest.raises(RuntimeError, match="unsupported"):
-        cl.batch_fast_kmedoids_with_split(dev(lattice(305, (1, 1024, 16))), 12)
 
 
 def _sweep_cases():

@@ -73,3 +73,21 @@ def test_n3_loader_normalize_is_three_ieee_ops():
     assert got.dtype == np.float32 and np.array_equal(got, want)
     got_chw = clo.loader_normalize(torch.from_numpy(np.ascontiguousarray(u.transpose(0, 3, 1, 2)))).numpy()
     assert np.array_equal(got_chw, want)
+
+
+def test_visual_forward_with_mean_residual_matches_reference(g):
+    """mean_residual inside the tower (cluster.py:228-235, clip.py:239-242; fixture oracle/gen_golden_r5.py): the oracle's
+    restatement against the reference's features, hidden state and medoids - and against the reference WITHOUT the flag."""
+    g5 = np.load(os.path.join(os.path.dirname(GOLDEN), "r5_golden.npz"))
+    sd = state_dict(g)
+    video = torch.from_numpy(g["video"])
+    T, T_new, n = [int(v) for v in g5["mrv_plan"]]
+    plan = {1: (T_new, n)}
+    feat, hidden = clo.visual_forward(sd, video, T, cluster_plan=plan, return_hidden=True, mean_residual=(1,))
+    np.testing.assert_allclose(hidden.numpy(), g5["mrv_hidden"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(feat.numpy(), g5["mrv_feat"], rtol=0, atol=2e-5)
+    forced = {1: torch.from_numpy(g5["mrv_medoids"].astype(np.int64))}
+    feat2 = clo.visual_forward(sd, video, T, cluster_plan=plan, forced_medoids=forced, mean_residual=(1,))
+    np.testing.assert_allclose(feat2.numpy(), g5["mrv_feat"], rtol=0, atol=2e-5)
+    plain = clo.visual_forward(sd, video, T, cluster_plan=plan)
+    np.testing.assert_allclose(plain.numpy(), g5["mrv_feat_plain"], rtol=0, atol=2e-5)

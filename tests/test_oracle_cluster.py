@@ -224,3 +224,14 @@ def test_aten_outer_sum_association_restatement(n, C):
         tt = t(m).reshape(1, n, C).repeat(3, 1, 1)
         assert np.array_equal(co.aten_outer_sums(m), tt.sum(dim=1)[1].numpy())
         assert np.array_equal(co.aten_outer_sums(m) / np.float32(n), tt.mean(dim=1)[2].numpy())
+
+
+@pytest.mark.parametrize("tag", ["p1n_ragged", "p1n_b16_64f"])
+def test_p1_lattice_above_1023_tokens(tag):
+    """Round 5: the oracle against the reference's indices above 1,023 tokens per problem (oracle/gen_golden_r5.py): the
+    cascade of ATen's row sum has folded more than once there."""
+    g5 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r5_golden.npz"))
+    seed, P, N, W, K, split, iters = [int(v) for v in g5[f"{tag}_cfg"]]
+    a, m = co.literal_batch_kmedoids_with_split(t(lattice(seed, (P, N, W))), K, "euclidean", 1e-6, iters, True, 2.0, split, False)
+    assert np.array_equal(m.numpy(), g5[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g5[f"{tag}_assign"].astype(np.int64))
