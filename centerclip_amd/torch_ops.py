@@ -712,12 +712,21 @@ def clip_encode_out(frames: torch.Tensor, ids: torch.Tensor, vhandle: int, thand
     written into caller-owned contiguous buffers (e.g. slices of the packed all-gather record).  medoids_out / forced_medoids:
     the ids of the last k-medoids block, reported / imposed (test hook, see cc_vit_encode)."""
     from .clip import frames_descriptor
-    vm, _vmeta, _k0 = _model(vhandle)
-    tm, _tmeta, _k1 = _model(thandle)
+    vm, vmeta, _k0 = _model(vhandle)
+    tm, tmeta, _k1 = _model(thandle)
     fr, frames = frames_descriptor(frames)
     Bt, Lt = ids.shape
     lib = L.lib()
     _check_forced_medoids(lib, vm, B, forced_medoids)
+    # (caller-owned outputs reach the library as bare pointers)
+    frames_out, _ltok, med_shape = vmeta["final"](T)
+    if (vfeat.dtype != torch.float32 or not vfeat.is_contiguous() or vfeat.numel() != B * frames_out * vmeta["embed_dim"]
+            or tfeat.dtype != torch.float32 or not tfeat.is_contiguous() or tfeat.numel() != Bt * tmeta["embed_dim"]):
+        raise ValueError("clip_encode_out: vfeat [B * %d, %d] and tfeat [%d, %d] contiguous fp32 expected"
+                         % (frames_out, vmeta["embed_dim"], Bt, tmeta["embed_dim"]))
+    if medoids_out is not None and (med_shape is None or medoids_out.dtype != torch.long or not medoids_out.is_contiguous()
+                                    or medoids_out.numel() != B * med_shape[0] * med_shape[1]):
+        raise ValueError("clip_encode_out: medoids_out = the last k-medoids block's [B * T_new, K] int64 ids")
     ws = L.workspace(lib.cc_clip_workspace_bytes(ctypes.byref(vm), B, T, ctypes.byref(tm), Bt, Lt), frames.device)
     L.check(lib.cc_clip_encode_frames(ctypes.byref(vm), ctypes.byref(fr), B, T, L.ptr(vfeat), L.ptr(medoids_out),
                                       L.ptr(forced_medoids), ctypes.byref(tm), L.ptr(ids), Bt, Lt, L.ptr(tfeat), L.ptr(ws),

@@ -392,7 +392,7 @@ def test_inproj_attention_argument_range():
     got = ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1)                # one token per sequence: softmax of one score
     qkv = ops.linear_ln_f16(h16, wf, c1, c2, st, 1)
     assert torch.equal(got, qkv[:, 128:192])                                        # attention output = v
-    with pytest.raises(RuntimeError, match="invalid"):
+    with pytest.raises(ValueError, match="seq_off and seq_len"):                   # (the C entry point: CC_ERR_INVALID)
         ops.inproj_attention_f16(h16, wf, c1, c2, st, 1, 8, 1, 1, seq_off=torch.zeros(8, dtype=torch.int32, device="cuda"))
 
 

@@ -103,3 +103,49 @@ def test_mean_residual_inside_the_fused_visual_tower(g5, gc):
     bad.visual.transformer.resblocks[1].tokencluster_inter.mean_residual = True
     with pytest.raises(ValueError, match="mean_residual"):
         bad.to(DEV).eval().visual.encode(video, T)
+
+
+def test_operator_wrappers_refuse_mismatched_tensors():
+    """The op-level wrappers (centerclip_amd/ops.py) hand bare pointers to the kernels: a tensor of the wrong dtype, shape or
+    layout is refused with a ValueError before anything is launched - it would be read or written past its end otherwise."""
+    from centerclip_amd import ops
+    a = torch.randn(128, 64, device=DEV).half()
+    w = torch.randn(192, 64, device=DEV).half()
+    b = torch.randn(192, device=DEV)
+    assert ops.linear_f16(a, w, b, "f32").shape == (128, 192)
+    for bad in (lambda: ops.linear_f16(a, w[:, :32].contiguous(), b, "f32"),              # K mismatch
+                lambda: ops.linear_f16(a.float(), w, b, "f32"),                           # dtype
+                lambda: ops.linear_f16(a, w, b[:100].contiguous(), "f32"),                # short bias
+                lambda: ops.linear_f16(a, w, b.half(), "f32"),                            # bias dtype
+                lambda: ops.linear_f16(a, w, b, "f32", out=torch.empty(128, 128, device=DEV)),              # small out
+                lambda: ops.linear_f16(a, w, b, "f16", out=torch.empty(128, 192, device=DEV)),              # out dtype
+                lambda: ops.linear_f16(a, w, b, "f32_resid"),                                                 # no out
+                lambda: ops.linear_f16(a, w, b, "nonsense")):
+        with pytest.raises(ValueError):
+            bad()
+    h = torch.randn(128, 192, device=DEV)
+    h16, st, slots, _ = ops.linear_resid_stats_f16(a, w, b, h.clone())
+    assert h16.shape == (128, 192) and st.shape == (128, slots, 2)
+    for bad in (lambda: ops.linear_resid_stats_f16(a, w, b, h[:64].contiguous()),                           # short residual
+                lambda: ops.linear_resid_stats_f16(a, w, b, h.clone(), h16=torch.empty(128, 64, device=DEV).half()),
+                lambda: ops.linear_resid_stats_f16(a, w, b, h.clone(), stats=torch.empty(16, device=DEV)),
+                lambda: ops.linear_resid_stats_f16(a, w, b, h.half())):
+        with pytest.raises(ValueError):
+            bad()
+    wl, c1, c2 = ops.fold_layernorm_linear(torch.randn(192, 192, device=DEV), None, torch.ones(192, device=DEV),
+                                           torch.zeros(192, device=DEV))
+    y = ops.linear_ln_f16(h16, wl, c1, c2, st, slots)
+    assert y.shape == (128, 192)
+    for bad in (lambda: ops.linear_ln_f16(h16, wl, c1[:10].contiguous(), c2, st, slots),
+                lambda: ops.linear_ln_f16(h16, wl, c1, c2, st.reshape(-1)[:64], slots),
+                lambda: ops.linear_ln_f16(h16, wl, c1, c2, st, 0),
+                lambda: ops.linear_ln_f16(h16.float(), wl, c1, c2, st, slots)):
+        with pytest.raises(ValueError):
+            bad()
+    g, bt, proj = torch.ones(192, device=DEV), torch.zeros(192, device=DEV), torch.randn(192, 64, device=DEV)
+    assert ops.head_project(h, g, bt, proj).shape == (128, 64)
+    for bad in (lambda: ops.head_project(h, g, bt, proj, rows=129),
+                lambda: ops.head_project(h, g[:10], bt, proj),
+                lambda: ops.head_project(h, g, bt, proj, row_idx=torch.zeros(128, dtype=torch.long, device=DEV))):
+        with pytest.raises(ValueError):
+            bad()
