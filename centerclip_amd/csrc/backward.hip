@@ -918,6 +918,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         for (int u = 0; u < 16; ++u) t += csum[u][tid];
         col_partial[(int64_t)blockIdx.y * cols + c0 + tid] = t;
     }
+    if (!out_t) return;                                           // (round 5: the weight gradient reads dY and X as they lie)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                                 // 64 columns x 8 row octets
         const int idx = q * 256 + tid, c = idx >> 3, r = (idx & 7) * 8;
@@ -1337,7 +1338,7 @@ size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols) 
 int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
                           int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, float* col_sums, void* ws,
                           size_t ws_bytes, void* stream) {
-    if ((!in && !in_f16) || !out_t_f16 || rows <= 0 || cols <= 0 || (cols & 3) || rows_pad < rows || (rows_pad & 63)) return CC_ERR_INVALID;
+    if ((!in && !in_f16) || (!out_t_f16 && !out_f16) || rows <= 0 || cols <= 0 || (cols & 3) || rows_pad < rows || (rows_pad & 63)) return CC_ERR_INVALID;
     if (scaled && (!in || !amax_scratch || !scale_out)) return CC_ERR_INVALID;
     if (col_sums && (!in || !ws || ws_bytes < cc_cast_transpose_colsum_workspace_bytes(rows_pad, cols))) return col_sums && in ? CC_ERR_WORKSPACE : CC_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -40,7 +40,7 @@ def _pad64(n):
     return -(-n // 64) * 64
 
 
-def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None):
+def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None, want_t=True):
     """One read of a matrix -> its fp16 operand copies for a Linear's backward (cc_cast_transpose_f16):
     x fp32 [M, C] -> (x16 [M, C], x16^T [C, Mp] zero padded to a multiple of 64, scale or None); x fp16 -> (x, x^T, None).
     scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor); amax: a 2-float
@@ -49,7 +49,7 @@ def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None):
     x = x.contiguous()
     M, C = x.shape
     Mp = _pad64(M)
-    out_t = torch.empty(C, Mp, device=x.device, dtype=torch.float16)
+    out_t = torch.empty(C, Mp, device=x.device, dtype=torch.float16) if want_t else None    # (want_t False: the fp16 copy only)
     lib = L.lib()
     if x.dtype == torch.float16:
         _check(lib.cc_cast_transpose_f16(None, L.ptr(x), None, L.ptr(out_t), M, C, Mp, 0, None, None, None, None, 0, _st(x)),
@@ -92,6 +92,20 @@ def _linear_unscaled(a16, w16, scale):
     _check(L.lib().cc_linear_unscaled_f16(L.ptr(a16), L.ptr(w16), L.ptr(out), M, N, K, L.ptr(scale), _st(a16)),
            "cc_linear_unscaled_f16")
     return out
+
+
+def _wgrad_tn(dy16, x16, scale):
+    """dW [N1, N2] fp32 = (dy16^T x16) / scale from the row-major fp16 matrices dy16 [M, N1], x16 [M, N2] (cc_wgrad_tn_f16)."""
+    M, N1 = dy16.shape
+    N2 = x16.shape[1]
+    assert dy16.dtype == torch.float16 and x16.dtype == torch.float16 and dy16.is_contiguous() and x16.is_contiguous()
+    assert x16.shape[0] == M and scale.dtype == torch.float32
+    lib = L.lib()
+    dw = torch.empty(N1, N2, device=dy16.device, dtype=torch.float32)
+    ws = L.workspace(lib.cc_wgrad_tn_workspace_bytes(M, N1, N2), dy16.device)
+    _check(lib.cc_wgrad_tn_f16(L.ptr(dy16), L.ptr(x16), L.ptr(dw), M, N1, N2, L.ptr(scale), L.ptr(ws), ws.numel(), _st(dy16)),
+           "cc_wgrad_tn_f16")
+    return dw
 
 
 def _column_sums(x32):
@@ -137,9 +151,16 @@ def _grad_linear(dy32, x16, w16_t, need_dx=True, amax=None, need_dw=True):
     """Gradients of y = x W^T + b for dy [M, N] fp32, x [M, K] fp16, W^T [K, N] fp16 -> (dx [M, K], dW [N, K], db [N]) fp32.
     The gradient is read ONCE for its two fp16 layouts (row-major for dX = dY W, transposed + padded for dW = dY^T X).
     need_dw False (a frozen layer, main.py's freeze_layer_num): no transposed copies, no wgrad GEMM, dW = None."""
-    dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True, amax=amax)   # (+ the bias gradient, same read)
+    # round 5: the weight gradient multiplies dY and X as they lie in memory (cc_wgrad_tn_f16: LDS transposing reads) wherever both
+    # widths are multiples of its 128-wide tile - every layer of the CLIP towers; other widths keep the transposed copies
+    M, N1 = dy32.shape
+    tn = need_dw and N1 % 128 == 0 and x16.shape[1] % 128 == 0
+    dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True, amax=amax,   # (+ the bias gradient, same read)
+                                              want_t=need_dw and not tn)
     dw = None
-    if need_dw:
+    if tn:
+        dw = _wgrad_tn(dy16, x16, scale)                                                      # dY^T X
+    elif need_dw:
         _, x16_t, _ = _cast_transpose(x16, scaled=False)
         dw = _linear_unscaled(dy16_t, x16_t, scale)                                           # dY^T X
     # (dX last: the kernel that consumes it runs next and finds it in the memory-side cache)

@@ -693,7 +693,7 @@ int cc_unscale_f32(float* x, int64_t n, const float* scale_a, const float* scale
 int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32_t M, int32_t N, int32_t K,
                            const float* scale_dev, void* stream);
 /* The fp16 operand copies a Linear's backward multiplies, from ONE read of the matrix: `in` fp32 [rows, cols] (or in_f16, a
- * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] = the transpose with zero columns
+ * saved fp16 activation) -> out_f16 [rows, cols] (may be null) and out_t_f16 [cols, rows_pad] (may be null) = the transpose with zero columns
  * behind `rows` (rows_pad >= rows, a multiple of 64: the contraction of dW = dY^T X; cols % 4 == 0).  scaled != 0: the fp32
  * input is scaled by cc_cast_scaled_f16's device-chosen power of two (amax_scratch: one device float, *scale_out the scale);
  * scaled == 2: *amax_scratch already holds the tensor's largest magnitude (written by the kernel that produced the tensor,
@@ -704,6 +704,16 @@ size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols);
 int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
                           int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, float* col_sums, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* Weight gradient of a Linear layer from the row-major matrices the backward holds - no transposed copies (round 5):
+ *   dw [N1, N2] fp32 = (dy^T x) / *scale_dev,   dy [M, N1], x [M, N2] fp16 row-major, the contraction over their rows
+ * (main.py:321: torch.autograd's dW = dY^T X of y = x W^T).  N1 % 128 == 0, N2 % 128 == 0.  The row range is cut into slices so
+ * that the grid fills the chip; the slices' partial products are added in slice order (bit-stable from run to run).
+ * scale_dev (may be null: 1): the power of two dy was multiplied by (cc_cast_transpose_f16 / cc_cast_scaled_f16).
+ * ws: cc_wgrad_tn_workspace_bytes(M, N1, N2). */
+size_t cc_wgrad_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
+int cc_wgrad_tn_f16(const void* dy_f16, const void* x_f16, float* dw, int32_t M, int32_t N1, int32_t N2,
+                    const float* scale_dev, void* ws, size_t ws_bytes, void* stream);
 /* One BertAdam step on one parameter tensor (utils/optimization.py:100-170: the optimizer main.py:161-167 builds): grad is
  * clipped in place to max_grad_norm (clip_grad_norm_ on the single tensor; <= 0: no clipping), next_m = b1 m + (1-b1) g,
  * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.

@@ -149,3 +149,27 @@ def test_operator_wrappers_refuse_mismatched_tensors():
                 lambda: ops.head_project(h, g, bt, proj, row_idx=torch.zeros(128, dtype=torch.long, device=DEV))):
         with pytest.raises(ValueError):
             bad()
+
+
+@pytest.mark.parametrize("M,N1,N2", [(9600, 768, 768), (9600, 2304, 768), (1232, 512, 2048), (200, 128, 256), (77, 384, 128)])
+def test_weight_gradient_without_transposed_copies(M, N1, N2):
+    """cc_wgrad_tn_f16 (round 5): dW = dY^T X / scale from the row-major fp16 matrices - the LDS transposing read
+    (ds_read_b64_tr_b16) feeds the MFMAs, the M rows are cut into slices whose partial products are added in slice order.
+    Against float64 on the same fp16 operands (N1 != N2 and random data: a transposed result cannot pass), a row count that is
+    not a multiple of the 32-row stage, and bit-identical from run to run."""
+    from centerclip_amd import train as cctrain
+    g = torch.Generator().manual_seed(M + 3 * N1 + 7 * N2)
+    dy = torch.randn(M, N1, generator=g).half().to(DEV)
+    x = torch.randn(M, N2, generator=g).half().to(DEV)
+    scale = torch.tensor([8.0], device=DEV)
+    dw = cctrain._wgrad_tn(dy, x, scale)
+    ref = (dy.double().t() @ x.double()) / 8.0
+    assert dw.shape == (N1, N2)
+    assert float((dw.double() - ref).abs().max()) <= 2e-6 * M ** 0.5 * float(ref.abs().max()) / max(1.0, M ** 0.5 / 8) + 1e-4
+    again = cctrain._wgrad_tn(dy, x, scale)
+    assert torch.equal(dw, again)
+    # the path it replaces (transposed copies through the forward GEMM kernel) gives the same product up to fp32 summation order
+    _, dyt, _ = cctrain._cast_transpose(dy, scaled=False)
+    _, xt, _ = cctrain._cast_transpose(x, scaled=False)
+    old = cctrain._linear_unscaled(dyt, xt, scale)
+    assert float((old - dw).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-5
