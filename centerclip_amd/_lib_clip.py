@@ -135,9 +135,11 @@ def declare(lib):
     lib.cc_cast_transpose_colsum_workspace_bytes.argtypes = [i32, i32]
     lib.cc_cast_transpose_colsum_workspace_bytes.restype = sz
     lib.cc_cast_transpose_f16.restype = c.c_int
+    lib.cc_linear_resid_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.cc_linear_resid_f16.restype = c.c_int
     lib.cc_wgrad_tn_workspace_bytes.restype = sz
     lib.cc_wgrad_tn_workspace_bytes.argtypes = [i32, i32, i32]
-    lib.cc_wgrad_tn_f16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.cc_wgrad_tn_f16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]
     lib.cc_wgrad_tn_f16.restype = c.c_int
     lib.cc_bertadam_workspace_bytes.argtypes = []
     lib.cc_bertadam_workspace_bytes.restype = sz

@@ -1351,7 +1351,8 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, rows_pad / 64), dim3(256), 0, st, in,
                        static_cast<const _Float16*>(in_f16), static_cast<_Float16*>(out_f16), static_cast<_Float16*>(out_t_f16), rows,
                        cols, rows_pad, scaled ? amax_scratch : nullptr, scaled ? scale_out : nullptr,
-                       col_sums ? static_cast<float*>(ws) : nullptr);
+                       // (col_sums null with a large enough ws: the per-tile partial column sums only - cc_wgrad_tn_f16 adds them)
+                       (in && ws && ws_bytes >= cc_cast_transpose_colsum_workspace_bytes(rows_pad, cols)) ? static_cast<float*>(ws) : nullptr);
     if (col_sums)
         hipLaunchKernelGGL(column_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), rows_pad / 64,
                            cols, col_sums, col_sums, cols);

@@ -18,6 +18,7 @@ struct GemmArgs {
     const _Float16* W;   // [N, K] fp16 (nn.Linear layout)
     const float* bias;   // [N] or null
     void* C;             // fp16 or fp32, row stride ldc
+    const float* R;      // residual epilogues: the rows that are added (row stride ldc); null = C (in place)
     const float* pos;    // EPI_F32_PATCH: positional embedding [1+n, N]
     int M, N, K, ldc;
     int lda, ldw;        // row strides of A / W in halfs; 0 = K (gemm_f16_kernel only: the similarity GEMM reads the first

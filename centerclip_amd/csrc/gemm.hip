@@ -45,6 +45,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ATTN_TAB_OFF (ATTN_Q_OFF + 2 * 256 * ATTN_QS * 2 + 64 * ATTN_VS * 2 + 8 * 16 * ATTN_QS * 2)
 #define ATTN_SMEM (ATTN_TAB_OFF + 64 + 1024)
 
+// the rows a residual epilogue adds: GemmArgs::R, or the output rows themselves (in place)
+#ifdef CC_NO_RESID_SRC                      /* A/B: the round-4 form (always in place) */
+#define CC_RESID_SRC(g) (reinterpret_cast<const float*>((g).C))
+#else
+#define CC_RESID_SRC(g) ((g).R ? (g).R : reinterpret_cast<const float*>((g).C))
+#endif
 __device__ __forceinline__ void glds16(const _Float16* g, _Float16* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
         if constexpr (RES_PREFETCH) {
             const int64_t first = (int64_t)(row0 + wr * (BM / WM)) * g.ldc;            // first element of this wave's rows
             const int64_t left = ((int64_t)g.M * g.ldc - first) * 4;                    // bytes from there to the end of C
-            res_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(g.C) + first, 0,
+            res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(CC_RESID_SRC(g)) + first, 0,
                                                          (int)(left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left)), 0x00020000);
             res_voff = ((lane / PF_LPRF) * g.ldc + col0 + wc * (BN / WN) + (lane % PF_LPRF) * 4) * 4;
         }
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int m = min(out_row(i, ps), g.M - 1);
-            resv[slot][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + (int64_t)m * g.ldc + ncol);
+            resv[slot][ps] = *reinterpret_cast<const float4*>(CC_RESID_SRC(g) + (int64_t)m * g.ldc + ncol);
         }
     };
     // Where the fp32 residual tile is fetched was measured four ways (profiles/r04_gemm_timeline.txt; 9600 x 768 x 768,
@@ -1623,7 +1629,7 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void gemm_rows_kernel(RowsPair pr)
     const float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), res = c1;
     if (LNFOLD) c1 = *reinterpret_cast<const float4*>(g.ln_c1 + n);
-    else res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + pm * g.ldc + n);
+    else res = *reinterpret_cast<const float4*>(CC_RESID_SRC(g) + pm * g.ldc + n);
     if (rowscal) {
         const int nslots = LNFOLD ? g.ln_slots : g.shift_slots;
         float sum = 0.f, sq = 0.f;
@@ -1781,6 +1787,21 @@ int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void*
     g.C = c;
     g.M = M; g.N = N; g.K = K; g.ldc = ldc;
     return cc_gemm_dispatch(g, epilogue, tile, static_cast<hipStream_t>(stream));
+}
+
+/* out [M, N] fp32 = resid + a w^T + bias: the residual epilogue of cc_linear_f16 ("f32_resid": out += ...) with the rows that
+ * are added read from a tensor of their own (row stride N) - a forward that keeps its input for the backward needs no copy. */
+int cc_linear_resid_f16(const void* a_f16, const void* w_f16, const float* bias, const float* resid, float* out, int32_t M,
+                        int32_t N, int32_t K, int32_t tile, void* stream) {
+    if (!a_f16 || !w_f16 || !resid || !out) return CC_ERR_INVALID;
+    GemmArgs g{};
+    g.A = static_cast<const _Float16*>(a_f16);
+    g.W = static_cast<const _Float16*>(w_f16);
+    g.bias = bias;
+    g.C = out;
+    g.R = resid;
+    g.M = M; g.N = N; g.K = K; g.ldc = N;
+    return cc_gemm_dispatch(g, EPI_F32_RESID, tile, static_cast<hipStream_t>(stream));
 }
 
 /* LayerNorm-folded Linear: y = LN(h) W^T + b evaluated as rstd (h16 Wln^T - mu c1) + c2 (see cc_fold_layernorm_linear_f32).

@@ -40,7 +40,7 @@ def _pad64(n):
     return -(-n // 64) * 64
 
 
-def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None, want_t=True):
+def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None, want_t=True, col_partials=False):
     """One read of a matrix -> its fp16 operand copies for a Linear's backward (cc_cast_transpose_f16):
     x fp32 [M, C] -> (x16 [M, C], x16^T [C, Mp] zero padded to a multiple of 64, scale or None); x fp16 -> (x, x^T, None).
     scaled: the device-chosen power-of-two scale of the gradients (returned as a 1-element device tensor); amax: a 2-float
@@ -57,11 +57,19 @@ def _cast_transpose(x, scaled, want_out=True, col_sums=False, amax=None, want_t=
         return x, out_t, None
     out = torch.empty(M, C, device=x.device, dtype=torch.float16) if want_out else None
     scratch = (amax if amax is not None else torch.empty(2, device=x.device, dtype=torch.float32)) if scaled else None
-    cs = torch.empty(C, device=x.device, dtype=torch.float32) if col_sums else None
-    ws = L.workspace(lib.cc_cast_transpose_colsum_workspace_bytes(Mp, C), x.device) if col_sums else None
+    cs = torch.empty(C, device=x.device, dtype=torch.float32) if (col_sums and not col_partials) else None
+    # col_partials: the per-tile partial column sums [Mp / 64, C] stay in a tensor of their own and are returned instead of the
+    # sums - cc_wgrad_tn_f16 adds them in the launch that adds its slices (the shared workspace is that call's scratch)
+    ws = None
+    if col_partials:
+        ws = torch.empty(Mp // 64, C, device=x.device, dtype=torch.float32)
+    elif col_sums:
+        ws = L.workspace(lib.cc_cast_transpose_colsum_workspace_bytes(Mp, C), x.device)
     _check(lib.cc_cast_transpose_f16(L.ptr(x), None, L.ptr(out), L.ptr(out_t), M, C, Mp, (2 if amax is not None else 1) if scaled else 0,
                                      L.ptr(scratch[0:1]) if scaled else None, L.ptr(scratch[1:2]) if scaled else None, L.ptr(cs),
-                                     L.ptr(ws), ws.numel() if col_sums else 0, _st(x)), "cc_cast_transpose_f16")
+                                     L.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _st(x)), "cc_cast_transpose_f16")
+    if col_partials:
+        return out, out_t, (scratch[1:2] if scaled else None), ws
     if col_sums:
         return out, out_t, (scratch[1:2] if scaled else None), cs
     return out, out_t, (scratch[1:2] if scaled else None)
@@ -94,18 +102,38 @@ def _linear_unscaled(a16, w16, scale):
     return out
 
 
-def _wgrad_tn(dy16, x16, scale):
-    """dW [N1, N2] fp32 = (dy16^T x16) / scale from the row-major fp16 matrices dy16 [M, N1], x16 [M, N2] (cc_wgrad_tn_f16)."""
+def _wgrad_tn(dy16, x16, scale, col_partial=None):
+    """dW [N1, N2] fp32 = (dy16^T x16) / scale from the row-major fp16 matrices dy16 [M, N1], x16 [M, N2] (cc_wgrad_tn_f16).
+    col_partial [chunks, N1] (cc_cast_transpose_f16's partial column sums of dY): also returns the bias gradient [N1]."""
     M, N1 = dy16.shape
     N2 = x16.shape[1]
     assert dy16.dtype == torch.float16 and x16.dtype == torch.float16 and dy16.is_contiguous() and x16.is_contiguous()
     assert x16.shape[0] == M and scale.dtype == torch.float32
     lib = L.lib()
     dw = torch.empty(N1, N2, device=dy16.device, dtype=torch.float32)
+    db = None
+    if col_partial is not None:
+        assert col_partial.dtype == torch.float32 and col_partial.is_contiguous() and col_partial.shape[1] == N1
+        db = torch.empty(N1, device=dy16.device, dtype=torch.float32)
     ws = L.workspace(lib.cc_wgrad_tn_workspace_bytes(M, N1, N2), dy16.device)
-    _check(lib.cc_wgrad_tn_f16(L.ptr(dy16), L.ptr(x16), L.ptr(dw), M, N1, N2, L.ptr(scale), L.ptr(ws), ws.numel(), _st(dy16)),
+    _check(lib.cc_wgrad_tn_f16(L.ptr(dy16), L.ptr(x16), L.ptr(dw), M, N1, N2, L.ptr(scale), L.ptr(col_partial),
+                               col_partial.shape[0] if col_partial is not None else 0, L.ptr(db), L.ptr(ws), ws.numel(), _st(dy16)),
            "cc_wgrad_tn_f16")
-    return dw
+    return dw if col_partial is None else (dw, db)
+
+
+def _linear_resid(a16, w16, bias, resid):
+    """resid + a w^T + bias in fp32 (cc_linear_resid_f16): the residual epilogue reading the rows it adds from ``resid`` - the
+    forward keeps its input for the backward, so it cannot accumulate in place and used to copy it first."""
+    M, K = a16.shape
+    N = w16.shape[0]
+    assert a16.dtype == torch.float16 and w16.dtype == torch.float16 and a16.is_contiguous() and w16.is_contiguous()
+    assert w16.shape[1] == K and resid.dtype == torch.float32 and resid.is_contiguous() and tuple(resid.shape) == (M, N)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == N)
+    out = torch.empty(M, N, device=a16.device, dtype=torch.float32)
+    _check(L.lib().cc_linear_resid_f16(L.ptr(a16), L.ptr(w16), L.ptr(bias), L.ptr(resid), L.ptr(out), M, N, K, 0, _st(a16)),
+           "cc_linear_resid_f16")
+    return out
 
 
 def _column_sums(x32):
@@ -156,10 +184,10 @@ def _grad_linear(dy32, x16, w16_t, need_dx=True, amax=None, need_dw=True):
     M, N1 = dy32.shape
     tn = need_dw and N1 % 128 == 0 and x16.shape[1] % 128 == 0
     dy16, dy16_t, scale, db = _cast_transpose(dy32, scaled=True, col_sums=True, amax=amax,   # (+ the bias gradient, same read)
-                                              want_t=need_dw and not tn)
+                                              want_t=need_dw and not tn, col_partials=tn)
     dw = None
     if tn:
-        dw = _wgrad_tn(dy16, x16, scale)                                                      # dY^T X
+        dw, db = _wgrad_tn(dy16, x16, scale, col_partial=db)                                  # dY^T X (+ the bias sums' last step)
     elif need_dw:
         _, x16_t, _ = _cast_transpose(x16, scaled=False)
         dw = _linear_unscaled(dy16_t, x16_t, scale)                                           # dY^T X
@@ -183,14 +211,12 @@ def block_forward_train(block, x_lnd):
     n1 = ops.layernorm(x, f32(block.ln_1.weight), f32(block.ln_1.bias), eps=block.ln_1.eps, out_f16=True)
     qkv = ops.linear_f16(n1, wq[0], f32(block.attn.in_proj_bias), "f16")
     att = ops.attention_f16(qkv, N, Lt, block.n_head, causal=causal)
-    y = x.clone()
-    ops.linear_f16(att, wo[0], f32(block.attn.out_proj.bias), "f32_resid", out=y)
+    y = _linear_resid(att, wo[0], f32(block.attn.out_proj.bias), x)           # x + out_proj(att): x itself is kept for the backward
     n2 = ops.layernorm(y, f32(block.ln_2.weight), f32(block.ln_2.bias), eps=block.ln_2.eps, out_f16=True)
     u_pre = ops.linear_f16(n2, wf[0], f32(block.mlp["c_fc"].bias), "f16")
     u = torch.empty_like(u_pre)
     _check(L.lib().cc_quick_gelu_f16(L.ptr(u_pre), L.ptr(u), u.numel(), _st(u)), "cc_quick_gelu_f16")
-    z = y.clone()
-    ops.linear_f16(u, wp[0], f32(block.mlp["c_proj"].bias), "f32_resid", out=z)
+    z = _linear_resid(u, wp[0], f32(block.mlp["c_proj"].bias), y)
     wt = dict(in_proj=wq[1], out_proj=wo[1], c_fc=wf[1], c_proj=wp[1])                  # W^T of the same read, for the dgrads
     saved = dict(x=x, n1=n1, qkv=qkv, att=att, y=y, n2=n2, u_pre=u_pre, u=u, shape=(Lt, N, W), causal=causal, wt=wt)
     # (a VIEW of the frame-major rows: the next block's permute + contiguous then costs nothing - a chain of plain blocks never

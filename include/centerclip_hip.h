@@ -314,6 +314,10 @@ int cc_token_gather_f32(const float* x, int64_t in_tok_stride, int64_t in_frame_
 int cc_linear_f16(const void* a_f16, const void* w_f16, const float* bias, void* c,
                   int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t epilogue, int32_t tile,
                   void* stream);
+/* out [M, N] fp32 = resid [M, N] + a w^T + bias (the "f32_resid" epilogue with a separate source of the rows that are added;
+ * resid == out is cc_linear_f16's in-place form). */
+int cc_linear_resid_f16(const void* a_f16, const void* w_f16, const float* bias, const float* resid, float* out, int32_t M,
+                        int32_t N, int32_t K, int32_t tile, void* stream);
 /* LayerNorm over the last dim (fp32 statistics, eps as given) - modules/clip.py:183-189.
  * Row r is read at in + r*in_stride and written at out + r*out_stride (elements); out is fp16
  * when out_f16 != 0, else fp32 (may alias in). */
@@ -699,7 +703,8 @@ int cc_linear_unscaled_f16(const void* a_f16, const void* w_f16, float* c, int32
  * scaled == 2: *amax_scratch already holds the tensor's largest magnitude (written by the kernel that produced the tensor,
  * see dx_amax / out_amax above) and the pass that finds it is skipped.
  * col_sums (may be null; fp32 input only): the column sums of the unscaled matrix [cols] from the same read - the Linear's bias
- * gradient - via per-tile partials in ws (cc_cast_transpose_colsum_workspace_bytes), added in tile order. */
+ * gradient - via per-tile partials in ws (cc_cast_transpose_colsum_workspace_bytes), added in tile order.  col_sums null with a
+ * ws of that size: the partials [rows_pad / 64][cols] are left in ws and nothing is added (cc_wgrad_tn_f16 adds them). */
 size_t cc_cast_transpose_colsum_workspace_bytes(int32_t rows_pad, int32_t cols);
 int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, void* out_t_f16, int32_t rows, int32_t cols,
                           int32_t rows_pad, int32_t scaled, float* amax_scratch, float* scale_out, float* col_sums, void* ws,
@@ -710,10 +715,14 @@ int cc_cast_transpose_f16(const float* in, const void* in_f16, void* out_f16, vo
  * (main.py:321: torch.autograd's dW = dY^T X of y = x W^T).  N1 % 128 == 0, N2 % 128 == 0.  The row range is cut into slices so
  * that the grid fills the chip; the slices' partial products are added in slice order (bit-stable from run to run).
  * scale_dev (may be null: 1): the power of two dy was multiplied by (cc_cast_transpose_f16 / cc_cast_scaled_f16).
+ * col_partial / col_chunks / bias_grad (all or none): the per-tile partial column sums [col_chunks][N1] cc_cast_transpose_f16
+ * leaves in its ws when called without col_sums (col_chunks = rows_pad / 64) -> bias_grad [N1], added in the association of
+ * cc_cast_transpose_f16's own reduction (same bits), in the launch that adds the slices.
  * ws: cc_wgrad_tn_workspace_bytes(M, N1, N2). */
 size_t cc_wgrad_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
 int cc_wgrad_tn_f16(const void* dy_f16, const void* x_f16, float* dw, int32_t M, int32_t N1, int32_t N2,
-                    const float* scale_dev, void* ws, size_t ws_bytes, void* stream);
+                    const float* scale_dev, const float* col_partial, int32_t col_chunks, float* bias_grad, void* ws,
+                    size_t ws_bytes, void* stream);
 /* One BertAdam step on one parameter tensor (utils/optimization.py:100-170: the optimizer main.py:161-167 builds): grad is
  * clipped in place to max_grad_norm (clip_grad_norm_ on the single tensor; <= 0: no clipping), next_m = b1 m + (1-b1) g,
  * next_v = b2 v + (1-b2) g^2, param -= lr_scheduled * (next_m / (sqrt(next_v) + e) + weight_decay * param); no bias correction.

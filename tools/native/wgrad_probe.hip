@@ -21,14 +21,14 @@ static int run(int M, int N1, int N2, bool check) {
     hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice);
     const float scale = 4.0f;
     hipMemcpy(dscale, &scale, 4, hipMemcpyHostToDevice);
-    int rc = cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, ws, wsb, nullptr);
+    int rc = cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, nullptr, 0, nullptr, ws, wsb, nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (rc || e != hipSuccess) { printf("M=%d N1=%d N2=%d: rc %d hip %d\n", M, N1, N2, rc, (int)e); return 1; }
     int bad = 0;
     if (check) {
         std::vector<float> dw((size_t)N1 * N2), dw2((size_t)N1 * N2);
         hipMemcpy(dw.data(), ddw, dw.size() * 4, hipMemcpyDeviceToHost);
-        cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, ws, wsb, nullptr);          // second call: tickets were left at zero
+        cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, nullptr, 0, nullptr, ws, wsb, nullptr);          // second call: tickets were left at zero
         hipDeviceSynchronize();
         hipMemcpy(dw2.data(), ddw, dw2.size() * 4, hipMemcpyDeviceToHost);
         double worst = 0;
@@ -46,9 +46,9 @@ static int run(int M, int N1, int N2, bool check) {
         printf("M=%d N1=%d N2=%d S=%d: worst |err| %.3g, %d bad\n", M, N1, N2, wgrad_slices(M, N1, N2), worst, bad);
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, ws, wsb, nullptr);
+    for (int i = 0; i < 3; ++i) cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, nullptr, 0, nullptr, ws, wsb, nullptr);
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, ws, wsb, nullptr);
+    for (int i = 0; i < 20; ++i) cc_wgrad_tn_f16(ddy, dx, ddw, M, N1, N2, dscale, nullptr, 0, nullptr, ws, wsb, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("M=%d N1=%d N2=%d: %.1f us  %.0f TFLOP/s\n", M, N1, N2, ms * 50, 2.0 * M * N1 * N2 / (ms / 20 * 1e-3) / 1e12);
