@@ -1,12 +1,14 @@
 #!/bin/bash
+# final refresh of the round's profiles (one GPU session)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_r5_gpu.py tests/test_r4_gpu.py -m gpu -x -q 2>&1 | tail -3
-bash tools/train_prof.sh 8 2>&1 | cut -c1-170 | tail -10
-python examples/train_synthetic.py --steps 1 2>&1 | tail -1
-for i in 1 2 3; do
-  for v in "" "$PWD/ab/lib_nors.so"; do
-    if [ -n "$v" ]; then export CENTERCLIP_HIP_LIB=$v; else unset CENTERCLIP_HIP_LIB; fi
-    echo -n "[$v] cfg2 "
-    python bench.py --steps 30 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
-  done
+mkdir -p gpurun_out/profiles
+bash tools/refresh_profiles.sh r05 > gpurun_out/profiles/refresh.log 2>&1
+tail -5 gpurun_out/profiles/refresh.log | cut -c1-300
+for k in cfg3 cfg4 cfg5; do
+  python bench.py --workload $k --steps 20 --warmup 3 > gpurun_out/profiles/r05_forward_${k}.json 2> gpurun_out/profiles/${k}.err
+  tail -c 400 gpurun_out/profiles/r05_forward_${k}.json; echo
+  bash tools/prof.sh r05$k python bench.py --workload $k --steps 6 --warmup 2 > gpurun_out/profiles/r05_forward_${k}_kernel_stats.txt 2>&1
 done
+bash tools/train_prof.sh 45 > gpurun_out/profiles/r05_train_step_body.txt 2>&1
+python examples/train_synthetic.py --steps 1 2>&1 | tail -2 > gpurun_out/profiles/r05_train_wall.txt
+cat gpurun_out/profiles/r05_train_wall.txt
