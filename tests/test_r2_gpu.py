@@ -719,10 +719,13 @@ def test_bench_line_contract_one_and_two_ranks():
     out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--min-seconds", "0.1"], cwd=root, env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout) < 4096 and len(out.stdout.strip().splitlines()) == 1      # ONE compact line, nothing else on stdout
     d = json.loads(out.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "token_cluster_mtokens_per_s", "pairs_per_s"):
         assert key in d, key
+    detail = json.load(open(os.path.join(root, d["detail"])))
+    assert detail["value"] == d["value"] and "by_symbol_in_situ" in detail["roofline"] and "forward_other_configs" in detail
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
@@ -732,4 +735,8 @@ def test_bench_line_contract_one_and_two_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     d2 = json.loads(out.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 32 and "feature_all_gather" in d2
-    assert d2["similarity_10k_x_1k"]["sharding"] != "single GPU" and "mtokens_per_s_all_ranks" in d2["token_cluster"]["cfg2"]
+    assert len(out.stdout) < 4096
+    assert d2["similarity_10k_x_1k"]["sharding"] != "single GPU"
+    detail2 = json.load(open(os.path.join(root, d2["detail"])))
+    assert "mtokens_per_s_all_ranks" in detail2["token_cluster"]["cfg2"]
+    assert d2["token_cluster_mtokens_per_s"] == detail2["token_cluster"]["cfg2"]["mtokens_per_s_all_ranks"]

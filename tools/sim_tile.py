@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import bench
+import bench, bench_side
 from centerclip_amd import ops
 dev = "cuda"
 for (M, N) in ((10000, 1024), (1250, 1024), (10000, 10240)):
@@ -14,4 +14,4 @@ for (M, N) in ((10000, 1024), (1250, 1024), (10000, 10240)):
             print("M=%d N=%d tile %d: %.1f us  %.0f TF issued" % (M, N, tile, ms * 1e3, 2.0 * M * N * 1536 / ms / 1e9), flush=True)
         except Exception as e:
             print("tile", tile, "failed", e)
-print(bench.similarity_bench(torch.device(dev)))
+print(bench_side.similarity_bench(torch.device(dev)))
