@@ -81,7 +81,7 @@ def compact_line(res, detail_path=None):
     sim = res.get("similarity_10k_x_1k")
     if sim:
         line["pairs_per_s"] = sim.get("pairs_per_s")
-        line["similarity_10k_x_1k"] = _pick(sim, ("us_per_call", "products", "frac_of_hbm_peak", "frac_of_f16_mfma_peak", "sharding"))
+        line["similarity_10k_x_1k"] = _pick(sim, ("us_per_call", "form", "raw_features_us", "frac_of_hbm_peak", "frac_of_f16_mfma_peak", "sharding"))
     if "timing" in res:
         line["timing"] = _pick(res["timing"], ("windows", "statistic", "min_window_ms_per_step", "max_window_ms_per_step"))
     if "feature_all_gather" in res:

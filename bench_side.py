@@ -406,8 +406,8 @@ def similarity_bench(device, world=1):
             prods[str(pr_)] = dict(gemm_us=round(msp * 1e3, 1), pairs_per_s=round(Nt * Nv / msp * 1e3, 0),
                                    max_abs_err_vs_float64=float("%.3g" % float(err.max())), rms_err=float("%.3g" % float((err ** 2).mean().sqrt())))
         parts["products"] = prods
-        parts["products_note"] = ("3 (default everywhere): hi.hi + hi.lo + lo.hi, both operands to 22 bits; 2: fp16(text) x video to 22 bits; "
-                                  "1: fp16 x fp16 - eval_epoch(..., similarity_products=p)")
+        parts["products_note"] = ("3: hi.hi + hi.lo + lo.hi, both operands to 22 bits (the stand-alone op); 2 (eval_epoch's default): fp16(text) x video "
+                                  "to 22 bits; 1: fp16 x fp16 - eval_epoch(..., similarity_products=p)")
     else:
         t0, t1 = ccdist.shard_rows(Nt)
         v0, v1 = ccdist.shard_rows(Nv)
@@ -421,12 +421,26 @@ def similarity_bench(device, world=1):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = float(tt)
     flops = 2.0 * Nt * Nv * E
-    # the NT GEMM runs 3 fp16 MFMA products per algorithmic multiply-add (hi.hi + hi.lo + lo.hi of 22-bit split operands)
-    return dict(pairs_per_s=round(Nt * Nv / ms * 1e3, 0), us_per_call=round(ms * 1e3, 1),
-                algorithmic_tflops=round(flops / ms / 1e9, 2), issued_f16_mfma_tflops=round(3 * flops / ms / 1e9, 2),
-                frac_of_f16_mfma_peak=round(3 * flops / ms / 1e9 / MFMA_F16_PEAK_TFLOPS / world, 4),
-                algorithmic_bytes=int((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4),
-                frac_of_hbm_peak=round(((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4) / ms / 1e6 / HBM_PEAK_GBS / world, 4),
+    # Headline form (1 GPU): the evaluation loop's matrix (main.py:502-534 -> eval._similarity_matrix) - the operand planes are
+    # by-products of encoding the batches, the 10k x 1k matrix is ONE GEMM at eval_epoch's default number of fp16 products
+    # per multiply-add (2: the text side rounded to fp16, error column below); the stand-alone op on raw fp32 features
+    # (cc_loose_similarity: pooling / normalising / plane writing + the 3-product GEMM) is reported beside it.
+    raw_us = round(ms * 1e3, 1)
+    products = 3
+    form = "stand-alone op on raw fp32 features (prepare launch + 3-product GEMM)"
+    if parts is not None:
+        from centerclip_amd.eval import HipBackend
+        products = int(HipBackend.similarity_products)
+        ms = parts["products"][str(products)]["gemm_us"] / 1e3
+        form = ("eval_epoch's matrix: ONE GEMM over the operand planes cached while the batches were encoded, %d fp16 products per "
+                "multiply-add (max |error| vs float64 %.1e)" % (products, parts["products"][str(products)]["max_abs_err_vs_float64"]))
+    plane_bytes = int(Nt * E * 2 * (2 if products == 3 else 1) + Nv * E * 2 * (1 if products == 1 else 2) + Nt * Nv * 4)
+    return dict(pairs_per_s=round(Nt * Nv / ms * 1e3, 0), us_per_call=round(ms * 1e3, 1), form=form, products=products,
+                raw_features_us=raw_us, raw_features_pairs_per_s=round(Nt * Nv / raw_us * 1e6, 0),
+                algorithmic_tflops=round(flops / ms / 1e9, 2), issued_f16_mfma_tflops=round(products * flops / ms / 1e9, 2),
+                frac_of_f16_mfma_peak=round(products * flops / ms / 1e9 / MFMA_F16_PEAK_TFLOPS / world, 4),
+                algorithmic_bytes=plane_bytes if parts is not None else int((Nt + Nv * Tn) * E * 4 + Nt * Nv * 4),
+                frac_of_hbm_peak=round((plane_bytes if parts is not None else (Nt + Nv * Tn) * E * 4 + Nt * Nv * 4) / ms / 1e6 / HBM_PEAK_GBS / world, 4),
                 sharding="rows over %d ranks, videos all-gathered (%.1f MB)" % (world, Nv * E * 4 / 1e6) if world > 1 else "single GPU",
                 parts=parts)
 

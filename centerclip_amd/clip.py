@@ -329,8 +329,6 @@ class VisualTransformer(nn.Module):
         has_cluster = any(b.tokencluster_inter is not None for b in self.transformer.resblocks)
         if self.linear_patch == '3d':
             assert video_frame and video_frame > 0, "linear_patch='3d' needs video_frame (clip.py:307)"
-            if x.dtype == torch.uint8:
-                raise NotImplementedError("uint8 frames are built for linear_patch='2d' only")
         elif not has_cluster:
             T_ = 1
         assert BT % T_ == 0

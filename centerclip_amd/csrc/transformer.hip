@@ -593,6 +593,87 @@ __global__ __launch_bounds__(256) void im2col_u8_f16_kernel(const unsigned char*
     }
 }
 
+// The same gather with the index arithmetic cut down to shifts (p a power of two: every CLIP patch size): the kernel above
+// spends ~300 instructions per 16 output bytes on two 64-bit divisions and five 32-bit ones - with 1 B/px coming in it was
+// instruction-bound, not HBM-bound (29 us, the time of the fp32 gather that reads 4x the bytes).  One workgroup per strip
+// (frame f, patch row ph): the g patches of the strip are g consecutive rows of A, so consecutive items write consecutive
+// 16-byte groups; one scalar division per workgroup, one constant division (by 3 or 9) per item.
+// P3D: linear_patch = '3d' from uint8 frames (columns (c, kt, kh, kw), frame f + kt - 1 of the same clip or zeros).
+template <bool HWC, bool P3D>
+__global__ __launch_bounds__(256) void im2col_u8_strip_kernel(const unsigned char* __restrict__ video,
+                                                              _Float16* __restrict__ A, int F, int T, int res, int lp,
+                                                              float m0, float m1, float m2, float s0, float s1, float s2) {
+    __shared__ _Float16 table[3][256];
+    {
+        const int u = threadIdx.x;                                   // blockDim.x == 256
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            float v = (float)u / 255.0f;
+            v = v - mean;
+            v = v / sd;
+            table[c][u] = (_Float16)v;
+        }
+    }
+    __syncthreads();
+    constexpr int KT = P3D ? 3 : 1;
+    const int g = res >> lp, n = g * g, lpp8 = 2 * lp - 3, lp8 = lp - 3, pp = 1 << (2 * lp);
+    const int Kc = 3 * KT * pp;
+    const int f = (int)blockIdx.x / g, ph = (int)blockIdx.x - f * g;
+    const int fc = P3D ? f % T : 0;                                  // position of the frame inside its clip
+    _Float16* Arow = A + ((int64_t)f * n + (int64_t)ph * g) * Kc;
+    const int rmask = (1 << lpp8) - 1, wmask = (1 << lp8) - 1;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (HWC) {
+        const int items = g * KT << lpp8;                            // order [pw][kt][kh][kw / 8]
+        for (int idx = threadIdx.x; idx < items; idx += 256) {
+            const int hi = idx >> lpp8, rem = idx & rmask;
+            const int pw = hi / KT, kt = hi - pw * KT;
+            const int kh = rem >> lp8, kw = (rem & wmask) << 3;
+            _Float16* dst = Arow + (int64_t)pw * Kc + (kt << (2 * lp)) + (rem << 3);
+            const bool live = !P3D || (fc + kt - 1 >= 0 && fc + kt - 1 < T);
+            unsigned wd[6] = {0, 0, 0, 0, 0, 0};
+            if (live) {
+                const unsigned char* src = video + (((int64_t)(f + (P3D ? kt - 1 : 0)) * res + (ph << lp) + kh) * res + (pw << lp) + kw) * 3;
+                const uint2 w0 = *reinterpret_cast<const uint2*>(src);
+                const uint2 w1 = *reinterpret_cast<const uint2*>(src + 8);
+                const uint2 w2 = *reinterpret_cast<const uint2*>(src + 16);
+                wd[0] = w0.x; wd[1] = w0.y; wd[2] = w1.x; wd[3] = w1.y; wd[4] = w2.x; wd[5] = w2.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int byte = 3 * q + c;
+                    o[q] = table[c][(wd[byte >> 2] >> (8 * (byte & 3))) & 0xFFu];
+                }
+                *reinterpret_cast<h8*>(dst + c * KT * pp) = live ? o : zero;
+            }
+        }
+    } else {
+        const int items = g * 3 * KT << lpp8;                        // order [pw][c][kt][kh][kw / 8] = the columns of A
+        for (int idx = threadIdx.x; idx < items; idx += 256) {
+            const int hi = idx >> lpp8, rem = idx & rmask;
+            const int pw = hi / (3 * KT), q = hi - pw * (3 * KT);
+            const int c = q / KT, kt = q - c * KT;
+            const int kh = rem >> lp8, kw = (rem & wmask) << 3;
+            _Float16* dst = Arow + (int64_t)pw * Kc + (q << (2 * lp)) + (rem << 3);
+            h8 o = zero;
+            if (!P3D || (fc + kt - 1 >= 0 && fc + kt - 1 < T)) {
+                const unsigned char* src = video + (((int64_t)(f + (P3D ? kt - 1 : 0)) * 3 + c) * res + (ph << lp) + kh) * res + (pw << lp) + kw;
+                const uint2 w = *reinterpret_cast<const uint2*>(src);          // x is a multiple of 8, res of 8
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    o[u] = table[c][(w.x >> (8 * u)) & 0xFFu];
+                    o[4 + u] = table[c][(w.y >> (8 * u)) & 0xFFu];
+                }
+            }
+            *reinterpret_cast<h8*>(dst) = o;
+        }
+    }
+}
+
 // text: h[b*Lt + t] = token_embedding[ids[b,t]] + positional_embedding[t]; eot[b] = first argmax ids[b,:]
 // (optionally also the fp16 copy of the row and its (sum, sum of squares), exactly as row_stats_kernel forms them)
 // first position of the largest id of caption b (the EOT token, modules/clip.py:484), one wave
@@ -933,7 +1014,22 @@ int cc_launch_attention2(const AttArgs& a0, const AttArgs* a1, hipStream_t st) {
 
 int cc_launch_im2col3d(const cc_frames& fr, _Float16* A, int F, int T, int res, int p, hipStream_t st) {
     if ((p & 7) || res % p || !fr.data || T <= 0 || F % T) return CC_ERR_INVALID;
-    if (fr.format != CC_FRAMES_F32_CHW) return CC_ERR_UNSUPPORTED;          // uint8 frames: '2d' patches only
+    if (fr.format == CC_FRAMES_U8_CHW || fr.format == CC_FRAMES_U8_HWC) {   // uint8 frames: the strip kernel (p a power of two)
+        if ((res & 7) || (p & (p - 1))) return (res & 7) ? CC_ERR_INVALID : CC_ERR_UNSUPPORTED;
+        for (int c = 0; c < 3; ++c)
+            if (!(fr.std[c] > 0.f)) return CC_ERR_INVALID;
+        const unsigned char* v = static_cast<const unsigned char*>(fr.data);
+        const int lp = __builtin_ctz((unsigned)p);
+        if (fr.format == CC_FRAMES_U8_HWC)
+            hipLaunchKernelGGL((im2col_u8_strip_kernel<true, true>), dim3(F * (res / p)), dim3(256), 0, st, v, A, F, T, res, lp,
+                               fr.mean[0], fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+        else
+            hipLaunchKernelGGL((im2col_u8_strip_kernel<false, true>), dim3(F * (res / p)), dim3(256), 0, st, v, A, F, T, res, lp,
+                               fr.mean[0], fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+        CC_LAUNCH_CHECK();
+        return CC_OK;
+    }
+    if (fr.format != CC_FRAMES_F32_CHW) return CC_ERR_INVALID;
     const int64_t total = (int64_t)F * (res / p) * (res / p) * 9 * p * p / 8;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(im2col3d_f16_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(fr.data), A, F, T, res, p);
@@ -952,7 +1048,15 @@ int cc_launch_im2col(const cc_frames& fr, _Float16* A, int F, int res, int p, hi
         for (int c = 0; c < 3; ++c)
             if (!(fr.std[c] > 0.f)) return CC_ERR_INVALID;
         const unsigned char* v = static_cast<const unsigned char*>(fr.data);
-        if (fr.format == CC_FRAMES_U8_HWC)
+        if (!(p & (p - 1))) {                                              // every CLIP patch size: the strip kernel
+            const int lp = __builtin_ctz((unsigned)p);
+            if (fr.format == CC_FRAMES_U8_HWC)
+                hipLaunchKernelGGL((im2col_u8_strip_kernel<true, false>), dim3(F * (res / p)), dim3(256), 0, st, v, A, F, 1, res, lp,
+                                   fr.mean[0], fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+            else
+                hipLaunchKernelGGL((im2col_u8_strip_kernel<false, false>), dim3(F * (res / p)), dim3(256), 0, st, v, A, F, 1, res, lp,
+                                   fr.mean[0], fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
+        } else if (fr.format == CC_FRAMES_U8_HWC)
             hipLaunchKernelGGL(im2col_u8_f16_kernel<true>, dim3(blocks), dim3(256), 0, st, v, A, F, res, p, fr.mean[0],
                                fr.mean[1], fr.mean[2], fr.std[0], fr.std[1], fr.std[2]);
         else

@@ -56,7 +56,11 @@ class HipBackend:
 
     video_operand_rows = staticmethod(T.padded_video_rows)          # rows to allocate (zeroed) for n videos
 
-    similarity_products = 3            # fp16 products per multiply-add of the final matrix (HipBackend.with_products)
+    # fp16 products per multiply-add of the final matrix (HipBackend.with_products).  2 = fp16(text) x the video operand to
+    # 22 bits: 5e-5 at the worst entry of a 10k x 1k cosine matrix against float64 (1e-5 rms) - 20x inside the 1e-3 the
+    # contract asks of similarities, and the towers' own fp16-operand error is larger - for 2/3 of the matrix-core work
+    # (29.8 vs 38.4 us at 10k x 1k).  3 (both operands to 22 bits, 2e-7) on request: eval_epoch(similarity_products=3).
+    similarity_products = 2
 
     @classmethod
     def dot_operands(cls, text_op, video_op, n_video, mult):
@@ -66,9 +70,9 @@ class HipBackend:
     @classmethod
     def with_products(cls, products):
         """A backend whose final matrix issues `products` (3, 2 or 1) of the three fp16 products per multiply-add: 3 = both
-        operands to 22 bits (the default: rank-exact on the reference's fixtures), 2 = the text side rounded to fp16, 1 = both
-        sides fp16 - 2/3 and 1/3 of the GEMM's work, ~1e-5 rms on a cosine, inside the contract's 1e-3
-        (cc_scaled_dot_planes_products_f32; ``eval_epoch(..., similarity_products=2)``)."""
+        operands to 22 bits (the reference's fp32 product to its own rounding), 2 = the text side rounded to fp16 (the
+        default), 1 = both sides fp16 - 2/3 and 1/3 of the GEMM's work, ~1e-5 rms on a cosine, inside the contract's 1e-3
+        (cc_scaled_dot_planes_products_f32; ``eval_epoch(..., similarity_products=3)``)."""
         if products not in (1, 2, 3):
             raise ValueError("similarity products: 1, 2 or 3")
         return type("HipBackendP%d" % products, (cls,), {"similarity_products": int(products)})
@@ -183,7 +187,7 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
     model (``CLIP4Clip.replica()``) on a stream of its own, so the small-grid kernels of one batch (k-medoids selection,
     launch tails) run under the other's GEMMs: 1.84 -> 1.60 ms per 16-clip batch at the cfg-2 shape, identical features.
     ``similarity_products`` (not in the reference): 3, 2 or 1 fp16 products per multiply-add of the final matrix
-    (``HipBackend.with_products``); None = the backend's own (3)."""
+    (``HipBackend.with_products``); None = the backend's own (2: the text side rounded to fp16, the video side to 22 bits)."""
     log = log or (lambda s: None)
     be = backend.with_products(similarity_products) if similarity_products is not None else backend
     world, rank = (ccdist.world_size(), ccdist.rank()) if shard else (1, 0)

@@ -289,13 +289,20 @@ def test_run_on_single_gpu_against_the_reference_matrix(g2, g3):
     ok = ~np.isnan(ref)
     err = float(np.abs(sim[ok] - ref[ok]).max())
     print(f"[S3] max |sim - reference| = {err:.2e} (logit multiplier {mult:.2f})")
-    assert err <= 5e-5 * mult
+    # default: 2 fp16 products per multiply-add (the text side rounded to fp16) - 1e-4 of a cosine, the contract asks 1e-3;
+    # the 3-product form (both operands to 22 bits), on request, to the fp32 reference's own rounding
+    assert err <= 1e-4 * mult
+    from centerclip_amd.eval import _similarity_matrix, HipBackend
+    with torch.no_grad():
+        sim3 = _similarity_matrix(model, to(list_t), to(list_v), to(seq_list), to(vis_list),
+                                  backend=HipBackend.with_products(3)).cpu().numpy()
+    assert float(np.abs(sim3[ok] - ref[ok]).max()) <= 5e-5 * mult
     # the pairwise form of the same API agrees (one get_similarity_logits call per text batch x video batch)
     with torch.no_grad():
         blocks = [[model.get_similarity_logits(s.to(DEV), v.to(DEV), lt[0].to(DEV), lv[0].to(DEV))[0].cpu()
                    for v, lv in zip(vis_list, list_v)] for s, lt in zip(seq_list, list_t)]
     pairwise = torch.cat([torch.cat(row, dim=1) for row in blocks], dim=0).numpy()
-    assert float(np.abs(pairwise[ok] - sim[ok]).max()) <= 2e-5 * mult
+    assert float(np.abs(pairwise[ok] - sim3[ok]).max()) <= 2e-5 * mult and float(np.abs(pairwise[ok] - sim[ok]).max()) <= 1e-4 * mult
 
 
 class _Loader(list):
