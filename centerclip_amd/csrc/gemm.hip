@@ -114,8 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     if (g.m_dev) g.M = *g.m_dev;                             // device-side row count (compacted captions): wave-uniform
     constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16x16 fragments per wave (wave tile BM/WM x BN/WN)
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int NST = GEMM_NST(BM, BN, WM * WN, BK);
+    // (in_proj + attention on 224-row tiles - one 197-token ViT-B/16 frame: 14 fragment rows are multiplied, 256 rows staged)
+    constexpr int BMS = (BM + 63) / 64 * 64;                 // rows of A staged per k-step
+    constexpr int A_BYTES = BMS * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int NST = GEMM_NST(BMS, BN, WM * WN, BK);
     constexpr int CH = BK / 8;                               // 16-byte chunks per staged row (8 or 16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NST * (A_BYTES + B_BYTES)
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int tm = first_m + in_group % gsz, tn = in_group / gsz;
     // (EPI_ATTN_LN: a row tile is att_spt whole sequences, a column tile the q | k | v columns of head tn)
     constexpr bool ATTN = (EPI == EPI_ATTN_LN);
-    static_assert(!ATTN || (BM == 256 && BN == 192 && WM == 2 && WN == 4 && BK == 64), "in_proj + attention form");
+    static_assert(!ATTN || ((BM == 256 || BM == 224 || BM == 192) && BN == 192 && WM == 2 && WN == 4 && BK == 64), "in_proj + attention form");
     const int att_s0 = ATTN ? tm * g.att_spt : 0;
     const int row0 = ATTN ? (g.att_seq_off ? g.att_seq_off[att_s0] : att_s0 * g.att_L) : tm * BM, col0 = tn * BN;
     if (row0 >= g.M) return;                                 // (only with m_dev: the grid was sized for the upper bound)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmPair pr) {
     const int wr = wave / WN, wc = wave % WN;
 
     // ---- staging addresses: LDS chunk idx -> (row r, chunk position cp); source chunk = cp ^ (r & (CH - 1))
-    constexpr int A_LOADS = BM * CH / THREADS, B_LOADS = BN * CH / THREADS;
+    constexpr int A_LOADS = BMS * CH / THREADS, B_LOADS = BN * CH / THREADS;
     const _Float16* asrc[A_LOADS];
     const _Float16* bsrc[B_LOADS];
 #pragma unroll
@@ -1244,7 +1246,8 @@ namespace {
 
 template <int BM, int BN, int WM, int WN, int EPI, int BK = GEMM_BK>
 int launch_one(const GemmPair& pr, int total, hipStream_t st) {
-    constexpr size_t smem_loop = (size_t)GEMM_NST(BM, BN, WM * WN, BK) * (size_t)(BM + BN) * BK * 2;
+    constexpr int BMS = (BM + 63) / 64 * 64;
+    constexpr size_t smem_loop = (size_t)GEMM_NST(BMS, BN, WM * WN, BK) * (size_t)(BMS + BN) * BK * 2;
     constexpr size_t smem = (EPI == EPI_ATTN_LN && smem_loop < ATTN_SMEM) ? (size_t)ATTN_SMEM : smem_loop;
     auto kern = gemm_f16_kernel<BM, BN, WM, WN, EPI, BK>;
     if (smem > 64 * 1024) {
@@ -1514,12 +1517,40 @@ bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1) {
 #endif
     return attn_problem_ok(g0) && (!g1 || attn_problem_ok(*g1));
 }
+// Row-tile height of the launch: 256 rows, or - uniform sequences only - 224 (one 197-token ViT-B/16 frame owns 14 fragment
+// rows instead of 16: 1/8 less matrix-core work per tile) or 192 (the clustered blocks: 48 sequences of 50 tokens are 10
+// tiles x 12 heads = 120 workgroups at 256 rows, 47 % of the CUs; 3 sequences per 192-row tile give 16 x 12 = 192 workgroups
+// of 3/4 the work and two rounds of attention items per wave instead of three).  The choice minimises
+// rounds x rows per tile over the whole launch (carrier + rider).
+static int attn_spt(const GemmArgs& g, int bm) {
+    // (V^T rows hold ATTN_VS - 8 = 320 keys; the sequence table 8 entries; L in (56, 64] takes the long form's path with 64-key slots)
+    const int by_rows = bm / g.att_L, slots = (ATTN_VS - 8) / attn_slot_keys(g.att_L), by_slots = slots < 8 ? slots : 8;
+    return by_rows < by_slots ? by_rows : by_slots;
+}
+static int attn_tile_rows(const GemmArgs& g0, const GemmArgs* g1) {
+#ifdef CC_ATTN_BM256_ONLY                                      /* A/B arm: the round-5 form */
+    return 256;
+#else
+    int best = 256;
+    long best_cost = -1;
+    const int cand[3] = {256, 224, 192};
+    for (int bm : cand) {
+        if (g0.att_L > bm || (g1 && g1->att_L > bm)) continue;
+        const int s0 = attn_spt(g0, bm), s1 = g1 ? attn_spt(*g1, bm) : 1;
+        if (s0 < 1 || s1 < 1) continue;
+        long wgs = (long)((g0.att_nseq + s0 - 1) / s0) * (g0.K / 64);
+        if (g1) wgs += (long)((g1->att_nseq + s1 - 1) / s1) * (g1->K / 64);
+        const long cost = ((wgs + 255) / 256) * (bm + 96);     // rounds x (rows + the height-independent part of a tile)
+        if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
+    }
+    return best;
+#endif
+}
 int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
     if (!gemm_shape_ok(g0) || (g1 && !gemm_shape_ok(*g1)) || !cc_gemm_attn_applies(g0, g1)) return CC_ERR_INVALID;
-    auto shape = [](GemmArgs& g) {
-        // (V^T rows hold ATTN_VS - 8 = 320 keys; the sequence table 8 entries; L in (56, 64] takes the long form's path with 64-key slots)
-        const int by_rows = 256 / g.att_L, slots = (ATTN_VS - 8) / attn_slot_keys(g.att_L), by_slots = slots < 8 ? slots : 8;
-        g.att_spt = by_rows < by_slots ? by_rows : by_slots;
+    const int bm = attn_tile_rows(g0, g1);
+    auto shape = [bm](GemmArgs& g) {
+        g.att_spt = attn_spt(g, bm);
         g.tiles_m = (g.att_nseq + g.att_spt - 1) / g.att_spt;
         g.tiles_n = g.K / 64;
     };
@@ -1536,6 +1567,8 @@ int cc_gemm_attn_dispatch2(GemmArgs g0, const GemmArgs* g1, hipStream_t st) {
     } else {
         pr.p[1] = g0;
     }
+    if (bm == 192) return launch_one<192, 192, 2, 4, EPI_ATTN_LN>(pr, total, st);
+    if (bm == 224) return launch_one<224, 192, 2, 4, EPI_ATTN_LN>(pr, total, st);
     return launch_one<256, 192, 2, 4, EPI_ATTN_LN>(pr, total, st);
 }
 

@@ -19,8 +19,8 @@
 Round 4, later: the towers themselves (encode_image_train / encode_text_train below: patch embedding, ln_pre, the blocks with
 a token-cluster module in front, the heads), BertAdam (utils/optimization.py) on cc_bertadam_step_f32 and train_epoch
 (main.py:291-378) - CLIP4Clip.forward in training mode runs on them, so a training step reaches every parameter.  What is NOT
-here: linear_patch='3d' and mean_residual in training, fp16 GradScaler semantics (the master weights are fp32 and the HIP
-backward scales per tensor on the device), and fusion - per-op launches from Python, checked against torch.autograd on the
+here: linear_patch='3d' and mean_residual in training, and fusion (train_epoch takes the reference's GradScaler; the master
+weights are fp32 and the HIP backward scales per tensor on the device) - per-op launches from Python, checked against torch.autograd on the
 reference model (tests/test_r4_gpu.py, fixture tests/golden/r4_golden.npz) to 1e-2 of each tensor's largest entry.
 Transposed fp16 copies (W^T, dY^T, X^T) come from cc_cast_transpose_f16 (one read per matrix); the scale of a gradient operand
 is divided out in the consuming GEMM's epilogue (cc_linear_unscaled_f16).
@@ -638,11 +638,17 @@ def prep_optim_params_groups(args, model, coef_lr=1.):
 
 # ================================================================================================ train_epoch
 def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_step, scheduler=None, buckets=None,
-                log=None):
-    """main.py:291-378 for this path (fp32 master weights, no GradScaler: the HIP backward scales the gradients it feeds the
-    matrix cores per tensor on the device): zero_grad -> forward (training branch of CLIP4Clip.forward) -> backward ->
+                log=None, scaler=None):
+    """main.py:291-378 for this path: zero_grad -> forward (training branch of CLIP4Clip.forward) -> backward ->
     [gradient average over the ranks, dist.GradientBuckets] -> [clip_grad_norm_] -> optimizer.step -> clamp logit_scale.
-    ``model``: a centerclip_amd.clip4clip.CLIP4Clip in training mode.  -> (mean loss, global_step)."""
+    ``model``: a centerclip_amd.clip4clip.CLIP4Clip in training mode.  -> (mean loss, global_step).
+
+    ``scaler`` (main.py:309-330, the reference's ``--fp16`` branch): a ``torch.cuda.amp.GradScaler`` (or anything with its
+    scale / unscale_ / step / update).  The forward here always feeds the matrix cores fp16 operands with fp32 accumulation
+    and keeps fp32 master weights - what ``autocast`` gives the reference - so the branch adds what the scaler itself does:
+    the loss is multiplied by the scale before backward (the HIP backward picks a power-of-two scale per gradient tensor on
+    the device, so the factor passes through exactly), gradients are unscaled (and averaged over the ranks) before clipping,
+    a step whose gradients hold an inf / NaN is skipped and the scale backed off, as GradScaler.step / update do."""
     model.train()
     total_loss, nb = 0.0, 0
     for step, batch in enumerate(train_dataloader):
@@ -654,13 +660,23 @@ def train_epoch(epoch, args, model, train_dataloader, device, optimizer, global_
         loss = output['loss'].mean()
         if args.gradient_accumulation_steps > 1:
             loss = loss / args.gradient_accumulation_steps
-        loss.backward()
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
         if (step + 1) % args.gradient_accumulation_steps == 0:
             if buckets is not None:
                 buckets.reduce()
-            if getattr(args, "clip_grad_norm", None) is not None:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_grad_norm)
-            optimizer.step()
+            if scaler is not None:
+                if getattr(args, "clip_grad_norm", None) is not None:
+                    scaler.unscale_(optimizer)           # (clipping sees the true gradients, main.py:324-326)
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_grad_norm)
+                scaler.step(optimizer)                   # skipped when a gradient holds an inf / NaN
+                scaler.update()
+            else:
+                if getattr(args, "clip_grad_norm", None) is not None:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_grad_norm)
+                optimizer.step()
             global_step += 1
         with torch.no_grad():                                    # (main.py:336-340; tracked, so the cached copies refresh)
             model.clip.logit_scale.clamp_(0.1, 4.6052)

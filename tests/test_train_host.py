@@ -90,3 +90,49 @@ def test_train_epoch_control_flow():
     assert calls == ["zero", ("sched", 10), "zero", ("sched", 10), "reduce", "step", "zero", ("sched", 11), "zero", ("sched", 11),
                      "reduce", "step"]
     assert float(m.clip.logit_scale.detach()) == pytest.approx(4.6052) and m.training
+
+
+def test_train_epoch_scaler_branch_control_flow():
+    """main.py:319-330 (the --fp16 branch): scale(loss).backward -> [reduce] -> unscale_ before clipping -> scaler.step(optimizer)
+    -> scaler.update; a step the scaler refuses (inf in a gradient) leaves the parameters alone."""
+    calls = []
+
+    class Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logit_scale = torch.nn.Parameter(torch.tensor(1.0))
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.clip = Clip()
+            self.w = torch.nn.Parameter(torch.ones(2))
+
+        def forward(self, ids, seg, mask, video, vmask):
+            loss = (self.w * video.float().mean()).sum() + 0 * self.clip.logit_scale
+            return {"loss": loss, "sim_loss": loss.detach(), "cluster_loss": torch.zeros(())}
+
+    class Scaler:                                                  # GradScaler's protocol, scale 8, overflow on request
+        def __init__(self, overflow_steps=()):
+            self.n, self.overflow_steps = 0, set(overflow_steps)
+        def scale(self, loss): calls.append("scale"); return loss * 8.0
+        def unscale_(self, opt):
+            calls.append("unscale")
+            for p in m.parameters():
+                if p.grad is not None:
+                    p.grad.div_(8.0)
+        def step(self, opt):
+            calls.append("sstep")
+            if self.n not in self.overflow_steps:
+                opt.step()
+            self.n += 1
+        def update(self): calls.append("update")
+
+    m = Model()
+    opt = torch.optim.SGD(m.parameters(), lr=0.5)
+    batch = tuple(torch.ones(2, 3) for _ in range(5))
+    args = Namespace(gradient_accumulation_steps=1, clip_grad_norm=10.0)
+    loss, gs = cctrain.train_epoch(0, args, m, [batch] * 2, "cpu", opt, 0, scaler=Scaler(overflow_steps=(1,)))
+    assert gs == 2 and calls == ["scale", "unscale", "sstep", "update"] * 2
+    # first step applied with the UNSCALED gradient (1 per element: w = 1 - 0.5), second one skipped
+    assert torch.allclose(m.w.detach(), torch.full((2,), 0.5))
