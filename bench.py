@@ -91,6 +91,9 @@ def compact_line(res, detail_path=None):
     if oc:
         line["other_configs"] = {k: dict(clips_per_s=v.get("clips_per_s"), ms_per_step=v.get("ms_per_step"),
                                          frac=v.get("whole_step_frac_of_f16_mfma_peak")) for k, v in oc.items()}
+    tf = res.get("two_batches_in_flight")
+    if tf:                            # the serving-loop form (eval_epoch(in_flight=2)): reported beside the headline, never as `value`
+        line["two_batches_in_flight"] = _pick(tf, ("clips_per_s", "ms_per_step"))
     if "forward_algorithmic_tflops" in res:
         line["whole_step_tflops"] = res["forward_algorithmic_tflops"]
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None

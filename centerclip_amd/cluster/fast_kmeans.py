@@ -22,9 +22,11 @@ def batch_fast_kmedoids_with_split(X, K, distance='euclidean', threshold=1e-5, i
 
     ``split_size`` no longer bounds memory (nothing of size [B,K,N,N] exists here); it is kept
     because it defines which problems share the max of the all-negative shift
-    (cluster_utils.py:36 takes the max over one chunk).  Each problem iterates to its fixed point, which is the
-    final state of the reference's chunk-mean stop test (fast_kmeans.py:85-88) for the thresholds in use (<= 1e-5;
-    SURVEY.md §8a, equivalence 4); a looser ``threshold`` raises CenterClipHipError instead of being ignored.
+    (cluster_utils.py:36 takes the max over one chunk) and the stop test.  ``threshold`` <= 1e-5 (the reference's default; the
+    scripts pass 1e-6): each problem iterates to its fixed point in ONE launch, which is the final state of the reference's
+    chunk-mean stop test (fast_kmeans.py:85-88; SURVEY.md §8a, equivalence 4).  A looser ``threshold`` (round 6) runs that test
+    literally: one iteration of every problem per launch, the chunk's center_shift in ATen's summation order after each,
+    chunks that passed it left alone - 2 * iter_limit + 2 launches, the reference's indices (tests/golden/r6_golden.npz).
     """
     return _run(X, K, distance, threshold, iter_limit, id_sort, norm_p,
                 split_size if X.shape[0] > split_size else X.shape[0], pre_norm)

@@ -598,6 +598,15 @@ struct GatherDesc {
 template <bool LEFT>
 __device__ void reduce_row_wave(const GatherDesc& g, int row, int lane, const int* med_lds);
 
+// One-iteration-per-launch form (a k-medoids `threshold` above CC_KMEDOIDS_MAX_THRESHOLD: the reference's chunk-mean stop test,
+// fast_kmeans.py:85-88, couples the problems of a split chunk, so the chunk is stepped in lockstep from the host side - see
+// batch_kmedoids_impl): start from given medoids instead of the KKZ init, pass through untouched once the chunk is done.
+struct SelStep {
+    const long long* init;       // [P, K] medoids to start from (null: KKZ init)
+    const int* done;             // [chunks] != 0: the chunk has passed the stop test - copy init to the output and leave
+    int accumulate_iters;        // iters_out[p] += the iterations of this launch
+};
+
 #define SEL_WAVES 16
 #define SEL_THREADS (64 * SEL_WAVES)
 template <bool IN_LDS, int NE>
@@ -607,8 +616,13 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
                                                               int apply_shift, int N, int K, int iter_limit,
                                                               int id_sort, long long* __restrict__ medoids_out,
                                                               long long* __restrict__ assign_out,
-                                                              int* __restrict__ iters_out, GatherDesc gd) {
+                                                              int* __restrict__ iters_out, GatherDesc gd, SelStep step) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (step.done && step.done[(int)blockIdx.x / chunk]) {         // (workgroup-uniform, before any barrier)
+        if (step.init != medoids_out)
+            for (int k = threadIdx.x; k < K; k += SEL_THREADS) medoids_out[(int64_t)blockIdx.x * K + k] = step.init[(int64_t)blockIdx.x * K + k];
+        return;
+    }
     const int E = (N + 63) >> 6;
     SelSmem s;
     {
@@ -726,7 +740,9 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
     // torch.max / argmax resolve ties), its slot by one readlane; then the new medoid's row is folded into the minimum
     // - the lane's TPL entries are contiguous (one ds_read_b128 at N = 196).  No barrier, no LDS exchange in the chain:
     // ~300 cycles per step at N = 196 against 780 for the four-wave form.
-    if (wave == 0) {
+    if (step.init) {
+        for (int k = tid; k < K; k += SEL_THREADS) s.med[k] = (int)step.init[(int64_t)p * K + k];
+    } else if (wave == 0) {
         constexpr int TPL = NE;
         // (the running minimum is kept as plain floats: v_max / v_min / v_cmp_eq order finite floats as torch.max / min do,
         //  -0 == +0 included, and save the 3-instruction key conversion per element that sat in the dependent chain)
@@ -1093,7 +1109,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
     for (int k = tid; k < K; k += SEL_THREADS) medoids_out[(int64_t)p * K + k] = s.med[k];
     if (assign_out)
         for (int n = tid; n < N; n += SEL_THREADS) assign_out[(int64_t)p * N + n] = (iter_limit > 0 || id_sort) ? s.asg[n] : 0;
-    if (iters_out && tid == 0) iters_out[p] = iters;
+    if (iters_out && tid == 0) iters_out[p] = step.accumulate_iters ? iters_out[p] + iters : iters;
     if (gd.out) {
         // K3 folded in: problem p = segment sgm of clip b (p = sgm * B + b, cluster.py:247-250) -> output frame b * T_new + sgm;
         // one wave per output row (CLS mean, K medoid tokens), ids straight from LDS (s.med is final and barrier-visible)
@@ -1433,6 +1449,8 @@ struct ClusterWs {
     float* xn;
     long long* med;
     long long* asg;
+    long long* med2;     // second medoid buffer + per-chunk stop flags of the stepped (loose threshold) selection
+    int* done;
     size_t total;
 };
 
@@ -1489,6 +1507,8 @@ ClusterWs carve(void* ws, int P, int N, int W, int pre_norm, int K_for_med) {
     c.draw = static_cast<float*>(take((size_t)P * N * N * 4));
     c.med = static_cast<long long*>(take((size_t)P * (size_t)K_for_med * 8));
     c.asg = static_cast<long long*>(take((size_t)P * N * 8));
+    c.med2 = static_cast<long long*>(take((size_t)P * (size_t)K_for_med * 8));
+    c.done = static_cast<int*>(take((size_t)P * 4));
     c.xn = pre_norm ? static_cast<float*>(take((size_t)P * N * W * 4)) : nullptr;
     c.total = off;
     return c;
@@ -1578,9 +1598,11 @@ int run_distance_sq(const float* x, cc_token_layout lay, int W, const ClusterWs&
 
 int run_select(const float* dist_in, float* dist_rw, const float* norms, const int* chunkmax, int slots_pp, int chunk,
                int apply_shift, int P, int N, int K, int iter_limit, int id_sort, long long* med, long long* assign,
-               int* iters, hipStream_t st, const GatherDesc* gather = nullptr) {
+               int* iters, hipStream_t st, const GatherDesc* gather = nullptr, const SelStep* step = nullptr) {
     GatherDesc gd{};
     if (gather) gd = *gather;
+    SelStep ss{};
+    if (step) ss = *step;
     const size_t lds_limit = 160 * 1024;
     const bool in_lds = sel_smem_bytes(N, K, true) <= lds_limit;
     const size_t smem = sel_smem_bytes(N, K, in_lds);
@@ -1593,7 +1615,7 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return CC_ERR_HIP;                                                                                         \
         hipLaunchKernelGGL(kern, dim3(P), dim3(SEL_THREADS), smem, st, dist_in, dist_rw, norms, chunkmax, slots_pp, chunk, apply_shift, \
-                           N, K, iter_limit, id_sort, med, assign, iters, gd);                                        \
+                           N, K, iter_limit, id_sort, med, assign, iters, gd, ss);                                    \
     } while (0)
     if (in_lds) {
         if (ne <= 1) SEL_LAUNCH(true, 1);
@@ -1612,6 +1634,79 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
 #undef SEL_LAUNCH
     CC_LAUNCH_CHECK();
     return CC_OK;
+}
+
+// ---- the reference's stop test, literally (fast_kmeans.py:85-88), for thresholds the fixed-point test cannot stand in for.
+// ATen's CPU sum of n fp32 terms along a contiguous dimension (SumKernel.cpp cascade_sum; the same tree as sum_rank above,
+// restated for a dense walk): 8 lanes x 4 interleaved accumulators over passes of 32 terms, level 0 folded into
+// level 1 every 16 passes, left-over vectors into accumulator 0, accumulators 1..3 added to 0, the scalar tail first, then the
+// lanes 0..7.  One thread walks the whole tree (n < 8,192: the third level is never reached).
+template <typename F>
+__device__ float aten_row_sum(int n, F term) {
+    if (n < 8) {                                              // the same scheme on scalars
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        const int s4 = n >> 2;
+        for (int i = 0; i < s4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] += term(4 * i + k);
+        for (int t = 4 * s4; t < n; ++t) q[0] += term(t);
+        q[0] += q[1]; q[0] += q[2]; q[0] += q[3];
+        return q[0];
+    }
+    const int vs = n >> 3, passes = vs >> 2;
+    float a0[32], a1[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { a0[u] = 0.f; a1[u] = 0.f; }
+    int i = 0;
+    while (i + 16 <= passes) {
+        for (int r = 0; r < 16; ++r, ++i)
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a0[u] += term(32 * i + u);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { a1[u] += a0[u]; a0[u] = 0.f; }
+    }
+    for (; i < passes; ++i)
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a0[u] += term(32 * i + u);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a0[u] += a1[u];
+    for (int v = 4 * passes; v < vs; ++v)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) a0[l] += term(8 * v + l);
+    float out = 0.f;
+    for (int t = 8 * vs; t < n; ++t) out += term(t);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) out += ((a0[l] + a0[8 + l]) + a0[16 + l]) + a0[24 + l];
+    return out;
+}
+
+// center_shift of one split chunk per workgroup: mean over the chunk's problems of sum_k |X[m_k] - X[m_k_prev]|_2, each of the
+// three sums in ATen's association; done[chunk] = 1 when it falls below the threshold (the reference's `break`).
+__global__ __launch_bounds__(256) void center_shift_kernel(const float* __restrict__ x, cc_token_layout lay, int W, int P, int K,
+                                                           int chunk, const long long* __restrict__ med_new,
+                                                           const long long* __restrict__ med_prev, float threshold,
+                                                           int* __restrict__ done, float* __restrict__ rows_ws) {
+    const int c = blockIdx.x, p0 = c * chunk, bc = min(chunk, P - p0);
+    if (done[c]) return;
+    float* rows = rows_ws + (int64_t)p0 * K;                  // [bc, K] scratch (global: K * chunk is unbounded)
+    for (int r = threadIdx.x; r < bc * K; r += 256) {
+        const int b = r / K, k = r - b * K, p = p0 + b;
+        const float* xa = cc_token_ptr(x, lay, p, (int)med_new[(int64_t)p * K + k]);
+        const float* xb = cc_token_ptr(x, lay, p, (int)med_prev[(int64_t)p * K + k]);
+        const float ss = aten_row_sum(W, [&](int j) { const float d = xa[j] - xb[j]; return d * d; });
+        rows[r] = sqrtf(ss);
+    }
+    __threadfence_block();
+    __syncthreads();
+    __shared__ float per_problem[1024];                       // (bc <= 1,024: checked by the caller)
+    for (int b = threadIdx.x; b < bc; b += 256)
+        per_problem[b] = aten_row_sum(K, [&](int k) { return rows[(int64_t)b * K + k]; });
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = aten_row_sum(bc, [&](int b) { return per_problem[b]; });
+        const float shift = total / (float)bc;
+        if (shift < threshold) done[c] = 1;
+    }
 }
 
 bool p_supported(int metric, float p) { return metric == CC_METRIC_COSINE || (p > 0.0f); }
@@ -1723,8 +1818,12 @@ static int batch_kmedoids_impl(const float* x, const cc_token_layout* lay, int32
                                size_t ws_bytes, void* stream, const GatherDesc* gather) {
     // Stop test: every problem iterates to its fixed point (medoids unchanged), which gives the final state of the
     // reference's chunk-mean test (fast_kmeans.py:85-88) whenever the threshold is below the distance between any two
-    // distinct tokens.  A loose threshold would stop the reference earlier: refused instead of silently ignored.
-    if (!(threshold <= CC_KMEDOIDS_MAX_THRESHOLD)) return CC_ERR_UNSUPPORTED;
+    // distinct tokens (threshold <= CC_KMEDOIDS_MAX_THRESHOLD: one launch).  A looser threshold stops the reference earlier,
+    // and at a point that depends on all problems of the split chunk: that case runs the literal loop - one iteration of
+    // every problem per launch, the chunk's center_shift in ATen's own summation order after each, chunks that passed the
+    // test passing through untouched (2 * iter_limit + 2 launches; not a hot path: no shipped script sets such a threshold).
+    const bool literal_stop = !(threshold <= CC_KMEDOIDS_MAX_THRESHOLD);
+    if (threshold != threshold) return CC_ERR_INVALID;
     if (!x || !medoids || !layout_ok(lay, W)) return CC_ERR_INVALID;
     const int P = lay->B * lay->S, N = lay->fd * lay->n;
     if (K <= 0 || K > N || iter_limit < 0) return CC_ERR_INVALID;
@@ -1737,8 +1836,39 @@ static int batch_kmedoids_impl(const float* x, const cc_token_layout* lay, int32
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = run_distance(x, *lay, W, metric, norm_p, split_size, pre_norm, c, st);
     if (rc != CC_OK) return rc;
-    return run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, iter_limit, id_sort,
-                      reinterpret_cast<long long*>(medoids), reinterpret_cast<long long*>(assign), iters, st, gather);
+    long long* med_out = reinterpret_cast<long long*>(medoids);
+    long long* asg_out = reinterpret_cast<long long*>(assign);
+    if (!literal_stop || iter_limit == 0)
+        return run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, iter_limit, id_sort, med_out,
+                          asg_out, iters, st, gather);
+    if (split_size > 1024 || W >= 8192 || K >= 8192) return CC_ERR_UNSUPPORTED;      // (center_shift_kernel's per-chunk table / tree depth)
+    const float* xs = pre_norm ? c.xn : x;                         // the tokens the reference's loop sees (fast_kmeans.py:21-22)
+    const cc_token_layout lays = pre_norm ? contiguous_layout(P, N, W) : *lay;
+    const int chunks = (P + split_size - 1) / split_size;
+    if (hipMemsetAsync(c.done, 0, (size_t)chunks * sizeof(int), st) != hipSuccess) return CC_ERR_HIP;
+    long long* cur = c.med;                                        // medoids entering a step / leaving it
+    long long* nxt = c.med2;
+    // KKZ init only (iter_limit 0, no sort): cur = the initial medoids, iters = 0
+    rc = run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, 0, 0, cur, nullptr, iters, st, nullptr);
+    if (rc != CC_OK) return rc;
+    float* rows_ws = c.sqn;                                        // [P, N] floats >= [P, K]: free once the distances exist
+    for (int it = 0; it < iter_limit; ++it) {
+        SelStep stp{cur, c.done, 1};
+        rc = run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, 1, 0, nxt, asg_out, iters, st,
+                        nullptr, &stp);
+        if (rc != CC_OK) return rc;
+        hipLaunchKernelGGL(center_shift_kernel, dim3(chunks), dim3(256), 0, st, xs, lays, W, P, K, split_size, nxt, cur, threshold,
+                           c.done, rows_ws);
+        CC_LAUNCH_CHECK();
+        long long* t = cur; cur = nxt; nxt = t;
+    }
+    if (id_sort || gather) {                                       // fast_kmeans.py:90-94 (+ the output rows)
+        SelStep stp{cur, nullptr, 0};
+        return run_select(c.draw, c.draw, c.nrm, c.tilemax, c.slots_pp, split_size, 1, P, N, K, 0, id_sort, med_out,
+                          id_sort ? asg_out : nullptr, nullptr, st, gather, &stp);
+    }
+    if (hipMemcpyAsync(med_out, cur, (size_t)P * K * sizeof(long long), hipMemcpyDeviceToDevice, st) != hipSuccess) return CC_ERR_HIP;
+    return CC_OK;
 }
 
 int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K, int32_t metric,

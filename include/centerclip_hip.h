@@ -37,10 +37,12 @@ typedef enum cc_status {
     CC_ERR_HIP = -4           /* a HIP runtime call failed (hipGetLastError after a launch ...)  */
 } cc_status;
 
-/* Largest `threshold` the k-medoids entry points accept (reference default 1e-5, fast_kmeans.py:14; the shipped scripts
- * pass 1e-6): every problem iterates to its fixed point, which is the final state of the reference's chunk-mean stop
- * test (fast_kmeans.py:85-88) for any threshold below the distance between two distinct tokens.  A looser threshold
- * would end the reference's loop earlier, so it is refused (CC_ERR_UNSUPPORTED) rather than ignored. */
+/* Largest `threshold` for which the k-medoids entry points run the whole selection in ONE launch (reference default 1e-5,
+ * fast_kmeans.py:14; the shipped scripts pass 1e-6): every problem iterates to its fixed point, which is the final state of
+ * the reference's chunk-mean stop test (fast_kmeans.py:85-88) for any threshold below the distance between two distinct
+ * tokens.  A looser threshold ends the reference's loop earlier, at a step that depends on all problems of the split chunk:
+ * the entry points then run the literal loop (one iteration of every problem per launch + the chunk's center_shift in
+ * ATen's summation order, 2 * iter_limit + 2 launches, split_size <= 1024); a NaN threshold is CC_ERR_INVALID. */
 #define CC_KMEDOIDS_MAX_THRESHOLD 1e-5f
 
 /* metric: reference strings 'euclidean' / 'cosine' (modules/cluster/cluster_utils.py:21-33) */
@@ -117,8 +119,8 @@ int cc_kmedoids_from_dist_f32(const float* dist, const float* norms, int32_t P, 
 /*
  * C2..C5 - replaces batch_fast_kmedoids_with_split(X, K, distance, threshold, iter_limit,
  *      id_sort, norm_p, split_size, pre_norm)  modules/cluster/fast_kmeans.py:14-40 and
- *      batch_fast_kmedoids (:45-97; pass split_size >= P).  The stop test is the fixed-point test (see above);
- *      threshold > CC_KMEDOIDS_MAX_THRESHOLD returns CC_ERR_UNSUPPORTED.
+ *      batch_fast_kmedoids (:45-97; pass split_size >= P).  The stop test: see CC_KMEDOIDS_MAX_THRESHOLD above (fixed point in
+ *      one launch up to it, the reference's literal chunk-mean test above it).
  */
 int cc_batch_kmedoids_f32(const float* x, const cc_token_layout* lay, int32_t W, int32_t K,
                           int32_t metric, float norm_p, float threshold, int32_t iter_limit,

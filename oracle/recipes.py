@@ -370,3 +370,23 @@ def block_grad_inputs(cfg):
     }
     sd = {k: v.astype(np.float32) for k, v in sd.items()}
     return x, dz, sd
+
+
+# Round 6: k-medoids with a loose `threshold` (the literal chunk-mean stop test, fast_kmeans.py:85-88).
+# name: (seed, P, N, W, K, split, iter_limit, distance, pre_norm, id_sort, (ca, sa, wa, cb, sb, wb), recipe) - inputs
+# recipe(seed, (P, N, W)) with recipe "dyadic" or "norm32" (pre_norm: X / (|X| + 1e-6) is then an exact division by 32);
+# threshold = wa * shift[chunk ca][step sa] + wb * shift[chunk cb][step sb] of the reference's own center_shift sequences
+# (oracle/gen_golden_r6.py records them), i.e. a value that falls between two steps the reference really takes
+LOOSE_THRESHOLD_CASES = {
+    "lt_two_chunks": (161, 6, 196, 64, 49, 4, 60, "euclidean", False, True, (0, 1, 0.5, 1, 1, 0.5), "dyadic"),
+    "lt_unsorted": (161, 6, 196, 64, 49, 4, 60, "euclidean", False, False, (0, 1, 0.5, 1, 1, 0.5), "dyadic"),
+    "lt_wide": (162, 3, 100, 768, 10, 2, 60, "euclidean", False, True, (0, 0, 0.5, 1, 0, 0.5), "dyadic"),
+    "lt_prenorm": (170, 4, 98, 96, 25, 2, 60, "euclidean", True, True, (0, 1, 0.5, 1, 1, 0.5), "norm32"),
+    "lt_tiny": (164, 4, 7, 8, 3, 4, 60, "euclidean", False, True, (0, 0, 1.5, 0, 0, 0.0), "dyadic"),
+    "lt_iter_limit": (165, 4, 196, 64, 49, 4, 2, "euclidean", False, True, (0, 2, 0.1, 0, 2, 0.0), "dyadic"),
+}
+
+
+def loose_threshold_inputs(tag):
+    seed, P, N, W = LOOSE_THRESHOLD_CASES[tag][:4]
+    return (norm32_tokens if LOOSE_THRESHOLD_CASES[tag][11] == "norm32" else dyadic)(seed, (P, N, W))

@@ -494,15 +494,21 @@ def test_pre_norm_generic_floats_objective_gap_vs_oracle():
 
 
 def test_threshold_contract():
-    """threshold <= 1e-5 (the reference's default and the scripts' 1e-6) runs; a loose threshold is refused, not ignored."""
+    """threshold <= 1e-5 (the reference's default and the scripts' 1e-6): every problem runs to its fixed point, one launch;
+    a looser threshold runs the reference's literal chunk-mean stop test (round 6; fixtures: tests/test_r6_gpu.py) - here: a
+    threshold above every possible shift stops after ONE iteration, which is not the fixed point; NaN is refused."""
     from centerclip_amd.cluster import batch_fast_kmedoids_with_split
     from centerclip_amd._lib import CenterClipHipError
+    from centerclip_amd.cluster.fast_kmeans import _run
     X = torch.randn(2, 40, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
     _, m1 = batch_fast_kmedoids_with_split(X, 5, threshold=1e-5)
     _, m2 = batch_fast_kmedoids_with_split(X, 5, threshold=1e-6)
     assert torch.equal(m1, m2)
-    with pytest.raises(CenterClipHipError, match="unsupported"):
-        batch_fast_kmedoids_with_split(X, 5, threshold=1e-2)
+    _, m3, it3 = _run(X, 5, 'euclidean', 1e9, 60, True, 2.0, 4, False, return_iters=True)
+    _, m4, it4 = _run(X, 5, 'euclidean', 1e-6, 1, True, 2.0, 4, False, return_iters=True)
+    assert torch.equal(m3, m4) and int(it3.max()) == 1 and int(it4.max()) == 1
+    with pytest.raises((CenterClipHipError, ValueError)):
+        batch_fast_kmedoids_with_split(X, 5, threshold=float("nan"))
 
 
 # ------------------------------------------------------------------------------------------------ folded LayerNorm stress

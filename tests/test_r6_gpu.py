@@ -96,3 +96,93 @@ def test_train_epoch_with_grad_scaler():
     l2, g2, p2 = run(big)
     assert g2 == 2 and abs(l2 - l0) <= 0.5 * max(1.0, abs(l0))              # (the reported loss is the unscaled one)
     assert all(torch.equal(p2[n], init[n]) for n in p2 if n != "clip.logit_scale")
+
+
+# ------------------------------------------------------------------------------------------------ loose k-medoids thresholds
+@pytest.fixture(scope="module")
+def g6():
+    return np.load(os.path.join(HERE, "golden", "r6_golden.npz"))
+
+
+def _loose_cases():
+    from oracle.recipes import LOOSE_THRESHOLD_CASES
+    return sorted(LOOSE_THRESHOLD_CASES)
+
+
+@pytest.mark.parametrize("tag", _loose_cases())
+def test_kmedoids_loose_threshold_against_reference(g6, tag):
+    """fast_kmeans.py:85-88 literally (was CC_ERR_UNSUPPORTED): a threshold between two values of the reference's own
+    center_shift sequence stops a split chunk in mid-course - the reference's medoids / assignment bit for bit, the number of
+    iterations each chunk executed, and NOT the fixed point's answer."""
+    from oracle.recipes import LOOSE_THRESHOLD_CASES, loose_threshold_inputs
+    from centerclip_amd.cluster.fast_kmeans import _run
+    seed, P, N, W, K, split, iters, distance, pre_norm, id_sort, _, _ = LOOSE_THRESHOLD_CASES[tag]
+    X = torch.from_numpy(loose_threshold_inputs(tag)).to(DEV)
+    thr = float(g6[f"{tag}_threshold"][0])
+    a, m, it = _run(X, K, distance, thr, iters, id_sort, 2.0, split if P > split else P, pre_norm, return_iters=True)
+    assert np.array_equal(m.cpu().numpy(), g6[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.cpu().numpy(), g6[f"{tag}_assign"].astype(np.int64))
+    steps = g6[f"{tag}_steps"]
+    want_it = np.concatenate([np.full(min(split, P - c * split), steps[c]) for c in range(len(steps))])
+    assert np.array_equal(it.cpu().numpy(), want_it), (it.cpu().numpy(), want_it)
+    _, m_fix = _run(X, K, distance, 1e-6, 100, id_sort, 2.0, split if P > split else P, pre_norm)
+    assert not torch.equal(m, m_fix)
+    a2, m2, _ = _run(X, K, distance, thr, iters, id_sort, 2.0, split if P > split else P, pre_norm, return_iters=True)
+    assert torch.equal(a, a2) and torch.equal(m, m2)
+
+
+def test_kmedoids_loose_threshold_seeded_sweep_against_oracle():
+    """Seeded problems (inputs exact in the fp16 split of the distance kernel: multiples of 1/32), thresholds spread over the
+    range of the shifts, with and without id_sort, ragged last chunks, iter_limit 1 / 3 / 60: the HIP path == the literal
+    oracle (oracle/cluster_oracle.py literal_batch_kmedoids_with_split), indices bit for bit (euclidean, level P1).  Cosine /
+    pre_norm on such inputs are level P3 (the normalisation rounds): the k-medoids objective within 1 % of the
+    oracle's at the same loose threshold, and the executed iteration counts equal."""
+    from oracle import cluster_oracle as co
+    from centerclip_amd.cluster.fast_kmeans import _run
+    rng = np.random.RandomState(606)
+    exact = 0
+    for case in range(16):
+        P, N, W = int(rng.randint(1, 8)), int(rng.choice([9, 40, 98, 196, 230])), int(rng.choice([8, 32, 64, 100]))
+        K = int(rng.randint(2, max(3, N // 4)))
+        split = int(rng.choice([1, 2, 3, 4, 16]))
+        distance = "cosine" if case % 5 == 4 else "euclidean"
+        pre_norm, id_sort = bool(case % 6 == 5), bool(case % 3 != 0)
+        X = torch.from_numpy((rng.randint(-64, 65, size=(P, N, W)) / 32.0).astype(np.float32))
+        scale = float(np.sqrt(2 * W) * 2.0 * K) if distance == "euclidean" and not pre_norm else float(1.4 * K)
+        thr = float(scale * rng.choice([0.02, 0.1, 0.3, 0.6]))
+        iters = int(rng.choice([1, 3, 60]))
+        chunk = split if P > split else P
+        a, m, it = _run(X.to(DEV), K, distance, thr, iters, id_sort, 2.0, chunk, pre_norm, return_iters=True)
+        outs = [co.literal_batch_kmedoids(c, K, distance, thr, iters, id_sort, 2.0, return_steps=True)
+                for c in torch.split(X / (X.norm(dim=-1, keepdim=True) + 1e-6) if pre_norm else X, chunk, dim=0)]
+        ao, mo = torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+        steps = np.concatenate([np.full(o[0].shape[0], o[2]) for o in outs])
+        what = (case, P, N, W, K, split, distance, pre_norm, id_sort, thr, iters)
+        if distance == "euclidean" and not pre_norm:
+            assert np.array_equal(m.cpu().numpy(), mo.numpy()), what
+            assert np.array_equal(a.cpu().numpy(), ao.numpy()), what
+            assert np.array_equal(it.cpu().numpy(), steps), what
+            exact += 1
+        else:
+            Xn = (X / (X.norm(dim=-1, keepdim=True) + 1e-6)).double()
+            d = torch.cdist(Xn, Xn)
+            obj = lambda med: float(sum(d[p][:, med[p]].min(dim=1).values.sum() for p in range(P)))
+            assert abs(obj(m.cpu()) - obj(mo)) <= 0.02 * obj(mo) + 1e-9, what
+    assert exact >= 8
+
+
+def test_token_cluster_module_with_loose_threshold():
+    """TokenClusterInter (cluster.py:206-352) with a loose threshold: output rows == gathering the oracle's medoids."""
+    from oracle import cluster_oracle as co
+    from centerclip_amd.cluster import TokenClusterInter
+    g = torch.Generator().manual_seed(12)
+    B, T, T_new, n, W, K = 2, 4, 2, 16, 64, 6
+    x = torch.randint(-64, 65, (1 + n, B * T, W), generator=g).float() / 32.0      # (exact in the distance kernel's fp16 split)
+    mod = TokenClusterInter(algorithm='kmediods++', block_id=1, before_cluster_num=n, cluster_num=K, before_block_frames=T,
+                            after_block_frames=T_new, original_frame=T, distance='euclidean', threshold=25.0, iter_limit=60,
+                            id_sort=True, aggregation=None, split_size=8, norm_p=2.0)
+    y = mod(x.to(DEV))
+    y = y[0] if isinstance(y, tuple) else y
+    ref = co.literal_token_cluster(x, T, T_new, K, "euclidean", 25.0, 60, split_size=8)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert y.shape == ref.shape and float((y.cpu() - ref).abs().max()) <= 1e-5
