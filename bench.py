@@ -94,6 +94,10 @@ def compact_line(res, detail_path=None):
     tf = res.get("two_batches_in_flight")
     if tf:                            # the serving-loop form (eval_epoch(in_flight=2)): reported beside the headline, never as `value`
         line["two_batches_in_flight"] = _pick(tf, ("clips_per_s", "ms_per_step"))
+    el = res.get("eval_loop")
+    if el:                            # the product's eval_epoch from pinned host batches (copies + host launches included)
+        line["eval_loop_clips_per_s"] = {f: {k: v["clips_per_s"] for k, v in r.items() if isinstance(v, dict)} for f, r in el.items()
+                                         if isinstance(r, dict)}
     if "forward_algorithmic_tflops" in res:
         line["whole_step_tflops"] = res["forward_algorithmic_tflops"]
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None

@@ -445,6 +445,52 @@ def similarity_bench(device, world=1):
                 parts=parts)
 
 
+def eval_loop_bench(c, sd, device, batches=24):
+    """The PRODUCT's evaluation loop (centerclip_amd.eval.eval_epoch, the mirror of main.py:381-499) over a list-backed loader
+    of pinned host batches of the headline shape - what a user of the reference's script gets, host -> device copies and host
+    launch overhead included: eager launches (the round-5 loop), graphed lanes (round 6: one hipGraph launch per batch), and
+    graphed lanes with two batches in flight.  fp32 CHW frames (what the reference's loader hands over: 115.6 MB per batch)
+    and the decoder's uint8 HWC frames (N3: 28.9 MB)."""
+    from argparse import Namespace
+    from centerclip_amd.clip4clip import CLIP4Clip
+    from centerclip_amd import eval as ev
+    model = CLIP4Clip.from_state_dict(dict(sd), task_config(c)).to(device).eval()
+    g = torch.Generator().manual_seed(9)
+    out = {}
+    for fmt in ("uint8_hwc", "f32_chw"):
+        host = []
+        for i in range(4):
+            ids, amask, video, vmask = [t.cpu() for t in synthetic_batch(c, "cpu", seed=500 + i)]
+            if fmt == "uint8_hwc":
+                video = torch.randint(0, 256, (c["B"], 1, c["T"], c["res"], c["res"], 3), dtype=torch.uint8, generator=g)
+            host.append(tuple(t.pin_memory() for t in (ids, amask, torch.zeros_like(ids), video, vmask)))
+
+        class Loader(list):
+            pass
+        loader = Loader(host[i % len(host)] for i in range(batches))
+        loader.dataset = Namespace(multi_sentence_per_video=False)
+        args = Namespace(inference_speed_test=True)               # the loop only (main.py:467-469), no metrics
+        res = {}
+        for name, kw in (("eager", dict()), ("graphed", dict(graphed=True)), ("graphed_two_in_flight", dict(graphed=True, in_flight=2)),
+                         ("eager_two_in_flight", dict(in_flight=2))):
+            ev.eval_epoch(model, loader, device, args=args, **kw)             # warm-up epoch (lanes, graphs, allocator)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ev.eval_epoch(model, loader, device, args=args, **kw)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                best = el if best is None else min(best, el)
+            res[name] = dict(clips_per_s=round(batches * c["B"] / best, 1), ms_per_batch=round(best / batches * 1e3, 3))
+        res["host_bytes_per_batch"] = int(sum(t.numel() * t.element_size() for t in host[0]))
+        out[fmt] = res
+        del loader, host
+    out["what"] = ("eval_epoch over %d pinned host batches of %d clips (inference loop only), best of 3 epochs after a warm-up epoch; "
+                   "copies and host launches included" % (batches, c["B"]))
+    return out
+
+
 def pcie_inclusive_bench(model, c, device, steps=150):
     """The same step fed FROM THE HOST: decoder-layout uint8 frames (N3) + ids / masks in pinned memory, staged by
     centerclip_amd.feeder.DeviceFeeder (two device slots filled on a copy stream while the encoders run on the other slot, one
@@ -654,6 +700,7 @@ def step_policies_and_variants(model, c, sd, device, step1, batch):
     ms_u8 = graph_time_ms(lambda: model(ids, zt, amask, u8, vmask), launches=1, replays=20)
     ms_f32 = graph_time_ms(lambda: model(ids, zt, amask, video, vmask), launches=1, replays=20)
     res["pcie_inclusive"] = pcie_inclusive_bench(model, c, device)
+    res["eval_loop"] = eval_loop_bench(c, sd, device)
     res["uint8_input"] = {"ms_per_forward_uint8_hwc": round(ms_u8, 3), "ms_per_forward_f32": round(ms_f32, 3),
                           "input_bytes_per_clip": {"uint8": c["T"] * 3 * 224 * 224, "f32": c["T"] * 3 * 224 * 224 * 4},
                           "launch": "hipGraph replay"}

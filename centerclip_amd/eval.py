@@ -179,16 +179,58 @@ def _item_positions(loader, world, rank, shard):
     return positions, None
 
 
-def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend, in_flight=1,
-               similarity_products=None):
+class _GraphedLane:
+    """One lane of eval_epoch(graphed=True): per batch signature (shapes + dtypes of the loader's five tensors) a set of
+    device-resident input tensors, and a hipGraph of `forward -> operand rows` captured on them.  A batch is then ONE
+    host -> device copy per tensor into the resident inputs + one graph launch (~70 kernel launches of the eager step leave
+    the host's critical path); the operand rows are cloned out of the graph's buffers before the next replay reuses them."""
+
+    def __init__(self, net, core, be, stream):
+        self.net, self.core, self.be, self.stream, self.graphs = net, core, be, stream, {}
+
+    def _step(self, bufs):
+        input_ids, input_mask, segment_ids, video, video_mask = bufs
+        out = self.net(input_ids, segment_ids, input_mask, video, video_mask)
+        seq = out['sequence_output']
+        return (self.be.text_operand(seq.reshape(seq.shape[0], -1)), _video_operand(self.core, out['visual_output'], video_mask, self.be))
+
+    def __call__(self, batch, device):
+        key = tuple((tuple(t.shape), t.dtype) for t in batch)
+        entry = self.graphs.get(key)
+        if entry is None:                                         # first batch of this signature: eager (warm-up), then capture
+            bufs = tuple(t.to(device) for t in batch)
+            result = tuple(o.clone() for o in self._step(bufs))
+            torch.cuda.current_stream(device).synchronize()
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, stream=self.stream):
+                outs = self._step(bufs)
+            self.graphs[key] = (gph, bufs, outs)
+            return result
+        gph, bufs, outs = entry
+        for d, h in zip(bufs, batch):
+            d.copy_(h, non_blocking=True)                          # (asynchronous from pinned memory; ordered before the replay)
+        gph.replay()
+        return tuple(o.clone() for o in outs)
+
+
+def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False, backend=HipBackend, in_flight=None,
+               similarity_products=None, graphed=False):
     """main.py:381-499 -> (R1, all_infer_time, info_str).  ``shard=True``: clip-sharded over the ranks of the default
     process group (module docstring) - every rank must call it and every rank returns the same numbers.
-    ``in_flight`` (not in the reference; GPU only): 2 keeps two batches in flight - batch b runs on instance b % 2 of the
-    model (``CLIP4Clip.replica()``) on a stream of its own, so the small-grid kernels of one batch (k-medoids selection,
-    launch tails) run under the other's GEMMs: 1.84 -> 1.60 ms per 16-clip batch at the cfg-2 shape, identical features.
+    ``in_flight`` (not in the reference; > 1 GPU only; default: 2 on a GPU, 1 on the CPU stand-in): n keeps n batches in flight -
+    batch b runs on instance b % n of the model (``CLIP4Clip.replica()``) on a stream of its own, so the host -> device copy and
+    the small-grid kernels of one batch (k-medoids selection, launch tails) run under another's GEMMs: from pinned uint8 host
+    batches of the cfg-2 shape 2.82 -> 1.82 ms per 16-clip batch (5,680 -> 8,780 clips/s; 4 lanes: 9,530), identical features.
     ``similarity_products`` (not in the reference): 3, 2 or 1 fp16 products per multiply-add of the final matrix
-    (``HipBackend.with_products``); None = the backend's own (2: the text side rounded to fp16, the video side to 22 bits)."""
+    (``HipBackend.with_products``); None = the backend's own (2: the text side rounded to fp16, the video side to 22 bits).
+    ``graphed`` (not in the reference; GPU only, single-sentence protocol): every full batch is a copy into device-resident
+    inputs + ONE hipGraph launch per lane (captured on the first batch of each shape; a ragged last batch gets a graph of its
+    own) instead of ~70 eager kernel launches - identical rows.  Measured (same loader): one lane 2.82 -> 2.41 ms per batch; with
+    two or more lanes the eager launches already overlap and the graphs add nothing (2.15 vs 1.82 ms at two lanes), so it is
+    for the case where a second model instance is not wanted (``in_flight=1``)."""
     log = log or (lambda s: None)
+    if in_flight is None:
+        in_flight = 2 if (torch.cuda.is_available() and torch.device(device).type == "cuda") else 1
     be = backend.with_products(similarity_products) if similarity_products is not None else backend
     world, rank = (ccdist.world_size(), ccdist.rank()) if shard else (1, 0)
     ds = test_dataloader.dataset
@@ -218,6 +260,18 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
         lanes = list(zip([model] + kept[2], kept[1]))
         for _, s_ in lanes:
             s_.wait_stream(here)
+    graphs, graph_stream = None, None
+    if graphed:
+        if not (torch.cuda.is_available() and torch.device(device).type == "cuda"):
+            raise ValueError("eval_epoch(graphed=True) needs a GPU")
+        # lane index -> _GraphedLane, kept on the model next to the lanes (same validity key: the weights' versions)
+        gkey = (in_flight, str(torch.device(device)), be.text_operand, be.video_operand,
+                tuple((p.data_ptr(), p._version) for p in core.parameters()))
+        kept_g = getattr(core, "_eval_graphs", None)
+        if kept_g is None or kept_g[0] != gkey:
+            kept_g = (gkey, {}, torch.cuda.Stream(device))
+            core._eval_graphs = kept_g
+        graphs, graph_stream = kept_g[1], kept_g[2]
     t_start = time.time()
     total = 0
     with torch.no_grad():
@@ -234,13 +288,20 @@ def eval_epoch(model, test_dataloader, device, args=None, log=None, shard=False,
                 batch, pos = tuple(t[keep] for t in batch), pos[keep]
             net, lane_stream = lanes[bid % in_flight] if lanes else (model, None)
             with (torch.cuda.stream(lane_stream) if lane_stream is not None else contextlib.nullcontext()):
-                input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
                 def keep_rows(t):
                     # rows produced on a lane's stream are read on the caller's stream at the end: tell the caching allocator,
                     # so their blocks are not handed out again on the lane while that read is still queued
                     if lane_stream is not None and t.is_cuda:
                         t.record_stream(here)
                     return t
+                if graphs is not None and not multi:
+                    lane = graphs.setdefault(bid % in_flight, _GraphedLane(net, core, be, lane_stream if lane_stream is not None
+                                                                           else graph_stream))
+                    t_op, v_op = lane(batch, device)
+                    cache.add_text(keep_rows(t_op), pos)
+                    cache.add_video(keep_rows(v_op), pos)
+                    continue
+                input_ids, input_mask, segment_ids, video, video_mask = (t.to(device) for t in batch)
                 if not multi:
                     out = net(input_ids, segment_ids, input_mask, video, video_mask)
                     cache.add_text(keep_rows(be.text_operand(out['sequence_output'].reshape(b if keep.numel() == b else keep.numel(), -1))), pos)

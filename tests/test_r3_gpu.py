@@ -361,7 +361,7 @@ def test_eval_epoch_two_batches_in_flight(g2, name, cluster):
         def dot_operands(t_op, v_op, n_video, mult):
             sims.append(ev.HipBackend.dot_operands(t_op, v_op, n_video, mult).clone())
             return sims[-1]
-    one = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy)
+    one = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy, in_flight=1)
     two = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy, in_flight=2)
     three = ev.eval_epoch(model, loader, torch.device(DEV), args=Namespace(inference_speed_test=False), backend=Spy, in_flight=3)
     assert torch.equal(sims[0], sims[1]) and torch.equal(sims[0], sims[2])
@@ -370,6 +370,41 @@ def test_eval_epoch_two_batches_in_flight(g2, name, cluster):
     assert rep is not model and rep.training == model.training
     for (k, a), (_, b) in zip(model.state_dict().items(), rep.state_dict().items()):
         assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
+
+
+@pytest.mark.parametrize("name", sorted(EVAL_CASES))
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_eval_epoch_graphed_lanes(g2, name, in_flight):
+    """eval_epoch(graphed=True) (round 6): every batch = a copy into device-resident inputs + ONE hipGraph launch per lane (a
+    graph per batch shape: the ragged last batch gets its own) - matrix, R@1 and metric strings equal the eager loop's; a
+    second epoch reuses the captured graphs; changed weights drop them."""
+    from centerclip_amd import eval as ev
+    model, sd, cfg = _small_model(g2, cluster_inter=1)
+    batches, attrs = eval_case_batches(EVAL_CASES[name], cfg)
+    loader = _Loader(batches)
+    loader.dataset = Namespace(**attrs)
+    sims = []
+
+    class Spy(ev.HipBackend):
+        @staticmethod
+        def dot_operands(t_op, v_op, n_video, mult):
+            sims.append(ev.HipBackend.dot_operands(t_op, v_op, n_video, mult).clone())
+            return sims[-1]
+    a = Namespace(inference_speed_test=False)
+    eager = ev.eval_epoch(model, loader, torch.device(DEV), args=a, backend=Spy, in_flight=in_flight)
+    g1 = ev.eval_epoch(model, loader, torch.device(DEV), args=a, backend=Spy, in_flight=in_flight, graphed=True)
+    kept = model._eval_graphs
+    g2_ = ev.eval_epoch(model, loader, torch.device(DEV), args=a, backend=Spy, in_flight=in_flight, graphed=True)
+    assert model._eval_graphs is kept                               # the second epoch replays the first one's graphs
+    multi = bool(attrs.get("multi_sentence_per_video", False))
+    if not multi:
+        assert sum(len(l.graphs) for l in kept[1].values()) >= 1
+    assert torch.equal(sims[0], sims[1]) and torch.equal(sims[0], sims[2])
+    assert eager[0] == g1[0] == g2_[0] and list(eager[2]) == list(g1[2]) == list(g2_[2])
+    with torch.no_grad():
+        model.clip.logit_scale.add_(0.0)                            # a tracked in-place write: the version key changes
+    ev.eval_epoch(model, loader, torch.device(DEV), args=a, backend=Spy, in_flight=in_flight, graphed=True)
+    assert model._eval_graphs is not kept
 
 
 # ------------------------------------------------------------------------------------------------ N4: loss gradient
