@@ -448,8 +448,8 @@ def similarity_bench(device, world=1):
 def eval_loop_bench(c, sd, device, batches=24):
     """The PRODUCT's evaluation loop (centerclip_amd.eval.eval_epoch, the mirror of main.py:381-499) over a list-backed loader
     of pinned host batches of the headline shape - what a user of the reference's script gets, host -> device copies and host
-    launch overhead included: eager launches (the round-5 loop), graphed lanes (round 6: one hipGraph launch per batch), and
-    graphed lanes with two batches in flight.  fp32 CHW frames (what the reference's loader hands over: 115.6 MB per batch)
+    launch overhead included: one lane of eager launches (the round-5 loop), one lane launching one hipGraph per batch (round 6),
+    two lanes (eval_epoch's default on a GPU since round 6: batch b on model instance b % 2, a stream each) and four.  fp32 CHW frames (what the reference's loader hands over: 115.6 MB per batch)
     and the decoder's uint8 HWC frames (N3: 28.9 MB)."""
     from argparse import Namespace
     from centerclip_amd.clip4clip import CLIP4Clip
@@ -471,8 +471,8 @@ def eval_loop_bench(c, sd, device, batches=24):
         loader.dataset = Namespace(multi_sentence_per_video=False)
         args = Namespace(inference_speed_test=True)               # the loop only (main.py:467-469), no metrics
         res = {}
-        for name, kw in (("eager", dict()), ("graphed", dict(graphed=True)), ("graphed_two_in_flight", dict(graphed=True, in_flight=2)),
-                         ("eager_two_in_flight", dict(in_flight=2))):
+        for name, kw in (("one_lane", dict(in_flight=1)), ("one_lane_graphed", dict(in_flight=1, graphed=True)),
+                         ("two_lanes", dict()), ("four_lanes", dict(in_flight=4))):      # (two lanes = eval_epoch's default on a GPU)
             ev.eval_epoch(model, loader, device, args=args, **kw)             # warm-up epoch (lanes, graphs, allocator)
             torch.cuda.synchronize()
             best = None
