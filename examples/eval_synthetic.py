@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--algo", default="kmediods++", choices=["kmediods++", "spectral", "pooling", "sparse_sampling"])
-    ap.add_argument("--in-flight", type=int, default=1, help="2: two batches in flight on two model instances / streams (+15 %% clips/s)")
+    ap.add_argument("--in-flight", type=int, default=None, help="batches in flight (model instances / streams); default: eval_epoch's own (2 on a GPU)")
     a = ap.parse_args()
     device = torch.device("cuda:0")
     c = bench.CFG2
