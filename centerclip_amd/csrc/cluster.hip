@@ -478,9 +478,9 @@ __global__ void shift_dist_kernel(float* __restrict__ d, int P, int N, const int
 // and the medoid falls out of a 64-bit LDS min over (key(sum), token).
 //
 // LDS carve (dynamic): [IN_LDS: D N*N f32] best K u64 | med K i32 | asg, order N u16
-#define SEL_MAX_E 64   /* N <= 4095: 128 passes of 32 terms = up to 8 runs of 16 passes, each folded into the second level of
+#define SEL_MAX_E 128  /* N <= 8191: 255 passes of 32 terms = up to 16 runs of 16 passes, each folded into the second level of
                         * ATen's row sum when it completes; the third level (pass 256, N = 8,192) is never reached */
-#define SEL_MAX_N 4095
+#define SEL_MAX_N 8191
 
 // development builds (-DCC_DEV_KNOBS) only: per-problem phase timestamps of K2
 #ifdef CC_DEV_KNOBS
@@ -518,13 +518,13 @@ __device__ __forceinline__ int sum_rank(int j, int N) {
     return (N - vec_end) + l * vs + off;
 }
 
-// mem[] entry: token (bits 0-11) | flags
-#define SEL_TOK 0x0FFFu
-#define SEL_F1 0x01000u   /* closes the current run of 16 passes  */
-#define SEL_F2 0x02000u   /* closes the current accumulator (k,l) */
-#define SEL_F3 0x04000u   /* closes the current lane l            */
-#define SEL_TREE 0x08000u /* vector part (not the scalar tail)    */
-#define SEL_LEFT 0x10000u /* left-over vector: joins accumulator 0 */
+// mem[] entry: token (bits 0-12) | flags
+#define SEL_TOK 0x1FFFu
+#define SEL_F1 0x02000u   /* closes the current run of 16 passes  */
+#define SEL_F2 0x04000u   /* closes the current accumulator (k,l) */
+#define SEL_F3 0x08000u   /* closes the current lane l            */
+#define SEL_TREE 0x10000u /* vector part (not the scalar tail)    */
+#define SEL_LEFT 0x20000u /* left-over vector: joins accumulator 0 */
 __device__ __forceinline__ float sel_and(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
 
 struct SelSmem {
@@ -953,8 +953,8 @@ __global__ __launch_bounds__(SEL_THREADS) void kmedoids_select_kernel(const floa
                 for (int u = 0; u < 8; ++u) {
                     // x & m keeps x or yields +0; x - (x & m) is then +0 or x, both exact
                     const int ev = e[u] < 0 ? 0 : e[u];                      // padding: no flags, v = 0
-                    const int m1 = -((ev >> 12) & 1), m2 = -((ev >> 13) & 1), m3 = -((ev >> 14) & 1);
-                    const int mt = -((ev >> 15) & 1), ml = -((ev >> 16) & 1);
+                    const int m1 = -((ev >> 13) & 1), m2 = -((ev >> 14) & 1), m3 = -((ev >> 15) & 1);
+                    const int mt = -((ev >> 16) & 1), ml = -((ev >> 17) & 1);
                     const float t1 = sel_and(c, m1);  P += t1;  c -= t1;     // new run of passes / accumulator / lane
                     const float t2 = sel_and(P, m2);  R += t2;  P -= t2;     // new accumulator or lane
                     const float t3 = sel_and(R, m3);  F += t3;  R -= t3;     // new lane
@@ -1629,6 +1629,7 @@ int run_select(const float* dist_in, float* dist_rw, const float* norms, const i
         else if (ne <= 16) SEL_LAUNCH(false, 16);
         else if (ne <= 25) SEL_LAUNCH(false, 25);           // N <= 1,600: ViT-B/16, 8 frames per segment (1,568)
         else if (ne <= 40) SEL_LAUNCH(false, 40);
+        else if (ne <= 64) SEL_LAUNCH(false, 64);
         else SEL_LAUNCH(false, SEL_MAX_E);
     }
 #undef SEL_LAUNCH

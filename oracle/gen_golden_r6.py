@@ -15,6 +15,12 @@
            lt_tiny            P = 4, N = 7,   W = 8,   K = 3,  split 4 (ATen's scalar path for the sum over K; N < 8): one step
            lt_iter_limit      P = 4, N = 196, W = 64,  K = 49, split 4, iter_limit 2 with a threshold those two steps do not reach
 
+  p1w_*  batch_fast_kmedoids_with_split above N = 4,095 (the limit of round 5; the selection kernel's member lists now carry 13-bit
+         token ids and up to 128 mask words per cluster: N <= 8,191 = the last length at which ATen's row sum stays within two
+         accumulator levels), integer lattices - parity level P1:
+           p1w_4500   P = 2, N = 4,500, W = 16, K = 6, split_size 1 (two chunks)
+           p1w_8191   P = 1, N = 8,191, W = 8,  K = 4 (255 passes of 32 terms: 15 full runs of 16 passes + a partial one)
+
     python oracle/gen_golden_r6.py   ->  tests/golden/r6_golden.npz
 """
 import os
@@ -29,7 +35,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
-from recipes import LOOSE_THRESHOLD_CASES, loose_threshold_inputs  # noqa: E402
+from recipes import LOOSE_THRESHOLD_CASES, P1_WIDE_CASES, lattice, loose_threshold_inputs  # noqa: E402
 
 
 def shift_sequences(fk, cu, X, K, distance, norm_p, split, pre_norm, iter_limit):
@@ -77,6 +83,12 @@ def main():
         out[f"{tag}_differs_from_fixed_point"] = np.array([int(not torch.equal(m, m_fix))], dtype=np.int8)
         print(tag, "threshold %.6g" % thr, "steps per chunk", stops, "differs from the fixed point:", not torch.equal(m, m_fix),
               "| shifts chunk 0:", ["%.4g" % v for v in seqs[0][:6]], flush=True)
+    for tag, (seed, P, N, W, K, split, iters) in P1_WIDE_CASES.items():
+        X = torch.from_numpy(lattice(seed, (P, N, W)))
+        a, m = fk.batch_fast_kmedoids_with_split(X, K, distance="euclidean", threshold=1e-6, iter_limit=iters,
+                                                 id_sort=True, norm_p=2.0, split_size=split, pre_norm=False)
+        out[f"{tag}_assign"], out[f"{tag}_medoids"] = a.numpy().astype(np.int16), m.numpy().astype(np.int16)
+        print(tag, tuple(a.shape), m.numpy().tolist(), flush=True)
     np.savez_compressed(os.path.join(GOLD, "r6_golden.npz"), **out)
     print("wrote", os.path.join(GOLD, "r6_golden.npz"), len(out), "arrays")
 

@@ -390,3 +390,7 @@ LOOSE_THRESHOLD_CASES = {
 def loose_threshold_inputs(tag):
     seed, P, N, W = LOOSE_THRESHOLD_CASES[tag][:4]
     return (norm32_tokens if LOOSE_THRESHOLD_CASES[tag][11] == "norm32" else dyadic)(seed, (P, N, W))
+
+
+# Round 6: k-medoids above 4,095 tokens per problem.  name: (seed, P, N, W, K, split, iter_limit) - lattice(seed, (P, N, W))
+P1_WIDE_CASES = {"p1w_4500": (181, 2, 4500, 16, 6, 1, 100), "p1w_8191": (182, 1, 8191, 8, 4, 16, 100)}

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import cluster_oracle as co
-from oracle.recipes import LOOSE_THRESHOLD_CASES, loose_threshold_inputs
+from oracle.recipes import LOOSE_THRESHOLD_CASES, P1_WIDE_CASES, lattice, loose_threshold_inputs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -36,3 +36,13 @@ def test_aten_row_sums_restates_torch_for_the_shift_shapes():
     for n in (1, 2, 3, 4, 5, 7, 8, 10, 16, 25, 49, 64, 100, 512, 768, 1024):
         M = (rng.standard_normal((6, n)) * 3).astype(np.float32) ** 2
         assert np.array_equal(co.aten_row_sums(M), torch.from_numpy(M).sum(dim=-1).numpy()), n
+
+
+def test_literal_oracle_matches_reference_above_4095_tokens(g6):
+    """The oracle's literal k-medoids at N = 4,500 (the smaller of the two wide fixtures: the [B, K, N, N] temporaries of the
+    literal form are 0.5 GB there) == the reference's indices."""
+    seed, P, N, W, K, split, iters = P1_WIDE_CASES["p1w_4500"]
+    X = torch.from_numpy(lattice(seed, (P, N, W)))
+    a, m = co.literal_batch_kmedoids_with_split(X, K, "euclidean", 1e-6, iters, True, 2.0, split, False)
+    assert np.array_equal(m.numpy(), g6["p1w_4500_medoids"].astype(np.int64))
+    assert np.array_equal(a.numpy(), g6["p1w_4500_assign"].astype(np.int64))

@@ -45,9 +45,10 @@ def test_p1_lattice_above_1023_tokens(g5, tag):
     assert np.array_equal(a.cpu().numpy(), g5[f"{tag}_assign"].astype(np.int64))
 
 
-def test_token_count_limit_is_4095():
-    """N = 4,095 runs (a 16-dimensional lattice, against the oracle's exact-distance selection); N = 4,096 is refused, not
-    mis-computed (the third level of ATen's cascade would start at 8,192 terms; the per-cluster masks live in LDS)."""
+def test_token_count_4095_and_the_limit():
+    """N = 4,095 runs (a 16-dimensional lattice, against the oracle's exact-distance selection); round 6 moved the limit to
+    N = 8,191 (reference fixtures above 4,095: tests/test_r6_gpu.py): N = 8,192 is refused, not mis-computed (the third level
+    of ATen's cascade starts at 8,192 terms; the per-cluster masks live in LDS)."""
     from centerclip_amd import cluster as cl
     from oracle import cluster_oracle as co
     from oracle.recipes import lattice
@@ -59,7 +60,7 @@ def test_token_count_limit_is_4095():
     ao, mo, _ = co.select_streamlined(D[0], first, K, iter_limit=100)
     assert np.array_equal(m.cpu().numpy()[0], mo) and np.array_equal(a.cpu().numpy()[0], ao)
     with pytest.raises(RuntimeError, match="unsupported"):
-        cl.batch_fast_kmedoids_with_split(torch.from_numpy(lattice(978, (1, 4096, 16))).to(DEV), K)
+        cl.batch_fast_kmedoids_with_split(torch.from_numpy(lattice(978, (1, 8192, 8))).to(DEV), 4)
 
 
 def test_mean_residual_inside_the_fused_visual_tower(g5, gc):

@@ -186,3 +186,19 @@ def test_token_cluster_module_with_loose_threshold():
     ref = co.literal_token_cluster(x, T, T_new, K, "euclidean", 25.0, 60, split_size=8)
     ref = ref[0] if isinstance(ref, tuple) else ref
     assert y.shape == ref.shape and float((y.cpu() - ref).abs().max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ N above 4,095
+@pytest.mark.parametrize("tag", ["p1w_4500", "p1w_8191"])
+def test_p1_lattice_above_4095_tokens(g6, tag):
+    """batch_fast_kmedoids_with_split at N = 4,500 (two chunks) and N = 8,191 (the largest length at which ATen's row sum
+    stays within two accumulator levels: 255 passes of 32 terms) - the reference's indices bit for bit (was CC_ERR_UNSUPPORTED
+    above 4,095: 13-bit token ids in the member lists, up to 128 mask words per cluster)."""
+    from centerclip_amd import cluster as cl
+    from oracle.recipes import P1_WIDE_CASES, lattice
+    seed, P, N, W, K, split, iters = P1_WIDE_CASES[tag]
+    X = torch.from_numpy(lattice(seed, (P, N, W))).to(DEV)
+    a, m = cl.batch_fast_kmedoids_with_split(X, K, distance="euclidean", threshold=1e-6, iter_limit=iters,
+                                             id_sort=True, norm_p=2.0, split_size=split, pre_norm=False)
+    assert np.array_equal(m.cpu().numpy(), g6[f"{tag}_medoids"].astype(np.int64))
+    assert np.array_equal(a.cpu().numpy(), g6[f"{tag}_assign"].astype(np.int64))
