@@ -64,6 +64,8 @@ def compact_line(res, detail_path=None):
         r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step",
                          "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "step_share_us"))
         r["traffic_source"] = (roof.get("traffic_detail") or {}).get("source")
+        if roof.get("by_shape"):
+            r["by_shape"] = [_pick(b, ("shape", "avg_us", "mfma_frac", "hbm_frac", "bound")) for b in roof["by_shape"]]
         line["roofline"] = r
     else:
         line["roofline"] = None

@@ -276,6 +276,21 @@ def gemm_roofline(c, device, insitu=None):
                                            frac=round(v["tflops"] / MFMA_F16_PEAK_TFLOPS, 4), shapes=v["shapes"])
                                    for k, v in (insitu or {}).items()},
                 by_symbol_stand_alone=standalone)
+    # The dominant symbol serves shapes on both sides of the machine balance (2,500 TFLOP/s : 8 TB/s = 312 flop / byte): per shape,
+    # the matrix-core fraction AND the HBM-side fraction of the launch's algorithmic bytes (fp16 A and W, for the residual
+    # epilogue the fp32 rows read + written, the centred fp16 copy and the partial statistics) - whichever is larger binds it.
+    if insitu and sym in insitu and "7," in sym.split("<")[1]:
+        by_shape = []
+        for key, sh in insitu[sym]["shapes"].items():
+            m0, n0, k0 = (int(v) for v in key.split(" ")[0].split("x"))
+            fl = 2.0 * m0 * n0 * k0
+            byt = m0 * k0 * 2 + n0 * k0 * 2 + m0 * n0 * (4 + 4 + 2) + m0 * 2 * 8 * max(1, n0 // 64 // 2)
+            us = sh["avg_us"]
+            mf, hf = fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS, byt / us / 1e3 / HBM_PEAK_GBS
+            by_shape.append(dict(shape="%dx%dx%d" % (m0, n0, k0), avg_us=us, launches_per_step=sh["launches_per_step"],
+                                 mfma_frac=round(mf, 3), algorithmic_bytes=int(byt), hbm_frac=round(hf, 3),
+                                 flop_per_byte=round(fl / byt, 1), bound="hbm" if hf > mf else "mfma"))
+        roof["by_shape"] = by_shape
     gemm_us = sum(r["step_share_us"] for r in rows)
     gemm_flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_step"] for r in rows)
     return roof, rows, gemm_us, gemm_flops
