@@ -202,3 +202,41 @@ def test_p1_lattice_above_4095_tokens(g6, tag):
                                              id_sort=True, norm_p=2.0, split_size=split, pre_norm=False)
     assert np.array_equal(m.cpu().numpy(), g6[f"{tag}_medoids"].astype(np.int64))
     assert np.array_equal(a.cpu().numpy(), g6[f"{tag}_assign"].astype(np.int64))
+
+
+def test_loose_threshold_inside_the_fused_tower_and_a_hipgraph(g2):
+    """The stepped selection (2 * iter_limit + 2 launches, a memset, no host read) inside the fused visual tower: the features
+    of a model whose cluster module carries a loose threshold differ from the tight-threshold model's, a captured hipGraph of the
+    forward replays to the eager result bit for bit, and the medoids the tower used are the stand-alone op's."""
+    from argparse import Namespace
+    from centerclip_amd.clip4clip import CLIP4Clip
+    sd = {k[6:]: torch.from_numpy(g2[k].astype(np.float32) if g2[k].dtype == np.float16 else g2[k])
+          for k in g2.files if k.startswith("s1_sd/")}
+    cfg = g2["s1_cfg"]
+    RES, T, T_new, B = int(cfg[1]), int(cfg[11]), int(cfg[12]), int(cfg[10])
+
+    def build(threshold):
+        a = Namespace(cluster_inter=1, deep_cluster=0, cluster_algo='kmediods++', max_frames=T,
+                      target_frames_blocks=[4, T_new, T_new], cluster_num_blocks=[16, 6, 6], cluster_distance='euclidean',
+                      cluster_threshold=threshold, cluster_iter_limit=20, minkowski_norm_p=2.0, aggregation=None,
+                      pretrained_clip_name='ViT-B/32', pre_norm=False, loose_type=True, sim_header='meanP', linear_patch='2d',
+                      pre_visual_pooling=0)
+        return CLIP4Clip.from_state_dict(dict(sd), a).to(DEV).eval()
+    gen = torch.Generator().manual_seed(21)
+    video = torch.randn(B * T, 3, RES, RES, generator=gen).to(DEV)
+    tight, loose = build(1e-6), build(30.0)
+    with torch.no_grad():
+        f_t, _ = tight.clip.visual.encode(video, T, want_medoids=True)
+        m_t = tight.clip.visual.last_medoids.clone()
+        f_l, _ = loose.clip.visual.encode(video, T, want_medoids=True)
+        m_l = loose.clip.visual.last_medoids.clone()
+        assert not torch.equal(m_t, m_l) and not torch.equal(f_t, f_l)
+        f_l2, _ = loose.clip.visual.encode(video, T)                       # the shipped call (no medoid buffer)
+        assert torch.equal(f_l, f_l2)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            f_g, _ = loose.clip.visual.encode(video, T)
+        gph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(f_g, f_l)
