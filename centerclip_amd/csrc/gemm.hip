@@ -1517,7 +1517,7 @@ bool cc_gemm_attn_applies(const GemmArgs& g0, const GemmArgs* g1) {
 #endif
     return attn_problem_ok(g0) && (!g1 || attn_problem_ok(*g1));
 }
-// Row-tile height of the launch: 256 rows, or - uniform sequences only - 224 (one 197-token ViT-B/16 frame owns 14 fragment
+// Row-tile height of the launch: 256 rows, or 224 (one 197-token ViT-B/16 frame owns 14 fragment
 // rows instead of 16: 1/8 less matrix-core work per tile) or 192 (the clustered blocks: 48 sequences of 50 tokens are 10
 // tiles x 12 heads = 120 workgroups at 256 rows, 47 % of the CUs; 3 sequences per 192-row tile give 16 x 12 = 192 workgroups
 // of 3/4 the work and two rounds of attention items per wave instead of three).  The choice minimises
