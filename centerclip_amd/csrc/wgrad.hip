@@ -282,14 +282,11 @@ int cc_wgrad_tn_f16(const void* dy_f16, const void* x_f16, float* dw, int32_t M,
     a.rows_per_slice = (steps + a.S - 1) / a.S * WG_BK;
     a.partial = static_cast<float*>(ws);
     const size_t tiles = (size_t)(N1 / WG_BN) * (N2 / WG_BN);
-    static bool configured = false;
     constexpr int smem = WG_NST * 2 * WG_TILE_BYTES;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess)
-            return CC_ERR_HIP;
-        configured = true;
-    }
+    // (set per call: the attribute is per device, the call is cheap and idempotent - a process-wide "configured" flag would
+    //  leave every device but the first one at the 64 KB default)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        return CC_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)(tiles * a.S)), dim3(256), smem, st, a);
     CC_LAUNCH_CHECK();

@@ -124,6 +124,7 @@ class GradientBuckets:
         self.world = world_size()
         order = list(reversed(self.params))
         self.buckets = []                       # (flat buffer, [(param, offset, numel)])
+        self._flags = {}                        # id(flat) -> [flag pattern, its device copy]
         cur, cur_n = [], 0
         cap = max(1, bucket_bytes // 4)
         for p in order:
@@ -159,7 +160,13 @@ class GradientBuckets:
                 elif p.grad.data_ptr() != dst.data_ptr():
                     dst.copy_(p.grad.reshape(-1))
             n_grad = slots[-1][1] + slots[-1][2]
-            flat[n_grad:n_grad + len(slots)].copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
+            # (the flags of a bucket normally never change between steps: one upload when the pattern changes, a device-to-
+            #  device copy per step - a pageable host tensor copied every step would stall the host once per bucket)
+            key = tuple(flags)
+            fc = self._flags.setdefault(id(flat), [None, None])
+            if fc[0] != key:
+                fc[0], fc[1] = key, torch.tensor(flags, dtype=torch.float32).to(flat.device)
+            flat[n_grad:n_grad + len(slots)].copy_(fc[1])
         if self.world > 1:
             works, shards = [], []
             for flat, _ in self.buckets:
